@@ -1,0 +1,999 @@
+/*
+ * jo_engine.c -- ORACLE physics step (fp64, CPU).  See jo_engine.h for scope and provenance.
+ * Test infrastructure only: never linked into, imported by, or called from the product path.
+ *
+ * Every block cites the MuJoCo pipeline stage it restates (MuJoCo 3.5 documentation, "Computation"
+ * chapter) and the reference call site that reaches it:
+ *   judo/utils/mj_rollout_backend.py:84 (mujoco.rollout -> mj_step), tasks/base.py:109 (mj_forward).
+ */
+#include "jo_engine.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MINVAL 1e-15 /* mjMINVAL */
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+#define MINMU 1e-5
+
+/* ------------------------------------------------------------------ small math */
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
+static inline void copy3(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static inline void addscl3(double* r, const double* a, double s) { r[0] += a[0] * s; r[1] += a[1] * s; r[2] += a[2] * s; }
+static void quat_mul(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void quat_normalize(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+/* row-major rotation matrix: world = R * local; column k of R is local axis k in world coordinates */
+static void quat2mat(double* R, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+static inline void rot(double* r, const double* R, const double* v) {
+  double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2], z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void rotT(double* r, const double* R, const double* v) {
+  double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2], z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void axisangle2quat(double* q, const double* axis, double angle) {
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+
+/* ------------------------------------------------------------------ model builder */
+jo_model* jo_model_new(double timestep, int integrator, int cone, double impratio, const double* gravity, int contact_enabled) {
+  jo_model* m = (jo_model*)calloc(1, sizeof(jo_model));
+  m->dt = timestep; m->integrator = integrator; m->cone = cone; m->impratio = impratio; m->contact_enabled = contact_enabled;
+  copy3(m->grav, gravity);
+  m->nbody = 1; /* world */
+  m->body_parent[0] = -1; m->body_quat[0][0] = 1; m->body_iquat[0][0] = 1;
+  m->solver_maxiter = 100; m->solver_tol = 1e-10;
+  return m;
+}
+void jo_model_free(jo_model* m) { free(m); }
+
+int jo_add_body(jo_model* m, int parent, const double* pos, const double* quat, double mass, const double* ipos, const double* iquat, const double* inertia) {
+  if (m->nbody >= JO_MAXBODY || parent < 0 || parent >= m->nbody) return -1;
+  int b = m->nbody++;
+  m->body_parent[b] = parent;
+  copy3(m->body_pos[b], pos); memcpy(m->body_quat[b], quat, 4 * sizeof(double)); quat_normalize(m->body_quat[b]);
+  m->body_mass[b] = mass; copy3(m->body_ipos[b], ipos); memcpy(m->body_iquat[b], iquat, 4 * sizeof(double)); quat_normalize(m->body_iquat[b]);
+  copy3(m->body_inertia[b], inertia);
+  m->body_jntadr[b] = -1; m->body_jntnum[b] = 0;
+  return b;
+}
+
+int jo_add_joint(jo_model* m, int body, int type, const double* pos, const double* axis, double damping, double armature, double frictionloss,
+                 int limited, const double* range, double margin, int frclimited, const double* frcrange, const double* solref_limit,
+                 const double* solimp_limit, const double* solref_fric, const double* solimp_fric) {
+  if (m->njnt >= JO_MAXJNT || body <= 0 || body >= m->nbody) return -1;
+  int j = m->njnt++;
+  int ndof = type == JO_JNT_FREE ? 6 : 1, nqj = type == JO_JNT_FREE ? 7 : 1;
+  if (m->nv + ndof > JO_MAXDOF || m->nq + nqj > JO_MAXQ) return -1;
+  /* joints of a body must be added consecutively, bodies in depth-first order (MuJoCo ordering) */
+  if (m->body_jntnum[body] == 0) m->body_jntadr[body] = j;
+  else if (m->body_jntadr[body] + m->body_jntnum[body] != j) return -2;
+  m->body_jntnum[body]++;
+  m->jnt_type[j] = type; m->jnt_body[j] = body; m->jnt_qposadr[j] = m->nq; m->jnt_dofadr[j] = m->nv;
+  copy3(m->jnt_pos[j], pos); copy3(m->jnt_axis[j], axis);
+  m->jnt_limited[j] = limited; m->jnt_range[j][0] = range[0]; m->jnt_range[j][1] = range[1]; m->jnt_margin[j] = margin;
+  memcpy(m->jnt_solref[j], solref_limit, 2 * sizeof(double)); memcpy(m->jnt_solimp[j], solimp_limit, 5 * sizeof(double));
+  for (int k = 0; k < ndof; k++) {
+    int d = m->nv + k;
+    m->dof_body[d] = body; m->dof_jnt[d] = j;
+    m->dof_damping[d] = damping; m->dof_armature[d] = armature; m->dof_frictionloss[d] = frictionloss;
+    m->dof_frclimited[d] = frclimited; m->dof_frcrange[d][0] = frcrange[0]; m->dof_frcrange[d][1] = frcrange[1];
+    memcpy(m->dof_solref[d], solref_fric, 2 * sizeof(double)); memcpy(m->dof_solimp[d], solimp_fric, 5 * sizeof(double));
+  }
+  m->nq += nqj; m->nv += ndof;
+  return j;
+}
+
+int jo_add_geom(jo_model* m, int body, int type, const double* size, const double* pos, const double* quat, const double* friction,
+                const double* solref, const double* solimp, double margin, double gap, int condim) {
+  if (m->ngeom >= JO_MAXGEOM) return -1;
+  int g = m->ngeom++;
+  m->geom_type[g] = type; m->geom_body[g] = body; m->geom_condim[g] = condim;
+  copy3(m->geom_size[g], size); copy3(m->geom_pos[g], pos); memcpy(m->geom_quat[g], quat, 4 * sizeof(double)); quat_normalize(m->geom_quat[g]);
+  copy3(m->geom_friction[g], friction); memcpy(m->geom_solref[g], solref, 2 * sizeof(double)); memcpy(m->geom_solimp[g], solimp, 5 * sizeof(double));
+  m->geom_margin[g] = margin; m->geom_gap[g] = gap;
+  switch (type) { /* bounding-sphere radius (mjModel.geom_rbound) */
+    case JO_GEOM_SPHERE: m->geom_rbound[g] = size[0]; break;
+    case JO_GEOM_CAPSULE: m->geom_rbound[g] = size[0] + size[1]; break;
+    case JO_GEOM_CYLINDER: m->geom_rbound[g] = sqrt(size[0] * size[0] + size[1] * size[1]); break;
+    case JO_GEOM_BOX: m->geom_rbound[g] = norm3(size); break;
+    default: return -3;
+  }
+  return g;
+}
+int jo_add_pair(jo_model* m, int g1, int g2) {
+  if (m->npair >= JO_MAXPAIR || g1 < 0 || g2 < 0 || g1 >= m->ngeom || g2 >= m->ngeom || g1 == g2) return -1;
+  if (g1 > g2) { int t = g1; g1 = g2; g2 = t; } /* MuJoCo orders a pair by geom id: geom1 < geom2 */
+  m->pair_g1[m->npair] = g1; m->pair_g2[m->npair] = g2;
+  return m->npair++;
+}
+int jo_add_site(jo_model* m, int body, const double* pos) {
+  if (m->nsite >= JO_MAXSITE) return -1;
+  m->site_body[m->nsite] = body; copy3(m->site_pos[m->nsite], pos);
+  return m->nsite++;
+}
+int jo_add_actuator(jo_model* m, int joint, double kp, double kv, int ctrllimited, const double* ctrlrange, int forcelimited, const double* forcerange) {
+  if (m->nact >= JO_MAXACT || joint < 0 || joint >= m->njnt || m->jnt_type[joint] == JO_JNT_FREE) return -1;
+  int a = m->nact++;
+  m->act_jnt[a] = joint; m->act_kp[a] = kp; m->act_kv[a] = kv;
+  m->act_ctrllimited[a] = ctrllimited; m->act_ctrlrange[a][0] = ctrlrange[0]; m->act_ctrlrange[a][1] = ctrlrange[1];
+  m->act_forcelimited[a] = forcelimited; m->act_forcerange[a][0] = forcerange[0]; m->act_forcerange[a][1] = forcerange[1];
+  return a;
+}
+int jo_add_sensor(jo_model* m, int type, int obj, int obj2, double cutoff) {
+  if (m->nsensor >= JO_MAXSENSOR) return -1;
+  int s = m->nsensor++;
+  int dim = (type == JO_SENS_JOINTPOS || type == JO_SENS_DISTANCE) ? 1 : 3;
+  if (m->nsensordata + dim > JO_MAXSENSORDATA) return -1;
+  m->sensor_type[s] = type; m->sensor_obj[s] = obj; m->sensor_obj2[s] = obj2; m->sensor_cutoff[s] = cutoff; m->sensor_adr[s] = m->nsensordata;
+  m->nsensordata += dim;
+  return s;
+}
+int jo_add_equality_joint(jo_model* m, int j1, int j2, const double* polycoef, const double* solref, const double* solimp) {
+  if (m->neq >= JO_MAXEQ) return -1;
+  int e = m->neq++;
+  m->eq_j1[e] = j1; m->eq_j2[e] = j2;
+  memcpy(m->eq_poly[e], polycoef, 5 * sizeof(double)); memcpy(m->eq_solref[e], solref, 2 * sizeof(double)); memcpy(m->eq_solimp[e], solimp, 5 * sizeof(double));
+  return e;
+}
+int jo_model_dims(const jo_model* m, int* out) {
+  out[0] = m->nq; out[1] = m->nv; out[2] = m->nact; out[3] = m->nsensordata; out[4] = m->nbody; out[5] = m->ngeom; out[6] = m->npair;
+  return 0;
+}
+void jo_model_get_invweight0(const jo_model* m, double* dofw, double* bodyw) {
+  memcpy(dofw, m->dof_invweight0, m->nv * sizeof(double));
+  for (int b = 0; b < m->nbody; b++) { bodyw[2 * b] = m->body_invweight0[b][0]; bodyw[2 * b + 1] = m->body_invweight0[b][1]; }
+}
+void jo_model_get_qpos0(const jo_model* m, double* q) { memcpy(q, m->qpos0, m->nq * sizeof(double)); }
+jo_data* jo_data_new(void) { return (jo_data*)calloc(1, sizeof(jo_data)); }
+void jo_data_free(jo_data* d) { free(d); }
+
+/* ------------------------------------------------------------------ kinematics (mj_kinematics) */
+static void kinematics(const jo_model* m, jo_data* d) {
+  for (int j = 0; j < m->njnt; j++) /* quaternions in qpos are normalised before use */
+    if (m->jnt_type[j] == JO_JNT_FREE) quat_normalize(d->qpos + m->jnt_qposadr[j] + 3);
+  d->xpos[0][0] = d->xpos[0][1] = d->xpos[0][2] = 0; d->xquat[0][0] = 1; d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;
+  quat2mat(d->xmat[0], d->xquat[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parent[b];
+    double pos[3], quat[4];
+    int nj = m->body_jntnum[b], j0 = m->body_jntadr[b];
+    if (nj == 1 && m->jnt_type[j0] == JO_JNT_FREE) { /* free body: pose read straight from qpos */
+      const double* q = d->qpos + m->jnt_qposadr[j0];
+      copy3(pos, q); memcpy(quat, q + 3, 4 * sizeof(double));
+      int da = m->jnt_dofadr[j0];
+      double R[9]; quat2mat(R, quat);
+      for (int k = 0; k < 3; k++) { /* translations: world axes */
+        double* S = d->S[da + k]; S[0] = S[1] = S[2] = 0; S[3] = S[4] = S[5] = 0; S[3 + k] = 1;
+      }
+      for (int k = 0; k < 3; k++) { /* rotations: body-frame axes (qvel[3:6] is angular velocity in the local frame) */
+        double* S = d->S[da + 3 + k]; double ax[3] = {R[k], R[3 + k], R[6 + k]};
+        copy3(S, ax); cross3(S + 3, pos, ax);
+      }
+    } else {
+      rot(pos, d->xmat[p], m->body_pos[b]); addscl3(pos, d->xpos[p], 1.0);
+      quat_mul(quat, d->xquat[p], m->body_quat[b]);
+      for (int jj = 0; jj < nj; jj++) {
+        int j = j0 + jj, da = m->jnt_dofadr[j];
+        double R[9], axis[3], anchor[3];
+        quat2mat(R, quat);
+        rot(axis, R, m->jnt_axis[j]);
+        rot(anchor, R, m->jnt_pos[j]); addscl3(anchor, pos, 1.0);
+        double q = d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
+        double* S = d->S[da];
+        if (m->jnt_type[j] == JO_JNT_SLIDE) {
+          addscl3(pos, axis, q);
+          S[0] = S[1] = S[2] = 0; copy3(S + 3, axis);
+        } else { /* hinge: rotate about the anchor */
+          double ql[4], qn[4], v[3];
+          axisangle2quat(ql, m->jnt_axis[j], q);
+          quat_mul(qn, quat, ql); memcpy(quat, qn, sizeof(qn)); quat_normalize(quat);
+          quat2mat(R, quat);
+          rot(v, R, m->jnt_pos[j]);
+          for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
+          copy3(S, axis); cross3(S + 3, anchor, axis);
+        }
+      }
+    }
+    quat_normalize(quat);
+    copy3(d->xpos[b], pos); memcpy(d->xquat[b], quat, sizeof(quat)); quat2mat(d->xmat[b], quat);
+    double iq[4]; quat_mul(iq, quat, m->body_iquat[b]); quat2mat(d->ximat[b], iq);
+    rot(d->xipos[b], d->xmat[b], m->body_ipos[b]); addscl3(d->xipos[b], pos, 1.0);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_body[g]; double gq[4];
+    rot(d->geom_xpos[g], d->xmat[b], m->geom_pos[g]); addscl3(d->geom_xpos[g], d->xpos[b], 1.0);
+    quat_mul(gq, d->xquat[b], m->geom_quat[g]); quat2mat(d->geom_xmat[g], gq);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_body[s];
+    rot(d->site_xpos[s], d->xmat[b], m->site_pos[s]); addscl3(d->site_xpos[s], d->xpos[b], 1.0);
+  }
+}
+
+/* ------------------------------------------------------------------ spatial inertia about the world origin */
+/* 6x6 symmetric, (angular, linear) ordering:  [[Ic + m(c.c 1 - c c'), m [c]x], [m [c]x', m 1]] */
+static void body_spatial_inertia(const jo_model* m, const jo_data* d, int b, double I[6][6]) {
+  memset(I, 0, 36 * sizeof(double));
+  double mass = m->body_mass[b];
+  const double* R = d->ximat[b]; const double* c = d->xipos[b]; const double* di = m->body_inertia[b];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double v = 0;
+      for (int k = 0; k < 3; k++) v += R[i * 3 + k] * di[k] * R[j * 3 + k];
+      I[i][j] = v + mass * ((i == j ? dot3(c, c) : 0.0) - c[i] * c[j]);
+    }
+  double cx[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { I[i][3 + j] = mass * cx[i][j]; I[3 + i][j] = mass * cx[j][i]; }
+  for (int i = 0; i < 3; i++) I[3 + i][3 + i] = mass;
+}
+static void mat6_vec(double* r, double I[6][6], const double* v) {
+  for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += I[i][j] * v[j]; r[i] = s; }
+}
+
+/* ------------------------------------------------------------------ CRB mass matrix (mj_crb) + Cholesky (mj_factorM) */
+static int cholesky(int n, double A[JO_MAXDOF][JO_MAXDOF], double L[JO_MAXDOF][JO_MAXDOF]) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+      if (i == j) { if (s <= 0) return -1; L[i][i] = sqrt(s); }
+      else L[i][j] = s / L[j][j];
+    }
+  return 0;
+}
+static void chol_solve(int n, double L[JO_MAXDOF][JO_MAXDOF], double* x /* in: rhs, out: solution */) {
+  for (int i = 0; i < n; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i][k] * x[k]; x[i] = s / L[i][i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+}
+
+static void crb(const jo_model* m, jo_data* d) {
+  static __thread double Ic[JO_MAXBODY][6][6];
+  int nv = m->nv;
+  for (int b = 0; b < m->nbody; b++) body_spatial_inertia(m, d, b, Ic[b]);
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parent[b];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Ic[p][i][j] += Ic[b][i][j];
+  }
+  for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) d->M[i][j] = 0;
+  for (int i = 0; i < nv; i++) {
+    double f[6]; mat6_vec(f, Ic[m->dof_body[i]], d->S[i]);
+    for (int j = i; j >= 0; j = m->dof_parent[j]) {
+      double v = 0; for (int k = 0; k < 6; k++) v += f[k] * d->S[j][k];
+      d->M[i][j] = d->M[j][i] = v;
+    }
+    d->M[i][i] += m->dof_armature[i];
+  }
+  cholesky(nv, d->M, d->L);
+}
+
+/* ------------------------------------------------------------------ RNE bias forces (mj_rne, flg_acc=0) incl. gravity */
+static void crossm(double* r, const double* v, const double* s) { /* motion cross product v x s */
+  double a[3], b[3], c[3];
+  cross3(a, v, s); cross3(b, v, s + 3); cross3(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+static void crossf(double* r, const double* v, const double* f) { /* force cross product v x* f */
+  double a[3], b[3], c[3];
+  cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+static void rne_bias(const jo_model* m, jo_data* d) {
+  static __thread double vel[JO_MAXBODY][6], acc[JO_MAXBODY][6], frc[JO_MAXBODY][6];
+  memset(vel[0], 0, sizeof(vel[0])); memset(acc[0], 0, sizeof(acc[0]));
+  acc[0][3] = -m->grav[0]; acc[0][4] = -m->grav[1]; acc[0][5] = -m->grav[2]; /* gravity as base acceleration */
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parent[b];
+    memcpy(vel[b], vel[p], sizeof(vel[b])); memcpy(acc[b], acc[p], sizeof(acc[b]));
+    for (int jj = 0; jj < m->body_jntnum[b]; jj++) {
+      int j = m->body_jntadr[b] + jj, da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == JO_JNT_FREE) {
+        /* translational axes are world-fixed (zero derivative); rotational axes use the velocity before
+         * the rotation is added (sum over the three is identical to using the full velocity) */
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) vel[b][c] += d->S[da + k][c] * d->qvel[da + k];
+        double Sd[3][6];
+        for (int k = 0; k < 3; k++) crossm(Sd[k], vel[b], d->S[da + 3 + k]);
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) { acc[b][c] += Sd[k][c] * d->qvel[da + 3 + k]; vel[b][c] += d->S[da + 3 + k][c] * d->qvel[da + 3 + k]; }
+      } else {
+        double Sd[6]; crossm(Sd, vel[b], d->S[da]);
+        for (int c = 0; c < 6; c++) { acc[b][c] += Sd[c] * d->qvel[da]; vel[b][c] += d->S[da][c] * d->qvel[da]; }
+      }
+    }
+    double I[6][6], Ia[6], Iv[6], vIv[6];
+    body_spatial_inertia(m, d, b, I);
+    mat6_vec(Ia, I, acc[b]); mat6_vec(Iv, I, vel[b]); crossf(vIv, vel[b], Iv);
+    for (int c = 0; c < 6; c++) frc[b][c] = Ia[c] + vIv[c];
+  }
+  memset(frc[0], 0, sizeof(frc[0]));
+  for (int b = m->nbody - 1; b > 0; b--) {
+    for (int jj = 0; jj < m->body_jntnum[b]; jj++) {
+      int j = m->body_jntadr[b] + jj, da = m->jnt_dofadr[j], nd = m->jnt_type[j] == JO_JNT_FREE ? 6 : 1;
+      for (int k = 0; k < nd; k++) { double s = 0; for (int c = 0; c < 6; c++) s += d->S[da + k][c] * frc[b][c]; d->qfrc_bias[da + k] = s; }
+    }
+    int p = m->body_parent[b];
+    for (int c = 0; c < 6; c++) frc[p][c] += frc[b][c];
+  }
+}
+
+/* ------------------------------------------------------------------ collision */
+typedef struct { double dist, pos[3], n[3]; } rawcon;
+
+/* frame = [normal; t1; t2], tangents as mju_makeFrame builds them */
+static void make_frame(double* frame) {
+  double* x = frame; double* y = frame + 3; double* z = frame + 6;
+  double nn = norm3(x); x[0] /= nn; x[1] /= nn; x[2] /= nn;
+  if (x[1] < -0.5 || x[1] > 0.5) { y[0] = 0; y[1] = 0; y[2] = 1; } else { y[0] = 0; y[1] = 1; y[2] = 0; }
+  double dp = dot3(x, y); addscl3(y, x, -dp);
+  nn = norm3(y); y[0] /= nn; y[1] /= nn; y[2] /= nn;
+  cross3(z, x, y);
+}
+
+static inline void col(double* a, const double* R, int k) { a[0] = R[k]; a[1] = R[3 + k]; a[2] = R[6 + k]; }
+
+/* Box-box: separating-axis test over the 15 candidate axes; face contact = incident face clipped against
+ * the reference face (up to 8 points), edge contact = closest points of the two edges (1 point).
+ * Contact position is midway between the surfaces, normal points from box 1 to box 2 (MuJoCo contact convention). */
+static int collide_box_box(const double* p1, const double* R1, const double* h1, const double* p2, const double* R2, const double* h2, double margin, rawcon* out) {
+  double A[3][3], B[3][3], dv[3], C[3][3], AC[3][3], dA[3], dB[3];
+  for (int k = 0; k < 3; k++) { col(A[k], R1, k); col(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
+  for (int i = 0; i < 3; i++) { dA[i] = dot3(dv, A[i]); dB[i] = dot3(dv, B[i]); for (int j = 0; j < 3; j++) { C[i][j] = dot3(A[i], B[j]); AC[i][j] = fabs(C[i][j]); } }
+  double best = -1e30; int btype = -1, bi = 0, bj = 0;
+  for (int i = 0; i < 3; i++) {
+    double s = fabs(dA[i]) - (h1[i] + h2[0] * AC[i][0] + h2[1] * AC[i][1] + h2[2] * AC[i][2]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; btype = 0; bi = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double s = fabs(dB[j]) - (h2[j] + h1[0] * AC[0][j] + h1[1] * AC[1][j] + h1[2] * AC[2][j]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; btype = 1; bj = j; }
+  }
+  double ebest = -1e30, eL[3] = {0, 0, 0}; int ei = -1, ej = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double L[3]; cross3(L, A[i], B[j]);
+      double l = norm3(L);
+      if (l < 1e-6) continue;
+      L[0] /= l; L[1] /= l; L[2] /= l;
+      double ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += h1[k] * fabs(dot3(A[k], L)); rb += h2[k] * fabs(dot3(B[k], L)); }
+      double s = fabs(dot3(dv, L)) - (ra + rb);
+      if (s > margin) return 0;
+      if (s > ebest) { ebest = s; ei = i; ej = j; copy3(eL, L); }
+    }
+  /* an edge axis wins only if it is clearly less penetrating than the best face axis */
+  int use_edge = ei >= 0 && (best < 0 ? ebest > best / 1.05 + 1e-12 : ebest > best * 1.05 + 1e-12);
+  if (use_edge) {
+    double n[3]; copy3(n, eL);
+    if (dot3(n, dv) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    double pa[3], pb[3]; copy3(pa, p1); copy3(pb, p2);
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) addscl3(pa, A[k], (dot3(n, A[k]) > 0 ? 1.0 : -1.0) * h1[k]);
+      if (k != ej) addscl3(pb, B[k], (dot3(n, B[k]) > 0 ? -1.0 : 1.0) * h2[k]);
+    }
+    /* closest points of lines pa + s A[ei], pb + t B[ej] */
+    double w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    double b = C[ei][ej], dd = dot3(A[ei], w), e = dot3(B[ej], w), den = 1 - b * b;
+    double s = den > 1e-12 ? (b * e - dd) / den : 0.0, t = den > 1e-12 ? (e - b * dd) / den : 0.0;
+    if (s > h1[ei]) s = h1[ei]; if (s < -h1[ei]) s = -h1[ei];
+    if (t > h2[ej]) t = h2[ej]; if (t < -h2[ej]) t = -h2[ej];
+    double ca[3], cb[3]; copy3(ca, pa); addscl3(ca, A[ei], s); copy3(cb, pb); addscl3(cb, B[ej], t);
+    out[0].dist = ebest; copy3(out[0].n, n);
+    for (int k = 0; k < 3; k++) out[0].pos[k] = 0.5 * (ca[k] + cb[k]);
+    return 1;
+  }
+  /* face contact */
+  const double *pr, *pi, *hr, *hi; double (*Ar)[3], (*Ai)[3]; int ri; double n[3];
+  if (btype == 0) { pr = p1; pi = p2; hr = h1; hi = h2; Ar = A; Ai = B; ri = bi; double sg = dA[bi] >= 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) n[k] = sg * A[bi][k]; }
+  else { pr = p2; pi = p1; hr = h2; hi = h1; Ar = B; Ai = A; ri = bj; double sg = dB[bj] >= 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) n[k] = sg * B[bj][k]; }
+  /* n points from the reference box towards the incident box */
+  int mi = 0; double mb = -1;
+  for (int k = 0; k < 3; k++) { double v = fabs(dot3(n, Ai[k])); if (v > mb) { mb = v; mi = k; } }
+  double sgi = dot3(n, Ai[mi]) > 0 ? -1.0 : 1.0;
+  int u = (mi + 1) % 3, v = (mi + 2) % 3;
+  double poly[16][3], tmp[16][3]; int np = 4;
+  static const double su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+  for (int q = 0; q < 4; q++)
+    for (int k = 0; k < 3; k++) poly[q][k] = pi[k] + sgi * hi[mi] * Ai[mi][k] + su[q] * hi[u] * Ai[u][k] + sv[q] * hi[v] * Ai[v][k];
+  int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
+  for (int pl = 0; pl < 4 && np > 0; pl++) { /* Sutherland-Hodgman against the four side planes of the reference face */
+    const double* ax = Ar[pl < 2 ? ra : rb]; double sg = (pl & 1) ? -1.0 : 1.0, lim = hr[pl < 2 ? ra : rb];
+    int nn = 0;
+    for (int q = 0; q < np; q++) {
+      const double* P = poly[q]; const double* Q = poly[(q + 1) % np];
+      double dp_[3] = {P[0] - pr[0], P[1] - pr[1], P[2] - pr[2]}, dq_[3] = {Q[0] - pr[0], Q[1] - pr[1], Q[2] - pr[2]};
+      double fp = sg * dot3(dp_, ax) - lim, fq = sg * dot3(dq_, ax) - lim;
+      if (fp <= 0) { copy3(tmp[nn], P); nn++; }
+      if ((fp < 0 && fq > 0) || (fp > 0 && fq < 0)) { double t = fp / (fp - fq); for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + t * (Q[k] - P[k]); nn++; }
+    }
+    np = nn; memcpy(poly, tmp, sizeof(double) * 3 * np);
+  }
+  int nc = 0;
+  for (int q = 0; q < np && nc < 8; q++) {
+    double dx[3] = {poly[q][0] - pr[0], poly[q][1] - pr[1], poly[q][2] - pr[2]};
+    double depth = hr[ri] - dot3(dx, n);
+    if (-depth >= margin) continue; /* keep dist < margin */
+    out[nc].dist = -depth;
+    for (int k = 0; k < 3; k++) { out[nc].pos[k] = poly[q][k] + 0.5 * depth * n[k]; out[nc].n[k] = btype == 0 ? n[k] : -n[k]; }
+    nc++;
+  }
+  return nc;
+}
+
+/* sphere (centre c, radius r) against box; normal returned points from the box to the sphere */
+static int collide_box_sphere(const double* pb, const double* Rb, const double* hb, const double* c, double r, double margin, rawcon* out) {
+  double dl[3] = {c[0] - pb[0], c[1] - pb[1], c[2] - pb[2]}, cl[3], q[3]; int outside = 0;
+  rotT(cl, Rb, dl);
+  for (int k = 0; k < 3; k++) { q[k] = cl[k]; if (q[k] > hb[k]) { q[k] = hb[k]; outside = 1; } else if (q[k] < -hb[k]) { q[k] = -hb[k]; outside = 1; } }
+  double nl[3], dist;
+  if (outside) {
+    double df[3] = {cl[0] - q[0], cl[1] - q[1], cl[2] - q[2]}; double l = norm3(df);
+    if (l - r >= margin) return 0;
+    nl[0] = df[0] / l; nl[1] = df[1] / l; nl[2] = df[2] / l; dist = l - r;
+  } else { /* centre inside the box: exit through the nearest face */
+    int kb = 0; double mn = 1e30;
+    for (int k = 0; k < 3; k++) { double s = hb[k] - fabs(cl[k]); if (s < mn) { mn = s; kb = k; } }
+    nl[0] = nl[1] = nl[2] = 0; nl[kb] = cl[kb] >= 0 ? 1.0 : -1.0;
+    q[kb] = nl[kb] * hb[kb]; dist = -mn - r;
+  }
+  double ql[3] = {q[0] + 0.5 * dist * nl[0], q[1] + 0.5 * dist * nl[1], q[2] + 0.5 * dist * nl[2]};
+  rot(out->pos, Rb, ql); addscl3(out->pos, pb, 1.0); rot(out->n, Rb, nl); out->dist = dist;
+  return 1;
+}
+
+/* two cylinders with parallel axes whose heights overlap: radial contact (the only cylinder case in the four models,
+ * cylinder_push.xml:23,30; MuJoCo itself routes cylinder-cylinder through its general convex collider) */
+static int collide_cyl_cyl_parallel(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin, rawcon* out) {
+  double a1[3], a2[3]; col(a1, R1, 2); col(a2, R2, 2);
+  if (fabs(dot3(a1, a2)) < 1 - 1e-9) return 0;
+  double dv[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double along = dot3(dv, a1);
+  if (fabs(along) >= s1[1] + s2[1]) return 0;
+  double rad[3] = {dv[0] - along * a1[0], dv[1] - along * a1[1], dv[2] - along * a1[2]};
+  double l = norm3(rad);
+  if (l < 1e-12) return 0;
+  double dist = l - (s1[0] + s2[0]);
+  if (dist >= margin) return 0;
+  for (int k = 0; k < 3; k++) { out->n[k] = rad[k] / l; }
+  for (int k = 0; k < 3; k++) out->pos[k] = p1[k] + out->n[k] * (s1[0] + 0.5 * dist) + 0.5 * along * a1[k];
+  out->dist = dist;
+  return 1;
+}
+
+static void collision(const jo_model* m, jo_data* d) {
+  d->ncon = 0;
+  if (!m->contact_enabled) return;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_g1[p], g2 = m->pair_g2[p];
+    double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+    double dc[3] = {d->geom_xpos[g2][0] - d->geom_xpos[g1][0], d->geom_xpos[g2][1] - d->geom_xpos[g1][1], d->geom_xpos[g2][2] - d->geom_xpos[g1][2]};
+    if (norm3(dc) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue; /* bounding-sphere filter */
+    rawcon rc[8]; int n = 0, flip = 0;
+    int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_BOX) n = collide_box_box(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
+    else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_SPHERE) n = collide_box_sphere(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2][0], margin, rc);
+    else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], d->geom_xpos[g1], m->geom_size[g1][0], margin, rc); flip = 1; }
+    else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) n = collide_cyl_cyl_parallel(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
+    for (int i = 0; i < n; i++) {
+      if (d->ncon >= JO_MAXCON) { d->con_overflow++; break; }
+      jo_contact* c = &d->con[d->ncon++];
+      c->dist = rc[i].dist; copy3(c->pos, rc[i].pos);
+      for (int k = 0; k < 3; k++) c->frame[k] = flip ? -rc[i].n[k] : rc[i].n[k];
+      make_frame(c->frame);
+      c->g1 = g1; c->g2 = g2;
+      /* contact parameter mixing (mj_contactParam, equal priority / solmix): condim max, friction max,
+       * solref/solimp average, margin/gap max */
+      c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+      double f[3]; for (int k = 0; k < 3; k++) f[k] = fmax(m->geom_friction[g1][k], m->geom_friction[g2][k]);
+      c->friction[0] = c->friction[1] = f[0]; c->friction[2] = f[1]; c->friction[3] = c->friction[4] = f[2];
+      for (int k = 0; k < 5; k++) if (c->friction[k] < MINMU) c->friction[k] = MINMU;
+      if (m->geom_solref[g1][0] > 0 && m->geom_solref[g2][0] > 0) for (int k = 0; k < 2; k++) c->solref[k] = 0.5 * (m->geom_solref[g1][k] + m->geom_solref[g2][k]);
+      else for (int k = 0; k < 2; k++) c->solref[k] = fmin(m->geom_solref[g1][k], m->geom_solref[g2][k]);
+      for (int k = 0; k < 5; k++) c->solimp[k] = 0.5 * (m->geom_solimp[g1][k] + m->geom_solimp[g2][k]);
+      c->includemargin = margin - fmax(m->geom_gap[g1], m->geom_gap[g2]);
+      c->efc_adr = -1; c->mu = c->friction[0];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ constraint rows (mj_makeConstraint, mj_makeImpedance) */
+static void point_jac(const jo_model* m, const jo_data* d, int body, const double* p, double Jp[3][JO_MAXDOF]) {
+  for (int k = 0; k < 3; k++) for (int i = 0; i < m->nv; i++) Jp[k][i] = 0;
+  if (body <= 0) return;
+  /* last dof of the body, then up the chain */
+  int b = body, i = -1;
+  while (b > 0 && m->body_jntnum[b] == 0) b = m->body_parent[b];
+  if (b <= 0) return;
+  int jl = m->body_jntadr[b] + m->body_jntnum[b] - 1;
+  i = m->jnt_dofadr[jl] + (m->jnt_type[jl] == JO_JNT_FREE ? 5 : 0);
+  for (; i >= 0; i = m->dof_parent[i]) {
+    double v[3]; cross3(v, d->S[i], p); /* omega x p + v_origin */
+    for (int k = 0; k < 3; k++) Jp[k][i] = v[k] + d->S[i][3 + k];
+  }
+}
+
+static void impedance(const double* solimp_in, double pos, double margin, double* imp) {
+  double si[5]; memcpy(si, solimp_in, sizeof(si));
+  si[0] = fmin(MAXIMP, fmax(MINIMP, si[0])); si[1] = fmin(MAXIMP, fmax(MINIMP, si[1]));
+  si[2] = fmax(0, si[2]); si[3] = fmin(MAXIMP, fmax(MINIMP, si[3])); si[4] = fmax(1, si[4]);
+  if (si[0] == si[1] || si[2] <= MINVAL) { *imp = 0.5 * (si[0] + si[1]); return; }
+  double x = fabs((pos - margin) / si[2]);
+  if (x >= 1) { *imp = si[1]; return; }
+  if (x <= 0) { *imp = si[0]; return; }
+  double y;
+  if (si[4] == 1) y = x;
+  else if (x <= si[3]) y = pow(x, si[4]) / pow(si[3], si[4] - 1);
+  else y = 1 - pow(1 - x, si[4]) / pow(1 - si[3], si[4] - 1);
+  *imp = si[0] + y * (si[1] - si[0]);
+}
+
+static int add_row(jo_data* d, int type, int id, double pos, double margin, double frictionloss) {
+  if (d->nefc >= JO_MAXEFC) return -1;
+  int r = d->nefc++;
+  d->efc_type[r] = type; d->efc_id[r] = id; d->efc_pos[r] = pos; d->efc_margin[r] = margin; d->efc_frictionloss[r] = frictionloss;
+  return r;
+}
+
+static void make_constraint(const jo_model* m, jo_data* d) {
+  int nv = m->nv;
+  d->nefc = 0;
+  /* 1. equality (joint coupling): (q1 - q1_0) - poly(q2 - q2_0) = 0 */
+  for (int e = 0; e < m->neq; e++) {
+    int j1 = m->eq_j1[e], j2 = m->eq_j2[e];
+    double x = d->qpos[m->jnt_qposadr[j2]] - m->qpos0[m->jnt_qposadr[j2]], y = d->qpos[m->jnt_qposadr[j1]] - m->qpos0[m->jnt_qposadr[j1]];
+    const double* a = m->eq_poly[e];
+    double poly = a[0] + x * (a[1] + x * (a[2] + x * (a[3] + x * a[4]))), dpoly = a[1] + x * (2 * a[2] + x * (3 * a[3] + x * 4 * a[4]));
+    int r = add_row(d, JO_EFC_EQUALITY, e, y - poly, 0, 0);
+    if (r < 0) return;
+    memset(d->efc_J[r], 0, sizeof(double) * nv);
+    d->efc_J[r][m->jnt_dofadr[j1]] = 1; d->efc_J[r][m->jnt_dofadr[j2]] = -dpoly;
+    d->efc_diagApprox[r] = m->dof_invweight0[m->jnt_dofadr[j1]] + m->dof_invweight0[m->jnt_dofadr[j2]];
+  }
+  /* 2. dof friction loss */
+  for (int i = 0; i < nv; i++)
+    if (m->dof_frictionloss[i] > 0) {
+      int r = add_row(d, JO_EFC_FRICTION, i, 0, 0, m->dof_frictionloss[i]);
+      if (r < 0) return;
+      memset(d->efc_J[r], 0, sizeof(double) * nv); d->efc_J[r][i] = 1;
+      d->efc_diagApprox[r] = m->dof_invweight0[i];
+    }
+  /* 3. joint limits (hinge / slide) */
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_limited[j] && m->jnt_type[j] != JO_JNT_FREE) {
+      double q = d->qpos[m->jnt_qposadr[j]];
+      for (int side = -1; side <= 1; side += 2) {
+        double dist = side * (m->jnt_range[j][(side + 1) / 2] - q);
+        if (dist < m->jnt_margin[j]) {
+          int r = add_row(d, JO_EFC_LIMIT, j, dist, m->jnt_margin[j], 0);
+          if (r < 0) return;
+          memset(d->efc_J[r], 0, sizeof(double) * nv); d->efc_J[r][m->jnt_dofadr[j]] = -side;
+          d->efc_diagApprox[r] = m->dof_invweight0[m->jnt_dofadr[j]];
+        }
+      }
+    }
+  /* 4. contacts */
+  static __thread double J1[3][JO_MAXDOF], J2[3][JO_MAXDOF];
+  for (int c = 0; c < d->ncon; c++) {
+    jo_contact* con = &d->con[c];
+    int b1 = m->geom_body[con->g1], b2 = m->geom_body[con->g2];
+    point_jac(m, d, b1, con->pos, J1); point_jac(m, d, b2, con->pos, J2);
+    double Jf[3][JO_MAXDOF]; /* relative-velocity Jacobian expressed in the contact frame */
+    for (int r = 0; r < 3; r++) for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < 3; k++) s += con->frame[3 * r + k] * (J2[k][i] - J1[k][i]); Jf[r][i] = s; }
+    double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+    if (con->dim == 1) {
+      int r = add_row(d, JO_EFC_CONTACT_FRICTIONLESS, c, con->dist, con->includemargin, 0);
+      if (r < 0) return;
+      con->efc_adr = r; memcpy(d->efc_J[r], Jf[0], sizeof(double) * nv); d->efc_diagApprox[r] = tran;
+    } else if (m->cone == JO_CONE_PYRAMIDAL) {
+      for (int k = 0; k < con->dim - 1; k++)
+        for (int sg = 1; sg >= -1; sg -= 2) {
+          int r = add_row(d, JO_EFC_CONTACT_PYRAMIDAL, c, con->dist, con->includemargin, 0);
+          if (r < 0) return;
+          if (k == 0 && sg == 1) con->efc_adr = r;
+          double fr = con->friction[k];
+          for (int i = 0; i < nv; i++) d->efc_J[r][i] = Jf[0][i] + sg * fr * Jf[1 + k][i];
+          d->efc_diagApprox[r] = tran + fr * fr * tran;
+        }
+    } else {
+      for (int k = 0; k < con->dim; k++) {
+        int r = add_row(d, JO_EFC_CONTACT_ELLIPTIC, c, k == 0 ? con->dist : 0.0, k == 0 ? con->includemargin : 0.0, 0);
+        if (r < 0) return;
+        if (k == 0) con->efc_adr = r;
+        memcpy(d->efc_J[r], Jf[k], sizeof(double) * nv);
+        d->efc_diagApprox[r] = tran; /* condim 3: both friction rows are translational */
+      }
+    }
+  }
+  /* impedance, regulariser, reference acceleration */
+  for (int r = 0; r < d->nefc; r++) {
+    const double *solref, *solimp; int tp = d->efc_type[r], id = d->efc_id[r];
+    switch (tp) {
+      case JO_EFC_EQUALITY: solref = m->eq_solref[id]; solimp = m->eq_solimp[id]; break;
+      case JO_EFC_FRICTION: solref = m->dof_solref[id]; solimp = m->dof_solimp[id]; break;
+      case JO_EFC_LIMIT: solref = m->jnt_solref[id]; solimp = m->jnt_solimp[id]; break;
+      default: solref = d->con[id].solref; solimp = d->con[id].solimp; break;
+    }
+    double imp; impedance(solimp, d->efc_pos[r], d->efc_margin[r], &imp);
+    double dmax = fmin(MAXIMP, fmax(MINIMP, solimp[1]));
+    double K, B;
+    if (solref[0] > 0) {
+      double tc = fmax(solref[0], 2 * m->dt) /* refsafe */, dr = solref[1];
+      K = 1 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr); B = 2 / fmax(MINVAL, dmax * tc);
+    } else { K = -solref[0] / fmax(MINVAL, dmax * dmax); B = -solref[1] / fmax(MINVAL, dmax); }
+    int is_friction = tp == JO_EFC_FRICTION || (tp == JO_EFC_CONTACT_ELLIPTIC && r != d->con[id].efc_adr);
+    if (is_friction) K = 0;
+    d->efc_KBIP[r][0] = K; d->efc_KBIP[r][1] = B; d->efc_KBIP[r][2] = imp; d->efc_KBIP[r][3] = 0;
+    d->efc_R[r] = fmax(MINVAL, (1 - imp) * d->efc_diagApprox[r] / imp);
+  }
+  for (int c = 0; c < d->ncon; c++) { /* frictional contacts: friction-row regularisers */
+    jo_contact* con = &d->con[c]; int id = con->efc_adr;
+    if (id < 0 || con->dim < 2) continue;
+    if (m->cone == JO_CONE_PYRAMIDAL) {
+      con->mu = con->friction[0];
+      double Rpy = 2 * con->mu * con->mu * d->efc_R[id];
+      for (int r = id; r < id + 2 * (con->dim - 1); r++) d->efc_R[r] = fmax(MINVAL, Rpy);
+    } else {
+      d->efc_R[id + 1] = d->efc_R[id] / fmax(MINVAL, m->impratio);
+      con->mu = con->friction[0] * sqrt(d->efc_R[id + 1] / d->efc_R[id]);
+      for (int k = 1; k < con->dim - 1; k++) d->efc_R[id + 1 + k] = d->efc_R[id + 1] * con->friction[0] * con->friction[0] / (con->friction[k] * con->friction[k]);
+    }
+  }
+  for (int r = 0; r < d->nefc; r++) {
+    d->efc_D[r] = 1 / d->efc_R[r];
+    double v = 0; for (int i = 0; i < nv; i++) v += d->efc_J[r][i] * d->qvel[i];
+    d->efc_vel[r] = v;
+    d->efc_aref[r] = -d->efc_KBIP[r][1] * v - d->efc_KBIP[r][0] * d->efc_KBIP[r][2] * (d->efc_pos[r] - d->efc_margin[r]);
+  }
+}
+
+/* ------------------------------------------------------------------ constraint cost s(jar): value, force = -ds/djar, Hessian weights */
+/* returns cost; force[] filled; if Hd != NULL: Hd[r] = diagonal quadratic weight of row r (0 if inactive),
+ * and for elliptic contacts in the cone zone Hc[c][3][3] holds the dense 3x3 block (flag in cone_zone[c]). */
+static double constraint_cost(const jo_model* m, const jo_data* d, const double* jar, double* force, double* Hd, double (*Hc)[9], int* cone_zone) {
+  (void)m;
+  double cost = 0;
+  for (int r = 0; r < d->nefc; r++) {
+    int tp = d->efc_type[r]; double D = d->efc_D[r], R = d->efc_R[r], x = jar[r];
+    if (Hd && !(tp == JO_EFC_CONTACT_ELLIPTIC && r != d->con[d->efc_id[r]].efc_adr)) Hd[r] = 0; /* elliptic friction rows are written with their normal row */
+    switch (tp) {
+      case JO_EFC_EQUALITY: force[r] = -D * x; cost += 0.5 * D * x * x; if (Hd) Hd[r] = D; break;
+      case JO_EFC_FRICTION: {
+        double fl = d->efc_frictionloss[r];
+        if (x <= -R * fl) { force[r] = fl; cost += -0.5 * R * fl * fl - fl * x; }
+        else if (x >= R * fl) { force[r] = -fl; cost += -0.5 * R * fl * fl + fl * x; }
+        else { force[r] = -D * x; cost += 0.5 * D * x * x; if (Hd) Hd[r] = D; }
+      } break;
+      case JO_EFC_LIMIT: case JO_EFC_CONTACT_FRICTIONLESS: case JO_EFC_CONTACT_PYRAMIDAL:
+        if (x < 0) { force[r] = -D * x; cost += 0.5 * D * x * x; if (Hd) Hd[r] = D; } else force[r] = 0;
+        break;
+      case JO_EFC_CONTACT_ELLIPTIC: {
+        int c = d->efc_id[r]; const jo_contact* con = &d->con[c];
+        if (r != con->efc_adr) break; /* handled with the normal row */
+        int dim = con->dim; double mu = con->mu, U[6], T2 = 0;
+        U[0] = jar[r] * mu;
+        for (int j = 1; j < dim; j++) { U[j] = jar[r + j] * con->friction[j - 1]; T2 += U[j] * U[j]; }
+        double N = U[0], T = sqrt(T2);
+        if (cone_zone) cone_zone[c] = 0;
+        if (Hd) for (int j = 0; j < dim; j++) Hd[r + j] = 0;
+        if (N >= mu * T || (T <= 0 && N >= 0)) { for (int j = 0; j < dim; j++) force[r + j] = 0; } /* top zone */
+        else if (mu * N + T <= 0 || (T <= 0 && N < 0)) { /* bottom zone: quadratic in every row */
+          for (int j = 0; j < dim; j++) { force[r + j] = -d->efc_D[r + j] * jar[r + j]; cost += 0.5 * d->efc_D[r + j] * jar[r + j] * jar[r + j]; if (Hd) Hd[r + j] = d->efc_D[r + j]; }
+        } else { /* middle zone: distance to the cone */
+          double Dm = d->efc_D[r] / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+          cost += 0.5 * Dm * NT * NT;
+          force[r] = -Dm * NT * mu;
+          for (int j = 1; j < dim; j++) force[r + j] = -force[r] / T * U[j] * con->friction[j - 1];
+          if (Hc && dim == 3) {
+            cone_zone[c] = 1;
+            double sc[3] = {mu, con->friction[0], con->friction[1]}, HU[3][3];
+            HU[0][0] = Dm;
+            for (int j = 1; j < 3; j++) HU[0][j] = HU[j][0] = -Dm * mu * U[j] / T;
+            for (int j = 1; j < 3; j++) for (int k = 1; k < 3; k++)
+              HU[j][k] = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
+            for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) Hc[c][3 * j + k] = sc[j] * HU[j][k] * sc[k];
+          }
+        }
+      } break;
+    }
+  }
+  return cost;
+}
+
+/* total cost + gradient at acceleration a */
+static double total_cost(const jo_model* m, jo_data* d, const double* a, double* grad, double* jar, double* Hd, double (*Hc)[9], int* cone_zone) {
+  int nv = m->nv;
+  for (int r = 0; r < d->nefc; r++) { double s = -d->efc_aref[r]; for (int i = 0; i < nv; i++) s += d->efc_J[r][i] * a[i]; jar[r] = s; }
+  double cost = constraint_cost(m, d, jar, d->efc_force, Hd, Hc, cone_zone);
+  double Ma[JO_MAXDOF];
+  for (int i = 0; i < nv; i++) { double s = 0; for (int j = 0; j < nv; j++) s += d->M[i][j] * (a[j] - d->qacc_smooth[j]); Ma[i] = s; }
+  for (int i = 0; i < nv; i++) cost += 0.5 * Ma[i] * (a[i] - d->qacc_smooth[i]);
+  if (grad) for (int i = 0; i < nv; i++) { double s = Ma[i]; for (int r = 0; r < d->nefc; r++) s -= d->efc_J[r][i] * d->efc_force[r]; grad[i] = s; }
+  return cost;
+}
+
+/* ------------------------------------------------------------------ primal Newton solver with exact line search (mj_solNewton) */
+static void solve_constraints(const jo_model* m, jo_data* d) {
+  int nv = m->nv, ne = d->nefc;
+  if (ne == 0) { memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv); memset(d->qfrc_constraint, 0, sizeof(double) * nv); d->solver_iter = 0; return; }
+  static __thread double jar[JO_MAXEFC], Hd[JO_MAXEFC], Hc[JO_MAXCON][9], jp[JO_MAXEFC], jar2[JO_MAXEFC], frc2[JO_MAXEFC], Hd2[JO_MAXEFC], Hc2[JO_MAXCON][9];
+  static __thread int cz[JO_MAXCON], cz2[JO_MAXCON];
+  static __thread double H[JO_MAXDOF][JO_MAXDOF], LH[JO_MAXDOF][JO_MAXDOF];
+  double a[JO_MAXDOF], grad[JO_MAXDOF], p[JO_MAXDOF], Mp[JO_MAXDOF];
+  /* warm start: the better of the previous acceleration and the unconstrained one (mj_fwdConstraint) */
+  double cw = total_cost(m, d, d->qacc_warmstart, NULL, jar, NULL, NULL, NULL);
+  double cs = total_cost(m, d, d->qacc_smooth, NULL, jar, NULL, NULL, NULL);
+  memcpy(a, cw < cs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
+  double scale = 0; for (int i = 0; i < nv; i++) scale += d->M[i][i]; scale = 1.0 / fmax(MINVAL, scale);
+  int it;
+  for (it = 0; it < m->solver_maxiter; it++) {
+    double cost = total_cost(m, d, a, grad, jar, Hd, Hc, cz);
+    double gn = 0; for (int i = 0; i < nv; i++) gn += grad[i] * grad[i]; gn = sqrt(gn);
+    d->solver_cost = cost; d->solver_gradnorm = gn;
+    if (gn * scale < m->solver_tol) break;
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) H[i][j] = d->M[i][j];
+    for (int r = 0; r < ne; r++) if (Hd[r] != 0) for (int i = 0; i < nv; i++) { double ji = d->efc_J[r][i]; if (ji != 0) for (int j = 0; j < nv; j++) H[i][j] += Hd[r] * ji * d->efc_J[r][j]; }
+    for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3 && cz[c]) {
+      int r0 = d->con[c].efc_adr;
+      for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) { double w = Hc[c][3 * u + v]; for (int i = 0; i < nv; i++) { double ji = d->efc_J[r0 + u][i]; if (ji != 0) for (int j = 0; j < nv; j++) H[i][j] += w * ji * d->efc_J[r0 + v][j]; } }
+    }
+    if (cholesky(nv, H, LH) != 0) break;
+    for (int i = 0; i < nv; i++) p[i] = -grad[i];
+    chol_solve(nv, LH, p);
+    /* exact line search: phi(al) = cost(a + al p); safeguarded 1-D Newton on phi' */
+    for (int r = 0; r < ne; r++) { double s = 0; for (int i = 0; i < nv; i++) s += d->efc_J[r][i] * p[i]; jp[r] = s; }
+    for (int i = 0; i < nv; i++) { double s = 0; for (int j = 0; j < nv; j++) s += d->M[i][j] * p[j]; Mp[i] = s; }
+    double pMp = 0, pMd = 0; for (int i = 0; i < nv; i++) { pMp += p[i] * Mp[i]; pMd += Mp[i] * (a[i] - d->qacc_smooth[i]); }
+    double lo = 0, hi = -1, al = 1.0, dlo = 0;
+    { double g0 = 0; for (int i = 0; i < nv; i++) g0 += grad[i] * p[i]; dlo = g0; if (g0 >= 0) break; }
+    for (int ls = 0; ls < 60; ls++) {
+      for (int r = 0; r < ne; r++) jar2[r] = jar[r] + al * jp[r];
+      constraint_cost(m, d, jar2, frc2, Hd2, Hc2, cz2);
+      double d1 = pMd + al * pMp, d2 = pMp;
+      for (int r = 0; r < ne; r++) { d1 -= frc2[r] * jp[r]; d2 += Hd2[r] * jp[r] * jp[r]; }
+      for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3 && cz2[c]) {
+        int r0 = d->con[c].efc_adr; for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) d2 += Hc2[c][3 * u + v] * jp[r0 + u] * jp[r0 + v];
+      }
+      if (fabs(d1) < 1e-14 * (fabs(dlo) + 1e-300) || fabs(d1) < 1e-300) break;
+      if (d1 < 0) lo = al; else hi = al;
+      double nx = al - d1 / d2;
+      if (hi < 0) { if (nx <= lo) nx = 2 * al + 1e-12; }
+      else if (nx <= lo || nx >= hi) nx = 0.5 * (lo + hi);
+      if (fabs(nx - al) <= 1e-15 * fabs(al)) { al = nx; break; }
+      al = nx;
+    }
+    for (int i = 0; i < nv; i++) a[i] += al * p[i];
+  }
+  d->solver_iter = it;
+  total_cost(m, d, a, grad, jar, NULL, NULL, NULL);
+  memcpy(d->qacc, a, sizeof(double) * nv);
+  for (int i = 0; i < nv; i++) { double s = 0; for (int r = 0; r < ne; r++) s += d->efc_J[r][i] * d->efc_force[r]; d->qfrc_constraint[i] = s; }
+}
+
+/* ------------------------------------------------------------------ sensors (position stage) */
+static void sensors(const jo_model* m, jo_data* d) {
+  for (int s = 0; s < m->nsensor; s++) {
+    double* o = d->sensordata + m->sensor_adr[s]; int obj = m->sensor_obj[s];
+    switch (m->sensor_type[s]) {
+      case JO_SENS_FRAMEPOS_SITE: copy3(o, d->site_xpos[obj]); break;
+      case JO_SENS_FRAMEPOS_BODY: copy3(o, d->xpos[obj]); break;
+      case JO_SENS_JOINTPOS: o[0] = d->qpos[m->jnt_qposadr[obj]]; break;
+      case JO_SENS_FRAMEZAXIS_BODY: col(o, d->xmat[obj], 2); break;
+      case JO_SENS_DISTANCE: o[0] = m->sensor_cutoff[s]; break; /* geom distance: filled by the fr3 extension */
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ forward / step */
+void jo_forward(const jo_model* m, jo_data* d) {
+  int nv = m->nv;
+  kinematics(m, d);
+  crb(m, d);
+  collision(m, d);
+  make_constraint(m, d);
+  sensors(m, d);
+  /* velocity stage: passive + bias */
+  for (int i = 0; i < nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
+  rne_bias(m, d);
+  /* actuation (mj_fwdActuation): position servo, ctrl clamp, force clamp, joint-level actuator force clamp */
+  for (int i = 0; i < nv; i++) d->qfrc_actuator[i] = 0;
+  for (int a = 0; a < m->nact; a++) {
+    int j = m->act_jnt[a]; double c = d->ctrl[a];
+    if (m->act_ctrllimited[a]) c = fmin(m->act_ctrlrange[a][1], fmax(m->act_ctrlrange[a][0], c));
+    double f = m->act_kp[a] * (c - d->qpos[m->jnt_qposadr[j]]) - m->act_kv[a] * d->qvel[m->jnt_dofadr[j]];
+    if (m->act_forcelimited[a]) f = fmin(m->act_forcerange[a][1], fmax(m->act_forcerange[a][0], f));
+    d->act_force[a] = f; d->qfrc_actuator[m->jnt_dofadr[j]] += f;
+  }
+  for (int i = 0; i < nv; i++) if (m->dof_frclimited[i]) d->qfrc_actuator[i] = fmin(m->dof_frcrange[i][1], fmax(m->dof_frcrange[i][0], d->qfrc_actuator[i]));
+  for (int i = 0; i < nv; i++) { d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i]; d->qacc_smooth[i] = d->qfrc_smooth[i]; }
+  chol_solve(nv, d->L, d->qacc_smooth);
+  solve_constraints(m, d);
+}
+
+static void integrate(const jo_model* m, jo_data* d) {
+  int nv = m->nv; double h = m->dt;
+  double extra[JO_MAXDOF]; int any = 0;
+  for (int i = 0; i < nv; i++) { extra[i] = m->dof_damping[i]; if (extra[i] > 0) any = 1; }
+  if (m->integrator == JO_INT_IMPLICITFAST) {
+    /* d(qfrc_actuator)/d(qvel) = -kv on the actuated dof, skipped while the actuator force sits on its forcerange */
+    for (int a = 0; a < m->nact; a++) {
+      if (m->act_forcelimited[a] && (d->act_force[a] <= m->act_forcerange[a][0] || d->act_force[a] >= m->act_forcerange[a][1])) continue;
+      if (m->act_kv[a] != 0) { extra[m->jnt_dofadr[m->act_jnt[a]]] += m->act_kv[a]; any = 1; }
+    }
+  }
+  double qacc[JO_MAXDOF];
+  if (any) {
+    static __thread double A[JO_MAXDOF][JO_MAXDOF], LA[JO_MAXDOF][JO_MAXDOF];
+    for (int i = 0; i < nv; i++) { for (int j = 0; j < nv; j++) A[i][j] = d->M[i][j]; A[i][i] += h * extra[i]; qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i]; }
+    cholesky(nv, A, LA); chol_solve(nv, LA, qacc);
+  } else memcpy(qacc, d->qacc, sizeof(double) * nv);
+  for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
+  for (int j = 0; j < m->njnt; j++) { /* mj_integratePos with the updated velocity */
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == JO_JNT_FREE) {
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k];
+      double w[3] = {d->qvel[da + 3], d->qvel[da + 4], d->qvel[da + 5]}, ang = norm3(w) * h;
+      if (ang > 0) {
+        double ax[3] = {w[0] / norm3(w), w[1] / norm3(w), w[2] / norm3(w)}, dq[4], qn[4];
+        axisangle2quat(dq, ax, ang); quat_mul(qn, d->qpos + qa + 3, dq); memcpy(d->qpos + qa + 3, qn, sizeof(qn));
+      }
+      quat_normalize(d->qpos + qa + 3);
+    } else d->qpos[qa] += h * d->qvel[da];
+  }
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+}
+
+void jo_step(const jo_model* m, jo_data* d) { jo_forward(m, d); integrate(m, d); }
+
+void jo_mass_matrix(const jo_model* m, jo_data* d, double* M_out) {
+  kinematics(m, d); crb(m, d);
+  for (int i = 0; i < m->nv; i++) for (int j = 0; j < m->nv; j++) M_out[i * m->nv + j] = d->M[i][j];
+}
+
+double jo_energy(const jo_model* m, jo_data* d, double* kinetic, double* potential) {
+  kinematics(m, d); crb(m, d);
+  double ke = 0, pe = 0;
+  for (int i = 0; i < m->nv; i++) for (int j = 0; j < m->nv; j++) ke += 0.5 * d->qvel[i] * d->M[i][j] * d->qvel[j];
+  for (int b = 1; b < m->nbody; b++) pe -= m->body_mass[b] * dot3(m->grav, d->xipos[b]);
+  if (kinetic) *kinetic = ke; if (potential) *potential = pe;
+  return ke + pe;
+}
+
+int jo_forward_probe(const jo_model* m, const double* qpos, const double* qvel, const double* ctrl, double* qacc, double* qacc_smooth, double* qfrc_bias,
+                     double* qfrc_constraint, double* sensordata, int* info, double* contacts, double* stats) {
+  jo_data* d = jo_data_new();
+  memcpy(d->qpos, qpos, sizeof(double) * m->nq); memcpy(d->qvel, qvel, sizeof(double) * m->nv); if (m->nact) memcpy(d->ctrl, ctrl, sizeof(double) * m->nact);
+  jo_forward(m, d);
+  if (qacc) memcpy(qacc, d->qacc, sizeof(double) * m->nv);
+  if (qacc_smooth) memcpy(qacc_smooth, d->qacc_smooth, sizeof(double) * m->nv);
+  if (qfrc_bias) memcpy(qfrc_bias, d->qfrc_bias, sizeof(double) * m->nv);
+  if (qfrc_constraint) memcpy(qfrc_constraint, d->qfrc_constraint, sizeof(double) * m->nv);
+  if (sensordata) memcpy(sensordata, d->sensordata, sizeof(double) * m->nsensordata);
+  if (info) { info[0] = d->ncon; info[1] = d->nefc; info[2] = d->solver_iter; info[3] = d->con_overflow; }
+  if (contacts) for (int c = 0; c < d->ncon; c++) { double* o = contacts + 16 * c; o[0] = d->con[c].dist; copy3(o + 1, d->con[c].pos); memcpy(o + 4, d->con[c].frame, 9 * sizeof(double)); o[13] = d->con[c].g1; o[14] = d->con[c].g2; o[15] = d->con[c].friction[0]; }
+  if (stats) { stats[0] = d->solver_cost; stats[1] = d->solver_gradnorm; double tr = 0; for (int i = 0; i < m->nv; i++) tr += d->M[i][i]; stats[2] = tr; }
+  int n = d->ncon;
+  jo_data_free(d);
+  return n;
+}
+
+/* ------------------------------------------------------------------ finalize: qpos0, dof tree, inverse weights at qpos0 (mjModel "set0") */
+int jo_model_finalize(jo_model* m) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], b = m->jnt_body[j];
+    if (m->jnt_type[j] == JO_JNT_FREE) { copy3(m->qpos0 + qa, m->body_pos[b]); memcpy(m->qpos0 + qa + 3, m->body_quat[b], 4 * sizeof(double)); }
+    else m->qpos0[qa] = 0; /* joint `ref` is 0 in all four models */
+  }
+  /* dof_parent: previous dof on the kinematic chain */
+  for (int i = 0; i < m->nv; i++) {
+    int j = m->dof_jnt[i], b = m->dof_body[i];
+    if (i > m->jnt_dofadr[j]) { m->dof_parent[i] = i - 1; continue; }                 /* inside a free joint */
+    if (j > m->body_jntadr[b]) { int jp = j - 1; m->dof_parent[i] = m->jnt_dofadr[jp] + (m->jnt_type[jp] == JO_JNT_FREE ? 5 : 0); continue; }
+    int p = m->body_parent[b]; m->dof_parent[i] = -1;
+    while (p > 0) {
+      if (m->body_jntnum[p] > 0) { int jp = m->body_jntadr[p] + m->body_jntnum[p] - 1; m->dof_parent[i] = m->jnt_dofadr[jp] + (m->jnt_type[jp] == JO_JNT_FREE ? 5 : 0); break; }
+      p = m->body_parent[p];
+    }
+  }
+  jo_data* d = jo_data_new();
+  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
+  kinematics(m, d); crb(m, d);
+  int nv = m->nv;
+  static double Minv[JO_MAXDOF][JO_MAXDOF];
+  for (int i = 0; i < nv; i++) { double e[JO_MAXDOF] = {0}; e[i] = 1; chol_solve(nv, d->L, e); for (int j = 0; j < nv; j++) Minv[j][i] = e[j]; }
+  for (int i = 0; i < nv; i++) m->dof_invweight0[i] = Minv[i][i];
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == JO_JNT_FREE) { /* average translational / rotational triplets */
+    int da = m->jnt_dofadr[j];
+    double t = (Minv[da][da] + Minv[da + 1][da + 1] + Minv[da + 2][da + 2]) / 3, r = (Minv[da + 3][da + 3] + Minv[da + 4][da + 4] + Minv[da + 5][da + 5]) / 3;
+    for (int k = 0; k < 3; k++) { m->dof_invweight0[da + k] = t; m->dof_invweight0[da + 3 + k] = r; }
+  }
+  for (int b = 1; b < m->nbody; b++) { /* tr(J Minv J')/3 at the body's centre of mass, translational and rotational */
+    static double Jp[3][JO_MAXDOF], Jr[3][JO_MAXDOF];
+    point_jac(m, d, b, d->xipos[b], Jp);
+    for (int k = 0; k < 3; k++) for (int i = 0; i < nv; i++) Jr[k][i] = 0;
+    { int bb = b; while (bb > 0 && m->body_jntnum[bb] == 0) bb = m->body_parent[bb];
+      if (bb > 0) { int jl = m->body_jntadr[bb] + m->body_jntnum[bb] - 1; for (int i = m->jnt_dofadr[jl] + (m->jnt_type[jl] == JO_JNT_FREE ? 5 : 0); i >= 0; i = m->dof_parent[i]) for (int k = 0; k < 3; k++) Jr[k][i] = d->S[i][k]; } }
+    double tt = 0, rr = 0;
+    for (int k = 0; k < 3; k++) for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) { tt += Jp[k][i] * Minv[i][j] * Jp[k][j]; rr += Jr[k][i] * Minv[i][j] * Jr[k][j]; }
+    m->body_invweight0[b][0] = tt / 3; m->body_invweight0[b][1] = rr / 3;
+  }
+  jo_data_free(d);
+  m->finalized = 1;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ rollouts */
+void jo_rollout(const jo_model* m, jo_data* d, const double* x0, const double* controls, int H, double* states, double* sensors_out) {
+  int nq = m->nq, nv = m->nv, nu = m->nact, ns = m->nsensordata;
+  memcpy(d->qpos, x0, sizeof(double) * nq); memcpy(d->qvel, x0 + nq, sizeof(double) * nv);
+  memset(d->qacc_warmstart, 0, sizeof(double) * nv);
+  for (int t = 0; t < H; t++) {
+    memcpy(d->ctrl, controls + (size_t)t * nu, sizeof(double) * nu);
+    jo_step(m, d);
+    if (states) { memcpy(states + (size_t)t * (nq + nv), d->qpos, sizeof(double) * nq); memcpy(states + (size_t)t * (nq + nv) + nq, d->qvel, sizeof(double) * nv); }
+    if (sensors_out) memcpy(sensors_out + (size_t)t * ns, d->sensordata, sizeof(double) * ns);
+  }
+}
+
+typedef struct { const jo_model* m; const double* x0; int x0_batched; const double* controls; int N, H, tid, nthread; double* states; double* sensors; } batch_arg;
+static void* batch_worker(void* p) {
+  batch_arg* a = (batch_arg*)p; const jo_model* m = a->m;
+  jo_data* d = jo_data_new();
+  int nx = m->nq + m->nv;
+  for (int n = a->tid; n < a->N; n += a->nthread)
+    jo_rollout(m, d, a->x0 + (a->x0_batched ? (size_t)n * nx : 0), a->controls + (size_t)n * a->H * m->nact, a->H,
+               a->states ? a->states + (size_t)n * a->H * nx : NULL, a->sensors ? a->sensors + (size_t)n * a->H * m->nsensordata : NULL);
+  jo_data_free(d);
+  return NULL;
+}
+void jo_rollout_batch(const jo_model* m, const double* x0, int x0_batched, const double* controls, int N, int H, double* states, double* sensors_out, int nthread) {
+  if (nthread < 1) nthread = 1; if (nthread > 256) nthread = 256; if (nthread > N) nthread = N;
+  pthread_t th[256]; batch_arg args[256];
+  for (int t = 0; t < nthread; t++) { args[t] = (batch_arg){m, x0, x0_batched, controls, N, H, t, nthread, states, sensors_out}; pthread_create(&th[t], NULL, batch_worker, &args[t]); }
+  for (int t = 0; t < nthread; t++) pthread_join(th[t], NULL);
+}
+
+/* ------------------------------------------------------------------ debugging aid for the tests: cost / gradient / Hessian at a given acceleration */
+double jo_debug_cost(const jo_model* m, const double* qpos, const double* qvel, const double* ctrl, const double* a, double* grad, double* Hout) {
+  jo_data* d = jo_data_new();
+  memcpy(d->qpos, qpos, sizeof(double) * m->nq); memcpy(d->qvel, qvel, sizeof(double) * m->nv); if (m->nact) memcpy(d->ctrl, ctrl, sizeof(double) * m->nact);
+  jo_forward(m, d);
+  static __thread double jar[JO_MAXEFC], Hd[JO_MAXEFC], Hc[JO_MAXCON][9]; static __thread int cz[JO_MAXCON];
+  int nv = m->nv;
+  double cost = total_cost(m, d, a, grad, jar, Hd, Hc, cz);
+  if (Hout) {
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Hout[i * nv + j] = d->M[i][j];
+    for (int r = 0; r < d->nefc; r++) if (Hd[r] != 0) for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Hout[i * nv + j] += Hd[r] * d->efc_J[r][i] * d->efc_J[r][j];
+    for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3 && cz[c]) {
+      int r0 = d->con[c].efc_adr;
+      for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Hout[i * nv + j] += Hc[c][3 * u + v] * d->efc_J[r0 + u][i] * d->efc_J[r0 + v][j];
+    }
+  }
+  jo_data_free(d);
+  return cost;
+}

@@ -1,0 +1,365 @@
+"""ctypes front-end of the ORACLE (`libjudo_oracle.so`, built by `oracle/Makefile`).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` -- never by `judo_amd/` (the product path fails loudly without
+its HIP library instead of falling back to this).
+
+`load_model(task)` reads the build's model description (`judo_amd/models/<task>.json`, numbers
+transcribed from the reference MJCF by `tools/compile_mjcf.py`) and instantiates the C engine's
+`jo_model` through its builder API; the candidate collision pairs are chosen here with MuJoCo's
+filter rules (same body, parent-child unless the parent is static, explicit excludes, both static).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_MODELS = os.path.join(os.path.dirname(_HERE), "judo_amd", "models")
+_LIB = None
+
+JNT = {"free": 0, "slide": 2, "hinge": 3}
+GEOM = {"sphere": 2, "capsule": 3, "cylinder": 5, "box": 6}
+SENS = {"framepos_site": 0, "framepos_body": 1, "jointpos": 2, "framezaxis_body": 3, "distance": 4}
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+def _d(a) -> "C._Pointer":
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    so = os.path.join(_HERE, "libjudo_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("jo_engine.c", "jo_plan.c", "jo_engine.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.jo_model_new.restype = C.c_void_p
+        L.jo_model_new.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, dp, C.c_int]
+        L.jo_model_free.argtypes = [C.c_void_p]
+        L.jo_add_body.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double, dp, dp, dp]
+        L.jo_add_joint.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_double, C.c_int, dp, dp, dp, dp, dp]
+        L.jo_add_geom.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int]
+        L.jo_add_pair.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.jo_add_site.argtypes = [C.c_void_p, C.c_int, dp]
+        L.jo_add_actuator.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, dp, C.c_int, dp]
+        L.jo_add_sensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.jo_add_equality_joint.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp]
+        L.jo_model_finalize.argtypes = [C.c_void_p]
+        L.jo_model_dims.argtypes = [C.c_void_p, ip]
+        L.jo_model_get_invweight0.argtypes = [C.c_void_p, dp, dp]
+        L.jo_model_get_qpos0.argtypes = [C.c_void_p, dp]
+        L.jo_data_new.restype = C.c_void_p
+        L.jo_data_free.argtypes = [C.c_void_p]
+        L.jo_mass_matrix.argtypes = [C.c_void_p, C.c_void_p, dp]
+        L.jo_energy.restype = C.c_double
+        L.jo_energy.argtypes = [C.c_void_p, C.c_void_p, dp, dp]
+        L.jo_forward_probe.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp]
+        L.jo_rollout_batch.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, C.c_int, dp, dp, C.c_int]
+        L.jo_spline_weights.argtypes = [C.c_int, C.c_int, dp, C.c_int, dp, dp]
+        L.jo_spline_eval.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.jo_mppi_sigma.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, dp]
+        L.jo_cem_sigma_ramp.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.jo_cem_pre_optimization.argtypes = [dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]
+        L.jo_sample_knots.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_int, dp]
+        L.jo_clip_knots.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.jo_mppi_update.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
+        L.jo_cem_update.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, ip]
+        L.jo_ps_update.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, dp]
+        L.jo_reward_cartpole.argtypes = [dp, dp, C.c_int, C.c_int, dp, dp]
+        L.jo_reward_cylinder.argtypes = [dp, C.c_int, C.c_int, dp, dp]
+        L.jo_reward_leap.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.jo_reward_fr3.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp]
+    return _LIB
+
+
+def load_description(task: str) -> dict:
+    with open(os.path.join(_MODELS, task + ".json")) as f:
+        return json.load(f)
+
+
+def collision_pairs(desc: dict, scope: str = "task") -> list[tuple[int, int]]:
+    """Candidate geom pairs after MuJoCo's static filters.
+
+    scope "task": the pairs the build models for this task (DESIGN.md "contacts modelled"):
+      leap_cube  -> cube geom vs every hand geom (hand self-collision is out of scope this round)
+      others     -> every pair that survives the filters and has a supported narrow-phase.
+    """
+    bodies, geoms = desc["bodies"], desc["geoms"]
+    nb = len(bodies)
+    njnt_body = [0] * nb
+    for j in desc["joints"]:
+        njnt_body[j["body"]] += 1
+
+    def weld(b: int) -> int:  # static bodies are welded to the world
+        while b > 0 and njnt_body[b] == 0:
+            b = bodies[b]["parent"]
+        return b
+
+    def weld_parent(b: int) -> int:
+        w = weld(b)
+        return weld(bodies[w]["parent"]) if w > 0 else 0
+
+    excl = {tuple(sorted(e)) for e in desc["excludes"]}
+    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("cylinder", "cylinder")}
+    pairs = []
+    for g1 in range(len(geoms)):
+        for g2 in range(g1 + 1, len(geoms)):
+            b1, b2 = geoms[g1]["body"], geoms[g2]["body"]
+            w1, w2 = weld(b1), weld(b2)
+            if w1 == w2:
+                continue  # same (welded) body, incl. both static
+            if tuple(sorted((b1, b2))) in excl:
+                continue
+            # parent-child filter, not applied when the parent is the (welded) world
+            if (weld_parent(b1) == w2 and w2 != 0) or (weld_parent(b2) == w1 and w1 != 0):
+                continue
+            if (geoms[g1]["type"], geoms[g2]["type"]) not in supported:
+                continue
+            if desc["task"] == "leap_cube" and scope == "task":
+                cube = next(i for i, g in enumerate(geoms) if g["name"] == "cube")
+                if cube not in (g1, g2):
+                    continue
+            pairs.append((g1, g2))
+    return pairs
+
+
+class Model:
+    """Owns a C `jo_model`."""
+
+    def __init__(self, task: str, desc: dict | None = None, pairs: list[tuple[int, int]] | None = None) -> None:
+        L = lib()
+        self.task = task
+        self.desc = d = desc if desc is not None else load_description(task)
+        o = d["option"]
+        integ = {"euler": 0, "implicitfast": 3}[o["integrator"]]
+        cone = {"pyramidal": 0, "elliptic": 1}[o["cone"]]
+        self.ptr = L.jo_model_new(o["timestep"], integ, cone, o["impratio"], _d(o["gravity"]), int(o["contact"]))
+        for b in d["bodies"][1:]:
+            r = L.jo_add_body(self.ptr, b["parent"], _d(b["pos"]), _d(b["quat"]), b["mass"], _d(b["ipos"]), _d(b["iquat"]), _d(b["inertia"]))
+            assert r >= 0
+        for j in d["joints"]:
+            rng = j["range"] or [0.0, 0.0]
+            fr = j["actuatorfrcrange"] or [0.0, 0.0]
+            r = L.jo_add_joint(self.ptr, j["body"], JNT[j["type"]], _d(j["pos"]), _d(j["axis"]), j["damping"], j["armature"], j["frictionloss"],
+                               int(j["range"] is not None), _d(rng), j["margin"], int(j["actuatorfrcrange"] is not None), _d(fr),
+                               _d(j["solreflimit"]), _d(j["solimplimit"]), _d(j["solreffriction"]), _d(j["solimpfriction"]))
+            assert r >= 0, (j["name"], r)
+        for g in d["geoms"]:
+            size = (list(g["size"]) + [0, 0, 0])[:3]
+            r = L.jo_add_geom(self.ptr, g["body"], GEOM[g["type"]], _d(size), _d(g["pos"]), _d(g["quat"]), _d(g["friction"]), _d(g["solref"]), _d(g["solimp"]), g["margin"], g["gap"], g["condim"])
+            assert r >= 0
+        self.pairs = pairs if pairs is not None else collision_pairs(d)
+        for g1, g2 in self.pairs:
+            assert L.jo_add_pair(self.ptr, g1, g2) >= 0
+        for s in d["sites"]:
+            assert L.jo_add_site(self.ptr, s["body"], _d(s["pos"])) >= 0
+        for a in d["actuators"]:
+            r = L.jo_add_actuator(self.ptr, a["joint"], a["kp"], a["kv"], int(a["ctrlrange"] is not None), _d(a["ctrlrange"] or [0, 0]),
+                                  int(a["forcerange"] is not None), _d(a["forcerange"] or [0, 0]))
+            assert r >= 0
+        for s in d["sensors"]:
+            if s["type"] == "framepos":
+                r = L.jo_add_sensor(self.ptr, SENS["framepos_site" if s["objtype"] == "site" else "framepos_body"], s["obj"], -1, 0.0)
+            elif s["type"] == "jointpos":
+                r = L.jo_add_sensor(self.ptr, SENS["jointpos"], s["obj"], -1, 0.0)
+            elif s["type"] == "framezaxis":
+                r = L.jo_add_sensor(self.ptr, SENS["framezaxis_body"], s["obj"], -1, 0.0)
+            else:
+                r = L.jo_add_sensor(self.ptr, SENS["distance"], s["body1"], s["body2"], s["cutoff"])
+            assert r >= 0
+        for e in d["equalities"]:
+            assert L.jo_add_equality_joint(self.ptr, e["joint1"], e["joint2"], _d(e["polycoef"]), _d(e["solref"]), _d(e["solimp"])) >= 0
+        assert L.jo_model_finalize(self.ptr) == 0
+        dims = (C.c_int * 7)()
+        L.jo_model_dims(self.ptr, dims)
+        self.nq, self.nv, self.nu, self.ns, self.nbody, self.ngeom, self.npair = list(dims)
+        self.nx = self.nq + self.nv
+        self.dt = o["timestep"]
+
+    def __del__(self) -> None:
+        try:
+            lib().jo_model_free(self.ptr)
+        except Exception:
+            pass
+
+    # ---- diagnostics
+    def invweight0(self) -> tuple[np.ndarray, np.ndarray]:
+        dw, bw = np.zeros(self.nv), np.zeros(2 * self.nbody)
+        lib().jo_model_get_invweight0(self.ptr, _d(dw), _d(bw))
+        return dw, bw.reshape(-1, 2)
+
+    def qpos0(self) -> np.ndarray:
+        q = np.zeros(self.nq)
+        lib().jo_model_get_qpos0(self.ptr, _d(q))
+        return q
+
+    def mass_matrix(self, qpos: np.ndarray) -> np.ndarray:
+        L = lib()
+        d = L.jo_data_new()
+        buf = np.zeros(8192 // 8)  # qpos is the first field of jo_data
+        C.memmove(d, np.ascontiguousarray(qpos, dtype=np.float64).ctypes.data, 8 * self.nq)
+        M = np.zeros((self.nv, self.nv))
+        L.jo_mass_matrix(self.ptr, d, _d(M))
+        L.jo_data_free(d)
+        del buf
+        return M
+
+    def forward(self, qpos, qvel, ctrl) -> dict:
+        L = lib()
+        out = {k: np.zeros(self.nv) for k in ("qacc", "qacc_smooth", "qfrc_bias", "qfrc_constraint")}
+        sens = np.zeros(max(self.ns, 1))
+        info = (C.c_int * 4)()
+        cons = np.zeros((96, 16))
+        stats = np.zeros(3)
+        ctrl = np.zeros(max(self.nu, 1)) if self.nu == 0 else np.ascontiguousarray(ctrl, dtype=np.float64)
+        n = L.jo_forward_probe(self.ptr, _d(qpos), _d(qvel), _d(ctrl), _d(out["qacc"]), _d(out["qacc_smooth"]), _d(out["qfrc_bias"]),
+                               _d(out["qfrc_constraint"]), _d(sens), info, _d(cons), _d(stats))
+        out.update(sensordata=sens[: self.ns], ncon=info[0], nefc=info[1], solver_iter=info[2], con_overflow=info[3], contacts=cons[:n], solver_cost=stats[0], solver_gradnorm=stats[1], trace_M=stats[2])
+        return out
+
+    def rollout(self, x0: np.ndarray, controls: np.ndarray, nthread: int | None = None) -> tuple[np.ndarray, np.ndarray]:
+        """controls (N,H,nu), x0 (nx,) or (N,nx) -> states (N,H,nx), sensors (N,H,ns)  [RolloutBackend.rollout semantics]."""
+        controls = np.ascontiguousarray(controls, dtype=np.float64)
+        N, H, nu = controls.shape
+        assert nu == self.nu
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        batched = int(x0.ndim == 2)
+        states = np.zeros((N, H, self.nx))
+        sensors = np.zeros((N, H, self.ns))
+        lib().jo_rollout_batch(self.ptr, _d(x0), batched, _d(controls), N, H, _d(states), _d(sensors), nthread or os.cpu_count() or 1)
+        return states, sensors
+
+
+# ---------------------------------------------------------------- plan-path primitives (numpy in / numpy out)
+def spline_weights(kind: str | int, knot_times, query_times) -> np.ndarray:
+    k = {"zero": 0, "linear": 1, "cubic": 3}.get(kind, kind)
+    t = np.ascontiguousarray(knot_times, dtype=np.float64)
+    q = np.ascontiguousarray(query_times, dtype=np.float64)
+    W = np.zeros((len(q), len(t)))
+    assert lib().jo_spline_weights(int(k), len(t), _d(t), len(q), _d(q), _d(W)) == 0
+    return W
+
+
+def spline_eval(W, knots) -> np.ndarray:
+    knots = np.ascontiguousarray(knots, dtype=np.float64)
+    N, K, nu = knots.shape
+    H = W.shape[0]
+    U = np.zeros((N, H, nu))
+    lib().jo_spline_eval(_d(W), _d(knots), N, H, K, nu, _d(U))
+    return U
+
+
+def mppi_sigma(sigma, use_ramp, noise_ramp, K, nu) -> np.ndarray:
+    out = np.zeros((K, nu))
+    lib().jo_mppi_sigma(float(sigma), int(use_ramp), float(noise_ramp), K, nu, _d(out))
+    return out
+
+
+def cem_sigma_ramp(sigma, use_ramp, noise_ramp, smin, smax) -> np.ndarray:
+    s = np.array(sigma, dtype=np.float64, order="C")
+    lib().jo_cem_sigma_ramp(_d(s), int(use_ramp), float(noise_ramp), float(smin), float(smax), s.shape[0], s.shape[1])
+    return s
+
+
+def cem_pre_optimization(sigma, old_times, new_times) -> np.ndarray:
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    out = np.zeros((len(new_times), sigma.shape[1]))
+    lib().jo_cem_pre_optimization(_d(sigma), sigma.shape[0], _d(old_times), len(new_times), _d(new_times), sigma.shape[1], _d(out))
+    return out
+
+
+def sample_knots(nominal, noise, sigma) -> np.ndarray:
+    noise = np.ascontiguousarray(noise, dtype=np.float64)
+    Nm1, K, nu = noise.shape
+    out = np.zeros((Nm1 + 1, K, nu))
+    lib().jo_sample_knots(_d(nominal), _d(noise), _d(np.broadcast_to(sigma, (K, nu))), Nm1 + 1, K, nu, _d(out))
+    return out
+
+
+def clip_knots(knots, lo, hi) -> np.ndarray:
+    k = np.array(knots, dtype=np.float64, order="C")
+    N, K, nu = k.shape
+    lib().jo_clip_knots(_d(k), N, K, nu, _d(lo), _d(hi))
+    return k
+
+
+def mppi_update(knots, rewards, temperature) -> np.ndarray:
+    knots = np.ascontiguousarray(knots, dtype=np.float64)
+    N, K, nu = knots.shape
+    out = np.zeros((K, nu))
+    lib().jo_mppi_update(_d(knots), _d(rewards), N, K, nu, float(temperature), _d(out))
+    return out
+
+
+def cem_update(knots, rewards, num_elites, smin, smax):
+    knots = np.ascontiguousarray(knots, dtype=np.float64)
+    N, K, nu = knots.shape
+    out, sig = np.zeros((K, nu)), np.zeros((K, nu))
+    idx = (C.c_int * num_elites)()
+    lib().jo_cem_update(_d(knots), _d(rewards), N, K, nu, num_elites, float(smin), float(smax), _d(out), _d(sig), idx)
+    return out, sig, np.array(list(idx))
+
+
+def ps_update(knots, rewards) -> np.ndarray:
+    knots = np.ascontiguousarray(knots, dtype=np.float64)
+    N, K, nu = knots.shape
+    out = np.zeros((K, nu))
+    lib().jo_ps_update(_d(knots), _d(rewards), N, K, nu, _d(out))
+    return out
+
+
+def reward_cartpole(states, controls, w=(10.0, 10.0, 0.1, 0.1, 0.01, 0.1)) -> np.ndarray:
+    states = np.ascontiguousarray(states, dtype=np.float64)
+    N, H, _ = states.shape
+    out = np.zeros(N)
+    lib().jo_reward_cartpole(_d(states), _d(controls), N, H, _d(w), _d(out))
+    return out
+
+
+def reward_cylinder(states, p=(0.5, 0.0, 0.1, 0.25, 0.0, 0.0)) -> np.ndarray:
+    states = np.ascontiguousarray(states, dtype=np.float64)
+    N, H, _ = states.shape
+    out = np.zeros(N)
+    lib().jo_reward_cylinder(_d(states), N, H, _d(p), _d(out))
+    return out
+
+
+def reward_leap(states, goal_quat=(1.0, 0.0, 0.0, 0.0), w_pos=100.0, w_rot=0.1, goal_pos=(0.0, 0.03, 0.1)) -> np.ndarray:
+    states = np.ascontiguousarray(states, dtype=np.float64)
+    N, H, nx = states.shape
+    out = np.zeros(N)
+    p = np.array([w_pos, w_rot, *goal_pos, *goal_quat], dtype=np.float64)
+    lib().jo_reward_leap(_d(states), N, H, nx, _d(p), _d(out))
+    return out
+
+
+FR3_DEFAULT_P = (1.0, 10.0, 1.0, 10.0, 1.0, 1.0, 0.25, 0.1, 0.005, 2.0, 0.6, 0.4, 0.3)
+FR3_ARM_HOME = (0, -0.7854, 0.0, -2.3562, 0.0, 1.5708, 0.7854, 0.04, 0.04)
+FR3_SADR = (2, 3, 4, 11, 5)  # left_finger_table, right_finger_table, obj_table, grasp_site, ee_z
+
+
+def reward_fr3(states, sensors, phase: int, p=FR3_DEFAULT_P, arm_home=FR3_ARM_HOME, sadr=FR3_SADR, nq=16, nv=15) -> np.ndarray:
+    states = np.ascontiguousarray(states, dtype=np.float64)
+    sensors = np.ascontiguousarray(sensors, dtype=np.float64)
+    N, H, _ = states.shape
+    out = np.zeros(N)
+    pp = np.array([*p, *arm_home], dtype=np.float64)
+    sa = (C.c_int * 5)(*sadr)
+    lib().jo_reward_fr3(_d(states), _d(sensors), N, H, nq, nv, sensors.shape[-1], int(phase), _d(pp), sa, _d(out))
+    return out

@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""Transcribe the four BASELINE task models into the build's own model-description JSON.
+
+Runs ONLY in the build container: it reads the reference's MJCF files
+(`/root/reference/judo/models/xml/{cartpole,cylinder_push,leap_cube,fr3_pick}.xml` and the
+`leap_components/`, `fr3_components/` includes), resolves the MJCF
+default classes / includes / `fromto` / `inheritrange` for the subset of MJCF these four files
+use, and writes `judo_amd/models/<task>.json`.  The JSON holds numbers only (topology, frames,
+inertias, joint/actuator/solver parameters, collision primitives, sensors) in this build's own
+schema; it is data, the runtime never sees MJCF.  Semantics of every field follow the MuJoCo 3.5
+XML reference (MuJoCo itself is absent from this image, see DESIGN.md "oracle").
+
+Documented substitutions (collision meshes are not in the reference repo, `.MISSING_LARGE_BLOBS`):
+  * leap fingertip meshes `tip` / `thumb_tip` -> spheres (see MESH_SUBSTITUTES below)
+  * fr3 link collision meshes -> capsule/box fits (see MESH_SUBSTITUTES below)
+"""
+
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+REF_XML = "/root/reference/judo/models/xml"
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "judo_amd", "models")
+
+# MuJoCo documented defaults (XML reference, MuJoCo 3.5)
+GEOM_DEFAULTS = dict(
+    type="sphere", contype="1", conaffinity="1", condim="3", friction="1 0.005 0.0001", solref="0.02 1",
+    solimp="0.9 0.95 0.001 0.5 2", margin="0", gap="0", density="1000", solmix="1", priority="0",
+    pos="0 0 0", quat="1 0 0 0",
+)
+JOINT_DEFAULTS = dict(
+    type="hinge", pos="0 0 0", axis="0 0 1", damping="0", armature="0", frictionloss="0", stiffness="0",
+    ref="0", margin="0", solreflimit="0.02 1", solimplimit="0.9 0.95 0.001 0.5 2",
+    solreffriction="0.02 1", solimpfriction="0.9 0.95 0.001 0.5 2",
+)
+
+# Collision-mesh substitutes: {mesh name: primitive in the geom's own frame}.  The tip sphere is placed so
+# that its far end reaches the reference's own `trace_*_tip` site (leap_hand.xml:118,163,208,250).
+MESH_SUBSTITUTES = {
+    "tip": dict(type="sphere", size=[0.012], pos=[0.0, -0.0365, 0.0145], quat=[1, 0, 0, 0]),
+    "thumb_tip": dict(type="sphere", size=[0.012], pos=[0.0, -0.0465, -0.0145], quat=[1, 0, 0, 0]),
+    # fr3 link hulls: capsules along the link axes (radius ~ hull half-width of the FR3 links), not used by
+    # the shipped fr3_pick cost except through contacts; fingers' mesh hull -> box over the finger body.
+    "link0_coll": dict(type="capsule", size=[0.07, 0.06], pos=[-0.04, 0, 0.06], quat=[0.7071068, 0, 0.7071068, 0]),
+    "link1_coll": dict(type="capsule", size=[0.06, 0.10], pos=[0, 0, -0.10], quat=[1, 0, 0, 0]),
+    "link2_coll": dict(type="capsule", size=[0.06, 0.06], pos=[0, -0.06, 0.0], quat=[0.7071068, 0.7071068, 0, 0]),
+    "link3_coll": dict(type="capsule", size=[0.055, 0.07], pos=[0.03, 0, -0.07], quat=[1, 0, 0, 0]),
+    "link4_coll": dict(type="capsule", size=[0.055, 0.05], pos=[-0.04, 0.04, 0.0], quat=[0.7071068, 0.7071068, 0, 0]),
+    "link5_coll": dict(type="capsule", size=[0.05, 0.13], pos=[0, 0.03, -0.13], quat=[1, 0, 0, 0]),
+    "link6_coll": dict(type="capsule", size=[0.045, 0.04], pos=[0.04, 0, 0.0], quat=[0.7071068, 0, 0.7071068, 0]),
+    "link7_coll": dict(type="capsule", size=[0.04, 0.03], pos=[0, 0, 0.05], quat=[1, 0, 0, 0]),
+    "hand_coll": dict(type="box", size=[0.032, 0.10, 0.034], pos=[0, 0, 0.032], quat=[1, 0, 0, 0]),
+    "finger_0": dict(type="box", size=[0.0105, 0.0075, 0.027], pos=[0, 0.0115, 0.027], quat=[1, 0, 0, 0]),
+}
+
+
+def fl(s: str) -> list[float]:
+    return [float(x) for x in s.split()]
+
+
+def load_xml(path: str) -> ET.Element:
+    """Parse an MJCF file, inlining <include file=.../> elements (relative to the including file)."""
+    root = ET.parse(path).getroot()
+
+    def expand(el: ET.Element, base: str) -> None:
+        i = 0
+        while i < len(el):
+            ch = el[i]
+            if ch.tag == "include":
+                inc = ET.parse(os.path.join(base, ch.get("file"))).getroot()
+                expand(inc, base)  # MuJoCo resolves nested includes relative to the top-level model file
+                el.remove(ch)
+                for k, sub in enumerate(list(inc)):
+                    el.insert(i + k, sub)
+                i += len(inc)
+            else:
+                expand(ch, base)
+                i += 1
+
+    expand(root, os.path.dirname(path))
+    return root
+
+
+class Defaults:
+    """MJCF default classes: nested <default class=..> inherit from the enclosing class."""
+
+    def __init__(self, root: ET.Element) -> None:
+        self.cls: dict[str, dict[str, dict[str, str]]] = {"main": {}}
+        for d in root.findall("default"):
+            self._walk(d, "main", top=True)
+
+    def _walk(self, d: ET.Element, parent: str, top: bool = False) -> None:
+        name = d.get("class") or ("main" if top else None)
+        if name is None:
+            raise ValueError("nested default without class")
+        if name not in self.cls or name == "main":
+            base = {t: dict(a) for t, a in self.cls[parent].items()} if name != "main" else self.cls["main"]
+            self.cls[name] = base
+        for ch in d:
+            if ch.tag == "default":
+                continue
+            self.cls[name].setdefault(ch.tag, {}).update(ch.attrib)
+        for ch in d.findall("default"):
+            self._walk(ch, name)
+
+    def resolve(self, tag: str, el: ET.Element, childclass: str | None, builtin: dict[str, str] | None = None) -> dict[str, str]:
+        cname = el.get("class") or childclass or "main"
+        out = dict(builtin or {})
+        out.update(self.cls.get(cname, {}).get(tag, {}))
+        out.update({k: v for k, v in el.attrib.items() if k != "class"})
+        return out
+
+
+def quat_mul(a, b):
+    return [
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0],
+    ]
+
+
+def quat_rot(q, v):
+    w, x, y, z = q
+    R = [
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ]
+    return [sum(R[i][j] * v[j] for j in range(3)) for i in range(3)]
+
+
+def qnorm(q):
+    n = math.sqrt(sum(x * x for x in q))
+    return [x / n for x in q]
+
+
+def quat_z_to(vec):
+    """Quaternion rotating +z onto `vec` (MuJoCo mju_quatZ2Vec), used for `fromto`."""
+    n = math.sqrt(sum(x * x for x in vec))
+    v = [x / n for x in vec]
+    axis = [-v[1], v[0], 0.0]  # z x v
+    s = math.sqrt(axis[0] ** 2 + axis[1] ** 2)
+    if s < 1e-10:
+        return [1, 0, 0, 0] if v[2] > 0 else [0, 1, 0, 0]
+    ang = math.atan2(s, v[2])
+    axis = [a / s for a in axis]
+    return [math.cos(ang / 2)] + [a * math.sin(ang / 2) for a in axis]
+
+
+def geom_inertia(g: dict) -> tuple[float, list[float]]:
+    """mass, diagonal inertia (in the geom frame, about its centre) of a primitive; MuJoCo formulas."""
+    t, s = g["type"], g["size"]
+    if t == "box":
+        vol = 8 * s[0] * s[1] * s[2]
+    elif t == "sphere":
+        vol = 4 / 3 * math.pi * s[0] ** 3
+    elif t == "cylinder":
+        vol = math.pi * s[0] ** 2 * 2 * s[1]
+    elif t == "capsule":
+        vol = math.pi * s[0] ** 2 * 2 * s[1] + 4 / 3 * math.pi * s[0] ** 3
+    else:
+        raise ValueError(t)
+    mass = g["mass"] if g.get("mass") is not None else g["density"] * vol
+    if t == "box":
+        I = [mass / 3 * (s[1] ** 2 + s[2] ** 2), mass / 3 * (s[0] ** 2 + s[2] ** 2), mass / 3 * (s[0] ** 2 + s[1] ** 2)]
+    elif t == "sphere":
+        I = [0.4 * mass * s[0] ** 2] * 3
+    elif t == "cylinder":
+        r, h = s[0], 2 * s[1]
+        I = [mass * (3 * r * r + h * h) / 12] * 2 + [mass * r * r / 2]
+    else:  # capsule: cylinder + two hemispherical caps
+        r, h = s[0], 2 * s[1]
+        m_cyl = mass * (math.pi * r * r * h) / vol
+        m_sph = mass - m_cyl
+        it = m_cyl * (3 * r * r + h * h) / 12 + m_sph * (0.4 * r * r + h * h / 4 + 3 * r * h / 8)
+        ia = m_cyl * r * r / 2 + m_sph * 0.4 * r * r
+        I = [it, it, ia]
+    return mass, I
+
+
+def compile_model(xml_name: str, task: str) -> dict:
+    root = load_xml(os.path.join(REF_XML, xml_name))
+    dfl = Defaults(root)
+    comp = {}
+    for c in root.findall("compiler"):
+        comp.update(c.attrib)
+    if comp.get("angle", "degree") != "radian":
+        # cartpole / cylinder_push declare no angle unit; they contain no angular attribute
+        # (hinge ranges, euler) so the default unit (degree) is never applied.
+        pass
+    opt = {}
+    flags = {}
+    for o in root.findall("option"):
+        opt.update(o.attrib)
+        for f in o.findall("flag"):
+            flags.update(f.attrib)
+    model: dict = {
+        "task": task,
+        "source": f"judo v0.0.7 judo/models/xml/{xml_name}",
+        "option": {
+            "timestep": float(opt.get("timestep", 0.002)),
+            "integrator": opt.get("integrator", "Euler").lower(),
+            "cone": opt.get("cone", "pyramidal"),
+            "impratio": float(opt.get("impratio", 1.0)),
+            "gravity": fl(opt.get("gravity", "0 0 -9.81")),
+            "contact": flags.get("contact", "enable") == "enable",
+        },
+        "bodies": [dict(name="world", parent=-1, pos=[0, 0, 0], quat=[1, 0, 0, 0], mass=0.0, ipos=[0, 0, 0], iquat=[1, 0, 0, 0], inertia=[0, 0, 0], mocap=False)],
+        "joints": [], "geoms": [], "sites": [], "actuators": [], "sensors": [], "excludes": [], "equalities": [],
+    }
+    body_id = {"world": 0}
+
+    def walk(el: ET.Element, parent: int, childclass: str | None) -> None:
+        for b in el.findall("body"):
+            cc = b.get("childclass") or childclass
+            bid = len(model["bodies"])
+            name = b.get("name", f"body{bid}")
+            body_id[name] = bid
+            rec = dict(name=name, parent=parent, pos=fl(b.get("pos", "0 0 0")), quat=qnorm(fl(b.get("quat", "1 0 0 0"))), mocap=b.get("mocap", "false") == "true")
+            model["bodies"].append(rec)
+            geoms_here = []
+            for ch in b:
+                if ch.tag in ("joint", "freejoint"):
+                    a = dfl.resolve("joint", ch, cc, JOINT_DEFAULTS) if ch.tag == "joint" else dict(JOINT_DEFAULTS, type="free", **ch.attrib)
+                    jr = dict(
+                        name=a.get("name", f"joint{len(model['joints'])}"), body=bid, type=a["type"], pos=fl(a["pos"]), axis=fl(a["axis"]),
+                        damping=float(a["damping"]), armature=float(a["armature"]), frictionloss=float(a["frictionloss"]),
+                        stiffness=float(a["stiffness"]), ref=float(a["ref"]), margin=float(a["margin"]),
+                        range=None, actuatorfrcrange=None,
+                        solreflimit=fl(a["solreflimit"]), solimplimit=fl(a["solimplimit"]),
+                        solreffriction=fl(a["solreffriction"]), solimpfriction=fl(a["solimpfriction"]),
+                    )
+                    if jr["type"] != "free":
+                        n = math.sqrt(sum(x * x for x in jr["axis"]))
+                        jr["axis"] = [x / n for x in jr["axis"]]
+                    # autolimits (MuJoCo >= 2.2.2 default): a `range` attribute implies limited unless limited="false"
+                    if "range" in a and a.get("limited", "auto") != "false":
+                        jr["range"] = fl(a["range"])
+                    if "actuatorfrcrange" in a and a.get("actuatorfrclimited", "auto") != "false":
+                        jr["actuatorfrcrange"] = fl(a["actuatorfrcrange"])
+                    model["joints"].append(jr)
+                elif ch.tag == "geom":
+                    a = dfl.resolve("geom", ch, cc, GEOM_DEFAULTS)
+                    g = dict(
+                        name=a.get("name", f"geom{len(model['geoms'])}"), body=bid, type=a["type"], contype=int(a["contype"]), conaffinity=int(a["conaffinity"]),
+                        condim=int(a["condim"]), friction=(fl(a["friction"]) + [0.005, 0.0001])[:3] if len(fl(a["friction"])) < 3 else fl(a["friction"]),
+                        solref=fl(a["solref"]), solimp=fl(a["solimp"]), margin=float(a["margin"]), gap=float(a["gap"]), solmix=float(a["solmix"]),
+                        priority=int(a["priority"]), density=float(a["density"]), mass=float(a["mass"]) if "mass" in a else None,
+                        pos=fl(a["pos"]), quat=qnorm(fl(a["quat"])), mesh=a.get("mesh"),
+                    )
+                    fr = fl(a["friction"])
+                    g["friction"] = [fr[0], fr[1] if len(fr) > 1 else 0.005, fr[2] if len(fr) > 2 else 0.0001]
+                    size = fl(a["size"]) if "size" in a else []
+                    if "fromto" in a:
+                        ft = fl(a["fromto"])
+                        p0, p1 = ft[:3], ft[3:]
+                        vec = [p1[i] - p0[i] for i in range(3)]
+                        g["pos"] = [(p0[i] + p1[i]) / 2 for i in range(3)]
+                        g["quat"] = quat_z_to(vec)
+                        size = [size[0], math.sqrt(sum(x * x for x in vec)) / 2]
+                    g["size"] = size
+                    geoms_here.append(g)
+                elif ch.tag == "site":
+                    a = dfl.resolve("site", ch, cc, dict(pos="0 0 0", quat="1 0 0 0"))
+                    model["sites"].append(dict(name=a["name"], body=bid, pos=fl(a["pos"]), quat=qnorm(fl(a["quat"]))))
+            # inertial: explicit <inertial> wins; else sum of geoms with mass (single-geom bodies in these models)
+            inert = b.find("inertial")
+            if inert is not None:
+                rec.update(mass=float(inert.get("mass")), ipos=fl(inert.get("pos", "0 0 0")), iquat=qnorm(fl(inert.get("quat", "1 0 0 0"))), inertia=fl(inert.get("diaginertia")))
+            else:
+                massive = []
+                for g in geoms_here:
+                    if g["type"] == "mesh":
+                        continue
+                    m, I = geom_inertia(g)
+                    if m > 0:
+                        massive.append((g, m, I))
+                if len(massive) == 0:
+                    rec.update(mass=0.0, ipos=[0, 0, 0], iquat=[1, 0, 0, 0], inertia=[0, 0, 0])
+                elif len(massive) == 1:
+                    g, m, I = massive[0]
+                    rec.update(mass=m, ipos=list(g["pos"]), iquat=list(g["quat"]), inertia=I)
+                else:
+                    raise NotImplementedError(f"body {name}: multi-geom inertia not needed by the four models")
+            for g in geoms_here:
+                if g["contype"] == 0 and g["conaffinity"] == 0:
+                    continue  # visual-only
+                if g["type"] == "mesh":
+                    sub = MESH_SUBSTITUTES.get(g["mesh"])
+                    if sub is None:
+                        raise KeyError(f"collision mesh {g['mesh']} has no substitute")
+                    # substitute is expressed in the mesh geom's frame
+                    g["pos"] = [g["pos"][i] + quat_rot(g["quat"], sub["pos"])[i] for i in range(3)]
+                    g["quat"] = qnorm(quat_mul(g["quat"], sub["quat"]))
+                    g["type"], g["size"] = sub["type"], list(sub["size"])
+                    g["substitute_for_mesh"] = g["mesh"]
+                for k in ("mesh", "density", "mass", "contype", "conaffinity"):
+                    g.pop(k, None)
+                model["geoms"].append(g)
+            walk(b, bid, cc)
+
+    wb = root.find("worldbody")
+    walk(wb, 0, None)
+
+    joint_id = {j["name"]: i for i, j in enumerate(model["joints"])}
+    for c in root.findall("contact"):
+        for e in c.findall("exclude"):
+            model["excludes"].append([body_id[e.get("body1")], body_id[e.get("body2")]])
+    for eq in root.findall("equality"):
+        for j in eq.findall("joint"):
+            model["equalities"].append(dict(
+                type="joint", joint1=joint_id[j.get("joint1")], joint2=joint_id[j.get("joint2")],
+                polycoef=(fl(j.get("polycoef", "0 1 0 0 0")) + [0, 0, 0, 0, 0])[:5],
+                solref=fl(j.get("solref", "0.02 1")), solimp=fl(j.get("solimp", "0.9 0.95 0.001 0.5 2")),
+            ))
+    for act in root.findall("actuator"):
+        for p in act.findall("position"):
+            a = dfl.resolve("position", p, None, dict(kp="1", kv="0", gear="1"))
+            j = joint_id[a["joint"]]
+            rec = dict(name=a.get("name"), joint=j, kp=float(a["kp"]), kv=float(a["kv"]), gear=fl(a["gear"])[0], ctrlrange=None, forcerange=None)
+            if "ctrlrange" in a and a.get("ctrllimited", "auto") != "false":
+                rec["ctrlrange"] = fl(a["ctrlrange"])
+            if "inheritrange" in a and float(a["inheritrange"]) > 0:
+                lo, hi = model["joints"][j]["range"]
+                mid, rad = (lo + hi) / 2, (hi - lo) / 2 * float(a["inheritrange"])
+                rec["ctrlrange"] = [mid - rad, mid + rad]
+            if "forcerange" in a and a.get("forcelimited", "auto") != "false":
+                rec["forcerange"] = fl(a["forcerange"])
+            model["actuators"].append(rec)
+    site_id = {s["name"]: i for i, s in enumerate(model["sites"])}
+    adr = 0
+    for sen in root.findall("sensor"):
+        for s in sen:
+            rec = dict(name=s.get("name"), type=s.tag, adr=adr)
+            if s.tag == "framepos" or s.tag == "framezaxis":
+                rec.update(objtype=s.get("objtype"), obj=(site_id if s.get("objtype") == "site" else body_id)[s.get("objname")], dim=3)
+            elif s.tag == "jointpos":
+                rec.update(obj=joint_id[s.get("joint")], dim=1)
+            elif s.tag == "distance":
+                rec.update(body1=body_id[s.get("body1")], body2=body_id[s.get("body2")], cutoff=float(s.get("cutoff", 0)), dim=1)
+            else:
+                raise NotImplementedError(s.tag)
+            adr += rec["dim"]
+            model["sensors"].append(rec)
+    model["nsensordata"] = adr
+    return model
+
+
+def main() -> None:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    for xml_name, task in (("cartpole.xml", "cartpole"), ("cylinder_push.xml", "cylinder_push"), ("leap_cube.xml", "leap_cube"), ("fr3_pick.xml", "fr3_pick")):
+        m = compile_model(xml_name, task)
+        path = os.path.join(OUT_DIR, task + ".json")
+        with open(path, "w") as f:
+            json.dump(m, f, indent=None, separators=(",", ":"))
+            f.write("\n")
+        nq = sum(7 if j["type"] == "free" else 1 for j in m["joints"])
+        nv = sum(6 if j["type"] == "free" else 1 for j in m["joints"])
+        print(f"{task}: bodies={len(m['bodies'])} joints={len(m['joints'])} nq={nq} nv={nv} geoms={len(m['geoms'])} "
+              f"act={len(m['actuators'])} ns={m['nsensordata']} -> {path}", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
