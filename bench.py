@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the sampling-MPC plan step on MI355X (driver contract: one JSON line on rank 0).
+
+A "step" is one full plan step (`Controller.update_action`): sample -> clip -> spline -> rollout -> cost -> update,
+including the all-gather when several GPUs take part and the device->host copy of the new nominal knots.
+Default workload = BASELINE.json's metric configuration: leap_cube MPPI, 65 536 rollouts x H = 64 (K = 4, cubic,
+sigma = 0.2 ramp 4, lambda = 0.0025), synthetic standard-normal noise drawn on the device (seed 1234 + rank), inputs
+resident in HBM; the plan time advances 0.05 s per step (control_freq 20 Hz).  With N GPUs the 65 536 rollouts are
+sharded (strong scaling: total work fixed) -- one process per GPU, one RCCL all-gather of a 66-float record per step.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = the fused rollout kernel; achieved = algorithmic bytes per launch
+               ((4*K*nu noise + 4 cost) bytes x rollouts on this GPU) / its mean duration measured
+               with HIP events on the launch stream; peak = 8 TB/s HBM3E.
+  cpu_baseline the fp64 oracle (oracle/, kind "port": MuJoCo itself is not installable here) rolling out a bounded
+               sample of the same workload on all host cores, rank 0 at N=1 only.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # task: (optimizer, rollouts, horizon steps)  -- BASELINE.json configs[1..4]
+    "cartpole": ("mppi", 4096, 64),
+    "cylinder_push": ("mppi", 16384, 64),
+    "fr3_pick": ("cem", 32768, 40),
+    "leap_cube": ("mppi", 65536, 64),
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
+    """Oracle rollouts (threaded C, fp64) on the host cores for a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from tests.harness import oracle_plan_step
+
+    cores = os.cpu_count() or 1
+    om = O.Model(task)
+    K, nu, H = ctrl.optimizer.num_nodes, ctrl.nu, ctrl.num_timesteps
+    rng = np.random.default_rng(0)
+    nom = np.tile(ctrl.task.optimizer_warm_start(), (K, 1))
+    n = 4 * cores
+    saved = ctrl.optimizer.config.num_rollouts
+    total_rollouts, total_t = 0, 0.0
+    while True:  # grow the sample until it takes a meaningful time, bounded by seconds_target
+        ctrl.optimizer.config.num_rollouts = n
+        noise = rng.standard_normal((n - 1, K, nu))
+        t0 = time.perf_counter()
+        oracle_plan_step(om, ctrl, nom, noise, nthread=cores)
+        dt = time.perf_counter() - t0
+        total_rollouts, total_t = n, dt
+        if dt > seconds_target / 4 or n >= 65536:
+            break
+        n = int(min(65536, max(2 * n, n * (seconds_target / 2) / max(dt, 1e-3))))
+    ctrl.optimizer.config.num_rollouts = saved
+    return {"value": total_rollouts / total_t, "unit": "rollouts/s", "cores": cores, "kind": "port",
+            "sample": f"{total_rollouts} rollouts x H={H} of the same plan step (fp64 oracle engine, {cores} pthreads), {total_t:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--task", default="leap_cube", choices=sorted(WORKLOADS))
+    ap.add_argument("--optimizer", default=None)
+    ap.add_argument("--rollouts", type=int, default=None)
+    ap.add_argument("--horizon-steps", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from judo_amd.controller import make_controller
+
+    opt_name, N, H = WORKLOADS[args.task]
+    opt_name = args.optimizer or opt_name
+    N = args.rollouts or N
+    H = args.horizon_steps or H
+    ctrl = make_controller(args.task, opt_name)
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.horizon = H * ctrl.task.dt
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if args.task == "leap_cube" else {}
+    ctrl.optimizer.seed(1234 + rank)
+    K, nu = ctrl.optimizer.num_nodes, ctrl.nu
+    assert ctrl.num_timesteps == H
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    t_plan = 0.0
+    for _ in range(args.warmup):
+        ctrl.time = t_plan
+        ctrl.update_action()
+        t_plan += 1.0 / ctrl.controller_cfg.control_freq
+    ctrl.record_kernel_events = True
+    ctrl.kernel_events.clear()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    per_step = []
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        ctrl.time = t_plan
+        ctrl.update_action()
+        t_plan += 1.0 / ctrl.controller_cfg.control_freq
+        per_step.append(time.perf_counter() - ts)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])) if ctrl.kernel_events else float("nan")
+    n_local = ctrl.last_shard.count
+    alg_bytes = (4 * K * nu + 4) * n_local
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        ms = np.array(per_step) * 1e3
+        line = {
+            "metric": "rollouts/sec + plan-step ms, leap_cube MPPI 65536xH64" if args.task == "leap_cube" else f"rollouts/sec + plan-step ms, {args.task}",
+            "value": N * args.steps / elapsed,
+            "unit": "rollouts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
+                       "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters},
+            "plan_step_ms": {"mean": float(ms.mean()), "std": float(ms.std()), "median": float(np.median(ms)), "iqr": float(np.percentile(ms, 75) - np.percentile(ms, 25)),
+                             "min": float(ms.min()), "max": float(ms.max())},
+            "physics_steps_per_s": N * H * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fused rollout+cost", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "latency/VALU-bound by construction (64 serial physics steps per lane); see DESIGN.md section 6"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.task, ctrl)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

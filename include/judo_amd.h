@@ -1,0 +1,115 @@
+/*
+ * judo_amd.h -- C ABI of libjudo_amd.so: the MI355X (gfx950) sampling-MPC rollout engine.
+ *
+ * Drop-in boundary for the hot path of bdaiinstitute/judo v0.0.7
+ * (sample -> clip -> spline -> rollout -> cost -> update).  The reference has no C ABI of its own for
+ * this path: the seam is three Python ABCs (Optimizer, RolloutBackend, Task) plus the pybind11 module
+ * mujoco_extensions/policy_rollout.  Each entry point below names the reference interface it replaces;
+ * INTEGRATION.md shows the ctypes binding a judo maintainer would add.
+ *
+ * Conventions
+ *   - every `const float*` / `float*` is a DEVICE pointer (fp32, contiguous) unless marked HOST;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises;
+ *   - the caller owns every buffer; the library owns only jh_model handles (model constants in device
+ *     memory) -- no hidden allocation on the step path;
+ *   - return 0 on success, a negative jh_status otherwise; jh_last_error() gives the message
+ *     (thread-local).  Functions are re-entrant per jh_model.
+ *   - rollouts are indexed n = 0..N-1 locally, n_offset + n globally; global sample 0 is the
+ *     unperturbed nominal (judo/optimizers/mppi.py:59 `concatenate([nominal[None], noised])`).
+ *   - noise layout is (K, nu, ldn) with the rollout index fastest (64 consecutive lanes read 256
+ *     contiguous bytes); element (k,u,n) at noise[(k*nu+u)*ldn + n].
+ */
+#ifndef JUDO_AMD_H
+#define JUDO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jh_model jh_model;
+
+enum jh_status {
+  JH_OK = 0,
+  JH_ERR_INVALID = -1,   /* bad argument (shape, null pointer, unsupported size) */
+  JH_ERR_HIP = -2,       /* HIP runtime error */
+  JH_ERR_UNSUPPORTED = -3,
+  JH_ERR_BLOB = -4       /* malformed model blob */
+};
+
+enum jh_task_kind { JH_TASK_CARTPOLE = 0, JH_TASK_CYLINDER_PUSH = 1, JH_TASK_LEAP_CUBE = 2, JH_TASK_FR3_PICK = 3 };
+enum jh_spline_kind { JH_SPLINE_ZERO = 0, JH_SPLINE_LINEAR = 1, JH_SPLINE_CUBIC = 3 };
+
+#define JH_MAX_TASK_PARAMS 32
+#define JH_MAX_KNOT_DIM 128 /* K * nu */
+#define JH_MAX_ELITES 8
+
+const char* jh_last_error(void);
+int jh_version(void);
+
+/* Model constants (the MjModel the reference deep-copies per thread, judo/utils/mj_rollout_backend.py:41):
+ * `blob` is a HOST buffer produced by judo_amd.models.pack_model(); it is parsed and uploaded to `device`. */
+int jh_model_create(const void* blob, size_t nbytes, int device, jh_model** out);
+void jh_model_destroy(jh_model* m);
+/* dims[0..5] = nq, nv, nu, nsensordata, task kind, ntaskparams */
+int jh_model_dims(const jh_model* m, int* dims /* HOST */);
+
+/* Fused plan-step kernel.  Replaces, for N rollouts in one launch:
+ *   Optimizer.sample_control_knots         judo/optimizers/{mppi.py:38-59,ps.py:29-50,cem.py:55-74}
+ *   np.clip to actuator_ctrlrange          judo/controller/controller.py:253-257
+ *   make_spline(...)(t + dt*arange(H))     judo/controller/controller.py:261-262  (as the H x K matrix W)
+ *   RolloutBackend.rollout                 judo/utils/mj_rollout_backend.py:45-88 (mj_step x H)
+ *   Task.reward                            judo/tasks/{cartpole.py:42,cylinder_push.py:50,leap_cube.py:63,fr3_pick.py:225}
+ * costs[n] = -reward of rollout n.  knots_out (optional, may be NULL) receives the clipped candidates in
+ * (K, nu, ldn) layout.  `phase` is the fr3_pick phase chosen on the host by Task.pre_rollout
+ * (judo/tasks/fr3_pick.py:191-223); ignored by the other tasks. */
+int jh_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                    const float* W, const float* ctrl_lo_hi, const float* task_params, int phase, int N, int n_offset, int H, int K,
+                    float* costs, float* knots_out, void* stream);
+
+/* Drop-in RolloutBackend.rollout(x0, controls) -> (states, sensors)   judo/utils/rollout_backend.py:20-39.
+ * controls (N,H,nu), states (N,H,nq+nv), sensors (N,H,nsensordata), all row-major; x0 is (nq+nv) or, when
+ * x0_batched, (N,nq+nv).  states[n,h] is the state AFTER applying controls[n,h]; sensors[n,h] is what the
+ * forward pass at the start of that step computed (MuJoCo semantics). */
+int jh_rollout_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
+                           float* sensors, void* stream);
+
+/* Task.reward on materialised device arrays (same task_params as jh_rollout_cost); rewards[n] (not negated). */
+int jh_task_reward(const jh_model* m, const float* states, const float* sensors, const float* controls, const float* task_params,
+                   int phase, int N, int H, float* rewards, void* stream);
+
+/* Optimizer.sample_control_knots for callers that want the (N,K,nu) row-major array itself
+ * (row n = nominal + sigma * noise[:, :, n], row 0 of global index 0 = nominal), optionally clipped. */
+int jh_sample_knots(const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi /* NULL = no clip */,
+                    int N, int n_offset, int K, int nu, float* knots_nku, void* stream);
+
+/* MPPI.update_nominal_knots (judo/optimizers/mppi.py:61-82), shard-local part.
+ * Writes one record rec[0] = beta = min cost, rec[1] = S = sum exp(-(c-beta)/lambda), rec[2..2+K*nu) = sum w*knots.
+ * Knots come either from `knots_nku` ((N,K,nu) row-major, the drop-in path) or, when it is NULL, are recomputed as
+ * clip(nominal + sigma*noise) from the (K,nu,ldn) noise (the fused path: noise is read once more, never stored).
+ * `scratch` must hold jh_update_scratch_floats(N,K,nu) floats. */
+size_t jh_update_scratch_floats(int N, int K, int nu);
+int jh_mppi_partial(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
+                    const float* ctrl_lo_hi, int N, int n_offset, int K, int nu, float lambda, float* scratch, float* rec, void* stream);
+/* Merge G shard records (after the all-gather) with a log-sum-exp rescale: nominal_out = sum_g e_g V_g / sum_g e_g S_g,
+ * e_g = exp(-(beta_g - min beta)/lambda).  Identical result on every rank. */
+int jh_mppi_merge(const float* recs, int G, int K, int nu, float lambda, float* nominal_out, void* stream);
+
+/* CrossEntropyMethod / PredictiveSampling updates (judo/optimizers/cem.py:76-92, ps.py:52-65), shard-local part:
+ * the k best rollouts (largest reward = smallest cost; ties: higher global index first when tie_high != 0, which is
+ * what flip(argsort(.)) yields for a stable sort, lower index first otherwise = np.argmax), each as a record
+ * [cost, global index, knots(K*nu)].  rec holds k such records. */
+int jh_topk_partial(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
+                    const float* ctrl_lo_hi, int N, int n_offset, int K, int nu, int k, int tie_high, float* scratch, float* rec,
+                    void* stream);
+/* Merge G*k records -> global k elites -> mean and clipped population std (ddof 0).  sigma_out may be NULL (PS, k=1). */
+int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float sigma_min, float sigma_max, float* nominal_out,
+                   float* sigma_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+"""ctypes binding of `libjudo_amd.so` (the C ABI declared in `include/judo_amd.h`).
+
+There is no fallback: if the HIP library is missing the import of any compute entry point raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjudo_amd.so")
+
+_lib: C.CDLL | None = None
+
+f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+_SIGNATURES = {
+    "jh_last_error": (C.c_char_p, []),
+    "jh_version": (C.c_int, []),
+    "jh_model_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "jh_model_destroy": (None, [C.c_void_p]),
+    "jh_model_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "jh_rollout_cost": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
+    "jh_rollout_materialize": (C.c_int, [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
+    "jh_task_reward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
+    "jh_sample_knots": (C.c_int, [f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
+    "jh_update_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "jh_mppi_partial": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p, f32p, C.c_void_p]),
+    "jh_mppi_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_float, f32p, C.c_void_p]),
+    "jh_topk_partial": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
+    "jh_elite_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class JudoAmdError(RuntimeError):
+    """A HIP/runtime failure reported by libjudo_amd.so."""
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the MI355X engine has no CPU fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    """Map a jh_status to the reference's error behaviour: shape/argument errors -> ValueError
+    (the conditions judo/utils/mj_rollout_backend.py:78-82 asserts), runtime errors -> RuntimeError."""
+    if status == 0:
+        return
+    msg = lib().jh_last_error().decode("utf-8", "replace")
+    if status == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise JudoAmdError(f"{what} failed (status {status}): {msg}")
+
+
+def ptr(t) -> int | None:
+    """data_ptr of a torch tensor (None passes a NULL pointer)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,117 @@
+"""Hyper-parameter dataclasses of the hot path, with the reference's task-keyed override table.
+
+Mirrors (names, fields, defaults, override semantics):
+  judo/config.py:13-96                  OverridableConfig.set_override / set_config_overrides
+  judo/optimizers/base.py:15-21         OptimizerConfig
+  judo/optimizers/mppi.py:14-18         MPPIConfig
+  judo/optimizers/cem.py:12-17          CrossEntropyMethodConfig
+  judo/optimizers/ps.py:11-14           PredictiveSamplingConfig
+  judo/controller/controller.py:34-42   ControllerConfig
+  judo/optimizers/overrides.py, judo/controller/overrides.py   (the shipped per-task values; checked
+                                        against tests/golden/configs.json, generated from the reference)
+The GUI `@slider` metadata of the reference is not part of the hot path and is not mirrored.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+from typing import Any, Literal
+
+import numpy as np
+
+_OVERRIDES: dict[type, dict[str, dict[str, Any]]] = {}
+
+
+def set_config_overrides(override_key: str, cls: type, field_override_values: dict[str, Any]) -> None:
+    """Register per-key field values for a config class (unknown field names are rejected)."""
+    if not dataclasses.is_dataclass(cls):
+        raise TypeError(f"{cls.__name__} is not a dataclass")
+    names = {f.name for f in dataclasses.fields(cls)}
+    unknown = set(field_override_values) - names
+    if unknown:
+        raise KeyError(f"{cls.__name__} has no field(s) {sorted(unknown)}")
+    _OVERRIDES.setdefault(cls, {}).setdefault(override_key, {}).update(field_override_values)
+
+
+@dataclass
+class OverridableConfig:
+    """A config whose fields can be switched to a registered per-key (per-task) set of values."""
+
+    def set_override(self, key: str, reset_to_defaults: bool = True) -> None:
+        chosen = _OVERRIDES.get(type(self), {}).get(key, {})
+        for f in dataclasses.fields(self):
+            if chosen.get(f.name) is not None:
+                setattr(self, f.name, chosen[f.name])
+            elif reset_to_defaults:
+                if f.default is not dataclasses.MISSING:
+                    setattr(self, f.name, f.default)
+                elif f.default_factory is not dataclasses.MISSING:  # type: ignore[misc]
+                    setattr(self, f.name, f.default_factory())  # type: ignore[misc]
+
+
+@dataclass
+class OptimizerConfig(OverridableConfig):
+    num_rollouts: int = 16
+    num_nodes: int = 4
+    use_noise_ramp: bool = False
+    noise_ramp: float = 2.5
+
+
+@dataclass
+class MPPIConfig(OptimizerConfig):
+    sigma: float = 0.1
+    temperature: float = 0.05
+
+
+@dataclass
+class CrossEntropyMethodConfig(OptimizerConfig):
+    sigma_min: float = 0.1
+    sigma_max: float = 1.0
+    num_elites: int = 2
+
+
+@dataclass
+class PredictiveSamplingConfig(OptimizerConfig):
+    sigma: float = 0.05
+
+
+@dataclass
+class ControllerConfig(OverridableConfig):
+    horizon: float = 1.0
+    spline_order: Literal["zero", "linear", "cubic"] = "linear"
+    control_freq: float = 20.0
+    max_opt_iters: int = 1
+    max_num_traces: int = 5
+    action_normalizer: Literal["none", "min_max", "running"] = "none"
+
+
+def _register_shipped_overrides() -> None:
+    """The values the reference ships for the four BASELINE tasks (+ the leap variants)."""
+    ramp = {"num_nodes": 4, "num_rollouts": 32, "use_noise_ramp": True}
+    for task in ("cylinder_push", "cartpole"):
+        set_config_overrides(task, PredictiveSamplingConfig, dict(ramp))
+        set_config_overrides(task, CrossEntropyMethodConfig, dict(ramp, num_elites=2))
+        set_config_overrides(task, MPPIConfig, dict(ramp))
+        set_config_overrides(task, ControllerConfig, {"horizon": 1.0, "spline_order": "zero"})
+    for task, n_cem_mppi in (("leap_cube", 32), ("leap_cube_down", 64), ("caltech_leap_cube", 32)):
+        set_config_overrides(task, PredictiveSamplingConfig, dict(ramp, noise_ramp=4.0, sigma=0.2))
+        set_config_overrides(task, CrossEntropyMethodConfig, dict(ramp, num_rollouts=n_cem_mppi, num_elites=3, noise_ramp=4.0))
+        set_config_overrides(task, MPPIConfig, dict(ramp, num_rollouts=n_cem_mppi, noise_ramp=4.0, sigma=0.2, temperature=0.0025))
+        set_config_overrides(task, ControllerConfig, {"horizon": 1.0, "spline_order": "cubic", "max_num_traces": 1})
+    fr3 = {"num_nodes": 4, "num_rollouts": 64, "use_noise_ramp": True, "noise_ramp": 4.0}
+    set_config_overrides("fr3_pick", PredictiveSamplingConfig, dict(fr3, num_nodes=8, sigma=0.2))
+    set_config_overrides("fr3_pick", CrossEntropyMethodConfig, dict(fr3, sigma_min=0.01, sigma_max=0.3, num_elites=3))
+    set_config_overrides("fr3_pick", MPPIConfig, dict(fr3, sigma=0.01, temperature=0.002))
+    set_config_overrides("fr3_pick", ControllerConfig, {"horizon": 1.0, "spline_order": "linear", "max_num_traces": 3})
+
+
+_register_shipped_overrides()
+
+
+def as_plain_dict(cfg: Any) -> dict[str, Any]:
+    out = {}
+    for f in dataclasses.fields(cfg):
+        v = getattr(cfg, f.name)
+        out[f.name] = v.tolist() if isinstance(v, np.ndarray) else v
+    return out

@@ -1,0 +1,99 @@
+// jh_api.hip -- C-ABI entry points of libjudo_amd.so (argument checks, model handles, dispatch).
+#include <cstring>
+
+#include "jh_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void jh_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* jh_last_error(void) { return g_err; }
+extern "C" int jh_version(void) { return 100; }
+
+extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_model** out) {
+  JH_REQUIRE(blob && out, "model_create: null pointer");
+  if (nbytes < sizeof(jh_blob_header)) { jh_set_error("model_create: blob too small (%zu bytes)", nbytes); return JH_ERR_BLOB; }
+  jh_blob_header h;
+  memcpy(&h, blob, sizeof(h));
+  if (h.magic != JH_BLOB_MAGIC || h.version != JH_BLOB_VERSION) { jh_set_error("model_create: bad magic/version (%08x, %u)", h.magic, h.version); return JH_ERR_BLOB; }
+  size_t need = sizeof(h) + 4 * ((size_t)h.nfloat + h.nint);
+  if (nbytes != need) { jh_set_error("model_create: blob size %zu != expected %zu", nbytes, need); return JH_ERR_BLOB; }
+  if (h.kind > JH_TASK_FR3_PICK) { jh_set_error("model_create: unknown task kind %u", h.kind); return JH_ERR_BLOB; }
+  if (h.kind == JH_TASK_CARTPOLE && h.nfloat < CP_NPARAM) { jh_set_error("model_create: cartpole blob has %u floats, need %d", h.nfloat, CP_NPARAM); return JH_ERR_BLOB; }
+  if (h.kind == JH_TASK_CYLINDER_PUSH && h.nfloat < CY_NPARAM) { jh_set_error("model_create: cylinder blob has %u floats, need %d", h.nfloat, CY_NPARAM); return JH_ERR_BLOB; }
+  if (h.ntaskparam > JH_MAX_TASK_PARAMS) { jh_set_error("model_create: too many task params"); return JH_ERR_BLOB; }
+  JH_HIP(hipSetDevice(device));
+  jh_model* m = new jh_model();
+  m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr;
+  const char* p = (const char*)blob + sizeof(h);
+  m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
+  m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
+  hipError_t e = hipMalloc(&m->d_f, 4 * (m->nf ? m->nf : 1));
+  if (e == hipSuccess) e = hipMalloc(&m->d_i, 4 * (m->ni ? m->ni : 1));
+  if (e == hipSuccess && m->nf) e = hipMemcpy(m->d_f, m->h_f.data(), 4 * m->nf, hipMemcpyHostToDevice);
+  if (e == hipSuccess && m->ni) e = hipMemcpy(m->d_i, m->h_i.data(), 4 * m->ni, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    jh_set_error("model_create: device upload failed: %s", hipGetErrorString(e));
+    if (m->d_f) (void)hipFree(m->d_f);
+    if (m->d_i) (void)hipFree(m->d_i);
+    delete m;
+    return JH_ERR_HIP;
+  }
+  *out = m;
+  return JH_OK;
+}
+
+extern "C" void jh_model_destroy(jh_model* m) {
+  if (!m) return;
+  if (m->d_f) (void)hipFree(m->d_f);
+  if (m->d_i) (void)hipFree(m->d_i);
+  delete m;
+}
+
+extern "C" int jh_model_dims(const jh_model* m, int* dims) {
+  JH_REQUIRE(m && dims, "model_dims: null pointer");
+  dims[0] = m->nq; dims[1] = m->nv; dims[2] = m->nu; dims[3] = m->ns; dims[4] = m->kind; dims[5] = m->ntaskparam;
+  return JH_OK;
+}
+
+extern "C" int jh_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                               const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
+                               float* knots_out, void* stream) {
+  JH_REQUIRE(m && x0 && nominal && noise && sigma && W && lohi && tp && costs, "rollout_cost: null pointer");
+  JH_REQUIRE(N > 0 && H > 0 && K >= 1, "rollout_cost: N, H, K must be positive (N=%d H=%d K=%d)", N, H, K);
+  JH_REQUIRE(ldn >= N, "rollout_cost: ldn (%d) < N (%d)", ldn, N);
+  JH_REQUIRE(K * m->nu <= JH_MAX_KNOT_DIM, "rollout_cost: K*nu = %d exceeds %d", K * m->nu, JH_MAX_KNOT_DIM);
+  JH_REQUIRE(n_offset >= 0, "rollout_cost: negative n_offset");
+  hipStream_t st = (hipStream_t)stream;
+  if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH)
+    return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+  return jh_engine_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
+}
+
+extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
+                                      float* sensors, void* stream) {
+  JH_REQUIRE(m && x0 && controls, "rollout_materialize: null pointer");
+  JH_REQUIRE(states || sensors, "rollout_materialize: both outputs are null");
+  JH_REQUIRE(N > 0 && H > 0, "rollout_materialize: N and H must be positive (N=%d H=%d)", N, H);
+  hipStream_t st = (hipStream_t)stream;
+  if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) return jh_simple_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  return jh_engine_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+}
+
+extern "C" int jh_task_reward(const jh_model* m, const float* states, const float* sensors, const float* controls, const float* tp, int phase, int N,
+                              int H, float* rewards, void* stream) {
+  JH_REQUIRE(m && states && tp && rewards, "task_reward: null pointer");
+  JH_REQUIRE(N > 0 && H > 0, "task_reward: N and H must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) {
+    JH_REQUIRE(m->kind != JH_TASK_CARTPOLE || controls, "task_reward: cartpole needs controls");
+    return jh_simple_reward(m, states, controls, tp, N, H, rewards, st);
+  }
+  return jh_engine_reward(m, states, sensors, controls, tp, phase, N, H, rewards, st);
+}

@@ -1,0 +1,94 @@
+// jh_internal.h -- shared definitions of libjudo_amd.so (gfx950 only; no other backend exists).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "judo_amd.h"
+
+#define JH_BLOB_MAGIC 0x314D484Au /* "JHM1" */
+#define JH_BLOB_VERSION 1u
+
+// Host-side blob header produced by judo_amd/models.py::pack_model (little-endian, 64 bytes):
+struct jh_blob_header {
+  uint32_t magic, version, kind, nq, nv, nu, ns, ntaskparam, nfloat, nint;
+  uint32_t reserved[6];
+};
+
+struct jh_model {
+  int device, kind, nq, nv, nu, ns, ntaskparam;
+  size_t nf, ni;
+  float* d_f;  // device copy of the float section
+  int* d_i;    // device copy of the int section
+  std::vector<float> h_f;
+  std::vector<int> h_i;
+};
+
+void jh_set_error(const char* fmt, ...);
+
+#define JH_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      jh_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return JH_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define JH_REQUIRE(cond, ...)    \
+  do {                           \
+    if (!(cond)) {               \
+      jh_set_error(__VA_ARGS__); \
+      return JH_ERR_INVALID;     \
+    }                            \
+  } while (0)
+
+// ---- float-section layouts of the two closed-form models (written by judo_amd/models.py) -------------------
+// cartpole (judo/models/xml/cartpole.xml): 2 DoF, contacts disabled, Euler + implicit joint damping
+enum {
+  CP_DT = 0, CP_G, CP_MCART, CP_MPOLE, CP_L, CP_IPOLE, CP_DAMP_X, CP_DAMP_TH, CP_KP, CP_KV, CP_CTRL_LO, CP_CTRL_HI, CP_CTRL_LIMITED,
+  CP_FRC_LO, CP_FRC_HI, CP_FRC_LIMITED, CP_X_LO, CP_X_HI, CP_X_LIMITED, CP_LIM_K, CP_LIM_B, CP_SOLIMP0, CP_SOLIMP1, CP_SOLIMP2,
+  CP_SOLIMP3, CP_SOLIMP4, CP_INVW_X, CP_TIP, CP_NPARAM
+};
+// cylinder_push (judo/models/xml/cylinder_push.xml): 4 slide DoF, one circle-circle contact, Euler + implicit damping
+enum {
+  CY_DT = 0, CY_MP, CY_MC, CY_DAMP_P, CY_DAMP_C, CY_KP, CY_KV, CY_CTRL_LO, CY_CTRL_HI, CY_CTRL_LIMITED, CY_FRC_LO, CY_FRC_HI,
+  CY_FRC_LIMITED, CY_RSUM, CY_CON_K, CY_CON_B, CY_SOLIMP0, CY_SOLIMP1, CY_SOLIMP2, CY_SOLIMP3, CY_SOLIMP4, CY_TRAN, CY_MU, CY_SITE_Z,
+  CY_MARGIN, CY_NPARAM
+};
+
+// ---- launchers implemented per translation unit ------------------------------------------------------------
+int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                           const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
+                           float* knots_out, hipStream_t st);
+int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
+                          float* sensors, hipStream_t st);
+int jh_simple_reward(const jh_model* m, const float* states, const float* controls, const float* tp, int N, int H, float* rewards, hipStream_t st);
+
+int jh_engine_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                           const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
+                           float* knots_out, hipStream_t st);
+int jh_engine_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
+                          float* sensors, hipStream_t st);
+int jh_engine_reward(const jh_model* m, const float* states, const float* sensors, const float* controls, const float* tp, int phase, int N,
+                     int H, float* rewards, hipStream_t st);
+
+// ---- device helpers ------------------------------------------------------------------------------------------
+// MuJoCo's impedance curve d(x) (solimp = dmin, dmax, width, midpoint, power), x = |pos - margin| / width.
+__device__ __forceinline__ float jh_impedance(float s0, float s1, float s2, float s3, float s4, float dist) {
+  if (s0 == s1 || s2 <= 1e-15f) return 0.5f * (s0 + s1);
+  float x = fabsf(dist / s2);
+  if (x >= 1.f) return s1;
+  if (x <= 0.f) return s0;
+  float y;
+  if (s4 == 1.f) y = x;
+  else if (x <= s3) y = __powf(x, s4) / __powf(s3, s4 - 1.f);
+  else y = 1.f - __powf(1.f - x, s4) / __powf(1.f - s3, s4 - 1.f);
+  return s0 + y * (s1 - s0);
+}
+
+__device__ __forceinline__ float jh_clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }

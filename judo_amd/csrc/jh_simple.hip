@@ -1,0 +1,295 @@
+// jh_simple.hip -- closed-form rollout kernels for the two low-DoF tasks (gfx950).
+//
+//   cartpole       judo/models/xml/cartpole.xml:1-45       2 DoF (slide x, hinge y), no contact, cart joint limit,
+//                                                          position servo kp=100 with +-10 N force clamp
+//   cylinder_push  judo/models/xml/cylinder_push.xml:1-45  4 slide DoF, one circle-circle contact (pusher <-> cart),
+//                                                          frictionless (mu clamped to 1e-5), pyramidal cone
+//
+// One lane owns one rollout (wave64, one wave per workgroup so that small N still spreads over the CUs).  The H x K
+// spline matrix, nominal knots, per-knot sigma, control bounds, x0, the model constants and the cost weights are
+// staged in LDS once per workgroup; each lane's clipped knots live in LDS (lane-fastest, bank-conflict free);
+// noise is read coalesced from the (K,nu,N) layout exactly once; the running cost is accumulated inside the
+// integration loop and only one float per rollout is written back.
+//
+// Physics = MuJoCo's Euler step with implicit joint damping, restated in closed form for these two models
+// (derivation in DESIGN.md section 4): semi-implicit update  v += h*a ; q += h*v  with
+// a = (M + h*diag(damping))^-1 (qfrc_smooth + qfrc_constraint); soft constraints by solref/solimp.
+#include "jh_internal.h"
+
+namespace {
+
+constexpr int kBlock = 64;
+
+struct SplineCtx {
+  const float* W;      // LDS  H*K
+  const float* knots;  // LDS  (K*nu) x kBlock, lane fastest
+  int K;
+};
+
+template <int NU>
+__device__ __forceinline__ void spline_controls(const SplineCtx& s, int h, int lane, float* u) {
+#pragma unroll
+  for (int j = 0; j < NU; j++) u[j] = 0.f;
+  for (int k = 0; k < s.K; k++) {
+    float w = s.W[h * s.K + k];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = fmaf(w, s.knots[(k * NU + j) * kBlock + lane], u[j]);
+  }
+}
+
+__device__ __forceinline__ float impedance_pow(const float* si, float dist) {
+  float s0 = si[0], s1 = si[1], s2 = si[2], s3 = si[3], s4 = si[4];
+  if (s0 == s1 || s2 <= 1e-15f) return 0.5f * (s0 + s1);
+  float x = fabsf(dist / s2);
+  if (x >= 1.f) return s1;
+  if (x <= 0.f) return s0;
+  float y;
+  if (s4 == 1.f) y = x;
+  else if (s4 == 2.f) y = (x <= s3) ? x * x / s3 : 1.f - (1.f - x) * (1.f - x) / (1.f - s3);
+  else if (x <= s3) y = powf(x, s4) / powf(s3, s4 - 1.f);
+  else y = 1.f - powf(1.f - x, s4) / powf(1.f - s3, s4 - 1.f);
+  return s0 + y * (s1 - s0);
+}
+
+// ------------------------------------------------------------------------------------------------ cartpole
+struct Cartpole {
+  static constexpr int NX = 4, NU = 1, NS = 6, NP = CP_NPARAM, NTP = 6;
+  float x, th, xd, thd;
+  __device__ void load(const float* x0) { x = x0[0]; th = x0[1]; xd = x0[2]; thd = x0[3]; }
+  __device__ void store(float* o) const { o[0] = x; o[1] = th; o[2] = xd; o[3] = thd; }
+  // framepos of the sites trace_cart (cart origin) and trace_pole (pole tip), cartpole.xml:27,31,41-42
+  __device__ void sensors(const float* P, float* s) const {
+    float sn, cs; sincosf(th, &sn, &cs);
+    s[0] = x; s[1] = 0.f; s[2] = 0.f; s[3] = x + P[CP_TIP] * sn; s[4] = 0.f; s[5] = P[CP_TIP] * cs;
+  }
+  __device__ void step(const float* P, const float* u) {
+    const float h = P[CP_DT], mp = P[CP_MPOLE], l = P[CP_L];
+    float sn, cs; sincosf(th, &sn, &cs);
+    // joint-space inertia and its inverse
+    float m11 = P[CP_MCART] + mp, m12 = mp * l * cs, m22 = P[CP_IPOLE] + mp * l * l;
+    // bias = Coriolis/centrifugal + gravity; passive = -damping*v; actuator = clamp(kp*(clamp(u) - x) - kv*xd)
+    float c = u[0];
+    if (P[CP_CTRL_LIMITED] != 0.f) c = jh_clampf(c, P[CP_CTRL_LO], P[CP_CTRL_HI]);
+    float fa = P[CP_KP] * (c - x) - P[CP_KV] * xd;
+    if (P[CP_FRC_LIMITED] != 0.f) fa = jh_clampf(fa, P[CP_FRC_LO], P[CP_FRC_HI]);
+    float f1 = -P[CP_DAMP_X] * xd + mp * l * sn * thd * thd + fa;
+    float f2 = -P[CP_DAMP_TH] * thd + mp * P[CP_G] * l * sn;
+    // cart joint limit: one-sided soft constraint, solved in closed form (a single row)
+    float fc = 0.f;
+    if (P[CP_X_LIMITED] != 0.f) {
+      float dlo = x - P[CP_X_LO], dhi = P[CP_X_HI] - x;
+      float dist = fminf(dlo, dhi);
+      if (dist < 0.f) {
+        float J = dlo < dhi ? 1.f : -1.f;
+        float det = m11 * m22 - m12 * m12;
+        float a0x = (m22 * f1 - m12 * f2) / det;  // unconstrained cart acceleration
+        float A = m22 / det;                      // J Minv J'
+        float imp = impedance_pow(P + CP_SOLIMP0, dist);
+        float R = fmaxf(1e-15f, (1.f - imp) / imp * P[CP_INVW_X]);
+        float aref = -P[CP_LIM_B] * (J * xd) - P[CP_LIM_K] * imp * dist;
+        float lam = fmaxf(0.f, (aref - J * a0x) / (A + R));
+        fc = J * lam;
+      }
+    }
+    // Euler with implicit damping: (M + h*D) a = qfrc_smooth + qfrc_constraint
+    float a11 = m11 + h * P[CP_DAMP_X], a22 = m22 + h * P[CP_DAMP_TH];
+    float r1 = f1 + fc, r2 = f2;
+    float det = a11 * a22 - m12 * m12;
+    float ax = (a22 * r1 - m12 * r2) / det, ath = (a11 * r2 - m12 * r1) / det;
+    xd = fmaf(h, ax, xd); thd = fmaf(h, ath, thd);
+    x = fmaf(h, xd, x); th = fmaf(h, thd, th);
+  }
+  // running cost of judo/tasks/cartpole.py:61-78 (w = w_vertical,w_centered,w_velocity,w_control,p_vertical,p_centered)
+  __device__ float cost(const float* w, const float* u) const {
+    float cv = cosf(th) - 1.f;
+    return w[0] * (sqrtf(cv * cv + w[4] * w[4]) - w[4]) + w[1] * (sqrtf(x * x + w[5] * w[5]) - w[5]) +
+           w[2] * 0.5f * (xd * xd + thd * thd) + w[3] * 0.5f * u[0] * u[0];
+  }
+  __device__ static float finish(float acc, int /*H*/) { return acc; }
+};
+
+// ------------------------------------------------------------------------------------------------ cylinder_push
+struct CylinderPush {
+  static constexpr int NX = 8, NU = 2, NS = 6, NP = CY_NPARAM, NTP = 6;
+  float px, py, cx, cy, pvx, pvy, cvx, cvy;
+  __device__ void load(const float* x0) { px = x0[0]; py = x0[1]; cx = x0[2]; cy = x0[3]; pvx = x0[4]; pvy = x0[5]; cvx = x0[6]; cvy = x0[7]; }
+  __device__ void store(float* o) const { o[0] = px; o[1] = py; o[2] = cx; o[3] = cy; o[4] = pvx; o[5] = pvy; o[6] = cvx; o[7] = cvy; }
+  __device__ void sensors(const float* P, float* s) const { s[0] = px; s[1] = py; s[2] = P[CY_SITE_Z]; s[3] = cx; s[4] = cy; s[5] = P[CY_SITE_Z]; }
+  __device__ void step(const float* P, const float* u) {
+    const float h = P[CY_DT];
+    float c0 = u[0], c1 = u[1];
+    if (P[CY_CTRL_LIMITED] != 0.f) { c0 = jh_clampf(c0, P[CY_CTRL_LO], P[CY_CTRL_HI]); c1 = jh_clampf(c1, P[CY_CTRL_LO], P[CY_CTRL_HI]); }
+    float fx = P[CY_KP] * (c0 - px) - P[CY_KV] * pvx, fy = P[CY_KP] * (c1 - py) - P[CY_KV] * pvy;
+    if (P[CY_FRC_LIMITED] != 0.f) { fx = jh_clampf(fx, P[CY_FRC_LO], P[CY_FRC_HI]); fy = jh_clampf(fy, P[CY_FRC_LO], P[CY_FRC_HI]); }
+    float mp = P[CY_MP], mc = P[CY_MC];
+    float sp0 = -P[CY_DAMP_P] * pvx + fx, sp1 = -P[CY_DAMP_P] * pvy + fy;  // qfrc_smooth (no gravity / Coriolis in the plane)
+    float sc0 = -P[CY_DAMP_C] * cvx, sc1 = -P[CY_DAMP_C] * cvy;
+    // circle-circle contact; normal from the pusher (geom 1) to the cart (geom 2)
+    float dx = cx - px, dy = cy - py, dn = sqrtf(dx * dx + dy * dy);
+    float dist = dn - P[CY_RSUM];
+    float q0 = 0.f, q1 = 0.f;  // constraint force on the cart (= -force on the pusher)
+    if (dist < P[CY_MARGIN] && dn > 1e-12f) {
+      float nx = dx / dn, ny = dy / dn;
+      float imp = impedance_pow(P + CY_SOLIMP0, dist - P[CY_MARGIN]);
+      float mu = P[CY_MU];
+      // pyramidal cone with mu -> 1e-5: the 2*(condim-1) edge rows coincide with the normal row up to O(mu); their common
+      // regulariser is Rpy = 2 mu^2 R_n, so the summed normal force obeys (A + Rpy/4) F = aref - J a0
+      float Rn = fmaxf(1e-15f, (1.f - imp) / imp * P[CY_TRAN] * (1.f + mu * mu));
+      float Rpy = fmaxf(1e-15f, 2.f * mu * mu * Rn);
+      float vn = (cvx - pvx) * nx + (cvy - pvy) * ny;
+      float aref = -P[CY_CON_B] * vn - P[CY_CON_K] * imp * (dist - P[CY_MARGIN]);
+      float a0n = (sc0 / mc - sp0 / mp) * nx + (sc1 / mc - sp1 / mp) * ny;
+      float A = 1.f / mp + 1.f / mc;
+      float F = fmaxf(0.f, (aref - a0n) / (A + 0.25f * Rpy));
+      q0 = F * nx; q1 = F * ny;
+    }
+    float ip = 1.f / (mp + h * P[CY_DAMP_P]), ic = 1.f / (mc + h * P[CY_DAMP_C]);
+    pvx = fmaf(h, (sp0 - q0) * ip, pvx); pvy = fmaf(h, (sp1 - q1) * ip, pvy);
+    cvx = fmaf(h, (sc0 + q0) * ic, cvx); cvy = fmaf(h, (sc1 + q1) * ic, cvy);
+    px = fmaf(h, pvx, px); py = fmaf(h, pvy, py); cx = fmaf(h, cvx, cx); cy = fmaf(h, cvy, cy);
+  }
+  // judo/tasks/cylinder_push.py:65-93 (w = w_pusher_proximity, w_pusher_velocity, w_cart_position, offset, goal_x, goal_y)
+  __device__ float cost(const float* w, const float* /*u*/) const {
+    float gx = w[4] - cx, gy = w[5] - cy, gn = sqrtf(gx * gx + gy * gy);
+    float tx = cx - w[3] * gx / gn, ty = cy - w[3] * gy / gn;  // no epsilon guard, as in the reference
+    float ex = px - tx, ey = py - ty;
+    return w[0] * 0.5f * (ex * ex + ey * ey) + w[1] * 0.5f * (pvx * pvx + pvy * pvy) + w[2] * 0.5f * (gx * gx + gy * gy);
+  }
+  __device__ static float finish(float acc, int /*H*/) { return acc; }
+};
+
+// ------------------------------------------------------------------------------------------------ kernels
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict__ P, const float* __restrict__ x0,
+                                                         const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
+                                                         const float* __restrict__ sigma, const float* __restrict__ W,
+                                                         const float* __restrict__ lohi, const float* __restrict__ tp, int N, int n_offset,
+                                                         int H, int K, float* __restrict__ costs, float* __restrict__ knots_out) {
+  extern __shared__ float lds[];
+  const int KU = K * T::NU;
+  float* sW = lds;                 // H*K
+  float* sKn = sW + H * K;         // KU * kBlock
+  float* sP = sKn + KU * kBlock;   // NP
+  float* sTp = sP + T::NP;         // NTP
+  float* sX0 = sTp + T::NTP;       // NX
+  const int lane = threadIdx.x;
+  for (int i = lane; i < H * K; i += kBlock) sW[i] = W[i];
+  for (int i = lane; i < T::NP; i += kBlock) sP[i] = P[i];
+  for (int i = lane; i < T::NTP; i += kBlock) sTp[i] = tp[i];
+  for (int i = lane; i < T::NX; i += kBlock) sX0[i] = x0[i];
+  const int n = blockIdx.x * kBlock + lane;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  // sample + clip: knot = clip(nominal + sigma * noise); global sample 0 keeps the nominal (also clipped, controller.py:253)
+  for (int i = 0; i < KU; i++) {
+    float v = nominal[i];
+    if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
+    int u = i % T::NU;
+    v = jh_clampf(v, lohi[u], lohi[T::NU + u]);
+    sKn[i * kBlock + lane] = v;
+    if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
+  }
+  __syncthreads();
+  T s; s.load(sX0);
+  SplineCtx sp{sW, sKn, K};
+  float acc = 0.f;
+  for (int h = 0; h < H; h++) {
+    float u[T::NU];
+    spline_controls<T::NU>(sp, h, lane, u);
+    s.step(sP, u);
+    acc += s.cost(sTp, u);
+  }
+  if (live) costs[n] = T::finish(acc, H);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_materialize(const float* __restrict__ P, const float* __restrict__ x0, int x0_batched,
+                                                        const float* __restrict__ controls, int N, int H, float* __restrict__ states,
+                                                        float* __restrict__ sensors) {
+  __shared__ float sP[T::NP];
+  for (int i = threadIdx.x; i < T::NP; i += kBlock) sP[i] = P[i];
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float xi[T::NX];
+#pragma unroll
+  for (int i = 0; i < T::NX; i++) xi[i] = x0[(x0_batched ? (size_t)n * T::NX : 0) + i];
+  T s; s.load(xi);
+  for (int h = 0; h < H; h++) {
+    float u[T::NU], o[T::NX], y[T::NS];
+#pragma unroll
+    for (int j = 0; j < T::NU; j++) u[j] = controls[((size_t)n * H + h) * T::NU + j];
+    s.sensors(sP, y);  // sensor values belong to the forward pass at the start of the step
+    s.step(sP, u);
+    s.store(o);
+    if (states) {
+#pragma unroll
+      for (int i = 0; i < T::NX; i++) states[((size_t)n * H + h) * T::NX + i] = o[i];
+    }
+    if (sensors) {
+#pragma unroll
+      for (int i = 0; i < T::NS; i++) sensors[((size_t)n * H + h) * T::NS + i] = y[i];
+    }
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_reward(const float* __restrict__ states, const float* __restrict__ controls,
+                                                   const float* __restrict__ tp, int N, int H, float* __restrict__ rewards) {
+  __shared__ float sTp[T::NTP];
+  for (int i = threadIdx.x; i < T::NTP; i += kBlock) sTp[i] = tp[i];
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int h = 0; h < H; h++) {
+    float xi[T::NX], u[T::NU];
+#pragma unroll
+    for (int i = 0; i < T::NX; i++) xi[i] = states[((size_t)n * H + h) * T::NX + i];
+#pragma unroll
+    for (int j = 0; j < T::NU; j++) u[j] = controls ? controls[((size_t)n * H + h) * T::NU + j] : 0.f;
+    T s; s.load(xi);
+    acc += s.cost(sTp, u);
+  }
+  rewards[n] = -T::finish(acc, H);
+}
+
+template <class T>
+int launch_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+  size_t lds = sizeof(float) * ((size_t)H * K + (size_t)K * T::NU * kBlock + T::NP + T::NTP + T::NX);
+  JH_REQUIRE(lds <= 64 * 1024, "rollout_cost: H*K too large for the LDS staging (%zu bytes)", lds);
+  int grid = (N + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_rollout_cost<T>, dim3(grid), dim3(kBlock), lds, st, m->d_f, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K,
+                     costs, knots_out);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+}  // namespace
+
+int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                           const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
+                           float* knots_out, hipStream_t st) {
+  if (m->kind == JH_TASK_CARTPOLE) return launch_cost<Cartpole>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+  return launch_cost<CylinderPush>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+}
+
+int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
+                          float* sensors, hipStream_t st) {
+  int grid = (N + kBlock - 1) / kBlock;
+  if (m->kind == JH_TASK_CARTPOLE)
+    hipLaunchKernelGGL(k_materialize<Cartpole>, dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
+  else
+    hipLaunchKernelGGL(k_materialize<CylinderPush>, dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+int jh_simple_reward(const jh_model* m, const float* states, const float* controls, const float* tp, int N, int H, float* rewards, hipStream_t st) {
+  int grid = (N + kBlock - 1) / kBlock;
+  if (m->kind == JH_TASK_CARTPOLE) hipLaunchKernelGGL(k_reward<Cartpole>, dim3(grid), dim3(kBlock), 0, st, states, controls, tp, N, H, rewards);
+  else hipLaunchKernelGGL(k_reward<CylinderPush>, dim3(grid), dim3(kBlock), 0, st, states, controls, tp, N, H, rewards);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

@@ -1,0 +1,276 @@
+// jh_update.hip -- sample / update kernels of the three optimizers (gfx950, wave64 reductions).
+//
+//   MPPI  judo/optimizers/mppi.py:76-82   beta = min c; w = exp(-(c-beta)/lambda); nominal = sum w*knots / sum w
+//   CEM   judo/optimizers/cem.py:88-92    k best by reward -> mean, clipped population std
+//   PS    judo/optimizers/ps.py:64-65     argmax reward
+//
+// Shard-local kernels emit a small record; a merge kernel combines G records after the all-gather (G = 1 on one GPU).
+// The exponential weighting is a two-level reduction: wave64 butterflies (`__shfl_xor`, lowered to DPP/permute) then LDS
+// across the four waves of a workgroup, one partial record per workgroup, finished by a single-workgroup merge with a
+// log-sum-exp rescale so that no global minimum pass is needed first.
+#include "jh_internal.h"
+
+namespace {
+
+constexpr int kUB = 256;  // threads per workgroup (4 waves)
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// knot (idx = k*nu+u) of local rollout n: explicit (N,K,nu) array, or recomputed clip(nominal + sigma*noise)
+struct KnotSrc {
+  const float* knots_nku; const float* nominal; const float* noise; const float* sigma; const float* lohi;
+  int ldn, n_offset, KU, nu;
+  __device__ __forceinline__ float get(int n, int idx) const {
+    if (knots_nku) return knots_nku[(size_t)n * KU + idx];
+    float v = nominal[idx];
+    if (n_offset + n != 0) v = fmaf(sigma[idx], noise[(size_t)idx * ldn + n], v);
+    if (lohi) { int u = idx % nu; v = jh_clampf(v, lohi[u], lohi[nu + u]); }
+    return v;
+  }
+};
+
+__global__ __launch_bounds__(kUB) void k_sample_knots(KnotSrc src, int N, float* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * kUB + threadIdx.x;
+  if (i >= (size_t)N * src.KU) return;
+  int n = (int)(i / src.KU), idx = (int)(i % src.KU);
+  out[i] = src.get(n, idx);
+}
+
+// ---------------------------------------------------------------- MPPI
+__global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ costs, KnotSrc src, int N, float inv_lambda,
+                                                   float* __restrict__ scratch) {
+  __shared__ float sred[4];
+  __shared__ float sV[4][JH_MAX_KNOT_DIM];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = blockIdx.x * kUB + tid;
+  const bool live = n < N;
+  float c = live ? costs[n] : INFINITY;
+  if (!(c == c)) c = INFINITY;  // a NaN cost (diverged rollout) gets zero weight
+  float m = wave_min(c);
+  if (lane == 0) sred[wave] = m;
+  __syncthreads();
+  float beta = fminf(fminf(sred[0], sred[1]), fminf(sred[2], sred[3]));
+  __syncthreads();
+  float w = (live && c < INFINITY) ? __expf(-(c - beta) * inv_lambda) : 0.f;
+  float s = wave_sum(w);
+  if (lane == 0) sred[wave] = s;
+  const int nc = live ? n : 0;
+  for (int idx = 0; idx < src.KU; idx++) {
+    float v = wave_sum(w * src.get(nc, idx));
+    if (lane == 0) sV[wave][idx] = v;
+  }
+  __syncthreads();
+  float* rec = scratch + (size_t)blockIdx.x * (2 + src.KU);
+  if (tid == 0) { rec[0] = beta; rec[1] = sred[0] + sred[1] + sred[2] + sred[3]; }
+  for (int idx = tid; idx < src.KU; idx += kUB) rec[2 + idx] = sV[0][idx] + sV[1][idx] + sV[2][idx] + sV[3][idx];
+}
+
+// merge nrec records [beta, S, V...] -> one record, or (finalize) the nominal knots V/S
+__global__ __launch_bounds__(kUB) void k_mppi_merge(const float* __restrict__ recs, int nrec, int KU, float inv_lambda, int finalize,
+                                                   float* __restrict__ out) {
+  __shared__ float sred[4];
+  __shared__ float sS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int stride = 2 + KU;
+  float m = INFINITY;
+  for (int r = tid; r < nrec; r += kUB) m = fminf(m, recs[(size_t)r * stride]);
+  m = wave_min(m);
+  if (lane == 0) sred[wave] = m;
+  __syncthreads();
+  float beta = fminf(fminf(sred[0], sred[1]), fminf(sred[2], sred[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int r = tid; r < nrec; r += kUB) s += __expf(-(recs[(size_t)r * stride] - beta) * inv_lambda) * recs[(size_t)r * stride + 1];
+  s = wave_sum(s);
+  if (lane == 0) sred[wave] = s;
+  __syncthreads();
+  if (tid == 0) sS = sred[0] + sred[1] + sred[2] + sred[3];
+  __syncthreads();
+  for (int idx = tid; idx < KU; idx += kUB) {
+    float v = 0.f;
+    for (int r = 0; r < nrec; r++) v += __expf(-(recs[(size_t)r * stride] - beta) * inv_lambda) * recs[(size_t)r * stride + 2 + idx];
+    if (finalize) out[idx] = v / sS; else out[2 + idx] = v;
+  }
+  if (!finalize && tid == 0) { out[0] = beta; out[1] = sS; }
+}
+
+// ---------------------------------------------------------------- top-k (CEM elites, PS argmax)
+struct Cand { float c; int i; };
+__device__ __forceinline__ bool better(const Cand& a, const Cand& b, int tie_high) {
+  if (a.c != b.c) return a.c < b.c;
+  if (a.i < 0 || b.i < 0) return a.i >= 0;
+  return tie_high ? a.i > b.i : a.i < b.i;
+}
+__device__ __forceinline__ Cand wave_best(Cand v, int tie_high) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Cand w{__shfl_xor(v.c, o, 64), __shfl_xor(v.i, o, 64)};
+    if (better(w, v, tie_high)) v = w;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kUB) void k_topk_block(const float* __restrict__ costs, int N, int n_offset, int k, int tie_high,
+                                                   float* __restrict__ scratch) {
+  __shared__ Cand sred[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = blockIdx.x * kUB + tid;
+  Cand mine{n < N ? costs[n] : INFINITY, n < N ? n_offset + n : -1};
+  if (mine.c != mine.c) mine.c = INFINITY;  // NaN costs never win
+  for (int e = 0; e < k; e++) {
+    Cand b = wave_best(mine, tie_high);
+    if (lane == 0) sred[wave] = b;
+    __syncthreads();
+    Cand best = sred[0];
+    for (int w = 1; w < 4; w++) if (better(sred[w], best, tie_high)) best = sred[w];
+    __syncthreads();
+    if (tid == 0) { scratch[((size_t)blockIdx.x * k + e) * 2] = best.c; scratch[((size_t)blockIdx.x * k + e) * 2 + 1] = __int_as_float(best.i); }
+    if (best.i == mine.i) { mine.c = INFINITY; mine.i = -1; }
+  }
+}
+
+// one workgroup: choose k best of ncand (cost, global index) pairs; emit records [cost, index, knots...]
+__global__ __launch_bounds__(kUB) void k_topk_select(const float* __restrict__ cand, int ncand, int k, int tie_high, KnotSrc src, int n_offset,
+                                                    float* __restrict__ rec) {
+  __shared__ Cand sred[4];
+  __shared__ Cand chosen[JH_MAX_ELITES];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int e = 0; e < k; e++) {
+    Cand mine{INFINITY, -1};
+    for (int r = tid; r < ncand; r += kUB) {
+      Cand c{cand[(size_t)r * 2], __float_as_int(cand[(size_t)r * 2 + 1])};
+      bool taken = false;
+      for (int q = 0; q < e; q++) taken |= (chosen[q].i == c.i);
+      if (!taken && c.i >= 0 && better(c, mine, tie_high)) mine = c;
+    }
+    Cand b = wave_best(mine, tie_high);
+    if (lane == 0) sred[wave] = b;
+    __syncthreads();
+    if (tid == 0) {
+      Cand best = sred[0];
+      for (int w = 1; w < 4; w++) if (better(sred[w], best, tie_high)) best = sred[w];
+      chosen[e] = best;
+    }
+    __syncthreads();
+  }
+  const int stride = 2 + src.KU;
+  for (int e = 0; e < k; e++) {
+    if (tid == 0) { rec[(size_t)e * stride] = chosen[e].c; rec[(size_t)e * stride + 1] = __int_as_float(chosen[e].i); }
+    int nl = chosen[e].i - n_offset;
+    for (int idx = tid; idx < src.KU; idx += kUB) rec[(size_t)e * stride + 2 + idx] = chosen[e].i >= 0 ? src.get(nl, idx) : 0.f;
+  }
+}
+
+// one workgroup: G*k records -> k elites -> mean / clipped population std
+__global__ __launch_bounds__(kUB) void k_elite_merge(const float* __restrict__ recs, int nrec, int k, int KU, int tie_high, float smin, float smax,
+                                                    float* __restrict__ nominal_out, float* __restrict__ sigma_out) {
+  __shared__ int chosen[JH_MAX_ELITES];
+  const int tid = threadIdx.x, stride = 2 + KU;
+  if (tid == 0) {
+    for (int e = 0; e < k; e++) {
+      int bi = -1; Cand best{INFINITY, -1};
+      for (int r = 0; r < nrec; r++) {
+        Cand c{recs[(size_t)r * stride], __float_as_int(recs[(size_t)r * stride + 1])};
+        bool taken = false;
+        for (int q = 0; q < e; q++) taken |= (chosen[q] == r);
+        if (!taken && c.i >= 0 && (bi < 0 || better(c, best, tie_high))) { best = c; bi = r; }
+      }
+      chosen[e] = bi;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < KU; idx += kUB) {
+    float mean = 0.f; int cnt = 0;
+    for (int e = 0; e < k; e++) if (chosen[e] >= 0) { mean += recs[(size_t)chosen[e] * stride + 2 + idx]; cnt++; }
+    mean /= (float)(cnt > 0 ? cnt : 1);
+    float var = 0.f;
+    for (int e = 0; e < k; e++) if (chosen[e] >= 0) { float d = recs[(size_t)chosen[e] * stride + 2 + idx] - mean; var += d * d; }
+    var /= (float)(cnt > 0 ? cnt : 1);
+    nominal_out[idx] = mean;
+    if (sigma_out) sigma_out[idx] = jh_clampf(sqrtf(var), smin, smax);
+  }
+}
+
+int check_dims(int N, int K, int nu) {
+  JH_REQUIRE(N > 0 && K > 0 && nu > 0, "N, K, nu must be positive (N=%d K=%d nu=%d)", N, K, nu);
+  JH_REQUIRE(K * nu <= JH_MAX_KNOT_DIM, "K*nu = %d exceeds JH_MAX_KNOT_DIM = %d", K * nu, JH_MAX_KNOT_DIM);
+  return JH_OK;
+}
+
+}  // namespace
+
+extern "C" size_t jh_update_scratch_floats(int N, int K, int nu) {
+  size_t nb = (size_t)(N + kUB - 1) / kUB;
+  size_t per = (size_t)(2 + K * nu);
+  size_t tk = 2 * (size_t)JH_MAX_ELITES;
+  return nb * (per > tk ? per : tk) + 16;
+}
+
+extern "C" int jh_sample_knots(const float* nominal, const float* noise, int ldn, const float* sigma, const float* lohi, int N, int n_offset, int K,
+                               int nu, float* knots_nku, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(nominal && noise && sigma && knots_nku, "sample_knots: null pointer");
+  JH_REQUIRE(ldn >= N, "sample_knots: ldn (%d) < N (%d)", ldn, N);
+  KnotSrc src{nullptr, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
+  size_t total = (size_t)N * K * nu;
+  hipLaunchKernelGGL(k_sample_knots, dim3((unsigned)((total + kUB - 1) / kUB)), dim3(kUB), 0, (hipStream_t)stream, src, N, knots_nku);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_mppi_partial(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
+                               const float* lohi, int N, int n_offset, int K, int nu, float lambda, float* scratch, float* rec, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(costs && scratch && rec, "mppi_partial: null pointer");
+  JH_REQUIRE(knots_nku || (nominal && noise && sigma), "mppi_partial: need either knots_nku or nominal+noise+sigma");
+  JH_REQUIRE(knots_nku || ldn >= N, "mppi_partial: ldn (%d) < N (%d)", ldn, N);
+  JH_REQUIRE(lambda > 0.f, "mppi_partial: temperature must be positive");
+  KnotSrc src{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
+  int nb = (N + kUB - 1) / kUB;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mppi_block, dim3(nb), dim3(kUB), 0, st, costs, src, N, 1.f / lambda, scratch);
+  hipLaunchKernelGGL(k_mppi_merge, dim3(1), dim3(kUB), 0, st, scratch, nb, K * nu, 1.f / lambda, 0, rec);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_mppi_merge(const float* recs, int G, int K, int nu, float lambda, float* nominal_out, void* stream) {
+  if (int e = check_dims(1, K, nu)) return e;
+  JH_REQUIRE(recs && nominal_out && G > 0, "mppi_merge: bad arguments");
+  hipLaunchKernelGGL(k_mppi_merge, dim3(1), dim3(kUB), 0, (hipStream_t)stream, recs, G, K * nu, 1.f / lambda, 1, nominal_out);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_topk_partial(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
+                               const float* lohi, int N, int n_offset, int K, int nu, int k, int tie_high, float* scratch, float* rec, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(k >= 1 && k <= JH_MAX_ELITES, "topk_partial: k = %d outside [1, %d]", k, JH_MAX_ELITES);
+  JH_REQUIRE(costs && scratch && rec, "topk_partial: null pointer");
+  JH_REQUIRE(knots_nku || (nominal && noise && sigma), "topk_partial: need either knots_nku or nominal+noise+sigma");
+  KnotSrc src{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
+  int nb = (N + kUB - 1) / kUB;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_topk_block, dim3(nb), dim3(kUB), 0, st, costs, N, n_offset, k, tie_high, scratch);
+  hipLaunchKernelGGL(k_topk_select, dim3(1), dim3(kUB), 0, st, scratch, nb * k, k, tie_high, src, n_offset, rec);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float smin, float smax, float* nominal_out, float* sigma_out,
+                              void* stream) {
+  if (int e = check_dims(1, K, nu)) return e;
+  JH_REQUIRE(recs && nominal_out && G > 0 && k >= 1 && k <= JH_MAX_ELITES, "elite_merge: bad arguments");
+  hipLaunchKernelGGL(k_elite_merge, dim3(1), dim3(kUB), 0, (hipStream_t)stream, recs, G * k, k, K * nu, tie_high, smin, smax, nominal_out, sigma_out);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

@@ -1,0 +1,58 @@
+"""Device plumbing: PyTorch-ROCm is used only as the container for device memory, streams and RCCL.
+
+`GpuModel` owns one `jh_model` handle (model constants resident in HBM) per (task, device).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from judo_amd import _lib
+from judo_amd.models import layout, load_description, pack_model
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("judo_amd needs an MI355X (HIP device): torch.cuda.is_available() is False and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def current_stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32(x, device) -> torch.Tensor:
+    """Host array -> contiguous fp32 device tensor."""
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(device, non_blocking=False)
+
+
+class GpuModel:
+    """Model constants of one task on one GPU (the counterpart of the per-thread MjModel copies,
+    judo/utils/mj_rollout_backend.py:38-43 -- here a single read-only image shared by every lane)."""
+
+    def __init__(self, task: str | dict, device: torch.device | None = None) -> None:
+        self.desc = load_description(task) if isinstance(task, str) else task
+        self.task = self.desc["task"]
+        lay = layout(self.desc)
+        self.nq, self.nv, self.nu, self.ns = lay.nq, lay.nv, lay.nu, lay.ns
+        self.nx = self.nq + self.nv
+        self.dt = float(self.desc["option"]["timestep"])
+        self.device = device if device is not None else require_gpu()
+        blob = pack_model(self.desc)
+        self._blob = blob
+        handle = C.c_void_p()
+        buf = C.create_string_buffer(blob, len(blob))
+        st = _lib.lib().jh_model_create(buf, len(blob), self.device.index or 0, C.byref(handle))
+        _lib.check(st, "jh_model_create")
+        self.handle = handle
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().jh_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
