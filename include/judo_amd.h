@@ -57,6 +57,11 @@ void jh_model_destroy(jh_model* m);
 /* dims[0..5] = nq, nv, nu, nsensordata, task kind, ntaskparams */
 int jh_model_dims(const jh_model* m, int* dims /* HOST */);
 
+/* Diagnostics accumulated by the articulated-body kernels since the last reset (synchronises the device):
+ * out[0] contacts dropped because a rollout exceeded the per-rollout contact capacity, out[1] constraint solves that hit the
+ * Newton iteration cap, out[2] Newton iterations, out[3] physics steps.  HOST pointer. */
+int jh_model_stats(jh_model* m, int* out /* HOST, 4 ints */, int reset);
+
 /* Fused plan-step kernel.  Replaces, for N rollouts in one launch:
  *   Optimizer.sample_control_knots         judo/optimizers/{mppi.py:38-59,ps.py:29-50,cem.py:55-74}
  *   np.clip to actuator_ctrlrange          judo/controller/controller.py:253-257

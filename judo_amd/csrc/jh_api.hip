@@ -30,18 +30,21 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
   hipError_t e = hipMalloc(&m->d_f, 4 * (m->nf ? m->nf : 1));
   if (e == hipSuccess) e = hipMalloc(&m->d_i, 4 * (m->ni ? m->ni : 1));
+  if (e == hipSuccess) e = hipMalloc(&m->d_stats, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(m->d_stats, 0, 4 * sizeof(int));
   if (e == hipSuccess && m->nf) e = hipMemcpy(m->d_f, m->h_f.data(), 4 * m->nf, hipMemcpyHostToDevice);
   if (e == hipSuccess && m->ni) e = hipMemcpy(m->d_i, m->h_i.data(), 4 * m->ni, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     jh_set_error("model_create: device upload failed: %s", hipGetErrorString(e));
     if (m->d_f) (void)hipFree(m->d_f);
     if (m->d_i) (void)hipFree(m->d_i);
+    if (m->d_stats) (void)hipFree(m->d_stats);
     delete m;
     return JH_ERR_HIP;
   }
@@ -53,12 +56,20 @@ extern "C" void jh_model_destroy(jh_model* m) {
   if (!m) return;
   if (m->d_f) (void)hipFree(m->d_f);
   if (m->d_i) (void)hipFree(m->d_i);
+  if (m->d_stats) (void)hipFree(m->d_stats);
   delete m;
 }
 
 extern "C" int jh_model_dims(const jh_model* m, int* dims) {
   JH_REQUIRE(m && dims, "model_dims: null pointer");
   dims[0] = m->nq; dims[1] = m->nv; dims[2] = m->nu; dims[3] = m->ns; dims[4] = m->kind; dims[5] = m->ntaskparam;
+  return JH_OK;
+}
+
+extern "C" int jh_model_stats(jh_model* m, int* out, int reset) {
+  JH_REQUIRE(m && out, "model_stats: null pointer");
+  JH_HIP(hipMemcpy(out, m->d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  if (reset) JH_HIP(hipMemset(m->d_stats, 0, 4 * sizeof(int)));
   return JH_OK;
 }
 

@@ -24,6 +24,7 @@ struct jh_model {
   size_t nf, ni;
   float* d_f;  // device copy of the float section
   int* d_i;    // device copy of the int section
+  int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
   std::vector<float> h_f;
   std::vector<int> h_i;
 };

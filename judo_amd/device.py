@@ -49,6 +49,12 @@ class GpuModel:
         _lib.check(st, "jh_model_create")
         self.handle = handle
 
+    def stats(self, reset: bool = True) -> dict:
+        """Diagnostic counters of the articulated-body kernels (synchronises)."""
+        out = (C.c_int * 4)()
+        _lib.check(_lib.lib().jh_model_stats(self.handle, out, int(reset)), "jh_model_stats")
+        return {"contact_overflow": out[0], "newton_cap_hits": out[1], "newton_iters": out[2], "steps": out[3]}
+
     def __del__(self) -> None:
         try:
             if getattr(self, "handle", None):
