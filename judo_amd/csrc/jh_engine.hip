@@ -119,6 +119,9 @@ struct Work {
   float fs[C::NV], a0[C::NV], a[C::NV];
   // constraints
   int ncon, overflow, iters, maxed;
+#ifdef JH_ENGINE_PROFILE
+  long long cyc[8], t0;
+#endif
   float cpos[C::NCON][3], cfr[C::NCON][9], caref[C::NCON][3], cD[C::NCON][3], cmu[C::NCON], cfri[C::NCON];
   int cbody[C::NCON];
   float faref[C::NV], lims[C::NV], laref[C::NV], lD[C::NV];
@@ -779,15 +782,26 @@ __device__ void engine_step(const EngineModel& m, Work<C>& w, const float* ctrl)
   (void)ctrl;
 }
 
+#ifdef JH_ENGINE_PROFILE
+#define JH_TICK(slot) { long long t__ = clock64(); w.cyc[slot] += t__ - w.t0; w.t0 = t__; }
+#else
+#define JH_TICK(slot)
+#endif
 template <class C>
 __device__ void engine_forward(const EngineModel& m, Work<C>& w, const float* ctrl) {
+  JH_TICK(7)
   kinematics(m, w);
+  JH_TICK(0)
   smooth_dynamics(m, w, ctrl);
+  JH_TICK(1)
   collision(m, w);
+  JH_TICK(2)
   constraint_rows(m, w);
+  JH_TICK(3)
   const int cap = (int)m.F[HF_MAXITER];
   int it = solve_constraints(m, w, cap, m.F[HF_TOL]);
   w.iters += it; w.maxed += (it >= cap);
+  JH_TICK(4)
 }
 
 // sensors of the forward pass (position stage): framepos of sites/bodies, jointpos, framezaxis
@@ -852,6 +866,10 @@ __global__ __launch_bounds__(kBlock) void k_engine_cost(const float* __restrict_
   for (int i = 0; i < C::NQ; i++) w.qpos[i] = x0[i];
   for (int i = 0; i < C::NV; i++) { w.qvel[i] = x0[C::NQ + i]; w.qws[i] = 0.f; }
   w.overflow = 0; w.iters = 0; w.maxed = 0;
+#ifdef JH_ENGINE_PROFILE
+  for (int k = 0; k < 8; k++) w.cyc[k] = 0;
+  w.t0 = clock64();
+#endif
   float acc = 0.f;
   for (int h = 0; h < H; h++) {
     float u[C::NU];
@@ -859,8 +877,12 @@ __global__ __launch_bounds__(kBlock) void k_engine_cost(const float* __restrict_
     for (int k = 0; k < K; k++) { float wk = sW[h * K + k]; for (int j = 0; j < C::NU; j++) u[j] = fmaf(wk, sKn[(k * C::NU + j) * kBlock + lane], u[j]); }
     engine_forward(m, w, u);
     engine_step(m, w, u);
+    JH_TICK(5)
     acc += leap_step_cost(sTp, w.qpos);
   }
+#ifdef JH_ENGINE_PROFILE
+  if (lane == 0 && overflow) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(overflow + 4) + k, (unsigned long long)w.cyc[k]);
+#endif
   if (live) {
     costs[n] = acc / (float)H;
     if (overflow) { if (w.overflow) atomicAdd(overflow, w.overflow); if (w.maxed) atomicAdd(overflow + 1, w.maxed); atomicAdd(overflow + 2, w.iters); atomicAdd(overflow + 3, H); }

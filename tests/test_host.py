@@ -1,0 +1,207 @@
+"""CPU tests of the product's host logic (no GPU, no compute calls through the C ABI)."""
+
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, ROOT
+
+
+def test_config_overrides_match_reference():
+    from judo_amd import config as c
+
+    g = json.load(open(os.path.join(GOLDEN, "configs.json")))
+    for task, d in g["optimizer"].items():
+        for name, cls in (("mppi", c.MPPIConfig), ("cem", c.CrossEntropyMethodConfig), ("ps", c.PredictiveSamplingConfig)):
+            cfg = cls()
+            if task != "default":
+                cfg.set_override(task)
+            assert c.as_plain_dict(cfg) == d[name], (task, name)
+    for task, d in g["controller"].items():
+        cfg = c.ControllerConfig()
+        if task != "default":
+            cfg.set_override(task)
+        assert c.as_plain_dict(cfg) == d, task
+    # switching override keys resets untouched fields to their defaults
+    cfg = c.MPPIConfig()
+    cfg.set_override("leap_cube")
+    assert cfg.temperature == 0.0025
+    cfg.set_override("cartpole")
+    assert cfg.temperature == 0.05 and cfg.sigma == 0.1 and cfg.use_noise_ramp
+    with pytest.raises(KeyError):
+        c.set_config_overrides("x", c.MPPIConfig, {"not_a_field": 1})
+
+
+def test_spline_weights_numpy_match_reference():
+    from judo_amd.spline import evaluate, spline_weights
+
+    g = np.load(os.path.join(GOLDEN, "spline.npz"))
+    for key in [k[: -len("_cfg")] for k in g.files if k.endswith("_cfg")]:
+        kind, K, H, dt, hor, t0 = g[key + "_cfg"]
+        kind = {0: "zero", 1: "linear", 3: "cubic"}[int(kind)]
+        kt = t0 + np.linspace(0, hor, int(K))
+        W = spline_weights(kind, kt, t0 + dt * np.arange(int(H)))
+        np.testing.assert_allclose(W, g[key + "_W"], atol=1e-12)
+        np.testing.assert_allclose(evaluate(kind, kt, g[key + "_knots"], t0 + dt * np.arange(int(H))), g[key + "_U"], atol=1e-12)
+        np.testing.assert_allclose(evaluate(kind, kt, g[key + "_knots"][0], g[key + "_shift_times"]), g[key + "_shift_knots"], atol=1e-12)
+        np.testing.assert_allclose(evaluate(kind, kt, g[key + "_knots"][0], np.array([t0 - 1.0, t0 + hor + 2.0])), g[key + "_far"], atol=1e-14)
+    with pytest.raises(ValueError):
+        spline_weights("cubic", np.linspace(0, 1, 3), np.zeros(2))
+    with pytest.raises(ValueError):
+        spline_weights("quintic", np.linspace(0, 1, 4), np.zeros(2))
+
+
+def test_min_max_normaliser_is_an_affine_sigma_scale():
+    """Sampling nominal_n + sigma*eps in MinMaxNormalizer units == nominal + sigma*(hi-lo)/2*eps in raw units."""
+    g = np.load(os.path.join(GOLDEN, "normalizer.npz"))
+    lo, hi, x = g["minmax_lo"], g["minmax_hi"], g["minmax_x"]
+    finite = np.isfinite(lo) & np.isfinite(hi)
+    scale = np.where(finite, (hi - lo) / 2, 1.0)
+    off = np.where(finite, (hi + lo) / 2, 0.0)
+    np.testing.assert_allclose((x - off) / scale, g["minmax_norm"], atol=1e-12)
+    np.testing.assert_allclose(x * scale + off, g["minmax_denorm"], atol=1e-12)
+
+
+@pytest.mark.parametrize("task", ["cartpole", "cylinder_push", "leap_cube", "fr3_pick"])
+def test_model_constants_agree_with_oracle(task):
+    """Two independent implementations (numpy here, C in the oracle) of the reference-pose inertia and inverse weights."""
+    from judo_amd import models as M
+    from oracle import oracle as O
+
+    d = M.load_description(task)
+    om = O.Model(task)
+    dw, bw = M.inverse_weights(d)
+    odw, obw = om.invweight0()
+    np.testing.assert_allclose(dw, odw, rtol=1e-10)
+    np.testing.assert_allclose(bw, obw, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(M.qpos0(d), om.qpos0())
+    q = M.qpos0(d)
+    q[-1] += 0.3
+    Mm, _ = M.mass_matrix(d, q)
+    np.testing.assert_allclose(Mm, om.mass_matrix(q), rtol=1e-10, atol=1e-14)
+    lay = M.layout(d)
+    assert (lay.nq, lay.nv, lay.nu, lay.ns) == (om.nq, om.nv, om.nu, om.ns)
+
+
+def test_model_dimensions_match_survey_table():
+    from judo_amd import models as M
+
+    dims = {"cartpole": (2, 2, 1, 6, 0.04), "cylinder_push": (4, 4, 2, 6, 0.02), "fr3_pick": (16, 15, 8, 14, 0.004), "leap_cube": (23, 22, 16, 31, 0.01)}
+    for task, (nq, nv, nu, ns, dt) in dims.items():
+        d = M.load_description(task)
+        lay = M.layout(d)
+        assert (lay.nq, lay.nv, lay.nu, lay.ns) == (nq, nv, nu, ns)
+        assert d["option"]["timestep"] == dt
+    r = M.actuator_ctrlrange(M.load_description("fr3_pick"))
+    np.testing.assert_allclose(r[-1], [-0.02, 0.06])  # inheritrange=2 about the finger joint range (0, 0.04)
+    with pytest.raises(ValueError):
+        M.load_description("no_such_task")
+
+
+def test_blob_packing():
+    import struct
+
+    from judo_amd import models as M
+
+    for task, kind in (("cartpole", 0), ("cylinder_push", 1), ("leap_cube", 2)):
+        blob = M.pack_model(M.load_description(task))
+        head = struct.unpack("<16I", blob[:64])
+        assert head[0] == M.BLOB_MAGIC and head[2] == kind
+        assert len(blob) == 64 + 4 * (head[8] + head[9])
+    from judo_amd.engine_model import engine_structure
+
+    st = engine_structure(M.load_description("leap_cube"))
+    assert len(st["moving"]) == 17 and [len(b) for b in st["blocks"]] == [4, 4, 4, 4]
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """include/judo_amd.h <-> libjudo_amd.so <-> the ctypes table agree (loading needs no GPU)."""
+    from judo_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "judo_amd.h")).read()
+    declared = set(re.findall(r"\b(jh_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().jh_version() >= 100
+    assert _lib.lib().jh_update_scratch_floats(65536, 4, 16) >= 256 * 66
+
+
+def test_optimizer_host_state_and_registry():
+    from judo_amd import config as c
+    from judo_amd import optimizers as o
+
+    assert set(o.get_registered_optimizers()) == {"cem", "mppi", "ps"}
+    m = o.GpuMPPI(c.MPPIConfig(num_nodes=4, use_noise_ramp=True, noise_ramp=4.0, sigma=0.2), 16)
+    np.testing.assert_allclose(m.knot_sigma()[:, 0], [0.2, 0.4, 0.6, 0.8])
+    cem = o.GpuCEM(c.CrossEntropyMethodConfig(num_nodes=4, sigma_min=0.01, sigma_max=0.3, use_noise_ramp=True, noise_ramp=4.0), 2)
+    np.testing.assert_allclose(cem.sigma, 0.155)
+    s1 = cem.knot_sigma().copy()
+    s2 = cem.knot_sigma().copy()
+    np.testing.assert_allclose(s1[:, 0], np.clip(0.155 * np.array([1, 2, 3, 4.0]), 0.01, 0.3))
+    np.testing.assert_allclose(s2[:, 0], np.clip(s1[:, 0] * np.array([1, 2, 3, 4.0]), 0.01, 0.3))  # cumulative
+    o.register_optimizer("mine", o.GpuPS, c.PredictiveSamplingConfig)
+    assert "mine" in o.get_registered_optimizers()
+    o.get_registered_optimizers().pop("mine")
+
+
+def test_tasks_host_side():
+    from judo_amd import tasks as T
+
+    assert set(T.get_registered_tasks()) >= {"cartpole", "cylinder_push", "leap_cube", "fr3_pick"}
+    t = T.FR3Pick()
+    x = t.default_state()
+    t.pre_rollout(x)
+    assert t.phase == T.Phase.LIFT.value
+    x2 = x.copy(); x2[2] = 0.1
+    t.pre_rollout(x2); assert t.phase == T.Phase.MOVE.value
+    x3 = x2.copy(); x3[:2] = t.config.goal_pos
+    t.pre_rollout(x3); assert t.phase == T.Phase.PLACE.value
+    x4 = x3.copy(); x4[2] = 0.02
+    t.pre_rollout(x4); assert t.phase == T.Phase.HOMING.value
+    assert len(t.task_params()) == 22
+    lc = T.LeapCube()
+    np.testing.assert_allclose(lc.task_params({"goal_quat": np.array([0, 1, 0, 0.0])}), [100, 0.1, 0, 0.03, 0.1, 0, 1, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(lc.optimizer_warm_start(), T.LEAP_QPOS_HOME[7:])
+    assert lc.dt == 0.01 and lc.nu == 16 and np.isfinite(lc.actuator_ctrlrange).all()
+    assert T.Cartpole().default_state().shape == (4,)
+
+
+def test_sharding():
+    from judo_amd.distributed import shard_rollouts
+
+    for total, world in ((65536, 8), (65536, 1), (1000, 3), (7, 7)):
+        shards = [shard_rollouts(total, world, r) for r in range(world)]
+        assert sum(s.count for s in shards) == total and shards[0].offset == 0
+        for a, b in zip(shards, shards[1:]):
+            assert a.offset + a.count == b.offset
+    with pytest.raises(ValueError):
+        shard_rollouts(3, 4, 0)
+    with pytest.raises(ValueError):
+        shard_rollouts(8, 2, 2)
+
+
+def test_compute_requires_gpu_and_never_falls_back():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from judo_amd import config as c
+    from judo_amd import optimizers as o
+
+    with pytest.raises(RuntimeError):
+        o.GpuMPPI(c.MPPIConfig(), 1).sample_control_knots(np.zeros((4, 1)))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "judo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "libjudo_oracle" not in src and "jo_engine" not in src.replace("oracle/jo_engine.c for the fp64 checker", ""), f

@@ -1,0 +1,262 @@
+"""CPU tests of the ORACLE: (1) pinned against the golden vectors generated from the reference's numpy code,
+(2) known-answer physics tests of the fp64 engine (no upstream test pins any rollout value)."""
+
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import GOLDEN
+
+
+# ------------------------------------------------------------------------------------------------ golden: plan primitives
+def test_spline_weights_match_reference():
+    g = np.load(os.path.join(GOLDEN, "spline.npz"))
+    keys = [k[: -len("_cfg")] for k in g.files if k.endswith("_cfg")]
+    assert len(keys) >= 18
+    for key in keys:
+        kind, K, H, dt, hor, t0 = g[key + "_cfg"]
+        kt, q = t0 + np.linspace(0, hor, int(K)), t0 + dt * np.arange(int(H))
+        W = O.spline_weights(int(kind), kt, q)
+        np.testing.assert_allclose(W, g[key + "_W"], atol=1e-12)
+        np.testing.assert_allclose(W.sum(1), 1.0, atol=1e-12)
+        np.testing.assert_allclose(O.spline_eval(W, g[key + "_knots"]), g[key + "_U"], atol=1e-12)
+        np.testing.assert_allclose(O.spline_weights(int(kind), kt, g[key + "_shift_times"]) @ g[key + "_knots"][0], g[key + "_shift_knots"], atol=1e-12)
+        far = O.spline_weights(int(kind), kt, np.array([t0 - 1.0, t0 + hor + 2.0])) @ g[key + "_knots"][0]
+        np.testing.assert_allclose(far, g[key + "_far"], atol=1e-14)  # hold first / last knot outside the span
+
+
+def test_sampling_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "optimizers.npz"))
+    n = 0
+    for key in sorted({k[: -len("_params")] for k in g.files if k.endswith("_params") and ("_mppi_" in k or "_ps_" in k)}):
+        N, K, nu, ramp, nr, sig = g[key + "_params"]
+        s = O.mppi_sigma(sig, ramp, nr, int(K), int(nu))
+        out = O.sample_knots(g[key + "_nominal"], g[key + "_noise"], s)
+        np.testing.assert_allclose(out, g[key + "_out"], atol=1e-15)
+        np.testing.assert_array_equal(out[0], g[key + "_nominal"])
+        n += 1
+    assert n == 24
+    for key in sorted({k[: -len("_params")] for k in g.files if k.endswith("_params") and "_cem_" in k}):
+        N, K, nu, ramp, nr, smin, smax = g[key + "_params"]
+        sig = g[key + "_sigma0"]
+        for call in range(2):  # the ramp multiplies the sigma STATE on every call
+            sig = O.cem_sigma_ramp(sig, ramp, nr, smin, smax)
+            np.testing.assert_allclose(sig, g[f"{key}_call{call}_sigma_after"], atol=1e-15)
+            np.testing.assert_allclose(O.sample_knots(g[f"{key}_call{call}_nominal"], g[f"{key}_call{call}_noise"], sig), g[f"{key}_call{call}_out"], atol=1e-15)
+        so = O.cem_pre_optimization(g[key + "_prek_sigma_in"], g[key + "_prek_old_times"], g[key + "_prek_new_times"])
+        np.testing.assert_allclose(so, g[key + "_prek_sigma_out"], atol=1e-14)
+
+
+def test_updates_match_reference():
+    g = np.load(os.path.join(GOLDEN, "optimizers.npz"))
+    keys = sorted({k[: -len("_knots")] for k in g.files if k.startswith("update_") and k.endswith("_knots")})
+    assert len(keys) == 16
+    for key in keys:
+        kn, rw = g[key + "_knots"], g[key + "_rewards"]
+        for lam in (0.05, 0.0025):
+            np.testing.assert_allclose(O.mppi_update(kn, rw, lam), g[f"{key}_mppi_{lam}"], atol=1e-13)
+        np.testing.assert_allclose(O.ps_update(kn, rw), g[key + "_ps"], atol=0)
+        for k in (2, 3):
+            nom, sg, idx = O.cem_update(kn, rw, k, 0.01, 0.3)
+            ref_idx = g[f"{key}_cem{k}_elite_idx"]
+            assert np.allclose(np.sort(rw[idx]), np.sort(rw[ref_idx]))  # same elite rewards even when ties reorder indices
+            if set(idx) == set(ref_idx):
+                np.testing.assert_allclose(nom, g[f"{key}_cem{k}_nominal"], atol=1e-14)
+                np.testing.assert_allclose(sg, g[f"{key}_cem{k}_sigma"], atol=1e-14)
+
+
+def test_rewards_match_reference():
+    g = np.load(os.path.join(GOLDEN, "rewards.npz"))
+    np.testing.assert_allclose(O.reward_cartpole(g["cartpole_states"], g["cartpole_controls"]), g["cartpole_reward"], rtol=1e-13)
+    for i in (0, 1):
+        np.testing.assert_allclose(O.reward_cylinder(g[f"cylinder{i}_states"], (0.5, 0.0, 0.1, 0.25, *g[f"cylinder{i}_goal"])), g[f"cylinder{i}_reward"], rtol=1e-13)
+    for i in (0, 1, 2):  # includes quat == goal, antipodal quat, |v| < 1e-6, angle > pi
+        np.testing.assert_allclose(O.reward_leap(g[f"leap{i}_states"], g[f"leap{i}_goal_quat"]), g[f"leap{i}_reward"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(O.reward_leap(g["leap0_states"]), g["leap_default_reward"], rtol=1e-12)
+    for ph, name in enumerate(["LIFT", "MOVE", "PLACE", "HOMING"]):
+        np.testing.assert_allclose(O.reward_fr3(g[f"fr3_{name}_states"], g[f"fr3_{name}_sensors"], ph), g[f"fr3_{name}_reward"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ known-answer physics
+def _variant(task, **edits):
+    d = copy.deepcopy(O.load_description(task))
+    for fn in edits.values():
+        fn(d)
+    return O.Model(task, d)
+
+
+def test_cartpole_mass_matrix_and_bias_closed_form():
+    m = O.Model("cartpole")
+    d = m.desc
+    mp, mc, l, I = d["bodies"][2]["mass"], d["bodies"][1]["mass"], d["bodies"][2]["ipos"][2], d["bodies"][2]["inertia"][0]
+    # capsule inertia: cylinder + hemispherical caps (mass split by volume)
+    r, L = 0.045, 1.0
+    m_cyl = mp * (np.pi * r * r * L) / (np.pi * r * r * L + 4 / 3 * np.pi * r**3)
+    m_sph = mp - m_cyl
+    assert I == pytest.approx(m_cyl * (3 * r * r + L * L) / 12 + m_sph * (0.4 * r * r + L * L / 4 + 3 * r * L / 8), rel=1e-12)
+    for th in (0.0, 0.7, 2.5, np.pi):
+        M = m.mass_matrix(np.array([0.3, th]))
+        np.testing.assert_allclose(M, [[mc + mp, mp * l * np.cos(th)], [mp * l * np.cos(th), I + mp * l * l]], atol=1e-14)
+        out = m.forward(np.array([0.3, th]), np.array([0.2, -0.5]), np.array([0.3]))
+        np.testing.assert_allclose(out["qfrc_bias"], [-mp * l * np.sin(th) * 0.25, -mp * 9.81 * l * np.sin(th)], atol=1e-13)
+
+
+def test_cartpole_energy_conservation_and_pendulum_period():
+    def free(d):
+        d["joints"][0]["damping"] = 0.0
+        d["joints"][0]["range"] = None
+        d["actuators"] = []
+        d["option"]["timestep"] = 0.0005
+
+    m = _variant("cartpole", a=free)
+    x0 = np.array([0.0, 2.0, 0.0, 0.0])
+    st, _ = m.rollout(x0, np.zeros((1, 4000, 0)))
+
+    def energy(x):
+        mp, mc, l, I = 0.1, 1.0, 0.5, m.desc["bodies"][2]["inertia"][0]
+        q, th, qd, thd = x
+        M = np.array([[mc + mp, mp * l * np.cos(th)], [mp * l * np.cos(th), I + mp * l * l]])
+        v = np.array([qd, thd])
+        return 0.5 * v @ M @ v + mp * 9.81 * l * np.cos(th)
+
+    assert abs(energy(st[0, -1]) - energy(x0)) < 2e-3 * abs(energy(x0))  # symplectic Euler at h = 0.5 ms
+    # heavy cart -> fixed-pivot physical pendulum: small oscillations about the hanging pose
+    def heavy(d):
+        free(d)
+        d["bodies"][1]["mass"] = 1e9
+
+    mh = _variant("cartpole", a=heavy)
+    st, _ = mh.rollout(np.array([0.0, np.pi + 0.01, 0.0, 0.0]), np.zeros((1, 8000, 0)))
+    th = st[0, :, 1] - np.pi
+    zc = np.where(np.diff(np.sign(th)) != 0)[0]
+    period = 2 * np.mean(np.diff(zc)) * 0.0005
+    I = mh.desc["bodies"][2]["inertia"][0]
+    assert period == pytest.approx(2 * np.pi * np.sqrt((I + 0.1 * 0.25) / (0.1 * 9.81 * 0.5)), rel=2e-3)
+
+
+def test_cartpole_servo_force_clamp_and_joint_limit():
+    m = O.Model("cartpole")
+    # kp*(u - x) = 100*1.8 is clamped to +10 N: first-step cart acceleration from rest with the pole hanging
+    out = m.forward(np.array([0.0, np.pi]), np.zeros(2), np.array([5.0]))  # ctrl also clamped to 1.8
+    M = m.mass_matrix(np.array([0.0, np.pi]))
+    np.testing.assert_allclose(out["qacc_smooth"], np.linalg.solve(M, [10.0, 0.0]), rtol=1e-12)
+    # cart pushed against its +1.8 limit: the soft limit holds it within a few mm
+    st, _ = m.rollout(np.array([1.75, np.pi, 2.0, 0.0]), np.full((1, 100, 1), 1.8))
+    assert st[0, :, 0].max() < 1.8 + 0.08 and st[0, -1, 0] < 1.81
+    out = m.forward(np.array([1.85, np.pi]), np.array([0.5, 0.0]), np.array([1.8]))
+    assert out["nefc"] == 1 and out["qfrc_constraint"][0] < 0  # limit force pushes back
+
+
+def test_cylinder_push_free_motion_closed_form_and_contact_momentum():
+    m = O.Model("cylinder_push")
+    # no contact: implicit-damping Euler of a PD-driven unit mass, per axis
+    x = np.array([1.0, 0.0, 2.0, 2.0, 0.3, -0.2, 0.1, 0.0])
+    u = np.array([0.5, 0.4])
+    st, _ = m.rollout(x, np.tile(u, (1, 30, 1)))
+    h, p, v = 0.02, x[:2].copy(), x[4:6].copy()
+    for t in range(30):
+        a = (10 * (u - p) - 4 * v) / (1 + h * 4)
+        v = v + h * a
+        p = p + h * v
+        np.testing.assert_allclose(st[0, t, :2], p, atol=1e-13)
+        np.testing.assert_allclose(st[0, t, 4:6], v, atol=1e-13)
+    # head-on contact with damping and the servo removed: momentum conserved, cylinders separate
+    def bare(d):
+        for j in d["joints"]:
+            j["damping"] = 0.0
+        d["actuators"] = []
+
+    mb = _variant("cylinder_push", a=bare)
+    x = np.array([0.0, 0.0, 0.6, 0.0, 1.0, 0.0, 0.0, 0.0])
+    st, _ = mb.rollout(x, np.zeros((1, 60, 0)))
+    mom = st[0, :, 4] + st[0, :, 6]
+    np.testing.assert_allclose(mom, 1.0, atol=1e-9)
+    assert st[0, -1, 6] > 0.3 and st[0, -1, 6] > st[0, -1, 4]  # the cart was pushed away
+    assert (np.linalg.norm(st[0, :, 2:4] - st[0, :, 0:2], axis=1) > 0.5 - 0.025).all()  # penetration stays within one step of approach (1 m/s * 0.02 s)
+
+
+def test_leap_free_fall_then_rest_on_palm():
+    m = O.Model("leap_cube")
+    q = np.array([0.0, 0.03, 0.1, 1, 0, 0, 0, 0.5, -0.75, 0.75, 0.25, 0.5, 0, 0.75, 0.25, 0.5, 0.75, 0.75, 0.25, 0.65, 0.9, 0.75, 0.6])
+    x0 = np.concatenate([q, np.zeros(22)])
+    U = np.tile(q[7:], (1, 150, 1))
+    st, se = m.rollout(x0, U)
+    h = 0.01
+    for k in range(1, 6):  # ballistic phase (no contact yet): semi-implicit Euler
+        assert st[0, k - 1, 2] == pytest.approx(0.1 - 9.81 * h * h * k * (k + 1) / 2, abs=1e-12)
+        assert st[0, k - 1, 25] == pytest.approx(-9.81 * h * k, abs=1e-12)
+    # after 1.5 s the cube rests on the palm: small velocity, constraint force balances its weight
+    assert np.abs(st[0, -1, 23:26]).max() < 0.02 and np.abs(st[0, -1, 26:29]).max() < 0.5  # settled up to a slow rocking on the tilted palm
+    out = m.forward(st[0, -1, :23], st[0, -1, 23:], U[0, -1])
+    assert out["ncon"] >= 3
+    assert out["qfrc_constraint"][2] == pytest.approx(0.108 * 9.81, rel=0.15)
+    # sensors: first 16 = joint positions of the state the step started from, then site positions
+    np.testing.assert_allclose(se[0, 1, :16], st[0, 0, 7:23], atol=1e-14)
+    np.testing.assert_allclose(se[0, 1, 16:19], st[0, 0, 0:3], atol=1e-14)
+
+
+def test_leap_joint_limits_and_friction_loss():
+    def nograv(d):
+        d["option"]["gravity"] = [0.0, 0.0, 0.0]
+
+    m = _variant("leap_cube", a=nograv)
+    q = np.array([0.0, 0.03, 0.3, 1, 0, 0, 0, 0.5, -0.75, 0.75, 0.25, 0.5, 0, 0.75, 0.25, 0.5, 0.75, 0.75, 0.25, 0.65, 0.9, 0.75, 0.6])
+    x0 = np.concatenate([q, np.zeros(22)])
+    # dof friction loss is a SOFT constraint: below saturation it acts as a damper of strength D*B, so a servo torque
+    # of 0.0006 Nm (< frictionloss 0.001) makes the joint creep at v = tau / (D*B + damping + kv)
+    U = np.tile(q[7:], (1, 50, 1))
+    U[0, :, 0] += 0.002  # kp = 0.3 -> 0.0006 Nm
+    st, _ = m.rollout(x0, U)
+    dofw, _ = m.invweight0()
+    R = (1 - 0.9) / 0.9 * dofw[6]
+    B = 2 / (0.95 * 0.02)
+    v_expected = 0.3 * (0.002 - (st[0, -1, 7] - q[7])) / (1 / R * B + 0.03 + 0.1)
+    assert st[0, -1, 29] == pytest.approx(v_expected, rel=0.05)
+    # far above saturation the friction force is exactly +-frictionloss
+    # (at rest the row's reference acceleration is 0, a 0.3 Nm servo torque drives the joint forward: force = -frictionloss)
+    big = q[7:].copy()
+    big[0] += 1.0
+    out = m.forward(q, np.zeros(22), big)
+    assert out["qfrc_constraint"][6] == pytest.approx(-0.001, rel=1e-6)
+    # command far outside the joint range (ctrl is clamped to the range, which equals the joint range): limit holds
+    U2 = np.tile(q[7:], (1, 200, 1))
+    U2[0, :, 3] = 5.0
+    st, _ = m.rollout(x0, U2)
+    hi = m.desc["joints"][4]["range"][1]
+    assert st[0, :, 10].max() < hi + 0.02 and st[0, -1, 10] == pytest.approx(hi, abs=0.02)
+
+
+def test_box_box_contacts_face_and_edge():
+    desc = {
+        "task": "boxes", "option": {"timestep": 0.01, "integrator": "implicitfast", "cone": "elliptic", "impratio": 1.0, "gravity": [0, 0, -9.81], "contact": True},
+        "bodies": [dict(name="world", parent=-1, pos=[0, 0, 0], quat=[1, 0, 0, 0], mass=0, ipos=[0, 0, 0], iquat=[1, 0, 0, 0], inertia=[0, 0, 0]),
+                   dict(name="a", parent=0, pos=[0, 0, 0.149], quat=[1, 0, 0, 0], mass=1.0, ipos=[0, 0, 0], iquat=[1, 0, 0, 0], inertia=[0.01, 0.01, 0.01]),
+                   dict(name="floor", parent=0, pos=[0, 0, 0], quat=[1, 0, 0, 0], mass=0, ipos=[0, 0, 0], iquat=[1, 0, 0, 0], inertia=[0, 0, 0])],
+        "joints": [dict(name="f", body=1, type="free", pos=[0, 0, 0], axis=[0, 0, 1], damping=0, armature=0, frictionloss=0, stiffness=0, ref=0, margin=0, range=None,
+                        actuatorfrcrange=None, solreflimit=[0.02, 1], solimplimit=[0.9, 0.95, 0.001, 0.5, 2], solreffriction=[0.02, 1], solimpfriction=[0.9, 0.95, 0.001, 0.5, 2])],
+        "geoms": [dict(name="ga", body=1, type="box", size=[0.05, 0.05, 0.05], pos=[0, 0, 0], quat=[1, 0, 0, 0], friction=[1, 0.005, 0.0001], solref=[0.02, 1],
+                       solimp=[0.9, 0.95, 0.001, 0.5, 2], margin=0, gap=0, condim=3),
+                  dict(name="gf", body=2, type="box", size=[1, 1, 0.1], pos=[0, 0, 0], quat=[1, 0, 0, 0], friction=[1, 0.005, 0.0001], solref=[0.02, 1],
+                       solimp=[0.9, 0.95, 0.001, 0.5, 2], margin=0, gap=0, condim=3)],
+        "sites": [], "actuators": [], "sensors": [], "excludes": [], "equalities": [], "nsensordata": 0,
+    }
+    m = O.Model("boxes", desc, pairs=[(0, 1)])
+    out = m.forward(np.array([0, 0, 0.149, 1, 0, 0, 0.0]), np.zeros(6), np.zeros(0))
+    assert out["ncon"] == 4  # face-face: the four corners of the small box
+    np.testing.assert_allclose(out["contacts"][:, 0], -0.001, atol=1e-12)
+    np.testing.assert_allclose(np.abs(out["contacts"][:, 4:7]), [[0, 0, 1]] * 4, atol=1e-12)
+    assert out["contacts"][0, 6] < 0  # normal points from geom 1 (box a) to geom 2 (floor): downwards
+    np.testing.assert_allclose(sorted(out["contacts"][:, 1]), [-0.05, -0.05, 0.05, 0.05], atol=1e-12)
+    # resting: total normal force ~ weight
+    st, _ = m.rollout(np.array([0, 0, 0.149, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]), np.zeros((1, 100, 0)))
+    o2 = m.forward(st[0, -1, :7], st[0, -1, 7:], np.zeros(0))
+    assert o2["qfrc_constraint"][2] == pytest.approx(9.81, rel=0.02)
+    # edge-edge: box rotated 45deg about x AND placed across the floor's top edge
+    c = np.cos(np.pi / 8)
+    s = np.sin(np.pi / 8)
+    q = np.array([1.0 + 0.03, 0.0, 0.1 + 0.0707 - 0.05, c, s, 0, 0])  # hanging over the x = 1 edge of the floor
+    o3 = m.forward(q, np.zeros(6), np.zeros(0))
+    assert o3["ncon"] >= 1
