@@ -62,6 +62,10 @@ int jh_model_dims(const jh_model* m, int* dims /* HOST */);
  * Newton iteration cap, out[2] Newton iterations, out[3] physics steps.  HOST pointer. */
 int jh_model_stats(jh_model* m, int* out /* HOST, 4 ints */, int reset);
 
+/* Articulated-body engine kernel generation for this model: 2 (default) = cooperative kernel, 16 lanes per rollout;
+ * 1 = one lane per rollout (kept as an independent second implementation for the parity tests). */
+int jh_model_set_kernel(jh_model* m, int generation);
+
 /* Fused plan-step kernel.  Replaces, for N rollouts in one launch:
  *   Optimizer.sample_control_knots         judo/optimizers/{mppi.py:38-59,ps.py:29-50,cem.py:55-74}
  *   np.clip to actuator_ctrlrange          judo/controller/controller.py:253-257

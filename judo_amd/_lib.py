@@ -23,6 +23,7 @@ _SIGNATURES = {
     "jh_model_destroy": (None, [C.c_void_p]),
     "jh_model_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "jh_model_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "jh_model_set_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_rollout_cost": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_rollout_materialize": (C.c_int, [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_task_reward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),

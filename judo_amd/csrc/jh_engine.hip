@@ -14,102 +14,13 @@
 // Precision: fp32 everywhere except the Newton Hessian (assembly + Cholesky + solve), which is fp64 -- the stiff
 // friction rows (impratio 100) against 1e-5 kg m^2 finger inertias give it a condition number ~1e7, and CDNA4's fp64
 // VALU rate is half its fp32 rate, so this costs little.
-#include "jh_internal.h"
+#include "jh_engine_common.h"
+
+using namespace jh_eng;
 
 namespace {
 
 constexpr int kBlock = 64;
-constexpr int JFREE = 0, JSLIDE = 2, JHINGE = 3;
-constexpr int GBOX = 6, GSPHERE = 2;
-constexpr int HEADER_I = 24, HEADER_F = 24;
-constexpr int BODY_I = 6, GEOM_I = 2, ACT_I = 2, BLOCK_I = 4, SENS_I = 3;
-constexpr int BODY_F = 32, DOF_F = 20, ACT_F = 8, GEOM_F = 20, SITE_F = 3;
-// header floats
-enum { HF_DT = 0, HF_IMPRATIO = 1, HF_TOL = 2, HF_MAXITER = 22, HF_GRAV = 3, HF_CK = 6, HF_CB = 7, HF_SOLIMP = 8, HF_CMASS = 13, HF_CINERTIA = 14, HF_CSIZE = 17, HF_CRBOUND = 20, HF_CTRAN = 21 };
-// body floats
-enum { BF_LPOS = 0, BF_LR = 3, BF_MASS = 12, BF_IPOS = 13, BF_IR = 16, BF_INERTIA = 25, BF_AXIS = 28, BF_TRAN = 31 };
-// dof floats
-enum { DF_DAMP = 0, DF_ARM, DF_FL, DF_FB, DF_FD, DF_INVW, DF_LIMITED, DF_LO, DF_HI, DF_LK, DF_LB, DF_SOLIMP, DF_FRCLIM = 16, DF_FRCLO, DF_FRCHI, DF_KV };
-// actuator floats
-enum { AF_KP = 0, AF_KV, AF_CLIM, AF_CLO, AF_CHI };
-// geom floats
-enum { GF_SIZE = 0, GF_POS = 3, GF_R = 6, GF_RBOUND = 15, GF_MU = 16, GF_TRAN = 17 };
-
-struct EngineModel {  // views into the LDS copy of the blob
-  const float* F;
-  const int* I;
-  int NM, NBLK, NV, NQ, NU, NG, NSITE, NS, NSENS;
-  int oBodyI, oBlockI, oActI, oGeomI, oSiteI, oSensI;
-  int oBodyF, oDofF, oActF, oGeomF, oSiteF;
-  __device__ void init(const float* f, const int* i) {
-    F = f; I = i;
-    NM = i[0]; NBLK = i[1]; NV = i[2]; NQ = i[3]; NU = i[4]; NG = i[5]; NSITE = i[6]; NS = i[7]; NSENS = i[10];
-    oBodyI = HEADER_I; oBlockI = oBodyI + NM * BODY_I; oActI = oBlockI + NBLK * BLOCK_I; oGeomI = oActI + NU * ACT_I;
-    oSiteI = oGeomI + NG * GEOM_I; oSensI = oSiteI + NSITE;
-    oBodyF = HEADER_F; oDofF = oBodyF + NM * BODY_F; oActF = oDofF + NV * DOF_F; oGeomF = oActF + NU * ACT_F; oSiteF = oGeomF + NG * GEOM_F;
-  }
-};
-
-template <int NM_, int NV_, int NQ_, int NU_, int NBLK_, int BD_, int NCON_, int NS_>
-struct Cfg {
-  static constexpr int NM = NM_, NV = NV_, NQ = NQ_, NU = NU_, NBLK = NBLK_, BD = BD_, NCON = NCON_, NS = NS_, NX = NQ_ + NV_;
-  static constexpr int TRI = BD_ * (BD_ + 1) / 2;
-};
-using LeapCfg = Cfg<17, 22, 23, 16, 4, 4, 32, 31>;
-
-// ------------------------------------------------------------------------------------------------ small vector helpers
-__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-__device__ __forceinline__ void cross3(float* r, const float* a, const float* b) {
-  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-__device__ __forceinline__ void mulMV(float* r, const float* R, const float* v) {  // r = R v (row-major 3x3)
-  float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2], z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-__device__ __forceinline__ void mulMTV(float* r, const float* R, const float* v) {  // r = R' v
-  float x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2], z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-__device__ __forceinline__ void mulMM(float* C, const float* A, const float* B) {
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
-}
-__device__ __forceinline__ void quat2mat(float* R, const float* q) {
-  float w = q[0], x = q[1], y = q[2], z = q[3];
-  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
-  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
-  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
-}
-__device__ __forceinline__ void col3(float* a, const float* R, int k) { a[0] = R[k]; a[1] = R[3 + k]; a[2] = R[6 + k]; }
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower triangle, j <= i
-
-__device__ __forceinline__ float impedance(const float* si, float dist) {
-  float s0 = si[0], s1 = si[1], s2 = si[2], s3 = si[3], s4 = si[4];
-  if (s0 == s1 || s2 <= 1e-15f) return 0.5f * (s0 + s1);
-  float x = fabsf(dist / s2);
-  if (x >= 1.f) return s1;
-  if (x <= 0.f) return s0;
-  float y;
-  if (s4 == 1.f) y = x;
-  else if (s4 == 2.f) y = (x <= s3) ? x * x / s3 : 1.f - (1.f - x) * (1.f - x) / (1.f - s3);
-  else if (x <= s3) y = powf(x, s4) / powf(s3, s4 - 1.f);
-  else y = 1.f - powf(1.f - x, s4) / powf(1.f - s3, s4 - 1.f);
-  return s0 + y * (s1 - s0);
-}
-
-// contact frame from the normal, tangents as MuJoCo's mju_makeFrame picks them
-__device__ __forceinline__ void make_frame(float* fr) {
-  float* x = fr; float* y = fr + 3; float* z = fr + 6;
-  float nn = rsqrtf(dot3(x, x)); x[0] *= nn; x[1] *= nn; x[2] *= nn;
-  if (x[1] < -0.5f || x[1] > 0.5f) { y[0] = 0; y[1] = 0; y[2] = 1; } else { y[0] = 0; y[1] = 1; y[2] = 0; }
-  float dp = dot3(x, y); y[0] -= x[0] * dp; y[1] -= x[1] * dp; y[2] -= x[2] * dp;
-  nn = rsqrtf(dot3(y, y)); y[0] *= nn; y[1] *= nn; y[2] *= nn;
-  cross3(z, x, y);
-}
-
 // ------------------------------------------------------------------------------------------------ per-lane working set
 template <class C>
 struct Work {
@@ -160,10 +71,6 @@ __device__ void kinematics(const EngineModel& m, Work<C>& w) {
   }
 }
 
-// world-frame inertia application: r = (Rk diag(I) Rk') v
-__device__ __forceinline__ void inertia_mul(float* r, const float* Rk, const float* di, const float* v) {
-  float t[3]; mulMTV(t, Rk, v); t[0] *= di[0]; t[1] *= di[1]; t[2] *= di[2]; mulMV(r, Rk, t);
-}
 
 // ------------------------------------------------------------------------------------------------ block inertia + bias + smooth forces
 template <class C>
@@ -486,31 +393,16 @@ __device__ void constraint_rows(const EngineModel& m, Work<C>& w) {
   }
 }
 
-// elliptic-cone contact: force = -ds/djar, cost s, Hessian block W (sym 3x3: 00,10,11,20,21,22)
-__device__ __forceinline__ float cone_eval(const float* jar, const float* D, float mu, float fri, float* f, float* W) {
-  float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
-  float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
-  if (N >= mu * T || (T <= 0.f && N >= 0.f)) { f[0] = f[1] = f[2] = 0.f; for (int k = 0; k < 6; k++) W[k] = 0.f; return 0.f; }
-  if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
-    f[0] = -D[0] * jar[0]; f[1] = -D[1] * jar[1]; f[2] = -D[2] * jar[2];
-    W[0] = D[0]; W[1] = 0.f; W[2] = D[1]; W[3] = 0.f; W[4] = 0.f; W[5] = D[2];
-    return 0.5f * (D[0] * jar[0] * jar[0] + D[1] * jar[1] * jar[1] + D[2] * jar[2] * jar[2]);
-  }
-  float Dm = D[0] / (mu * mu * (1.f + mu * mu)), NT = N - mu * T, iT = 1.f / T;
-  f[0] = -Dm * NT * mu; f[1] = -f[0] * iT * U1 * fri; f[2] = -f[0] * iT * U2 * fri;
-  float h00 = Dm, h01 = -Dm * mu * U1 * iT, h02 = -Dm * mu * U2 * iT;
-  float k1 = Dm * mu * mu * iT * iT, k2 = Dm * NT * mu * iT;
-  float h11 = k1 * U1 * U1 - k2 * (1.f - U1 * U1 * iT * iT), h12 = k1 * U1 * U2 + k2 * U1 * U2 * iT * iT, h22 = k1 * U2 * U2 - k2 * (1.f - U2 * U2 * iT * iT);
-  W[0] = mu * h00 * mu; W[1] = fri * h01 * mu; W[2] = fri * h11 * fri; W[3] = fri * h02 * mu; W[4] = fri * h12 * fri; W[5] = fri * h22 * fri;
-  return 0.5f * Dm * NT * NT;
-}
-
 // ------------------------------------------------------------------------------------------------ Newton solver (arrow Hessian, fp64 linear algebra)
+#ifndef JH_HESS_T
+#define JH_HESS_T double
+#endif
+typedef JH_HESS_T hreal;
 template <class C>
 struct Hess {
-  double cc[21];
-  double bb[C::NBLK][C::TRI];
-  double cb[C::NBLK][6 * C::BD];
+  hreal cc[21];
+  hreal bb[C::NBLK][C::TRI];
+  hreal cb[C::NBLK][6 * C::BD];
 };
 
 // row data of the current iterate: jar (= J a - aref) for contacts / friction-loss / limits
@@ -644,10 +536,10 @@ __device__ int solve_constraints(const EngineModel& m, Work<C>& w, int max_iter,
       float Gc[6][3], Gb[C::BD][3];
       for (int k = 0; k < 6; k++) { const float* j = Jc[k]; Gc[k][0] = W[0] * j[0] + W[1] * j[1] + W[3] * j[2]; Gc[k][1] = W[1] * j[0] + W[2] * j[1] + W[4] * j[2]; Gc[k][2] = W[3] * j[0] + W[4] * j[1] + W[5] * j[2]; }
       for (int k = 0; k < nbcol; k++) { const float* j = Jb[k]; Gb[k][0] = W[0] * j[0] + W[1] * j[1] + W[3] * j[2]; Gb[k][1] = W[1] * j[0] + W[2] * j[1] + W[4] * j[2]; Gb[k][2] = W[3] * j[0] + W[4] * j[1] + W[5] * j[2]; }
-      for (int u = 0; u < 6; u++) for (int v = 0; v <= u; v++) H.cc[tri(u, v)] += (double)(Jc[u][0] * Gc[v][0] + Jc[u][1] * Gc[v][1] + Jc[u][2] * Gc[v][2]);
+      for (int u = 0; u < 6; u++) for (int v = 0; v <= u; v++) H.cc[tri(u, v)] += (hreal)(Jc[u][0] * Gc[v][0] + Jc[u][1] * Gc[v][1] + Jc[u][2] * Gc[v][2]);
       for (int u = 0; u < nbcol; u++) {
-        for (int v = 0; v < nbcol; v++) if (lb[v] <= lb[u]) H.bb[blkid][tri(lb[u], lb[v])] += (double)(Jb[u][0] * Gb[v][0] + Jb[u][1] * Gb[v][1] + Jb[u][2] * Gb[v][2]);
-        for (int q = 0; q < 6; q++) H.cb[blkid][q * C::BD + lb[u]] += (double)(Jc[q][0] * Gb[u][0] + Jc[q][1] * Gb[u][1] + Jc[q][2] * Gb[u][2]);
+        for (int v = 0; v < nbcol; v++) if (lb[v] <= lb[u]) H.bb[blkid][tri(lb[u], lb[v])] += (hreal)(Jb[u][0] * Gb[v][0] + Jb[u][1] * Gb[v][1] + Jb[u][2] * Gb[v][2]);
+        for (int q = 0; q < 6; q++) H.cb[blkid][q * C::BD + lb[u]] += (hreal)(Jc[q][0] * Gb[u][0] + Jc[q][1] * Gb[u][1] + Jc[q][2] * Gb[u][2]);
       }
     }
     for (int c = 0; c < C::NBLK; c++) {
@@ -656,9 +548,9 @@ __device__ int solve_constraints(const EngineModel& m, Work<C>& w, int max_iter,
         int d = d0 + l; const float* df = F + m.oDofF + d * DOF_F; float fl = df[DF_FL];
         if (fl > 0.f) {
           float D = df[DF_FD], R = 1.f / D, x = r.fj[d];
-          if (x <= -R * fl) g[d] -= fl; else if (x >= R * fl) g[d] += fl; else { g[d] += D * x; H.bb[c][tri(l, l)] += (double)D; }
+          if (x <= -R * fl) g[d] -= fl; else if (x >= R * fl) g[d] += fl; else { g[d] += D * x; H.bb[c][tri(l, l)] += (hreal)D; }
         }
-        if (w.lims[d] != 0.f && r.lj[d] < 0.f) { g[d] += w.lims[d] * w.lD[d] * r.lj[d]; H.bb[c][tri(l, l)] += (double)w.lD[d]; }
+        if (w.lims[d] != 0.f && r.lj[d] < 0.f) { g[d] += w.lims[d] * w.lD[d] * r.lj[d]; H.bb[c][tri(l, l)] += (hreal)w.lD[d]; }
       }
     }
     // ---- convergence: gradient norm scaled by the inertia diagonal
@@ -672,41 +564,41 @@ __device__ int solve_constraints(const EngineModel& m, Work<C>& w, int max_iter,
     // ---- arrow Cholesky: chains first, Schur complement on the cube block
     for (int c = 0; c < C::NBLK; c++) {
       const int nb = m.I[m.oBlockI + c * BLOCK_I + 1];
-      double* L = H.bb[c];
+      hreal* L = H.bb[c];
       for (int i = 0; i < nb; i++)
         for (int j = 0; j <= i; j++) {
-          double s = L[tri(i, j)];
+          hreal s = L[tri(i, j)];
           for (int k = 0; k < j; k++) s -= L[tri(i, k)] * L[tri(j, k)];
-          L[tri(i, j)] = (i == j) ? sqrt(fmax(s, 1e-300)) : s / L[tri(j, j)];
+          L[tri(i, j)] = (i == j) ? (hreal)sqrt(fmax((double)s, 1e-30)) : s / L[tri(j, j)];
         }
       for (int q = 0; q < 6; q++) {
-        double* y = H.cb[c] + q * C::BD;
-        for (int i = 0; i < nb; i++) { double s = y[i]; for (int k = 0; k < i; k++) s -= L[tri(i, k)] * y[k]; y[i] = s / L[tri(i, i)]; }
+        hreal* y = H.cb[c] + q * C::BD;
+        for (int i = 0; i < nb; i++) { hreal s = y[i]; for (int k = 0; k < i; k++) s -= L[tri(i, k)] * y[k]; y[i] = s / L[tri(i, i)]; }
       }
-      for (int q = 0; q < 6; q++) for (int s2 = 0; s2 <= q; s2++) { double acc = 0; for (int i = 0; i < nb; i++) acc += H.cb[c][q * C::BD + i] * H.cb[c][s2 * C::BD + i]; H.cc[tri(q, s2)] -= acc; }
+      for (int q = 0; q < 6; q++) for (int s2 = 0; s2 <= q; s2++) { hreal acc = 0; for (int i = 0; i < nb; i++) acc += H.cb[c][q * C::BD + i] * H.cb[c][s2 * C::BD + i]; H.cc[tri(q, s2)] -= acc; }
     }
     for (int i = 0; i < 6; i++)
       for (int j = 0; j <= i; j++) {
-        double s = H.cc[tri(i, j)];
+        hreal s = H.cc[tri(i, j)];
         for (int k = 0; k < j; k++) s -= H.cc[tri(i, k)] * H.cc[tri(j, k)];
-        H.cc[tri(i, j)] = (i == j) ? sqrt(fmax(s, 1e-300)) : s / H.cc[tri(j, j)];
+        H.cc[tri(i, j)] = (i == j) ? (hreal)sqrt(fmax((double)s, 1e-30)) : s / H.cc[tri(j, j)];
       }
     // ---- p = -H^-1 g
-    double zc[6], zb[C::NBLK][C::BD];
-    for (int q = 0; q < 6; q++) zc[q] = -(double)g[q];
+    hreal zc[6], zb[C::NBLK][C::BD];
+    for (int q = 0; q < 6; q++) zc[q] = -(hreal)g[q];
     for (int c = 0; c < C::NBLK; c++) {
-      const int* blk = m.I + m.oBlockI + c * BLOCK_I; const int nb = blk[1], d0 = blk[2]; const double* L = H.bb[c];
-      for (int i = 0; i < nb; i++) { double s = -(double)g[d0 + i]; for (int k = 0; k < i; k++) s -= L[tri(i, k)] * zb[c][k]; zb[c][i] = s / L[tri(i, i)]; }
-      for (int q = 0; q < 6; q++) { double acc = 0; for (int i = 0; i < nb; i++) acc += H.cb[c][q * C::BD + i] * zb[c][i]; zc[q] -= acc; }
+      const int* blk = m.I + m.oBlockI + c * BLOCK_I; const int nb = blk[1], d0 = blk[2]; const hreal* L = H.bb[c];
+      for (int i = 0; i < nb; i++) { hreal s = -(hreal)g[d0 + i]; for (int k = 0; k < i; k++) s -= L[tri(i, k)] * zb[c][k]; zb[c][i] = s / L[tri(i, i)]; }
+      for (int q = 0; q < 6; q++) { hreal acc = 0; for (int i = 0; i < nb; i++) acc += H.cb[c][q * C::BD + i] * zb[c][i]; zc[q] -= acc; }
     }
-    for (int i = 0; i < 6; i++) { double s = zc[i]; for (int k = 0; k < i; k++) s -= H.cc[tri(i, k)] * zc[k]; zc[i] = s / H.cc[tri(i, i)]; }
-    for (int i = 5; i >= 0; i--) { double s = zc[i]; for (int k = i + 1; k < 6; k++) s -= H.cc[tri(k, i)] * zc[k]; zc[i] = s / H.cc[tri(i, i)]; }
+    for (int i = 0; i < 6; i++) { hreal s = zc[i]; for (int k = 0; k < i; k++) s -= H.cc[tri(i, k)] * zc[k]; zc[i] = s / H.cc[tri(i, i)]; }
+    for (int i = 5; i >= 0; i--) { hreal s = zc[i]; for (int k = i + 1; k < 6; k++) s -= H.cc[tri(k, i)] * zc[k]; zc[i] = s / H.cc[tri(i, i)]; }
     float p[C::NV];
     for (int q = 0; q < 6; q++) p[q] = (float)zc[q];
     for (int c = 0; c < C::NBLK; c++) {
-      const int* blk = m.I + m.oBlockI + c * BLOCK_I; const int nb = blk[1], d0 = blk[2]; const double* L = H.bb[c];
-      for (int i = 0; i < nb; i++) { double acc = 0; for (int q = 0; q < 6; q++) acc += H.cb[c][q * C::BD + i] * zc[q]; zb[c][i] -= acc; }
-      for (int i = nb - 1; i >= 0; i--) { double s = zb[c][i]; for (int k = i + 1; k < nb; k++) s -= L[tri(k, i)] * zb[c][k]; zb[c][i] = s / L[tri(i, i)]; }
+      const int* blk = m.I + m.oBlockI + c * BLOCK_I; const int nb = blk[1], d0 = blk[2]; const hreal* L = H.bb[c];
+      for (int i = 0; i < nb; i++) { hreal acc = 0; for (int q = 0; q < 6; q++) acc += H.cb[c][q * C::BD + i] * zc[q]; zb[c][i] -= acc; }
+      for (int i = nb - 1; i >= 0; i--) { hreal s = zb[c][i]; for (int k = i + 1; k < nb; k++) s -= L[tri(k, i)] * zb[c][k]; zb[c][i] = s / L[tri(i, i)]; }
       for (int i = 0; i < nb; i++) p[d0 + i] = (float)zb[c][i];
     }
     // ---- exact line search along p: safeguarded 1-D Newton on phi'(alpha)
@@ -815,23 +707,6 @@ __device__ void engine_sensors(const EngineModel& m, const Work<C>& w, float* y)
     else if (tp == 3) { float z[3]; col3(z, w.xR[obj], 2); for (int k = 0; k < 3; k++) y[adr + k] = z[k]; }
     else y[adr] = 0.f;
   }
-}
-
-// ------------------------------------------------------------------------------------------------ task costs
-// leap_cube (judo/tasks/leap_cube.py:63-88): tp = (w_pos, w_rot, goal_pos[3], goal_quat[4]); MEAN over time
-__device__ __forceinline__ float leap_step_cost(const float* tp, const float* qpos) {
-  float d0 = qpos[0] - tp[2], d1 = qpos[1] - tp[3], d2 = qpos[2] - tp[4];
-  const float* v = tp + 5;
-  float u0 = qpos[3], u1 = -qpos[4], u2 = -qpos[5], u3 = -qpos[6];
-  float ww = u0 * v[0] - u1 * v[1] - u2 * v[2] - u3 * v[3];
-  float x = u0 * v[1] + u1 * v[0] + u2 * v[3] - u3 * v[2];
-  float y = u0 * v[2] - u1 * v[3] + u2 * v[0] + u3 * v[1];
-  float z = u0 * v[3] + u1 * v[2] - u2 * v[1] + u3 * v[0];
-  float sn = sqrtf(x * x + y * y + z * z);
-  float speed = 2.f * atan2f(sn, ww);
-  if (speed > 3.14159265358979f) speed -= 6.28318530717959f;
-  // |axis| = 1 in both branches of safe_normalize_axis, so |log map|^2 = speed^2
-  return tp[0] * 0.5f * (d0 * d0 + d1 * d1 + d2 * d2) + tp[1] * 0.5f * speed * speed;
 }
 
 // ------------------------------------------------------------------------------------------------ kernels

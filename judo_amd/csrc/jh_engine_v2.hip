@@ -1,0 +1,776 @@
+// jh_engine_v2.hip -- cooperative articulated-body rollout kernel for leap_cube (gfx950): 16 lanes per rollout.
+//
+// Why: the one-lane-per-rollout kernel (jh_engine.hip) keeps ~7.5 KB of per-lane working set in scratch and is bound by
+// that traffic (profiles/r01_v1_*: 670 GB of HBM traffic per launch for 17 MB of algorithmic bytes); at 65 536 rollouts it
+// also gives the chip only one wave per SIMD.  Here a rollout is spread over one DPP row of 16 lanes (4 rollouts per
+// wave64), which maps the model exactly: lane (c,s) owns link s of finger chain c, its joint, its actuator, its dof
+// constraint rows and a share of the collision geoms; the cube state is replicated in registers.  Per-rollout shared
+// state (body poses, the 22-vectors of the solver, the arrow Hessian, the contact pool) lives in LDS; contacts are
+// balanced over the lanes (<= 2 per lane, Jacobian columns in registers); cross-lane sums are DPP/permute butterflies
+// inside the row, contact contributions to the gradient and Hessian are LDS float atomics.  Nothing spills except the
+// box-box clipping polygon.  Workgroup = one wave, so `__syncthreads()` is a free intra-wave LDS fence and rollouts
+// in different waves never wait for each other.
+//
+// The arithmetic is the same restatement of MuJoCo's step as jh_engine.hip / oracle/jo_engine.c;
+// fp32 throughout (an fp32 Hessian was measured to need the same number of Newton iterations as fp64).
+#include "jh_engine_common.h"
+
+using namespace jh_eng;
+
+namespace {
+
+constexpr int G = 16, RPW = 4, WAVE = 64;
+constexpr int NCH = 4, NLK = 4;
+constexpr int NCP = 32;     // contact pool per rollout = 2 slots per lane
+constexpr int MAXHIT = 32;  // broad-phase survivors per rollout
+constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
+constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
+
+struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
+  float xpos[NMB][3], xR[NMB][9], axw[NMB][3];
+  float qv[NV], a[NV], a0[NV], g[NV], p[NV];
+  float Hcc[21], Hbb[NCH][10], Hcb[NCH][24];  // Hcb[c][j*6+q]: chain column j, cube row q
+  float rhs6[6];
+  float pool[NCP][POOL_F];
+  int hits[MAXHIT];
+  int ncon, nhit;
+};
+
+__device__ __forceinline__ float gsum(float v) {  // sum over the 16 lanes of a rollout
+  v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE); v += __shfl_xor(v, 4, WAVE); v += __shfl_xor(v, 8, WAVE);
+  return v;
+}
+__device__ __forceinline__ float csum(float v) {  // sum over the 4 lanes of a chain
+  v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE);
+  return v;
+}
+__device__ __forceinline__ int gor(int v) {
+  v |= __shfl_xor(v, 1, WAVE); v |= __shfl_xor(v, 2, WAVE); v |= __shfl_xor(v, 4, WAVE); v |= __shfl_xor(v, 8, WAVE);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ collision into the LDS pool
+struct PoolCtx { RS* S; int* overflow; };
+
+__device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos, const float* n, float dist, int body, float mu, float tran) {
+  int i = atomicAdd(&pc.S->ncon, 1);
+  if (i >= NCP) { if (pc.overflow) atomicAdd(pc.overflow, 1); return; }
+  float* e = pc.S->pool[i];
+  e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = dist; e[7] = mu; e[8] = __int_as_float(body); e[9] = tran;
+}
+
+// box 1 = the cube (geom 1), box 2 = hand geom; normal from box 1 to box 2 (same algorithm as jh_engine.hip / the oracle)
+__device__ void collide_box_box(const PoolCtx& pc, const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2, int body, float mu, float tran) {
+  float A[3][3], B[3][3], dv[3], Cm[3][3], AC[3][3], dA[3], dB[3];
+  for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
+  for (int i = 0; i < 3; i++) { dA[i] = dot3(dv, A[i]); dB[i] = dot3(dv, B[i]); for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); AC[i][j] = fabsf(Cm[i][j]); } }
+  float best = -1e30f; int btype = -1, bi = 0, bj = 0;
+  for (int i = 0; i < 3; i++) {
+    float s = fabsf(dA[i]) - (h1[i] + h2[0] * AC[i][0] + h2[1] * AC[i][1] + h2[2] * AC[i][2]);
+    if (s > 0.f) return;
+    if (s > best) { best = s; btype = 0; bi = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    float s = fabsf(dB[j]) - (h2[j] + h1[0] * AC[0][j] + h1[1] * AC[1][j] + h1[2] * AC[2][j]);
+    if (s > 0.f) return;
+    if (s > best) { best = s; btype = 1; bj = j; }
+  }
+  float ebest = -1e30f, eL[3] = {0, 0, 0}; int ei = -1, ej = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float L[3]; cross3(L, A[i], B[j]);
+      float l2 = dot3(L, L);
+      if (l2 < 1e-12f) continue;
+      float il = rsqrtf(l2); L[0] *= il; L[1] *= il; L[2] *= il;
+      float ra = 0.f, rb = 0.f;
+      for (int k = 0; k < 3; k++) { ra += h1[k] * fabsf(dot3(A[k], L)); rb += h2[k] * fabsf(dot3(B[k], L)); }
+      float s = fabsf(dot3(dv, L)) - (ra + rb);
+      if (s > 0.f) return;
+      if (s > ebest) { ebest = s; ei = i; ej = j; eL[0] = L[0]; eL[1] = L[1]; eL[2] = L[2]; }
+    }
+  bool use_edge = ei >= 0 && (best < 0.f ? ebest > best / 1.05f + 1e-12f : ebest > best * 1.05f + 1e-12f);
+  if (use_edge) {
+    float n[3] = {eL[0], eL[1], eL[2]};
+    if (dot3(n, dv) < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    float pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) { float s = (dot3(n, A[k]) > 0.f ? 1.f : -1.f) * h1[k]; pa[0] += A[k][0] * s; pa[1] += A[k][1] * s; pa[2] += A[k][2] * s; }
+      if (k != ej) { float s = (dot3(n, B[k]) > 0.f ? -1.f : 1.f) * h2[k]; pb[0] += B[k][0] * s; pb[1] += B[k][1] * s; pb[2] += B[k][2] * s; }
+    }
+    float wv[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    float b = Cm[ei][ej], dd = dot3(A[ei], wv), e = dot3(B[ej], wv), den = 1.f - b * b;
+    float s = den > 1e-12f ? (b * e - dd) / den : 0.f, t = den > 1e-12f ? (e - b * dd) / den : 0.f;
+    s = jh_clampf(s, -h1[ei], h1[ei]); t = jh_clampf(t, -h2[ej], h2[ej]);
+    float pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + A[ei][k] * s) + (pb[k] + B[ej][k] * t));
+    push_contact(pc, pos, n, ebest, body, mu, tran);
+    return;
+  }
+  const float *pr, *pi, *hr, *hi; float (*Ar)[3], (*Ai)[3]; int ri; float n[3];
+  if (btype == 0) { pr = p1; pi = p2; hr = h1; hi = h2; Ar = A; Ai = B; ri = bi; float sg = dA[bi] >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = sg * A[bi][k]; }
+  else { pr = p2; pi = p1; hr = h2; hi = h1; Ar = B; Ai = A; ri = bj; float sg = dB[bj] >= 0.f ? -1.f : 1.f; for (int k = 0; k < 3; k++) n[k] = sg * B[bj][k]; }
+  int mi = 0; float mb = -1.f;
+  for (int k = 0; k < 3; k++) { float v = fabsf(dot3(n, Ai[k])); if (v > mb) { mb = v; mi = k; } }
+  float sgi = dot3(n, Ai[mi]) > 0.f ? -1.f : 1.f;
+  int u = (mi + 1) % 3, v = (mi + 2) % 3;
+  float poly[8][3], tmp[8][3]; int np = 4;
+  const float su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+  for (int q = 0; q < 4; q++)
+    for (int k = 0; k < 3; k++) poly[q][k] = pi[k] + sgi * hi[mi] * Ai[mi][k] + su[q] * hi[u] * Ai[u][k] + sv[q] * hi[v] * Ai[v][k];
+  int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
+  for (int pl = 0; pl < 4 && np > 0; pl++) {
+    const float* ax = Ar[pl < 2 ? ra : rb]; float sg = (pl & 1) ? -1.f : 1.f, lim = hr[pl < 2 ? ra : rb];
+    int nq = 0;
+    for (int q = 0; q < np; q++) {
+      const float* P = poly[q]; const float* Q = poly[(q + 1) % np];
+      float dp[3] = {P[0] - pr[0], P[1] - pr[1], P[2] - pr[2]}, dq[3] = {Q[0] - pr[0], Q[1] - pr[1], Q[2] - pr[2]};
+      float fp = sg * dot3(dp, ax) - lim, fq = sg * dot3(dq, ax) - lim;
+      if (fp <= 0.f && nq < 8) { tmp[nq][0] = P[0]; tmp[nq][1] = P[1]; tmp[nq][2] = P[2]; nq++; }
+      if (((fp < 0.f && fq > 0.f) || (fp > 0.f && fq < 0.f)) && nq < 8) { float t = fp / (fp - fq); for (int k = 0; k < 3; k++) tmp[nq][k] = P[k] + t * (Q[k] - P[k]); nq++; }
+    }
+    np = nq;
+    for (int q = 0; q < np; q++) { poly[q][0] = tmp[q][0]; poly[q][1] = tmp[q][1]; poly[q][2] = tmp[q][2]; }
+  }
+  for (int q = 0; q < np; q++) {
+    float dx[3] = {poly[q][0] - pr[0], poly[q][1] - pr[1], poly[q][2] - pr[2]};
+    float depth = hr[ri] - dot3(dx, n);
+    if (-depth >= 0.f) continue;
+    float pos[3], nn[3];
+    for (int k = 0; k < 3; k++) { pos[k] = poly[q][k] + 0.5f * depth * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
+    push_contact(pc, pos, nn, -depth, body, mu, tran);
+  }
+}
+
+__device__ void collide_box_sphere(const PoolCtx& pc, const float* pb, const float* Rb, const float* hb, const float* c, float r, int body, float mu, float tran) {
+  float dl[3] = {c[0] - pb[0], c[1] - pb[1], c[2] - pb[2]}, cl[3], q[3]; bool outside = false;
+  mulMTV(cl, Rb, dl);
+  for (int k = 0; k < 3; k++) { q[k] = cl[k]; if (q[k] > hb[k]) { q[k] = hb[k]; outside = true; } else if (q[k] < -hb[k]) { q[k] = -hb[k]; outside = true; } }
+  float nl[3], dist;
+  if (outside) {
+    float df[3] = {cl[0] - q[0], cl[1] - q[1], cl[2] - q[2]}; float l = sqrtf(dot3(df, df));
+    if (l - r >= 0.f) return;
+    nl[0] = df[0] / l; nl[1] = df[1] / l; nl[2] = df[2] / l; dist = l - r;
+  } else {
+    int kb = 0; float mn = 1e30f;
+    for (int k = 0; k < 3; k++) { float s = hb[k] - fabsf(cl[k]); if (s < mn) { mn = s; kb = k; } }
+    nl[0] = nl[1] = nl[2] = 0.f; nl[kb] = cl[kb] >= 0.f ? 1.f : -1.f;
+    q[kb] = nl[kb] * hb[kb]; dist = -mn - r;
+  }
+  float ql[3] = {q[0] + 0.5f * dist * nl[0], q[1] + 0.5f * dist * nl[1], q[2] + 0.5f * dist * nl[2]}, pos[3], n[3];
+  mulMV(pos, Rb, ql); for (int k = 0; k < 3; k++) pos[k] += pb[k];
+  mulMV(n, Rb, nl);
+  push_contact(pc, pos, n, dist, body, mu, tran);
+}
+
+// ------------------------------------------------------------------------------------------------ per-lane contact slot
+struct Slot {
+  bool valid;
+  int chain;         // finger chain of geom 2's body, -1 = static
+  float fr[9];       // contact frame rows (normal, t1, t2)
+  float Jr[3][3];    // cube rotational columns (negated), Jr[k][row]
+  float Jb[NLK][3];  // chain columns, Jb[j][row] (0 beyond the body's depth)
+  float aref[3], D[3], mu, fri;
+  float jar[3], jp[3];
+};
+
+// J x for one slot: xc = cube part (6, registers), chain part read from the LDS vector `vec`
+__device__ __forceinline__ void slot_Jx(const Slot& s, const float* xc, const float* vec, float* out) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float v = -(s.fr[3 * r] * xc[0] + s.fr[3 * r + 1] * xc[1] + s.fr[3 * r + 2] * xc[2]) + s.Jr[0][r] * xc[3] + s.Jr[1][r] * xc[4] + s.Jr[2][r] * xc[5];
+    out[r] = v;
+  }
+  if (s.chain >= 0) {
+    const float* xb = vec + 6 + 4 * s.chain;
+#pragma unroll
+    for (int j = 0; j < NLK; j++) { float xj = xb[j]; out[0] += s.Jb[j][0] * xj; out[1] += s.Jb[j][1] * xj; out[2] += s.Jb[j][2] * xj; }
+  }
+}
+
+// cost / derivative / curvature of this lane's rows at jar + al*jp (contacts in both slots + own dof friction/limit rows)
+struct DofRows { float fl, fD, faref, lims, laref, lD, jf, jl, pf, pl; };
+
+__device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr, float al, bool with_dir, float* cost, float* d1, float* d2) {
+  float cs = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (!sl[k].valid) continue;
+    float jar[3], f[3], W[6];
+    const float* jp = sl[k].jp;
+    for (int r = 0; r < 3; r++) jar[r] = sl[k].jar[r] + (with_dir ? al * jp[r] : 0.f);
+    cs += cone_eval(jar, sl[k].D, sl[k].mu, sl[k].fri, f, W);
+    if (with_dir) {
+      g1 -= f[0] * jp[0] + f[1] * jp[1] + f[2] * jp[2];
+      g2 += W[0] * jp[0] * jp[0] + W[2] * jp[1] * jp[1] + W[5] * jp[2] * jp[2] + 2.f * (W[1] * jp[0] * jp[1] + W[3] * jp[0] * jp[2] + W[4] * jp[1] * jp[2]);
+    }
+  }
+  if (dr.fl > 0.f) {
+    float D = dr.fD, R = 1.f / D, jp = dr.pf, x = dr.jf + (with_dir ? al * jp : 0.f), fl = dr.fl;
+    if (x <= -R * fl) { cs += -0.5f * R * fl * fl - fl * x; g1 -= fl * jp; }
+    else if (x >= R * fl) { cs += -0.5f * R * fl * fl + fl * x; g1 += fl * jp; }
+    else { cs += 0.5f * D * x * x; g1 += D * x * jp; g2 += D * jp * jp; }
+  }
+  if (dr.lims != 0.f) {
+    float jp = dr.pl, x = dr.jl + (with_dir ? al * jp : 0.f);
+    if (x < 0.f) { cs += 0.5f * dr.lD * x * x; g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; }
+  }
+  *cost = cs; *d1 = g1; *d2 = g2;
+}
+
+// 4x4 Cholesky (packed lower) + solve helpers on registers
+__device__ __forceinline__ void chol4(float* L) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = L[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[tri(i, k)] * L[tri(j, k)];
+      L[tri(i, j)] = (i == j) ? sqrtf(fmaxf(s, 1e-30f)) : s / L[tri(j, j)];
+    }
+}
+__device__ __forceinline__ void fwd4(const float* L, float* x) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) { float s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
+    x[i] = s / L[tri(i, i)]; }
+}
+__device__ __forceinline__ void bwd4(const float* L, float* x) {
+#pragma unroll
+  for (int i = 3; i >= 0; i--) { float s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < 4; k++) s -= L[tri(k, i)] * x[k];
+    x[i] = s / L[tri(i, i)]; }
+}
+
+struct LaneConst {  // per-lane model constants (own joint / actuator / dof rows), loaded once
+  float damp, kvd, kp, kv, clo, chi, clim, fl, fB, fD, invw, limited, lo, hi, lK, lB, si[5];
+};
+
+// ------------------------------------------------------------------------------------------------ the kernel
+template <bool MATERIALIZE>
+__global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
+                                                   const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
+                                                   const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
+                                                   const float* __restrict__ tp, int N, int n_offset, int H, int K, float* __restrict__ costs,
+                                                   float* __restrict__ knots_out, const float* __restrict__ controls, float* __restrict__ states,
+                                                   float* __restrict__ sensors, int* __restrict__ stats) {
+  __shared__ RS sRS[RPW];
+  __shared__ float sBody[16 * BODY_F];  // records of the 16 finger links
+  __shared__ float sTp[16];
+  const int lane = threadIdx.x, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3, cb = lane & ~3;
+  RS& S = sRS[r];
+  const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6];
+  const int oBodyF = HEADER_F, oDofF = oBodyF + nmI * BODY_F, oActF = oDofF + gI[2] * DOF_F, oGeomF = oActF + nuI * ACT_F, oSiteF = oGeomF + ngI * GEOM_F;
+  const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
+  const int oLane = gI[11], lgm = gI[12];
+  for (int i = lane; i < 16 * BODY_F; i += WAVE) sBody[i] = gF[oBodyF + BODY_F + i];
+  if (!MATERIALIZE && lane < 9) sTp[lane] = tp[lane];
+  const int n = blockIdx.x * RPW + r;  // rollout handled by this row of 16 lanes
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  // ---- per-lane constants
+  LaneConst lc;
+  {
+    const float* df = gF + oDofF + (6 + l) * DOF_F; const float* af = gF + oActF + l * ACT_F;
+    lc.damp = df[DF_DAMP]; lc.kvd = df[DF_KV]; lc.fl = df[DF_FL]; lc.fB = df[DF_FB]; lc.fD = df[DF_FD]; lc.invw = df[DF_INVW];
+    lc.limited = df[DF_LIMITED]; lc.lo = df[DF_LO]; lc.hi = df[DF_HI]; lc.lK = df[DF_LK]; lc.lB = df[DF_LB];
+    for (int k = 0; k < 5; k++) lc.si[k] = df[DF_SOLIMP + k];
+    lc.kp = af[AF_KP]; lc.kv = af[AF_KV]; lc.clim = af[AF_CLIM]; lc.clo = af[AF_CLO]; lc.chi = af[AF_CHI];
+  }
+  const float h = gF[HF_DT], impratio = gF[HF_IMPRATIO], tol = gF[HF_TOL]; const int cap = (int)gF[HF_MAXITER];
+  const float grav[3] = {gF[HF_GRAV], gF[HF_GRAV + 1], gF[HF_GRAV + 2]};
+  const float cmass = gF[HF_CMASS], cI[3] = {gF[HF_CINERTIA], gF[HF_CINERTIA + 1], gF[HF_CINERTIA + 2]};
+  const float chs[3] = {gF[HF_CSIZE], gF[HF_CSIZE + 1], gF[HF_CSIZE + 2]}, crb = gF[HF_CRBOUND], ctran = gF[HF_CTRAN];
+  const float cK = gF[HF_CK], cB = gF[HF_CB];
+  float csi[5]; for (int k = 0; k < 5; k++) csi[k] = gF[HF_SOLIMP + k];
+  // ---- state: own joint + replicated cube
+  float q, qd, qws = 0.f, qc[7], vc[6], wsc[6] = {0, 0, 0, 0, 0, 0};
+  {
+    const float* xi = x0 + ((MATERIALIZE && x0_batched) ? (size_t)nc * NX : 0);
+    for (int k = 0; k < 7; k++) qc[k] = xi[k];
+    for (int k = 0; k < 6; k++) vc[k] = xi[NQ + k];
+    q = xi[7 + l]; qd = xi[NQ + 6 + l];
+  }
+  // ---- own actuator's spline knots (fused mode): clip(nominal + sigma*noise); global sample 0 keeps the nominal
+  float kn[8];
+  if (!MATERIALIZE) {
+    for (int k = 0; k < 8; k++) kn[k] = 0.f;
+    for (int k = 0; k < K && k < 8; k++) {
+      int i = k * NU + l;
+      float v = nominal[i];
+      if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
+      v = jh_clampf(v, lohi[l], lohi[NU + l]);
+      kn[k] = v;
+      if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
+    }
+  }
+  int n_overflow = 0, n_iters = 0, n_maxed = 0;
+  float acc = 0.f;
+  __syncthreads();
+
+  for (int hh = 0; hh < H; hh++) {
+    // ================================================================ controls
+    float u;
+    if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + l];
+    else { u = 0.f; for (int k = 0; k < K && k < 8; k++) u = fmaf(W[hh * K + k], kn[k], u); }
+    // ================================================================ kinematics (each lane walks its chain up to its own link)
+    float ax[NLK][3], og[NLK][3], Rown[9], pown[3], Rc[9];
+    {
+      float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
+      qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+      quat2mat(Rc, qc + 3);
+      float P[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+      for (int j = 0; j < NLK; j++) {
+        const float* bf = sBody + (4 * c + j) * BODY_F;
+        float qj = __shfl(q, cb + j, WAVE);
+        float P2[3], R0[9];
+        if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
+        else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
+        const float* al = bf + BF_AXIS;
+        mulMV(ax[j], R0, al);
+        for (int k = 0; k < 3; k++) { og[j][k] = P2[k]; P[k] = P2[k]; }
+        float sn, cs; sincosf(qj, &sn, &cs); float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
+        float Rq[9] = {t * x * x + cs, t * x * y - sn * z, t * x * z + sn * y, t * x * y + sn * z, t * y * y + cs, t * y * z - sn * x, t * x * z - sn * y, t * y * z + sn * x, t * z * z + cs};
+        mulMM(R, R0, Rq);
+        if (j == s) { for (int k = 0; k < 3; k++) pown[k] = P2[k]; for (int k = 0; k < 9; k++) Rown[k] = R[k]; }
+      }
+      for (int k = 0; k < 3; k++) { S.xpos[1 + l][k] = pown[k]; S.axw[1 + l][k] = ax[s][k]; }
+      for (int k = 0; k < 9; k++) S.xR[1 + l][k] = Rown[k];
+      if (l == 0) { for (int k = 0; k < 3; k++) S.xpos[0][k] = qc[k]; for (int k = 0; k < 9; k++) S.xR[0][k] = Rc[k]; S.ncon = 0; S.nhit = 0; }
+      S.qv[6 + l] = qd;
+      if (l < 6) S.qv[l] = vc[l];
+    }
+    // sensors of this forward pass (materialise mode): 16 joint positions, then 5 site positions
+    if (MATERIALIZE && sensors) {
+      float* y = sensors + ((size_t)nc * H + hh) * NS;
+      if (live) y[l] = q;
+      __syncthreads();
+      if (live && l < nsiteI && l < 5) {
+        int b = gI[oSiteI + l]; float p3[3]; mulMV(p3, S.xR[b], gF + oSiteF + l * SITE_F);
+        for (int k = 0; k < 3; k++) y[16 + 3 * l + k] = p3[k] + S.xpos[b][k];
+      }
+    }
+    // ================================================================ chain dynamics: inertia block, bias, smooth force
+    float Mc[10], fs_own, a0_own, fsc[6], a0c[6];
+    {
+      const float* bf = sBody + (4 * c + s) * BODY_F;
+      float Rk[9], rr[3], cs3[3]; mulMM(Rk, Rown, bf + BF_IR); mulMV(rr, Rown, bf + BF_IPOS);
+      for (int k = 0; k < 3; k++) cs3[k] = pown[k] + rr[k];
+      const float mass = bf[BF_MASS]; const float* di = bf + BF_INERTIA;
+      // velocities / bias accelerations of the own link (walk down the chain; parent of link 0 is static)
+      float wv[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao[3] = {-grav[0], -grav[1], -grav[2]};
+#pragma unroll
+      for (int j = 0; j < NLK; j++) {
+        float qdj = __shfl(qd, cb + j, WAVE);
+        if (j <= s) {
+          if (j > 0) {
+            float d[3] = {og[j][0] - og[j - 1][0], og[j][1] - og[j - 1][1], og[j][2] - og[j - 1][2]}, t1[3], t2[3], t3[3];
+            cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d);
+            for (int k = 0; k < 3; k++) ao[k] += t3[k] + t2[k];
+          }
+          float wxa[3]; cross3(wxa, wv, ax[j]);
+          for (int k = 0; k < 3; k++) { al[k] += wxa[k] * qdj; wv[k] += ax[j][k] * qdj; }
+        }
+      }
+      float t1[3], t2[3], t3[3], ac[3];
+      cross3(t1, wv, rr); cross3(t2, wv, t1); cross3(t3, al, rr);
+      for (int k = 0; k < 3; k++) ac[k] = ao[k] + t3[k] + t2[k];
+      float Iw[3], Ia[3], gy[3]; inertia_mul(Iw, Rk, di, wv); inertia_mul(Ia, Rk, di, al); cross3(gy, wv, Iw);
+      float Fk[3] = {mass * ac[0], mass * ac[1], mass * ac[2]}, Nk[3] = {Ia[0] + gy[0], Ia[1] + gy[1], Ia[2] + gy[2]};
+      // contributions of the own link to the chain's bias vector and inertia block
+      float bias[NLK];
+      for (int k = 0; k < 10; k++) Mc[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NLK; i++) {
+        bias[i] = 0.f;
+        if (i <= s) {
+          float ri[3] = {cs3[0] - og[i][0], cs3[1] - og[i][1], cs3[2] - og[i][2]}, rxF[3], Jvi[3], tB[3];
+          cross3(rxF, ri, Fk);
+          bias[i] = ax[i][0] * (Nk[0] + rxF[0]) + ax[i][1] * (Nk[1] + rxF[1]) + ax[i][2] * (Nk[2] + rxF[2]);
+          cross3(Jvi, ax[i], ri); inertia_mul(tB, Rk, di, ax[i]);
+#pragma unroll
+          for (int j = 0; j <= i; j++) {
+            float rj[3] = {cs3[0] - og[j][0], cs3[1] - og[j][1], cs3[2] - og[j][2]}, Jvj[3]; cross3(Jvj, ax[j], rj);
+            Mc[tri(i, j)] = mass * dot3(Jvi, Jvj) + dot3(tB, ax[j]);
+          }
+        }
+      }
+      for (int k = 0; k < 10; k++) Mc[k] = csum(Mc[k]);
+      float bown = 0.f;
+#pragma unroll
+      for (int i = 0; i < NLK; i++) { float b = csum(bias[i]); if (i == s) bown = b; }
+      // position servo on the own joint
+      float cc = u; if (lc.clim != 0.f) cc = jh_clampf(cc, lc.clo, lc.chi);
+      fs_own = -lc.damp * qd - bown + lc.kp * (cc - q) - lc.kv * qd;
+      float x4[4], L[10];
+#pragma unroll
+      for (int j = 0; j < NLK; j++) x4[j] = __shfl(fs_own, cb + j, WAVE);
+      for (int k = 0; k < 10; k++) L[k] = Mc[k];
+      chol4(L); fwd4(L, x4); bwd4(L, x4);
+      a0_own = x4[0];
+#pragma unroll
+      for (int j = 1; j < NLK; j++) if (j == s) a0_own = x4[j];
+      // free cube: M = diag(m,m,m,I)
+      float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
+      for (int k = 0; k < 3; k++) { fsc[k] = cmass * grav[k]; a0c[k] = grav[k]; fsc[3 + k] = -gc[k]; a0c[3 + k] = -gc[k] / cI[k]; }
+      S.a0[6 + l] = a0_own;
+      if (l < 6) S.a0[l] = a0c[l];
+    }
+    __syncthreads();
+    // ================================================================ collision: broad phase on the lane's geoms, balanced narrow phase
+    {
+      int nh = 0;
+      for (int i = 0; i < lgm; i++) {
+        int gid = gI[oLane + l * lgm + i];
+        bool hit = false;
+        if (gid >= 0) {
+          const float* gf = gF + oGeomF + gid * GEOM_F;
+          float gp[3];
+          if (gI[oGeomI + gid * GEOM_I] < 0) { gp[0] = gf[GF_POS]; gp[1] = gf[GF_POS + 1]; gp[2] = gf[GF_POS + 2]; }
+          else { mulMV(gp, Rown, gf + GF_POS); gp[0] += pown[0]; gp[1] += pown[1]; gp[2] += pown[2]; }
+          float dc[3] = {gp[0] - qc[0], gp[1] - qc[1], gp[2] - qc[2]}, rs = gf[GF_RBOUND] + crb;
+          hit = dot3(dc, dc) <= rs * rs;
+        }
+        unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+        int pos = nh + __popc(m16 & ((1u << l) - 1u));
+        if (hit && pos < MAXHIT) S.hits[pos] = gid;
+        nh += __popc(m16);
+      }
+      nh = nh < MAXHIT ? nh : MAXHIT;
+      __syncthreads();
+      PoolCtx pc{&S, stats};
+      for (int base = 0; __any(base < nh); base += G) {
+        int idx = base + l;
+        if (idx < nh) {
+          int gid = S.hits[idx];
+          const float* gf = gF + oGeomF + gid * GEOM_F; int body = gI[oGeomI + gid * GEOM_I], gtype = gI[oGeomI + gid * GEOM_I + 1];
+          float gp[3], gR[9];
+          if (body < 0) { for (int k = 0; k < 3; k++) gp[k] = gf[GF_POS + k]; for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; }
+          else {
+            float bR[9]; for (int k = 0; k < 9; k++) bR[k] = S.xR[body][k];
+            mulMV(gp, bR, gf + GF_POS); for (int k = 0; k < 3; k++) gp[k] += S.xpos[body][k];
+            mulMM(gR, bR, gf + GF_R);
+          }
+          float tran = ctran + gf[GF_TRAN];
+          if (gtype == GBOX) collide_box_box(pc, qc, Rc, chs, gp, gR, gf + GF_SIZE, body, gf[GF_MU], tran);
+          else collide_box_sphere(pc, qc, Rc, chs, gp, gf[GF_SIZE], body, gf[GF_MU], tran);
+        }
+      }
+    }
+    __syncthreads();
+    // ================================================================ constraint rows: <= 2 contacts per lane + the own dof's friction-loss / limit rows
+    const int ncon = S.ncon < NCP ? S.ncon : NCP;
+    Slot sl[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      int idx = l + 16 * k;
+      sl[k].valid = idx < ncon;
+      sl[k].chain = -1;
+      if (sl[k].valid) {
+        const float* e = S.pool[idx];
+        float pos[3] = {e[0], e[1], e[2]};
+        sl[k].fr[0] = e[3]; sl[k].fr[1] = e[4]; sl[k].fr[2] = e[5];
+        make_frame(sl[k].fr);
+        float dist = e[6], mu = e[7], tran = e[9]; int body = __float_as_int(e[8]);
+        float rc3[3] = {pos[0] - qc[0], pos[1] - qc[1], pos[2] - qc[2]};
+        for (int a3 = 0; a3 < 3; a3++) { float axc[3], c3[3]; col3(axc, Rc, a3); cross3(c3, axc, rc3); for (int rw = 0; rw < 3; rw++) sl[k].Jr[a3][rw] = -dot3(sl[k].fr + 3 * rw, c3); }
+        for (int j = 0; j < NLK; j++) sl[k].Jb[j][0] = sl[k].Jb[j][1] = sl[k].Jb[j][2] = 0.f;
+        if (body > 0) {
+          int ch = (body - 1) >> 2, dep = (body - 1) & 3;
+          sl[k].chain = ch;
+          for (int j = 0; j < NLK; j++) if (j <= dep) {
+            int bj = 1 + 4 * ch + j;
+            float rb[3] = {pos[0] - S.xpos[bj][0], pos[1] - S.xpos[bj][1], pos[2] - S.xpos[bj][2]}, aj[3] = {S.axw[bj][0], S.axw[bj][1], S.axw[bj][2]}, c3[3];
+            cross3(c3, aj, rb);
+            for (int rw = 0; rw < 3; rw++) sl[k].Jb[j][rw] = dot3(sl[k].fr + 3 * rw, c3);
+          }
+        }
+        float imp = impedance(csi, dist);
+        float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
+        sl[k].D[0] = 1.f / R0; sl[k].D[1] = 1.f / R1; sl[k].D[2] = 1.f / R1;
+        sl[k].fri = mu; sl[k].mu = mu * sqrtf(R1 / R0);
+        float vel[3]; slot_Jx(sl[k], vc, S.qv, vel);
+        sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
+      }
+    }
+    DofRows dr;
+    dr.fl = lc.fl; dr.fD = lc.fD; dr.faref = -lc.fB * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
+    if (lc.limited != 0.f) {
+      float dlo = q - lc.lo, dhi = lc.hi - q, dist = fminf(dlo, dhi);
+      if (dist < 0.f) {
+        float sg = dlo < dhi ? 1.f : -1.f, imp = impedance(lc.si, dist), R = fmaxf(1e-15f, (1.f - imp) / imp * lc.invw);
+        dr.lims = sg; dr.lD = 1.f / R; dr.laref = -lc.lB * (sg * qd) - lc.lK * imp * dist;
+      }
+    }
+    // ================================================================ Newton solver (rows distributed over the 16 lanes)
+    float a_own, ac[6];
+    float Mdiag_own = Mc[0];
+#pragma unroll
+    for (int j = 1; j < NLK; j++) if (j == s) Mdiag_own = Mc[tri(j, j)];
+    float Mrow[NLK];  // row s of the chain inertia block
+#pragma unroll
+    for (int j = 0; j < NLK; j++) { float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < NLK; i++) if (i == s) v = Mc[i >= j ? tri(i, j) : tri(j, i)];
+      Mrow[j] = v; }
+    const float snorm = gsum(fs_own * fs_own / Mdiag_own + (l < 3 ? fsc[l] * fsc[l] / cmass : (l < 6 ? fsc[l] * fsc[l] / cI[l - 3] : 0.f)));
+    const bool has_rows = gor((int)(sl[0].valid || sl[1].valid || dr.fl > 0.f || dr.lims != 0.f)) != 0;
+    int iters_this = 0;
+    if (!has_rows) { a_own = a0_own; for (int k = 0; k < 6; k++) ac[k] = a0c[k]; }
+    else {
+      // ---- warm start: the better of last step's acceleration and the unconstrained one
+      float cost_ws, cost_0;
+      {
+        S.a[6 + l] = qws; if (l < 6) S.a[l] = wsc[l];
+        __syncthreads();
+        float cs, d1, d2, jx[3];
+        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], wsc, S.a, jx); for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; }
+        dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
+        lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
+        float dws = qws - a0_own, md = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLK; j++) md += Mrow[j] * (__shfl(qws, cb + j, WAVE) - __shfl(a0_own, cb + j, WAVE));
+        cs += 0.5f * dws * md;
+        if (l < 6) { float dcw = wsc[l] - a0c[l]; cs += 0.5f * dcw * dcw * (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]); }
+        cost_ws = gsum(cs);
+        __syncthreads();
+        S.a[6 + l] = a0_own; if (l < 6) S.a[l] = a0c[l];
+        __syncthreads();
+        float jar0[2][3];
+        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], a0c, S.a, jx); for (int rw = 0; rw < 3; rw++) { jar0[k][rw] = sl[k].jar[rw]; sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; } }
+        float jf_ws = dr.jf, jl_ws = dr.jl;
+        dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
+        lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
+        cost_0 = gsum(cs);
+        const bool use_ws = cost_ws < cost_0;
+        if (use_ws) {
+          a_own = qws; for (int k = 0; k < 6; k++) ac[k] = wsc[k];
+          for (int k = 0; k < 2; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar0[k][rw];
+          dr.jf = jf_ws; dr.jl = jl_ws;
+        } else { a_own = a0_own; for (int k = 0; k < 6; k++) ac[k] = a0c[k]; }
+        __syncthreads();
+        S.a[6 + l] = a_own; if (l < 6) S.a[l] = ac[l];
+      }
+      bool act = true;
+      for (int it = 0; it < cap && __any(act); it++) {
+        // ---- (1) owner lanes: M (a - a0) rows, dof-row forces and weights, Hessian initialised with M
+        float da_own = a_own - a0_own, g_own = 0.f, hd = 0.f, dac[NLK];
+#pragma unroll
+        for (int j = 0; j < NLK; j++) { dac[j] = __shfl(da_own, cb + j, WAVE); g_own += Mrow[j] * dac[j]; }
+        if (dr.fl > 0.f) {
+          float D = dr.fD, R = 1.f / D, x = dr.jf, fl = dr.fl;
+          if (x <= -R * fl) g_own -= fl; else if (x >= R * fl) g_own += fl; else { g_own += D * x; hd += D; }
+        }
+        if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
+        if (act) {
+          S.g[6 + l] = g_own;
+          if (l < 6) { S.g[l] = (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]) * (ac[l] - a0c[l]); }
+#pragma unroll
+          for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
+          for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
+          for (int e = l; e < 21; e += G) S.Hcc[e] = 0.f;
+        }
+        __syncthreads();
+        if (act && l < 6) S.Hcc[tri(l, l)] = (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]);
+        __syncthreads();
+        // ---- (2) contacts: -J'f into g, J'WJ into the arrow Hessian (LDS float atomics)
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < 2; k++) if (sl[k].valid) {
+            float f[3], Wm[6];
+            cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wm);
+            const Slot& t = sl[k];
+            // cube columns: translation k3 -> -fr[row][k3]; rotation -> Jr[k3][row]
+            float Jc[6][3];
+            for (int q3 = 0; q3 < 3; q3++) { Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3]; Jc[3 + q3][0] = t.Jr[q3][0]; Jc[3 + q3][1] = t.Jr[q3][1]; Jc[3 + q3][2] = t.Jr[q3][2]; }
+            for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.g[q6], -(Jc[q6][0] * f[0] + Jc[q6][1] * f[1] + Jc[q6][2] * f[2]));
+            if (t.chain >= 0) for (int j = 0; j < NLK; j++) atomicAdd(&S.g[6 + 4 * t.chain + j], -(t.Jb[j][0] * f[0] + t.Jb[j][1] * f[1] + t.Jb[j][2] * f[2]));
+            if (!(Wm[0] == 0.f && Wm[2] == 0.f && Wm[5] == 0.f)) {
+              float Gc[6][3], Gb[NLK][3];
+              for (int q6 = 0; q6 < 6; q6++) { const float* j3 = Jc[q6]; Gc[q6][0] = Wm[0] * j3[0] + Wm[1] * j3[1] + Wm[3] * j3[2]; Gc[q6][1] = Wm[1] * j3[0] + Wm[2] * j3[1] + Wm[4] * j3[2]; Gc[q6][2] = Wm[3] * j3[0] + Wm[4] * j3[1] + Wm[5] * j3[2]; }
+              for (int u6 = 0; u6 < 6; u6++) for (int v6 = 0; v6 <= u6; v6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * Gc[v6][0] + Jc[u6][1] * Gc[v6][1] + Jc[u6][2] * Gc[v6][2]);
+              if (t.chain >= 0) {
+                for (int j = 0; j < NLK; j++) { const float* j3 = t.Jb[j]; Gb[j][0] = Wm[0] * j3[0] + Wm[1] * j3[1] + Wm[3] * j3[2]; Gb[j][1] = Wm[1] * j3[0] + Wm[2] * j3[1] + Wm[4] * j3[2]; Gb[j][2] = Wm[3] * j3[0] + Wm[4] * j3[1] + Wm[5] * j3[2]; }
+                for (int u4 = 0; u4 < NLK; u4++) {
+                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[t.chain][tri(u4, v4)], t.Jb[u4][0] * Gb[v4][0] + t.Jb[u4][1] * Gb[v4][1] + t.Jb[u4][2] * Gb[v4][2]);
+                  for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[t.chain][u4 * 6 + q6], Jc[q6][0] * Gb[u4][0] + Jc[q6][1] * Gb[u4][1] + Jc[q6][2] * Gb[u4][2]);
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+        // ---- (3) convergence on the scaled gradient
+        g_own = S.g[6 + l];
+        float gcl = l < 6 ? S.g[l] : 0.f;
+        float gn = gsum(g_own * g_own / Mdiag_own + (l < 3 ? gcl * gcl / cmass : (l < 6 ? gcl * gcl / cI[l - 3] : 0.f)));
+        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        if (act) iters_this++;
+        // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly), 6x6 Schur complement on the cube
+        float L[10], Y[6][NLK], zb[NLK], xc6[6], pc4[NLK];
+        {
+          for (int k = 0; k < 10; k++) L[k] = S.Hbb[c][k];
+          chol4(L);
+          for (int q6 = 0; q6 < 6; q6++) { for (int j = 0; j < NLK; j++) Y[q6][j] = S.Hcb[c][j * 6 + q6]; fwd4(L, Y[q6]); }
+          for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
+          fwd4(L, zb);
+          if (act && l < 6) S.rhs6[l] = -gcl;
+        }
+        __syncthreads();
+        if (act && s == 0) {
+          for (int q6 = 0; q6 < 6; q6++) {
+            for (int r6 = 0; r6 <= q6; r6++) { float v = 0.f; for (int j = 0; j < NLK; j++) v += Y[q6][j] * Y[r6][j]; atomicAdd(&S.Hcc[tri(q6, r6)], -v); }
+            float v = 0.f; for (int j = 0; j < NLK; j++) v += Y[q6][j] * zb[j];
+            atomicAdd(&S.rhs6[q6], -v);
+          }
+        }
+        __syncthreads();
+        {
+          float Lc[21];
+          for (int k = 0; k < 21; k++) Lc[k] = S.Hcc[k];
+          for (int k = 0; k < 6; k++) xc6[k] = S.rhs6[k];
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+              float sv = Lc[tri(i, j)];
+#pragma unroll
+              for (int k = 0; k < j; k++) sv -= Lc[tri(i, k)] * Lc[tri(j, k)];
+              Lc[tri(i, j)] = (i == j) ? sqrtf(fmaxf(sv, 1e-30f)) : sv / Lc[tri(j, j)];
+            }
+#pragma unroll
+          for (int i = 0; i < 6; i++) { float sv = xc6[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) sv -= Lc[tri(i, k)] * xc6[k];
+            xc6[i] = sv / Lc[tri(i, i)]; }
+#pragma unroll
+          for (int i = 5; i >= 0; i--) { float sv = xc6[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) sv -= Lc[tri(k, i)] * xc6[k];
+            xc6[i] = sv / Lc[tri(i, i)]; }
+          for (int j = 0; j < NLK; j++) { float v = zb[j]; for (int q6 = 0; q6 < 6; q6++) v -= Y[q6][j] * xc6[q6]; pc4[j] = v; }
+          bwd4(L, pc4);
+        }
+        float p_own = pc4[0];
+#pragma unroll
+        for (int j = 1; j < NLK; j++) if (j == s) p_own = pc4[j];
+        if (act) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xc6[l]; }
+        __syncthreads();
+        // ---- (5) exact line search along p
+        float Mp_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLK; j++) Mp_own += Mrow[j] * pc4[j];
+        float mck = (l < 3 ? cmass : (l < 6 ? cI[l < 3 ? 0 : l - 3] : 0.f));
+        float xcl = 0.f, dcl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k == l) { xcl = xc6[k]; dcl = ac[k] - a0c[k]; }
+        float pMp = gsum(p_own * Mp_own + mck * xcl * xcl);
+        float pMd = gsum(Mp_own * da_own + mck * xcl * dcl);
+        float gp = gsum(g_own * p_own + gcl * xcl);
+        if (act && !(gp < 0.f)) act = false;
+        for (int k = 0; k < 2; k++) if (sl[k].valid) slot_Jx(sl[k], xc6, S.p, sl[k].jp);
+        dr.pf = p_own; dr.pl = dr.lims * p_own;
+        float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
+        for (int ls = 0; ls < 12 && __any(lsact); ls++) {
+          float cs, d1, d2;
+          lane_rows_eval(sl, dr, alpha, true, &cs, &d1, &d2);
+          d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
+          if (lsact) {
+            if (fabsf(d1) <= 1e-6f * fabsf(gp)) lsact = false;
+            else {
+              if (d1 < 0.f) lo = alpha; else hi = alpha;
+              float nx = alpha - d1 / d2;
+              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
+              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
+              alpha = nx;
+            }
+          }
+        }
+        // ---- (6) step
+        if (act) {
+          a_own += alpha * p_own; for (int k = 0; k < 6; k++) ac[k] += alpha * xc6[k];
+          for (int k = 0; k < 2; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
+          dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
+          S.a[6 + l] = a_own; if (l < 6) S.a[l] = ac[l];
+          if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        }
+        __syncthreads();
+      }
+      if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
+    }
+    // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
+    {
+      float da_own = a_own - a0_own, rhs_own = fs_own, x4[NLK], L[10];
+#pragma unroll
+      for (int j = 0; j < NLK; j++) rhs_own += Mrow[j] * __shfl(da_own, cb + j, WAVE);
+#pragma unroll
+      for (int j = 0; j < NLK; j++) x4[j] = __shfl(rhs_own, cb + j, WAVE);
+      for (int k = 0; k < 10; k++) L[k] = Mc[k];
+#pragma unroll
+      for (int j = 0; j < NLK; j++) L[tri(j, j)] += h * __shfl(lc.damp + lc.kvd, cb + j, WAVE);
+      chol4(L); fwd4(L, x4); bwd4(L, x4);
+      float qacc = x4[0];
+#pragma unroll
+      for (int j = 1; j < NLK; j++) if (j == s) qacc = x4[j];
+      qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); qws = a_own;
+      for (int k = 0; k < 3; k++) {
+        float al = (fsc[k] + cmass * (ac[k] - a0c[k])) / cmass, aw = (fsc[3 + k] + cI[k] * (ac[3 + k] - a0c[3 + k])) / cI[k];
+        vc[k] = fmaf(h, al, vc[k]); vc[3 + k] = fmaf(h, aw, vc[3 + k]); wsc[k] = ac[k]; wsc[3 + k] = ac[3 + k];
+      }
+      for (int k = 0; k < 3; k++) qc[k] = fmaf(h, vc[k], qc[k]);
+      float wn = sqrtf(vc[3] * vc[3] + vc[4] * vc[4] + vc[5] * vc[5]), ang = wn * h;
+      if (ang > 0.f) {
+        float sn, cs; sincosf(0.5f * ang, &sn, &cs); float kk = sn / wn;
+        float dq[4] = {cs, vc[3] * kk, vc[4] * kk, vc[5] * kk}, *qq = qc + 3;
+        float r0 = qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2] - qq[3] * dq[3];
+        float r1 = qq[0] * dq[1] + qq[1] * dq[0] + qq[2] * dq[3] - qq[3] * dq[2];
+        float r2 = qq[0] * dq[2] - qq[1] * dq[3] + qq[2] * dq[0] + qq[3] * dq[1];
+        float r3 = qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1] + qq[3] * dq[0];
+        qq[0] = r0; qq[1] = r1; qq[2] = r2; qq[3] = r3;
+      }
+      float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
+      qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+    }
+    if (MATERIALIZE) {
+      if (states && live) {
+        float* o = states + ((size_t)nc * H + hh) * NX;
+        o[7 + l] = q; o[NQ + 6 + l] = qd;
+        if (l < 7) o[l] = qc[l];
+        if (l < 6) o[NQ + l] = vc[l];
+      }
+    } else acc += leap_step_cost(sTp, qc);
+    __syncthreads();
+  }
+  if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
+  if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
+  (void)n_overflow;
+}
+
+bool model_is_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 13 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0; }
+
+}  // namespace
+
+int jh_engine2_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+  if (!model_is_leap(m)) { jh_set_error("rollout_cost: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
+  JH_REQUIRE(K <= 8, "rollout_cost: the cooperative leap kernel keeps at most 8 knots per actuator in registers (K=%d)", K);
+  int grid = (N + RPW - 1) / RPW;
+  hipLaunchKernelGGL(k_leap_v2<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
+                     knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+int jh_engine2_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                           hipStream_t st) {
+  if (!model_is_leap(m)) { jh_set_error("rollout_materialize: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
+  int grid = (N + RPW - 1) / RPW;
+  hipLaunchKernelGGL(k_leap_v2<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
+                     controls, states, sensors, m->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

@@ -49,6 +49,10 @@ class GpuModel:
         _lib.check(st, "jh_model_create")
         self.handle = handle
 
+    def set_kernel(self, generation: int) -> None:
+        """Select the articulated-engine kernel generation (2 = cooperative, default; 1 = one lane per rollout)."""
+        _lib.check(_lib.lib().jh_model_set_kernel(self.handle, int(generation)), "jh_model_set_kernel")
+
     def stats(self, reset: bool = True) -> dict:
         """Diagnostic counters of the articulated-body kernels (synchronises)."""
         out = (C.c_int * 4)()

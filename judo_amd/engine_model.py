@@ -227,6 +227,21 @@ def pack_engine_model(desc: dict) -> bytes:
             I += [3, midx[s["obj"]], s["adr"]]
         else:
             I += [4, 0, s["adr"]]  # geom distance: not produced by the engine yet (fr3_pick, next round)
+    # ---- cooperative kernel (16 lanes per rollout, one lane per finger link): per-lane list of geoms to broad-phase.
+    # lane l tests the geoms of moving body 1+l; static geoms are dealt greedily to the least-loaded lanes.
+    if NM - 1 <= 16:
+        lists: list[list[int]] = [[] for _ in range(16)]
+        for gi, g in enumerate(others):
+            b = g["body"]
+            if not st["is_static"][b]:
+                lists[midx[b] - 1].append(gi)
+        for gi, g in enumerate(others):
+            if st["is_static"][g["body"]]:
+                min(lists, key=len).append(gi)
+        lgm = max(len(x) for x in lists)
+        I[11], I[12] = len(I), lgm
+        for x in lists:
+            I += x + [-1] * (lgm - len(x))
     ntp = 9 if desc["task"] == "leap_cube" else 22
     return _pack(TASK_KIND[desc["task"]], lay, ntp, F, I)
 

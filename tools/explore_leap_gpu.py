@@ -2,6 +2,8 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from judo_amd import _lib
+if os.environ.get("JH_LIB"): _lib.LIB_PATH = os.environ["JH_LIB"]
 from oracle import oracle as O
 from judo_amd.rollout_backend import GpuRolloutBackend
 from judo_amd.tasks import LEAP_QPOS_HOME
