@@ -36,8 +36,8 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
   hipError_t e = hipMalloc(&m->d_f, 4 * (m->nf ? m->nf : 1));
   if (e == hipSuccess) e = hipMalloc(&m->d_i, 4 * (m->ni ? m->ni : 1));
-  if (e == hipSuccess) e = hipMalloc(&m->d_stats, 24 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(m->d_stats, 0, 24 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&m->d_stats, 64 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(m->d_stats, 0, 64 * sizeof(int));
   if (e == hipSuccess && m->nf) e = hipMemcpy(m->d_f, m->h_f.data(), 4 * m->nf, hipMemcpyHostToDevice);
   if (e == hipSuccess && m->ni) e = hipMemcpy(m->d_i, m->h_i.data(), 4 * m->ni, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -69,7 +69,13 @@ extern "C" int jh_model_dims(const jh_model* m, int* dims) {
 extern "C" int jh_model_stats(jh_model* m, int* out, int reset) {
   JH_REQUIRE(m && out, "model_stats: null pointer");
   JH_HIP(hipMemcpy(out, m->d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
-  if (reset) JH_HIP(hipMemset(m->d_stats, 0, 24 * sizeof(int)));
+  if (reset) JH_HIP(hipMemset(m->d_stats, 0, 64 * sizeof(int)));
+  return JH_OK;
+}
+
+extern "C" int jh_model_hist(jh_model* m, int* out /* 24 ints: Newton-iteration histogram (profile builds only) */) {
+  JH_REQUIRE(m && out, "model_hist: null pointer");
+  JH_HIP(hipMemcpy(out, m->d_stats + 24, 40 * sizeof(int), hipMemcpyDeviceToHost));
   return JH_OK;
 }
 

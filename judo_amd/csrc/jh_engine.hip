@@ -607,12 +607,13 @@ __device__ int solve_constraints(const EngineModel& m, Work<C>& w, int max_iter,
     float pMp = 0.f, pMd = 0.f, gp = 0.f;
     for (int d = 0; d < C::NV; d++) { pMp += p[d] * Mp[d]; pMd += Mp[d] * da[d]; gp += g[d] * p[d]; }
     if (!(gp < 0.f)) break;
+    const float lstol = F[HF_LSTOL];
     float lo = 0.f, hi = -1.f, al = 1.f;
     for (int ls = 0; ls < 12; ls++) {
       float cs, d1, d2;
       rows_eval<C>(m, w, r, &rp, al, &cs, &d1, &d2);
       d1 += pMd + al * pMp; d2 += pMp;
-      if (fabsf(d1) <= 1e-6f * fabsf(gp)) break;
+      if (fabsf(d1) <= lstol * fabsf(gp)) break;
       if (d1 < 0.f) lo = al; else hi = al;
       float nx = al - d1 / d2;
       if (hi < 0.f) { if (nx <= lo) nx = 2.f * al; }

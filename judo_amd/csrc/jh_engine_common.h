@@ -12,7 +12,7 @@ constexpr int HEADER_I = 24, HEADER_F = 24;
 constexpr int BODY_I = 6, GEOM_I = 2, ACT_I = 2, BLOCK_I = 4, SENS_I = 3;
 constexpr int BODY_F = 32, DOF_F = 20, ACT_F = 8, GEOM_F = 20, SITE_F = 3;
 // header floats
-enum { HF_DT = 0, HF_IMPRATIO = 1, HF_TOL = 2, HF_MAXITER = 22, HF_GRAV = 3, HF_CK = 6, HF_CB = 7, HF_SOLIMP = 8, HF_CMASS = 13, HF_CINERTIA = 14, HF_CSIZE = 17, HF_CRBOUND = 20, HF_CTRAN = 21 };
+enum { HF_DT = 0, HF_IMPRATIO = 1, HF_TOL = 2, HF_MAXITER = 22, HF_LSTOL = 23, HF_GRAV = 3, HF_CK = 6, HF_CB = 7, HF_SOLIMP = 8, HF_CMASS = 13, HF_CINERTIA = 14, HF_CSIZE = 17, HF_CRBOUND = 20, HF_CTRAN = 21 };
 // body floats
 enum { BF_LPOS = 0, BF_LR = 3, BF_MASS = 12, BF_IPOS = 13, BF_IR = 16, BF_INERTIA = 25, BF_AXIS = 28, BF_TRAN = 31 };
 // dof floats
@@ -105,14 +105,15 @@ __device__ __forceinline__ void inertia_mul(float* r, const float* Rk, const flo
 // elliptic-cone contact: force = -ds/djar, cost s, Hessian block W (sym 3x3: 00,10,11,20,21,22)
 __device__ __forceinline__ float cone_eval(const float* jar, const float* D, float mu, float fri, float* f, float* W) {
   float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
-  float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
+  float N = U0, T2 = U1 * U1 + U2 * U2;
+  float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
   if (N >= mu * T || (T <= 0.f && N >= 0.f)) { f[0] = f[1] = f[2] = 0.f; for (int k = 0; k < 6; k++) W[k] = 0.f; return 0.f; }
   if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
     f[0] = -D[0] * jar[0]; f[1] = -D[1] * jar[1]; f[2] = -D[2] * jar[2];
     W[0] = D[0]; W[1] = 0.f; W[2] = D[1]; W[3] = 0.f; W[4] = 0.f; W[5] = D[2];
     return 0.5f * (D[0] * jar[0] * jar[0] + D[1] * jar[1] * jar[1] + D[2] * jar[2] * jar[2]);
   }
-  float Dm = D[0] / (mu * mu * (1.f + mu * mu)), NT = N - mu * T, iT = 1.f / T;
+  float Dm = D[0] * __frcp_rn(mu * mu * (1.f + mu * mu)), NT = N - mu * T;
   f[0] = -Dm * NT * mu; f[1] = -f[0] * iT * U1 * fri; f[2] = -f[0] * iT * U2 * fri;
   float h00 = Dm, h01 = -Dm * mu * U1 * iT, h02 = -Dm * mu * U2 * iT;
   float k1 = Dm * mu * mu * iT * iT, k2 = Dm * NT * mu * iT;

@@ -24,6 +24,7 @@ constexpr int NCH = 4, NLK = 4;
 constexpr int NCP = 32;     // contact pool per rollout = 2 slots per lane
 constexpr int MAXHIT = 32;  // broad-phase survivors per rollout
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
+constexpr int MAXG = 72, MAXLG = 8;  // collision geoms / broad-phase list length per lane staged in LDS
 constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
 
 struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
@@ -36,21 +37,37 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   int ncon, nhit;
 };
 
-__device__ __forceinline__ float gsum(float v) {  // sum over the 16 lanes of a rollout
-  v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE); v += __shfl_xor(v, 4, WAVE); v += __shfl_xor(v, 8, WAVE);
+// Cross-lane traffic stays inside one DPP row (the 16 lanes of a rollout): row-local DPP modifiers instead of
+// ds_bpermute.  A sum butterfly only needs each step to pair a lane with one from the "other half" of the group that is
+// already uniform: quad_perm xor 1, quad_perm xor 2, row_half_mirror (i <-> 7-i), row_mirror (i <-> 15-i).
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+__device__ __forceinline__ float csum(float v) {  // sum over the 4 lanes of a chain (= one quad)
+  v += dppf<DPP_XOR1>(v); v += dppf<DPP_XOR2>(v);
   return v;
 }
-__device__ __forceinline__ float csum(float v) {  // sum over the 4 lanes of a chain
-  v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE);
+__device__ __forceinline__ float gsum(float v) {  // sum over the 16 lanes of a rollout (= one DPP row)
+  v = csum(v); v += dppf<DPP_HALF_MIRROR>(v); v += dppf<DPP_MIRROR>(v);
   return v;
 }
 __device__ __forceinline__ int gor(int v) {
-  v |= __shfl_xor(v, 1, WAVE); v |= __shfl_xor(v, 2, WAVE); v |= __shfl_xor(v, 4, WAVE); v |= __shfl_xor(v, 8, WAVE);
+  v |= dppi<DPP_XOR1>(v); v |= dppi<DPP_XOR2>(v); v |= dppi<DPP_HALF_MIRROR>(v); v |= dppi<DPP_MIRROR>(v);
   return v;
+}
+// value held by lane j of the caller's quad (j is a compile-time constant after unrolling)
+__device__ __forceinline__ float quad_get(float v, int j) {
+  switch (j) { case 0: return dppf<0x00>(v); case 1: return dppf<0x55>(v); case 2: return dppf<0xAA>(v); default: return dppf<0xFF>(v); }
 }
 
 // ------------------------------------------------------------------------------------------------ collision into the LDS pool
-struct PoolCtx { RS* S; int* overflow; };
+struct PoolCtx { RS* S; int* overflow; float* poly; /* LDS: [2][8][3][64], this lane's column */ };
+#define POLY(buf, q, k) pc.poly[(((buf) * 8 + (q)) * 3 + (k)) * WAVE]
 
 __device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos, const float* n, float dist, int body, float mu, float tran) {
   int i = atomicAdd(&pc.S->ncon, 1);
@@ -113,30 +130,33 @@ __device__ void collide_box_box(const PoolCtx& pc, const float* p1, const float*
   for (int k = 0; k < 3; k++) { float v = fabsf(dot3(n, Ai[k])); if (v > mb) { mb = v; mi = k; } }
   float sgi = dot3(n, Ai[mi]) > 0.f ? -1.f : 1.f;
   int u = (mi + 1) % 3, v = (mi + 2) % 3;
-  float poly[8][3], tmp[8][3]; int np = 4;
+  int np = 4, cur = 0;
   const float su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
   for (int q = 0; q < 4; q++)
-    for (int k = 0; k < 3; k++) poly[q][k] = pi[k] + sgi * hi[mi] * Ai[mi][k] + su[q] * hi[u] * Ai[u][k] + sv[q] * hi[v] * Ai[v][k];
+    for (int k = 0; k < 3; k++) POLY(0, q, k) = pi[k] + sgi * hi[mi] * Ai[mi][k] + su[q] * hi[u] * Ai[u][k] + sv[q] * hi[v] * Ai[v][k];
   int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
   for (int pl = 0; pl < 4 && np > 0; pl++) {
     const float* ax = Ar[pl < 2 ? ra : rb]; float sg = (pl & 1) ? -1.f : 1.f, lim = hr[pl < 2 ? ra : rb];
-    int nq = 0;
+    int nq = 0; const int nxt = cur ^ 1;
+    float P[3] = {POLY(cur, 0, 0), POLY(cur, 0, 1), POLY(cur, 0, 2)};
+    float fp = sg * ((P[0] - pr[0]) * ax[0] + (P[1] - pr[1]) * ax[1] + (P[2] - pr[2]) * ax[2]) - lim;
     for (int q = 0; q < np; q++) {
-      const float* P = poly[q]; const float* Q = poly[(q + 1) % np];
-      float dp[3] = {P[0] - pr[0], P[1] - pr[1], P[2] - pr[2]}, dq[3] = {Q[0] - pr[0], Q[1] - pr[1], Q[2] - pr[2]};
-      float fp = sg * dot3(dp, ax) - lim, fq = sg * dot3(dq, ax) - lim;
-      if (fp <= 0.f && nq < 8) { tmp[nq][0] = P[0]; tmp[nq][1] = P[1]; tmp[nq][2] = P[2]; nq++; }
-      if (((fp < 0.f && fq > 0.f) || (fp > 0.f && fq < 0.f)) && nq < 8) { float t = fp / (fp - fq); for (int k = 0; k < 3; k++) tmp[nq][k] = P[k] + t * (Q[k] - P[k]); nq++; }
+      int qn = (q + 1 == np) ? 0 : q + 1;
+      float Q[3] = {POLY(cur, qn, 0), POLY(cur, qn, 1), POLY(cur, qn, 2)};
+      float fq = sg * ((Q[0] - pr[0]) * ax[0] + (Q[1] - pr[1]) * ax[1] + (Q[2] - pr[2]) * ax[2]) - lim;
+      if (fp <= 0.f && nq < 8) { POLY(nxt, nq, 0) = P[0]; POLY(nxt, nq, 1) = P[1]; POLY(nxt, nq, 2) = P[2]; nq++; }
+      if (((fp < 0.f && fq > 0.f) || (fp > 0.f && fq < 0.f)) && nq < 8) { float t = fp / (fp - fq); for (int k = 0; k < 3; k++) POLY(nxt, nq, k) = P[k] + t * (Q[k] - P[k]); nq++; }
+      P[0] = Q[0]; P[1] = Q[1]; P[2] = Q[2]; fp = fq;
     }
-    np = nq;
-    for (int q = 0; q < np; q++) { poly[q][0] = tmp[q][0]; poly[q][1] = tmp[q][1]; poly[q][2] = tmp[q][2]; }
+    np = nq; cur = nxt;
   }
   for (int q = 0; q < np; q++) {
-    float dx[3] = {poly[q][0] - pr[0], poly[q][1] - pr[1], poly[q][2] - pr[2]};
+    float X[3] = {POLY(cur, q, 0), POLY(cur, q, 1), POLY(cur, q, 2)};
+    float dx[3] = {X[0] - pr[0], X[1] - pr[1], X[2] - pr[2]};
     float depth = hr[ri] - dot3(dx, n);
     if (-depth >= 0.f) continue;
     float pos[3], nn[3];
-    for (int k = 0; k < 3; k++) { pos[k] = poly[q][k] + 0.5f * depth * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
+    for (int k = 0; k < 3; k++) { pos[k] = X[k] + 0.5f * depth * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
     push_contact(pc, pos, nn, -depth, body, mu, tran);
   }
 }
@@ -217,8 +237,9 @@ __device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr
   *cost = cs; *d1 = g1; *d2 = g2;
 }
 
-// 4x4 Cholesky (packed lower) + solve helpers on registers
-__device__ __forceinline__ void chol4(float* L) {
+// 4x4 Cholesky (packed lower) + triangular solves on registers; the diagonal is kept as its reciprocal (one v_rsq per
+// pivot, no divisions in the solves)
+__device__ __forceinline__ void chol4(float* L, float* inv) {
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -226,22 +247,23 @@ __device__ __forceinline__ void chol4(float* L) {
       float s = L[tri(i, j)];
 #pragma unroll
       for (int k = 0; k < j; k++) s -= L[tri(i, k)] * L[tri(j, k)];
-      L[tri(i, j)] = (i == j) ? sqrtf(fmaxf(s, 1e-30f)) : s / L[tri(j, j)];
+      if (i == j) { float r = __frsqrt_rn(fmaxf(s, 1e-30f)); inv[i] = r; L[tri(i, i)] = s * r; }
+      else L[tri(i, j)] = s * inv[j];
     }
 }
-__device__ __forceinline__ void fwd4(const float* L, float* x) {
+__device__ __forceinline__ void fwd4(const float* L, const float* inv, float* x) {
 #pragma unroll
   for (int i = 0; i < 4; i++) { float s = x[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
-    x[i] = s / L[tri(i, i)]; }
+    x[i] = s * inv[i]; }
 }
-__device__ __forceinline__ void bwd4(const float* L, float* x) {
+__device__ __forceinline__ void bwd4(const float* L, const float* inv, float* x) {
 #pragma unroll
   for (int i = 3; i >= 0; i--) { float s = x[i];
 #pragma unroll
     for (int k = i + 1; k < 4; k++) s -= L[tri(k, i)] * x[k];
-    x[i] = s / L[tri(i, i)]; }
+    x[i] = s * inv[i]; }
 }
 
 struct LaneConst {  // per-lane model constants (own joint / actuator / dof rows), loaded once
@@ -249,8 +271,11 @@ struct LaneConst {  // per-lane model constants (own joint / actuator / dof rows
 };
 
 // ------------------------------------------------------------------------------------------------ the kernel
+#ifndef JH_V2_WAVES_PER_EU
+#define JH_V2_WAVES_PER_EU 1
+#endif
 template <bool MATERIALIZE>
-__global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
+__global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
                                                    const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
                                                    const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                    const float* __restrict__ tp, int N, int n_offset, int H, int K, float* __restrict__ costs,
@@ -259,6 +284,10 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
   __shared__ RS sRS[RPW];
   __shared__ float sBody[16 * BODY_F];  // records of the 16 finger links
   __shared__ float sTp[16];
+  __shared__ float sGeomF[MAXG * GEOM_F];
+  __shared__ int sGeomI[MAXG * GEOM_I];
+  __shared__ int sLaneG[16 * MAXLG];
+  __shared__ float sPoly[2 * 8 * 3 * WAVE];
   const int lane = threadIdx.x, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3, cb = lane & ~3;
   RS& S = sRS[r];
   const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6];
@@ -266,6 +295,9 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
   const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
   const int oLane = gI[11], lgm = gI[12];
   for (int i = lane; i < 16 * BODY_F; i += WAVE) sBody[i] = gF[oBodyF + BODY_F + i];
+  for (int i = lane; i < ngI * GEOM_F; i += WAVE) sGeomF[i] = gF[oGeomF + i];
+  for (int i = lane; i < ngI * GEOM_I; i += WAVE) sGeomI[i] = gI[oGeomI + i];
+  for (int i = lane; i < 16 * lgm; i += WAVE) sLaneG[i] = gI[oLane + i];
   if (!MATERIALIZE && lane < 9) sTp[lane] = tp[lane];
   const int n = blockIdx.x * RPW + r;  // rollout handled by this row of 16 lanes
   const bool live = n < N;
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
     for (int k = 0; k < 5; k++) lc.si[k] = df[DF_SOLIMP + k];
     lc.kp = af[AF_KP]; lc.kv = af[AF_KV]; lc.clim = af[AF_CLIM]; lc.clo = af[AF_CLO]; lc.chi = af[AF_CHI];
   }
-  const float h = gF[HF_DT], impratio = gF[HF_IMPRATIO], tol = gF[HF_TOL]; const int cap = (int)gF[HF_MAXITER];
+  const float h = gF[HF_DT], impratio = gF[HF_IMPRATIO], tol = gF[HF_TOL], lstol = gF[HF_LSTOL]; const int cap = (int)gF[HF_MAXITER];
   const float grav[3] = {gF[HF_GRAV], gF[HF_GRAV + 1], gF[HF_GRAV + 2]};
   const float cmass = gF[HF_CMASS], cI[3] = {gF[HF_CINERTIA], gF[HF_CINERTIA + 1], gF[HF_CINERTIA + 2]};
   const float chs[3] = {gF[HF_CSIZE], gF[HF_CSIZE + 1], gF[HF_CSIZE + 2]}, crb = gF[HF_CRBOUND], ctran = gF[HF_CTRAN];
@@ -308,6 +340,12 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
   }
   int n_overflow = 0, n_iters = 0, n_maxed = 0;
   float acc = 0.f;
+#ifdef JH_ENGINE_PROFILE
+  long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
+#define V2_TICK(slot) { long long t__ = clock64(); cyc[slot] += t__ - t0; t0 = t__; }
+#else
+#define V2_TICK(slot)
+#endif
   __syncthreads();
 
   for (int hh = 0; hh < H; hh++) {
@@ -325,7 +363,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
 #pragma unroll
       for (int j = 0; j < NLK; j++) {
         const float* bf = sBody + (4 * c + j) * BODY_F;
-        float qj = __shfl(q, cb + j, WAVE);
+        float qj = quad_get(q, j);
         float P2[3], R0[9];
         if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
         else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
@@ -353,6 +391,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
         for (int k = 0; k < 3; k++) y[16 + 3 * l + k] = p3[k] + S.xpos[b][k];
       }
     }
+    V2_TICK(0)
     // ================================================================ chain dynamics: inertia block, bias, smooth force
     float Mc[10], fs_own, a0_own, fsc[6], a0c[6];
     {
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
       float wv[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao[3] = {-grav[0], -grav[1], -grav[2]};
 #pragma unroll
       for (int j = 0; j < NLK; j++) {
-        float qdj = __shfl(qd, cb + j, WAVE);
+        float qdj = quad_get(qd, j);
         if (j <= s) {
           if (j > 0) {
             float d[3] = {og[j][0] - og[j - 1][0], og[j][1] - og[j - 1][1], og[j][2] - og[j - 1][2]}, t1[3], t2[3], t3[3];
@@ -407,9 +446,9 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
       fs_own = -lc.damp * qd - bown + lc.kp * (cc - q) - lc.kv * qd;
       float x4[4], L[10];
 #pragma unroll
-      for (int j = 0; j < NLK; j++) x4[j] = __shfl(fs_own, cb + j, WAVE);
+      for (int j = 0; j < NLK; j++) x4[j] = quad_get(fs_own, j);
       for (int k = 0; k < 10; k++) L[k] = Mc[k];
-      chol4(L); fwd4(L, x4); bwd4(L, x4);
+      float inv4[4]; chol4(L, inv4); fwd4(L, inv4, x4); bwd4(L, inv4, x4);
       a0_own = x4[0];
 #pragma unroll
       for (int j = 1; j < NLK; j++) if (j == s) a0_own = x4[j];
@@ -420,19 +459,30 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
       if (l < 6) S.a0[l] = a0c[l];
     }
     __syncthreads();
+    V2_TICK(1)
     // ================================================================ collision: broad phase on the lane's geoms, balanced narrow phase
     {
       int nh = 0;
       for (int i = 0; i < lgm; i++) {
-        int gid = gI[oLane + l * lgm + i];
+        int gid = sLaneG[l * lgm + i];
         bool hit = false;
         if (gid >= 0) {
-          const float* gf = gF + oGeomF + gid * GEOM_F;
+          const float* gf = sGeomF + gid * GEOM_F;
           float gp[3];
-          if (gI[oGeomI + gid * GEOM_I] < 0) { gp[0] = gf[GF_POS]; gp[1] = gf[GF_POS + 1]; gp[2] = gf[GF_POS + 2]; }
+          if (sGeomI[gid * GEOM_I] < 0) { gp[0] = gf[GF_POS]; gp[1] = gf[GF_POS + 1]; gp[2] = gf[GF_POS + 2]; }
           else { mulMV(gp, Rown, gf + GF_POS); gp[0] += pown[0]; gp[1] += pown[1]; gp[2] += pown[2]; }
           float dc[3] = {gp[0] - qc[0], gp[1] - qc[1], gp[2] - qc[2]}, rs = gf[GF_RBOUND] + crb;
           hit = dot3(dc, dc) <= rs * rs;
+          if (hit) {  // second filter: the geom's bounding sphere against the cube's box, and the cube's bounding sphere against the geom's box
+            float cl[3]; mulMTV(cl, Rc, dc);
+            hit = fabsf(cl[0]) <= chs[0] + gf[GF_RBOUND] && fabsf(cl[1]) <= chs[1] + gf[GF_RBOUND] && fabsf(cl[2]) <= chs[2] + gf[GF_RBOUND];
+            if (hit && sGeomI[gid * GEOM_I + 1] == GBOX) {
+              float gR[9], gl[3];
+              if (sGeomI[gid * GEOM_I] < 0) { for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; } else mulMM(gR, Rown, gf + GF_R);
+              mulMTV(gl, gR, dc);
+              hit = fabsf(gl[0]) <= gf[GF_SIZE] + crb && fabsf(gl[1]) <= gf[GF_SIZE + 1] + crb && fabsf(gl[2]) <= gf[GF_SIZE + 2] + crb;
+            }
+          }
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nh + __popc(m16 & ((1u << l) - 1u));
@@ -440,13 +490,16 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
         nh += __popc(m16);
       }
       nh = nh < MAXHIT ? nh : MAXHIT;
+#ifdef JH_ENGINE_PROFILE
+      if (l == 0 && live && stats) atomicAdd(stats + 48 + (nh < 15 ? nh : 15), 1);
+#endif
       __syncthreads();
-      PoolCtx pc{&S, stats};
+      PoolCtx pc{&S, stats, sPoly + lane};
       for (int base = 0; __any(base < nh); base += G) {
         int idx = base + l;
         if (idx < nh) {
           int gid = S.hits[idx];
-          const float* gf = gF + oGeomF + gid * GEOM_F; int body = gI[oGeomI + gid * GEOM_I], gtype = gI[oGeomI + gid * GEOM_I + 1];
+          const float* gf = sGeomF + gid * GEOM_F; int body = sGeomI[gid * GEOM_I], gtype = sGeomI[gid * GEOM_I + 1];
           float gp[3], gR[9];
           if (body < 0) { for (int k = 0; k < 3; k++) gp[k] = gf[GF_POS + k]; for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; }
           else {
@@ -461,6 +514,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
       }
     }
     __syncthreads();
+    V2_TICK(2)
     // ================================================================ constraint rows: <= 2 contacts per lane + the own dof's friction-loss / limit rows
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
     Slot sl[2];
@@ -505,6 +559,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
         dr.lims = sg; dr.lD = 1.f / R; dr.laref = -lc.lB * (sg * qd) - lc.lK * imp * dist;
       }
     }
+    V2_TICK(3)
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     float a_own, ac[6];
     float Mdiag_own = Mc[0];
@@ -532,7 +587,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
         lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
         float dws = qws - a0_own, md = 0.f;
 #pragma unroll
-        for (int j = 0; j < NLK; j++) md += Mrow[j] * (__shfl(qws, cb + j, WAVE) - __shfl(a0_own, cb + j, WAVE));
+        for (int j = 0; j < NLK; j++) md += Mrow[j] * (quad_get(qws, j) - quad_get(a0_own, j));
         cs += 0.5f * dws * md;
         if (l < 6) { float dcw = wsc[l] - a0c[l]; cs += 0.5f * dcw * dcw * (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]); }
         cost_ws = gsum(cs);
@@ -555,11 +610,12 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
         S.a[6 + l] = a_own; if (l < 6) S.a[l] = ac[l];
       }
       bool act = true;
+      V2_TICK(3)
       for (int it = 0; it < cap && __any(act); it++) {
         // ---- (1) owner lanes: M (a - a0) rows, dof-row forces and weights, Hessian initialised with M
         float da_own = a_own - a0_own, g_own = 0.f, hd = 0.f, dac[NLK];
 #pragma unroll
-        for (int j = 0; j < NLK; j++) { dac[j] = __shfl(da_own, cb + j, WAVE); g_own += Mrow[j] * dac[j]; }
+        for (int j = 0; j < NLK; j++) { dac[j] = quad_get(da_own, j); g_own += Mrow[j] * dac[j]; }
         if (dr.fl > 0.f) {
           float D = dr.fD, R = 1.f / D, x = dr.jf, fl = dr.fl;
           if (x <= -R * fl) g_own -= fl; else if (x >= R * fl) g_own += fl; else { g_own += D * x; hd += D; }
@@ -571,12 +627,11 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
-          for (int e = l; e < 21; e += G) S.Hcc[e] = 0.f;
         }
         __syncthreads();
-        if (act && l < 6) S.Hcc[tri(l, l)] = (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]);
-        __syncthreads();
-        // ---- (2) contacts: -J'f into g, J'WJ into the arrow Hessian (LDS float atomics)
+        // ---- (2) contacts: -J'f into g, J'WJ into the arrow Hessian (chain parts: LDS float atomics; cube parts: row sums)
+        float gcp[6] = {0, 0, 0, 0, 0, 0}, hcp[21];
+        for (int e = 0; e < 21; e++) hcp[e] = 0.f;
         if (act) {
 #pragma unroll
           for (int k = 0; k < 2; k++) if (sl[k].valid) {
@@ -586,12 +641,12 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
             // cube columns: translation k3 -> -fr[row][k3]; rotation -> Jr[k3][row]
             float Jc[6][3];
             for (int q3 = 0; q3 < 3; q3++) { Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3]; Jc[3 + q3][0] = t.Jr[q3][0]; Jc[3 + q3][1] = t.Jr[q3][1]; Jc[3 + q3][2] = t.Jr[q3][2]; }
-            for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.g[q6], -(Jc[q6][0] * f[0] + Jc[q6][1] * f[1] + Jc[q6][2] * f[2]));
+            for (int q6 = 0; q6 < 6; q6++) gcp[q6] -= Jc[q6][0] * f[0] + Jc[q6][1] * f[1] + Jc[q6][2] * f[2];
             if (t.chain >= 0) for (int j = 0; j < NLK; j++) atomicAdd(&S.g[6 + 4 * t.chain + j], -(t.Jb[j][0] * f[0] + t.Jb[j][1] * f[1] + t.Jb[j][2] * f[2]));
             if (!(Wm[0] == 0.f && Wm[2] == 0.f && Wm[5] == 0.f)) {
               float Gc[6][3], Gb[NLK][3];
               for (int q6 = 0; q6 < 6; q6++) { const float* j3 = Jc[q6]; Gc[q6][0] = Wm[0] * j3[0] + Wm[1] * j3[1] + Wm[3] * j3[2]; Gc[q6][1] = Wm[1] * j3[0] + Wm[2] * j3[1] + Wm[4] * j3[2]; Gc[q6][2] = Wm[3] * j3[0] + Wm[4] * j3[1] + Wm[5] * j3[2]; }
-              for (int u6 = 0; u6 < 6; u6++) for (int v6 = 0; v6 <= u6; v6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * Gc[v6][0] + Jc[u6][1] * Gc[v6][1] + Jc[u6][2] * Gc[v6][2]);
+              for (int u6 = 0; u6 < 6; u6++) for (int v6 = 0; v6 <= u6; v6++) hcp[tri(u6, v6)] += Jc[u6][0] * Gc[v6][0] + Jc[u6][1] * Gc[v6][1] + Jc[u6][2] * Gc[v6][2];
               if (t.chain >= 0) {
                 for (int j = 0; j < NLK; j++) { const float* j3 = t.Jb[j]; Gb[j][0] = Wm[0] * j3[0] + Wm[1] * j3[1] + Wm[3] * j3[2]; Gb[j][1] = Wm[1] * j3[0] + Wm[2] * j3[1] + Wm[4] * j3[2]; Gb[j][2] = Wm[3] * j3[0] + Wm[4] * j3[1] + Wm[5] * j3[2]; }
                 for (int u4 = 0; u4 < NLK; u4++) {
@@ -602,7 +657,22 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
             }
           }
         }
+        {  // every lane ends up with the full cube gradient and cube Hessian block; lanes write their share to LDS
+          float gsel = 0.f, hsel0 = 0.f, hsel1 = 0.f;
+#pragma unroll
+          for (int q6 = 0; q6 < 6; q6++) { float v = gsum(gcp[q6]); if (q6 == l) gsel = v; }
+#pragma unroll
+          for (int e = 0; e < 21; e++) { float v = gsum(hcp[e]); if (e == l) hsel0 = v; if (e == l + 16) hsel1 = v; }
+          if (act) {
+            if (l < 6) S.g[l] += gsel;
+            bool d0 = (l == 0 || l == 2 || l == 5 || l == 9 || l == 14), d1 = (l + 16 == 20);  // packed indices of the diagonal
+            int k0 = l == 0 ? 0 : (l == 2 ? 1 : (l == 5 ? 2 : (l == 9 ? 3 : 4)));
+            S.Hcc[l] = hsel0 + (d0 ? (k0 < 3 ? cmass : cI[k0 - 3]) : 0.f);
+            if (l + 16 < 21) S.Hcc[l + 16] = hsel1 + (d1 ? cI[2] : 0.f);
+          }
+        }
         __syncthreads();
+        V2_TICK(4)
         // ---- (3) convergence on the scaled gradient
         g_own = S.g[6 + l];
         float gcl = l < 6 ? S.g[l] : 0.f;
@@ -610,13 +680,13 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (act) iters_this++;
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly), 6x6 Schur complement on the cube
-        float L[10], Y[6][NLK], zb[NLK], xc6[6], pc4[NLK];
+        float L[10], Linv[4], Y[6][NLK], zb[NLK], xc6[6], pc4[NLK];
         {
           for (int k = 0; k < 10; k++) L[k] = S.Hbb[c][k];
-          chol4(L);
-          for (int q6 = 0; q6 < 6; q6++) { for (int j = 0; j < NLK; j++) Y[q6][j] = S.Hcb[c][j * 6 + q6]; fwd4(L, Y[q6]); }
+          chol4(L, Linv);
+          for (int q6 = 0; q6 < 6; q6++) { for (int j = 0; j < NLK; j++) Y[q6][j] = S.Hcb[c][j * 6 + q6]; fwd4(L, Linv, Y[q6]); }
           for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
-          fwd4(L, zb);
+          fwd4(L, Linv, zb);
           if (act && l < 6) S.rhs6[l] = -gcl;
         }
         __syncthreads();
@@ -632,6 +702,7 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
           float Lc[21];
           for (int k = 0; k < 21; k++) Lc[k] = S.Hcc[k];
           for (int k = 0; k < 6; k++) xc6[k] = S.rhs6[k];
+          float ci[6];
 #pragma unroll
           for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -639,26 +710,28 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
               float sv = Lc[tri(i, j)];
 #pragma unroll
               for (int k = 0; k < j; k++) sv -= Lc[tri(i, k)] * Lc[tri(j, k)];
-              Lc[tri(i, j)] = (i == j) ? sqrtf(fmaxf(sv, 1e-30f)) : sv / Lc[tri(j, j)];
+              if (i == j) { float rr = __frsqrt_rn(fmaxf(sv, 1e-30f)); ci[i] = rr; Lc[tri(i, i)] = sv * rr; }
+              else Lc[tri(i, j)] = sv * ci[j];
             }
 #pragma unroll
           for (int i = 0; i < 6; i++) { float sv = xc6[i];
 #pragma unroll
             for (int k = 0; k < i; k++) sv -= Lc[tri(i, k)] * xc6[k];
-            xc6[i] = sv / Lc[tri(i, i)]; }
+            xc6[i] = sv * ci[i]; }
 #pragma unroll
           for (int i = 5; i >= 0; i--) { float sv = xc6[i];
 #pragma unroll
             for (int k = i + 1; k < 6; k++) sv -= Lc[tri(k, i)] * xc6[k];
-            xc6[i] = sv / Lc[tri(i, i)]; }
+            xc6[i] = sv * ci[i]; }
           for (int j = 0; j < NLK; j++) { float v = zb[j]; for (int q6 = 0; q6 < 6; q6++) v -= Y[q6][j] * xc6[q6]; pc4[j] = v; }
-          bwd4(L, pc4);
+          bwd4(L, Linv, pc4);
         }
         float p_own = pc4[0];
 #pragma unroll
         for (int j = 1; j < NLK; j++) if (j == s) p_own = pc4[j];
         if (act) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xc6[l]; }
         __syncthreads();
+        V2_TICK(5)
         // ---- (5) exact line search along p
         float Mp_own = 0.f;
 #pragma unroll
@@ -679,10 +752,10 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
           lane_rows_eval(sl, dr, alpha, true, &cs, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
-            if (fabsf(d1) <= 1e-6f * fabsf(gp)) lsact = false;
+            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
               if (d1 < 0.f) lo = alpha; else hi = alpha;
-              float nx = alpha - d1 / d2;
+              float nx = alpha - d1 * __frcp_rn(d2);
               if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
               else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
               alpha = nx;
@@ -698,20 +771,24 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         }
         __syncthreads();
+        V2_TICK(6)
       }
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
+#ifdef JH_ENGINE_PROFILE
+      if (l == 0 && live && stats) atomicAdd(stats + 24 + (iters_this < 23 ? iters_this : 23), 1);
+#endif
     }
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
       float da_own = a_own - a0_own, rhs_own = fs_own, x4[NLK], L[10];
 #pragma unroll
-      for (int j = 0; j < NLK; j++) rhs_own += Mrow[j] * __shfl(da_own, cb + j, WAVE);
+      for (int j = 0; j < NLK; j++) rhs_own += Mrow[j] * quad_get(da_own, j);
 #pragma unroll
-      for (int j = 0; j < NLK; j++) x4[j] = __shfl(rhs_own, cb + j, WAVE);
+      for (int j = 0; j < NLK; j++) x4[j] = quad_get(rhs_own, j);
       for (int k = 0; k < 10; k++) L[k] = Mc[k];
 #pragma unroll
-      for (int j = 0; j < NLK; j++) L[tri(j, j)] += h * __shfl(lc.damp + lc.kvd, cb + j, WAVE);
-      chol4(L); fwd4(L, x4); bwd4(L, x4);
+      for (int j = 0; j < NLK; j++) L[tri(j, j)] += h * quad_get(lc.damp + lc.kvd, j);
+      float inv4[4]; chol4(L, inv4); fwd4(L, inv4, x4); bwd4(L, inv4, x4);
       float qacc = x4[0];
 #pragma unroll
       for (int j = 1; j < NLK; j++) if (j == s) qacc = x4[j];
@@ -743,13 +820,17 @@ __global__ __launch_bounds__(WAVE) void k_leap_v2(const float* __restrict__ gF, 
       }
     } else acc += leap_step_cost(sTp, qc);
     __syncthreads();
+    V2_TICK(7)
   }
+#ifdef JH_ENGINE_PROFILE
+  if (lane == 0 && stats) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)cyc[k]);
+#endif
   if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
   (void)n_overflow;
 }
 
-bool model_is_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 13 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0; }
+bool model_is_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 13 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG; }
 
 }  // namespace
 

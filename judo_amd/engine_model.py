@@ -40,7 +40,7 @@ BODY_F, DOF_F, ACT_F, GEOM_F, SITE_F = 32, 20, 8, 20, 3
 HEADER_I, HEADER_F = 24, 24
 # Newton termination on the GPU: |grad|_Minv <= tol * |qfrc_smooth|_Minv (or the expected decrease of a step falls below
 # tol^2 of the same scale), at most SOLVER_MAX_ITER iterations (MuJoCo: tolerance 1e-8 in fp64, 100 iterations)
-SOLVER_TOL, SOLVER_MAX_ITER = 1e-4, 20
+SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-3
 
 
 def _static_world_pose(desc: dict, b: int) -> tuple[np.ndarray, np.ndarray]:
@@ -141,6 +141,7 @@ def pack_engine_model(desc: dict) -> bytes:
     F[20] = float(np.linalg.norm(cube["size"]))
     F[21] = bodyw[st["free"]][0]
     F[22] = float(SOLVER_MAX_ITER)
+    F[23] = float(SOLVER_LS_TOL)
 
     # ---- moving bodies
     for i, b in enumerate(moving):

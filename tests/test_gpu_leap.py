@@ -171,3 +171,27 @@ def test_leap_full_size_properties(gpu):
     np.testing.assert_allclose(ctrl3.nominal_knots, nominal0, atol=1e-6)
     st = ctrl.model.stats()
     assert st["contact_overflow"] < 1e-5 * st["steps"]
+
+
+def test_leap_two_kernel_generations_agree(gpu):
+    """The cooperative kernel (16 lanes per rollout) and the one-lane-per-rollout kernel are independent implementations of
+    the same step; on identical inputs their rollouts agree to solver tolerance."""
+    import torch
+
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.tasks import LEAP_QPOS_HOME
+
+    N = 96
+    om, knots, U, _ = _mppi_controls(N, seed=9)
+    x0 = np.concatenate([LEAP_QPOS_HOME, np.zeros(22)])
+    b2 = GpuRolloutBackend("leap_cube", N)
+    s2, y2, _ = b2.rollout(x0, U)
+    b1 = GpuRolloutBackend("leap_cube", N)
+    b1.model.set_kernel(1)
+    s1, y1, _ = b1.rollout(x0, U)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y2, y1, atol=5e-3)
+    e = np.abs(s2 - s1)
+    assert np.median(e) < 1e-6 and np.percentile(e[:, -1, :3], 95) < 5e-3
+    with pytest.raises(ValueError):
+        b1.model.set_kernel(3)

@@ -18,8 +18,15 @@ torch.cuda.synchronize(); ctrl.model.stats()
 t = time.perf_counter(); ctrl.update_action(); torch.cuda.synchronize(); dt = time.perf_counter() - t
 L = _lib.lib(); L.jh_model_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 out = (C.c_longlong * 8)(); L.jh_model_profile(ctrl.model.handle, out)
-names = ['kinematics', 'smooth', 'collision', 'rows', 'solve', 'integrate', '-', 'spline/cost']
+names = ['kinematics', 'dynamics', 'collision', 'rows+warmstart', 'newton:assemble', 'newton:factor', 'newton:linesearch', 'integrate+cost']
 tot = sum(out)
-print(f'N={N} plan step {dt*1e3:.1f} ms; waves={N//64}; stats={ctrl.model.stats()}')
+print(f'N={N} plan step {dt*1e3:.1f} ms; waves={N//4}; stats={ctrl.model.stats(reset=False)}')
 for n, v in zip(names, out):
-    print(f'  {n:12s} {v/ (N//64) / 64 / 1e3:10.1f} kcyc/step/wave  {100*v/max(tot,1):5.1f}%')
+    print(f'  {n:12s} {v/ (N//4) / 64 / 1e3:10.1f} kcyc/step/wave  {100*v/max(tot,1):5.1f}%')
+
+L.jh_model_hist.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+hh = (C.c_int * 40)(); L.jh_model_hist(ctrl.model.handle, hh)
+nhh = list(hh)[24:40]; hh = list(hh)[:24]
+tot = sum(hh)
+print('broad-phase survivors per rollout-step:', ' '.join(f'{i}:{100*v/max(sum(nhh),1):.1f}%' for i, v in enumerate(nhh) if v))
+print('newton iterations per solve (only steps with constraint rows):', ' '.join(f'{i}:{100*v/max(tot,1):.1f}%' for i, v in enumerate(hh) if v))
