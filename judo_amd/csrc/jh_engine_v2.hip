@@ -29,11 +29,13 @@ constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
 
 struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float xpos[NMB][3], xR[NMB][9], axw[NMB][3];
-  float qv[NV], a[NV], a0[NV], g[NV], p[NV];
-  float Hcc[21], Hbb[NCH][10], Hcb[NCH][24];  // Hcb[c][j*6+q]: chain column j, cube row q
+  float qv[NV], g[NV], p[NV];
   float rhs6[6];
-  float pool[NCP][POOL_F];
   int hits[MAXHIT];
+  union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
+    float pool[NCP][POOL_F];
+    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24]; };  // Hcb[c][j*6+q]: chain column j, cube row q
+  };
   int ncon, nhit;
 };
 
@@ -66,8 +68,7 @@ __device__ __forceinline__ float quad_get(float v, int j) {
 }
 
 // ------------------------------------------------------------------------------------------------ collision into the LDS pool
-struct PoolCtx { RS* S; int* overflow; float* poly; /* LDS: [2][8][3][64], this lane's column */ };
-#define POLY(buf, q, k) pc.poly[(((buf) * 8 + (q)) * 3 + (k)) * WAVE]
+struct PoolCtx { RS* S; int* overflow; };
 
 __device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos, const float* n, float dist, int body, float mu, float tran) {
   int i = atomicAdd(&pc.S->ncon, 1);
@@ -130,34 +131,48 @@ __device__ void collide_box_box(const PoolCtx& pc, const float* p1, const float*
   for (int k = 0; k < 3; k++) { float v = fabsf(dot3(n, Ai[k])); if (v > mb) { mb = v; mi = k; } }
   float sgi = dot3(n, Ai[mi]) > 0.f ? -1.f : 1.f;
   int u = (mi + 1) % 3, v = (mi + 2) % 3;
-  int np = 4, cur = 0;
-  const float su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
-  for (int q = 0; q < 4; q++)
-    for (int k = 0; k < 3; k++) POLY(0, q, k) = pi[k] + sgi * hi[mi] * Ai[mi][k] + su[q] * hi[u] * Ai[u][k] + sv[q] * hi[v] * Ai[v][k];
-  int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
-  for (int pl = 0; pl < 4 && np > 0; pl++) {
-    const float* ax = Ar[pl < 2 ? ra : rb]; float sg = (pl & 1) ? -1.f : 1.f, lim = hr[pl < 2 ? ra : rb];
-    int nq = 0; const int nxt = cur ^ 1;
-    float P[3] = {POLY(cur, 0, 0), POLY(cur, 0, 1), POLY(cur, 0, 2)};
-    float fp = sg * ((P[0] - pr[0]) * ax[0] + (P[1] - pr[1]) * ax[1] + (P[2] - pr[2]) * ax[2]) - lim;
-    for (int q = 0; q < np; q++) {
-      int qn = (q + 1 == np) ? 0 : q + 1;
-      float Q[3] = {POLY(cur, qn, 0), POLY(cur, qn, 1), POLY(cur, qn, 2)};
-      float fq = sg * ((Q[0] - pr[0]) * ax[0] + (Q[1] - pr[1]) * ax[1] + (Q[2] - pr[2]) * ax[2]) - lim;
-      if (fp <= 0.f && nq < 8) { POLY(nxt, nq, 0) = P[0]; POLY(nxt, nq, 1) = P[1]; POLY(nxt, nq, 2) = P[2]; nq++; }
-      if (((fp < 0.f && fq > 0.f) || (fp > 0.f && fq < 0.f)) && nq < 8) { float t = fp / (fp - fq); for (int k = 0; k < 3; k++) POLY(nxt, nq, k) = P[k] + t * (Q[k] - P[k]); nq++; }
-      P[0] = Q[0]; P[1] = Q[1]; P[2] = Q[2]; fp = fq;
-    }
-    np = nq; cur = nxt;
-  }
-  for (int q = 0; q < np; q++) {
-    float X[3] = {POLY(cur, q, 0), POLY(cur, q, 1), POLY(cur, q, 2)};
-    float dx[3] = {X[0] - pr[0], X[1] - pr[1], X[2] - pr[2]};
-    float depth = hr[ri] - dot3(dx, n);
-    if (-depth >= 0.f) continue;
-    float pos[3], nn[3];
-    for (int k = 0; k < 3; k++) { pos[k] = X[k] + 0.5f * depth * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
+  // Face manifold without polygon buffers: the vertices of (incident quad) n (reference rectangle) are exactly
+  //   (a) incident vertices inside the rectangle, (b) incident-edge x rectangle-edge crossings, (c) rectangle corners inside the quad;
+  // contact order is irrelevant, so they are emitted as found (same point set as Sutherland-Hodgman clipping).
+  const int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
+  const float ha = hr[ra], hb = hr[rb];
+  float ci[3], e1[3], e2[3];
+  for (int k = 0; k < 3; k++) { ci[k] = pi[k] + sgi * hi[mi] * Ai[mi][k] - pr[k]; e1[k] = hi[u] * Ai[u][k]; e2[k] = hi[v] * Ai[v][k]; }
+  const float ca = dot3(ci, Ar[ra]), cbb = dot3(ci, Ar[rb]), cg = dot3(ci, n);
+  const float e1a = dot3(e1, Ar[ra]), e1b = dot3(e1, Ar[rb]), e1g = dot3(e1, n), e2a = dot3(e2, Ar[ra]), e2b = dot3(e2, Ar[rb]), e2g = dot3(e2, n);
+  const float href = hr[ri];
+  auto emit = [&](float al, float be, float ga) {
+    float depth = href - ga;
+    if (depth <= 0.f) return;
+    float pos[3], nn[3], gm = ga + 0.5f * depth;
+    for (int k = 0; k < 3; k++) { pos[k] = pr[k] + al * Ar[ra][k] + be * Ar[rb][k] + gm * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
     push_contact(pc, pos, nn, -depth, body, mu, tran);
+  };
+  const float s1[4] = {1, -1, -1, 1}, s2[4] = {1, 1, -1, -1};
+  float va[4], vb[4], vg[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { va[q] = ca + s1[q] * e1a + s2[q] * e2a; vb[q] = cbb + s1[q] * e1b + s2[q] * e2b; vg[q] = cg + s1[q] * e1g + s2[q] * e2g; }
+#pragma unroll
+  for (int q = 0; q < 4; q++) if (fabsf(va[q]) <= ha && fabsf(vb[q]) <= hb) emit(va[q], vb[q], vg[q]);   // (a)
+#pragma unroll
+  for (int q = 0; q < 4; q++) {                                                                        // (b)
+    const int qn = (q + 1) & 3;
+    const float da = va[qn] - va[q], db = vb[qn] - vb[q], dg = vg[qn] - vg[q];
+#pragma unroll
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      if (da != 0.f) { float t = (sgn * ha - va[q]) / da; float bb2 = vb[q] + t * db; if (t > 0.f && t < 1.f && fabsf(bb2) < hb) emit(sgn * ha, bb2, vg[q] + t * dg); }
+      if (db != 0.f) { float t = (sgn * hb - vb[q]) / db; float aa2 = va[q] + t * da; if (t > 0.f && t < 1.f && fabsf(aa2) < ha) emit(aa2, sgn * hb, vg[q] + t * dg); }
+    }
+  }
+  const float det = e1a * e2b - e1b * e2a;                                                               // (c)
+  if (fabsf(det) > 1e-12f) {
+    const float idet = 1.f / det;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float pa = s1[q] * ha - ca, pb2 = s2[q] * hb - cbb;
+      const float t1 = (pa * e2b - pb2 * e2a) * idet, t2 = (e1a * pb2 - e1b * pa) * idet;
+      if (fabsf(t1) < 1.f && fabsf(t2) < 1.f) emit(s1[q] * ha, s2[q] * hb, cg + t1 * e1g + t2 * e2g);
+    }
   }
 }
 
@@ -287,7 +302,6 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
   __shared__ float sGeomF[MAXG * GEOM_F];
   __shared__ int sGeomI[MAXG * GEOM_I];
   __shared__ int sLaneG[16 * MAXLG];
-  __shared__ float sPoly[2 * 8 * 3 * WAVE];
   const int lane = threadIdx.x, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3, cb = lane & ~3;
   RS& S = sRS[r];
   const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6];
@@ -455,8 +469,6 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       // free cube: M = diag(m,m,m,I)
       float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
       for (int k = 0; k < 3; k++) { fsc[k] = cmass * grav[k]; a0c[k] = grav[k]; fsc[3 + k] = -gc[k]; a0c[3 + k] = -gc[k] / cI[k]; }
-      S.a0[6 + l] = a0_own;
-      if (l < 6) S.a0[l] = a0c[l];
     }
     __syncthreads();
     V2_TICK(1)
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       if (l == 0 && live && stats) atomicAdd(stats + 48 + (nh < 15 ? nh : 15), 1);
 #endif
       __syncthreads();
-      PoolCtx pc{&S, stats, sPoly + lane};
+      PoolCtx pc{&S, stats};
       for (int base = 0; __any(base < nh); base += G) {
         int idx = base + l;
         if (idx < nh) {
@@ -579,10 +591,10 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       // ---- warm start: the better of last step's acceleration and the unconstrained one
       float cost_ws, cost_0;
       {
-        S.a[6 + l] = qws; if (l < 6) S.a[l] = wsc[l];
+        S.p[6 + l] = qws; if (l < 6) S.p[l] = wsc[l];
         __syncthreads();
         float cs, d1, d2, jx[3];
-        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], wsc, S.a, jx); for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; }
+        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], wsc, S.p, jx); for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; }
         dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
         lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
         float dws = qws - a0_own, md = 0.f;
@@ -592,10 +604,10 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         if (l < 6) { float dcw = wsc[l] - a0c[l]; cs += 0.5f * dcw * dcw * (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]); }
         cost_ws = gsum(cs);
         __syncthreads();
-        S.a[6 + l] = a0_own; if (l < 6) S.a[l] = a0c[l];
+        S.p[6 + l] = a0_own; if (l < 6) S.p[l] = a0c[l];
         __syncthreads();
         float jar0[2][3];
-        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], a0c, S.a, jx); for (int rw = 0; rw < 3; rw++) { jar0[k][rw] = sl[k].jar[rw]; sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; } }
+        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], a0c, S.p, jx); for (int rw = 0; rw < 3; rw++) { jar0[k][rw] = sl[k].jar[rw]; sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; } }
         float jf_ws = dr.jf, jl_ws = dr.jl;
         dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
         lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
@@ -607,7 +619,6 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
           dr.jf = jf_ws; dr.jl = jl_ws;
         } else { a_own = a0_own; for (int k = 0; k < 6; k++) ac[k] = a0c[k]; }
         __syncthreads();
-        S.a[6 + l] = a_own; if (l < 6) S.a[l] = ac[l];
       }
       bool act = true;
       V2_TICK(3)
@@ -767,7 +778,6 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
           a_own += alpha * p_own; for (int k = 0; k < 6; k++) ac[k] += alpha * xc6[k];
           for (int k = 0; k < 2; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
           dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
-          S.a[6 + l] = a_own; if (l < 6) S.a[l] = ac[l];
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         }
         __syncthreads();
