@@ -1,4 +1,6 @@
-// jh_engine.hip -- articulated-body rollout engine for the contact-rich tasks (leap_cube; fr3_pick next), gfx950.
+// jh_engine.hip -- generic articulated-body rollout engine, ONE LANE PER ROLLOUT (reference kernel): leap_cube and fr3_pick, gfx950.
+// (leap_cube's production kernel is the cooperative jh_engine_v2.hip; this one is model-generic: explicit geom pairs with
+// arbitrary sides, pyramidal or elliptic cones, joint equalities, geom-distance sensors.)
 //
 // One lane owns one rollout.  Per step (MuJoCo's pipeline, restated -- see oracle/jo_engine.c for the fp64 checker and
 // DESIGN.md section 5 for the derivation):
@@ -29,13 +31,14 @@ struct Work {
   float Mb[C::NBLK][C::TRI];
   float fs[C::NV], a0[C::NV], a[C::NV];
   // constraints
-  int ncon, overflow, iters, maxed;
+  int ncon, overflow, iters, maxed, cur_bodyA, cur_pair;
 #ifdef JH_ENGINE_PROFILE
   long long cyc[8], t0;
 #endif
   float cpos[C::NCON][3], cfr[C::NCON][9], caref[C::NCON][3], cD[C::NCON][3], cmu[C::NCON], cfri[C::NCON];
-  int cbody[C::NCON];
+  int cbody[C::NCON], cbodyA[C::NCON], cpair[C::NCON];  // geom 2's body / geom 1's body: -1 static, 0 the free body, >0 articulated
   float faref[C::NV], lims[C::NV], laref[C::NV], lD[C::NV];
+  float earef[2], eD[2];  // joint equalities
 };
 
 // ------------------------------------------------------------------------------------------------ kinematics
@@ -179,6 +182,7 @@ template <class C>
 __device__ __forceinline__ void push_contact(Work<C>& w, const float* pos, const float* n, float dist, int body, float mu, float tran) {
   if (w.ncon >= C::NCON) { w.overflow++; return; }
   int i = w.ncon++;
+  w.cbodyA[i] = w.cur_bodyA; w.cpair[i] = w.cur_pair;
   for (int k = 0; k < 3; k++) { w.cpos[i][k] = pos[k]; w.cfr[i][k] = n[k]; }
   make_frame(w.cfr[i]);
   w.caref[i][0] = dist;  // finished in constraint_rows
@@ -295,25 +299,44 @@ __device__ void collide_box_sphere(Work<C>& w, const float* pb, const float* Rb,
 }
 
 template <class C>
+__device__ __forceinline__ void geom_pose(const EngineModel& m, const Work<C>& w, int g, float* gp, float* gR, bool want_R) {
+  const float* gf = m.F + m.oAGF + g * GEOM_F; int body = m.I[m.oAGI + g * GEOM_I];
+  if (body < 0) { for (int k = 0; k < 3; k++) gp[k] = gf[GF_POS + k]; if (want_R) for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; }
+  else {
+    mulMV(gp, w.xR[body], gf + GF_POS); for (int k = 0; k < 3; k++) gp[k] += w.xpos[body][k];
+    if (want_R) mulMM(gR, w.xR[body], gf + GF_R);
+  }
+}
+
+template <class C>
 __device__ void collision(const EngineModel& m, Work<C>& w) {
   w.ncon = 0;
   const float* F = m.F;
-  const float* pc = w.xpos[0]; const float* Rc = w.xR[0]; const float* hc = F + HF_CSIZE; const float rbc = F[HF_CRBOUND];
-  for (int g = 0; g < m.NG; g++) {
-    const float* gf = F + m.oGeomF + g * GEOM_F; const int* gi = m.I + m.oGeomI + g * GEOM_I;
-    int body = gi[0];
-    float gp[3];
-    if (body < 0) { gp[0] = gf[GF_POS]; gp[1] = gf[GF_POS + 1]; gp[2] = gf[GF_POS + 2]; }
-    else { mulMV(gp, w.xR[body], gf + GF_POS); gp[0] += w.xpos[body][0]; gp[1] += w.xpos[body][1]; gp[2] += w.xpos[body][2]; }
-    float dc[3] = {gp[0] - pc[0], gp[1] - pc[1], gp[2] - pc[2]}, rs = gf[GF_RBOUND] + rbc;
+  for (int pi = 0; pi < m.NPAIR; pi++) {
+    int g1 = m.I[m.oPairI + 2 * pi], g2 = m.I[m.oPairI + 2 * pi + 1];
+    const float* f1 = F + m.oAGF + g1 * GEOM_F; const float* f2 = F + m.oAGF + g2 * GEOM_F;
+    int t1 = m.I[m.oAGI + g1 * GEOM_I + 1], t2 = m.I[m.oAGI + g2 * GEOM_I + 1];
+    float p1[3], p2[3], R1[9], R2[9];
+    geom_pose(m, w, g1, p1, R1, false); geom_pose(m, w, g2, p2, R2, false);
+    float dc[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, rs = f1[GF_RBOUND] + f2[GF_RBOUND];
     if (dot3(dc, dc) > rs * rs) continue;  // bounding-sphere filter
-    float tran = F[HF_CTRAN] + gf[GF_TRAN];
-    if (gi[1] == GBOX) {
-      float gR[9];
-      if (body < 0) { for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; } else mulMM(gR, w.xR[body], gf + GF_R);
-      collide_box_box(w, pc, Rc, hc, gp, gR, gf + GF_SIZE, body, gf[GF_MU], tran);
-    } else {
-      collide_box_sphere(w, pc, Rc, hc, gp, gf[GF_SIZE], body, gf[GF_MU], tran);
+    float mu = fmaxf(f1[GF_MU], f2[GF_MU]), tran = f1[GF_TRAN] + f2[GF_TRAN];
+    int b1 = m.I[m.oAGI + g1 * GEOM_I], b2 = m.I[m.oAGI + g2 * GEOM_I];
+    w.cur_pair = pi;
+    if (t1 == GBOX && t2 == GBOX) {
+      geom_pose(m, w, g1, p1, R1, true); geom_pose(m, w, g2, p2, R2, true);
+      w.cur_bodyA = b1;
+      collide_box_box(w, p1, R1, f1 + GF_SIZE, p2, R2, f2 + GF_SIZE, b2, mu, tran);
+    } else if (t1 == GBOX && t2 == GSPHERE) {
+      geom_pose(m, w, g1, p1, R1, true);
+      w.cur_bodyA = b1;
+      collide_box_sphere(w, p1, R1, f1 + GF_SIZE, p2, f2[GF_SIZE], b2, mu, tran);
+    } else if (t1 == GSPHERE && t2 == GBOX) {  // normal must point from geom 1 (sphere) to geom 2 (box): swap the sides of the box-sphere routine
+      geom_pose(m, w, g2, p2, R2, true);
+      int before = w.ncon;
+      w.cur_bodyA = b1;
+      collide_box_sphere(w, p2, R2, f2 + GF_SIZE, p1, f1[GF_SIZE], b2, mu, tran);
+      for (int i = before; i < w.ncon; i++) { for (int k = 0; k < 9; k++) w.cfr[i][k] = (k < 3) ? -w.cfr[i][k] : w.cfr[i][k]; make_frame(w.cfr[i]); }
     }
   }
 }
@@ -349,13 +372,25 @@ __device__ __forceinline__ void cube_point_force(const Work<C>& w, const float* 
   cross3(c, r, Fw); mulMTV(cl, w.xR[0], c);
   g[0] += Fw[0]; g[1] += Fw[1]; g[2] += Fw[2]; g[3] += cl[0]; g[4] += cl[1]; g[5] += cl[2];
 }
-// contact-frame relative velocity J x = frame * (v_geom2 - v_cube)
+// velocity of / generalized force on a world point attached to `body` (-1 static, 0 the free body, >0 articulated)
+template <class C>
+__device__ __forceinline__ void side_point_vel(const EngineModel& m, const Work<C>& w, int body, const float* p, const float* x, float* v) {
+  if (body < 0) { v[0] = v[1] = v[2] = 0.f; }
+  else if (body == 0) cube_point_vel(w, p, x, v);
+  else body_point_vel(m, w, body, p, x, v);
+}
+template <class C>
+__device__ __forceinline__ void side_point_force(const EngineModel& m, const Work<C>& w, int body, const float* p, const float* Fw, float* g) {
+  if (body == 0) cube_point_force(w, p, Fw, g);
+  else if (body > 0) body_point_force(m, w, body, p, Fw, g);
+}
+// contact-frame relative velocity J x = frame * (v_geom2 - v_geom1)
 template <class C>
 __device__ __forceinline__ void contact_Jx(const EngineModel& m, const Work<C>& w, int i, const float* x, float* out) {
-  float vb[3] = {0, 0, 0}, vc[3];
-  if (w.cbody[i] > 0) body_point_vel(m, w, w.cbody[i], w.cpos[i], x, vb);
-  cube_point_vel(w, w.cpos[i], x, vc);
-  float d[3] = {vb[0] - vc[0], vb[1] - vc[1], vb[2] - vc[2]};
+  float vb[3], va[3];
+  side_point_vel(m, w, w.cbody[i], w.cpos[i], x, vb);
+  side_point_vel(m, w, w.cbodyA[i], w.cpos[i], x, va);
+  float d[3] = {vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]};
   out[0] = dot3(w.cfr[i], d); out[1] = dot3(w.cfr[i] + 3, d); out[2] = dot3(w.cfr[i] + 6, d);
 }
 
@@ -382,14 +417,35 @@ __device__ void constraint_rows(const EngineModel& m, Work<C>& w) {
   const float impratio = F[HF_IMPRATIO];
   for (int i = 0; i < w.ncon; i++) {
     float dist = w.caref[i][0], tran = w.cD[i][0];
-    float imp = impedance(F + HF_SOLIMP, dist);
-    float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
-    w.cD[i][0] = 1.f / R0; w.cD[i][1] = 1.f / R1; w.cD[i][2] = 1.f / R1;
-    w.cmu[i] = w.cfri[i] * sqrtf(R1 / R0);
+    // contact parameters are mixed per pair: solref and solimp averaged (equal solmix), refsafe clamp on the time constant
+    const float* q1 = F + m.oGPF + m.I[m.oPairI + 2 * w.cpair[i]] * GP_F; const float* q2 = F + m.oGPF + m.I[m.oPairI + 2 * w.cpair[i] + 1] * GP_F;
+    float si[5]; for (int k = 0; k < 5; k++) si[k] = 0.5f * (q1[2 + k] + q2[2 + k]);
+    float tc = fmaxf(0.5f * (q1[0] + q2[0]), 2.f * F[HF_DT]), dr = 0.5f * (q1[1] + q2[1]);
+    float cK = 1.f / fmaxf(1e-15f, si[1] * si[1] * tc * tc * dr * dr), cB = 2.f / fmaxf(1e-15f, si[1] * tc);
+    float imp = impedance(si, dist);
+    if (m.cone == 1) {  // elliptic: friction rows R/impratio, regularised cone coefficient
+      float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
+      w.cD[i][0] = 1.f / R0; w.cD[i][1] = 1.f / R1; w.cD[i][2] = 1.f / R1;
+      w.cmu[i] = w.cfri[i] * sqrtf(R1 / R0);
+    } else {  // pyramidal: every edge row gets Rpy = 2 mu_reg^2 Rn, Rn from diagApprox = tran (1 + mu^2)
+      float mu = w.cfri[i], R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran * (1.f + mu * mu));
+      float mr2 = mu * mu / fmaxf(1e-15f, impratio);
+      float Rpy = fmaxf(1e-15f, 2.f * mr2 * R0);
+      w.cD[i][0] = w.cD[i][1] = w.cD[i][2] = 1.f / Rpy;
+      w.cmu[i] = mu;
+    }
     float vel[3]; contact_Jx(m, w, i, w.qvel, vel);
-    w.caref[i][0] = -F[HF_CB] * vel[0] - F[HF_CK] * imp * dist;
-    w.caref[i][1] = -F[HF_CB] * vel[1];
-    w.caref[i][2] = -F[HF_CB] * vel[2];
+    w.caref[i][0] = -cB * vel[0] - cK * imp * dist;
+    w.caref[i][1] = -cB * vel[1];
+    w.caref[i][2] = -cB * vel[2];
+  }
+  for (int e = 0; e < m.NEQ && e < 2; e++) {  // joint coupling (q1 - q1_0) - a0 - a1 (q2 - q2_0) = 0, always-active quadratic row
+    const int* ei = m.I + m.oEqI + e * EQ_I; const float* ef = F + m.oEqF + e * EQ_F;
+    float pos = w.qpos[ei[0] + 1] - ef[EF_A0] - ef[EF_A1] * w.qpos[ei[1] + 1];
+    float vel = w.qvel[ei[0]] - ef[EF_A1] * w.qvel[ei[1]];
+    float imp = impedance(ef + EF_SOLIMP, pos);
+    float R = fmaxf(1e-15f, (1.f - imp) / imp * ef[EF_INVW]);
+    w.eD[e] = 1.f / R; w.earef[e] = -ef[EF_B] * vel - ef[EF_K] * imp * pos;
   }
 }
 
@@ -409,7 +465,7 @@ struct Hess {
 template <class C>
 struct Rows {
   float cj[C::NCON][3];
-  float fj[C::NV], lj[C::NV];
+  float fj[C::NV], lj[C::NV], ej[2];
 };
 
 template <class C>
@@ -421,6 +477,10 @@ __device__ void rows_Jx(const EngineModel& m, const Work<C>& w, const float* x, 
   for (int d = 6; d < C::NV; d++) {
     r.fj[d] = x[d] - (subtract_aref ? w.faref[d] : 0.f);
     r.lj[d] = w.lims[d] * x[d] - (subtract_aref ? w.laref[d] : 0.f);
+  }
+  for (int e = 0; e < m.NEQ && e < 2; e++) {
+    const int* ei = m.I + m.oEqI + e * EQ_I;
+    r.ej[e] = x[ei[0]] - m.F[m.oEqF + e * EQ_F + EF_A1] * x[ei[1]] - (subtract_aref ? w.earef[e] : 0.f);
   }
 }
 
@@ -447,7 +507,7 @@ __device__ void rows_eval(const EngineModel& m, const Work<C>& w, const Rows<C>&
   for (int i = 0; i < w.ncon; i++) {
     float jar[3], jp[3] = {0, 0, 0}, f[3], W[6];
     for (int k = 0; k < 3; k++) { jar[k] = r0.cj[i][k]; if (rp) { jp[k] = rp->cj[i][k]; jar[k] += alpha * jp[k]; } }
-    cs += cone_eval(jar, w.cD[i], w.cmu[i], w.cfri[i], f, W);
+    cs += contact_eval(m.cone, jar, w.cD[i], w.cmu[i], w.cfri[i], f, W);
     if (rp) {
       g1 -= f[0] * jp[0] + f[1] * jp[1] + f[2] * jp[2];
       g2 += W[0] * jp[0] * jp[0] + W[2] * jp[1] * jp[1] + W[5] * jp[2] * jp[2] + 2.f * (W[1] * jp[0] * jp[1] + W[3] * jp[0] * jp[2] + W[4] * jp[1] * jp[2]);
@@ -467,6 +527,10 @@ __device__ void rows_eval(const EngineModel& m, const Work<C>& w, const Rows<C>&
       if (x < 0.f) { cs += 0.5f * w.lD[d] * x * x; g1 += w.lD[d] * x * jp; g2 += w.lD[d] * jp * jp; }
     }
   }
+  for (int e = 0; e < m.NEQ && e < 2; e++) {
+    float jp = rp ? rp->ej[e] : 0.f, x = r0.ej[e] + alpha * jp;
+    cs += 0.5f * w.eD[e] * x * x; g1 += w.eD[e] * x * jp; g2 += w.eD[e] * jp * jp;
+  }
   *cost = cs; if (d1) *d1 = g1; if (d2) *d2 = g2;
 }
 
@@ -484,7 +548,7 @@ __device__ float total_cost(const EngineModel& m, const Work<C>& w, const float*
 template <class C>
 __device__ int solve_constraints(const EngineModel& m, Work<C>& w, int max_iter, float tol) {
   const float* F = m.F;
-  bool any = w.ncon > 0;
+  bool any = w.ncon > 0 || m.NEQ > 0;
   for (int d = 6; d < C::NV; d++) any |= (F[m.oDofF + d * DOF_F + DF_FL] > 0.f) || (w.lims[d] != 0.f);
   if (!any) { for (int d = 0; d < C::NV; d++) w.a[d] = w.a0[d]; return 0; }
   Rows<C> r, rp;
@@ -507,40 +571,59 @@ __device__ int solve_constraints(const EngineModel& m, Work<C>& w, int max_iter,
     for (int c = 0; c < C::NBLK; c++) { for (int k = 0; k < C::TRI; k++) H.bb[c][k] = w.Mb[c][k]; for (int k = 0; k < 6 * C::BD; k++) H.cb[c][k] = 0.0; }
     for (int i = 0; i < w.ncon; i++) {
       float f[3], W[6];
-      cone_eval(r.cj[i], w.cD[i], w.cmu[i], w.cfri[i], f, W);
-      // J' f: world force on geom 2's body at the contact point, opposite on the cube
+      contact_eval(m.cone, r.cj[i], w.cD[i], w.cmu[i], w.cfri[i], f, W);
+      // J' f: world force on geom 2's body at the contact point, the opposite on geom 1's body; the gradient gets -J'f
       const float* fr = w.cfr[i];
       float Fw[3] = {fr[0] * f[0] + fr[3] * f[1] + fr[6] * f[2], fr[1] * f[0] + fr[4] * f[1] + fr[7] * f[2], fr[2] * f[0] + fr[5] * f[1] + fr[8] * f[2]};
       float nF[3] = {-Fw[0], -Fw[1], -Fw[2]};
-      // gradient gets -J'f
-      if (w.cbody[i] > 0) body_point_force(m, w, w.cbody[i], w.cpos[i], nF, g);
-      cube_point_force(w, w.cpos[i], Fw, g);
+      side_point_force(m, w, w.cbody[i], w.cpos[i], nF, g);
+      side_point_force(m, w, w.cbodyA[i], w.cpos[i], Fw, g);
       if (W[0] == 0.f && W[2] == 0.f && W[5] == 0.f) continue;
-      // explicit Jacobian columns in contact-frame coordinates: cube (6, negated) then the chain's ancestors
-      float Jc[6][3], Jb[C::BD][3]; int lb[C::BD], nbcol = 0, blkid = -1, d0 = 0;
+      // explicit Jacobian columns in contact-frame coordinates: the free body's 6 (if it is a side) and a dense row over the
+      // dofs of the ONE articulated block involved (side B adds, side A subtracts)
+      float Jc[6][3], Jb[C::BD][3]; int blkid = -1, d0 = 0; bool has_cube = false;
       const float* p = w.cpos[i];
-      float rr[3] = {p[0] - w.xpos[0][0], p[1] - w.xpos[0][1], p[2] - w.xpos[0][2]};
-      for (int k = 0; k < 3; k++) { Jc[k][0] = -fr[k]; Jc[k][1] = -fr[3 + k]; Jc[k][2] = -fr[6 + k]; }
-      for (int k = 0; k < 3; k++) { float ax[3], c3[3]; col3(ax, w.xR[0], k); cross3(c3, ax, rr); Jc[3 + k][0] = -dot3(fr, c3); Jc[3 + k][1] = -dot3(fr + 3, c3); Jc[3 + k][2] = -dot3(fr + 6, c3); }
-      if (w.cbody[i] > 0) {
-        blkid = m.I[m.oBodyI + w.cbody[i] * BODY_I + 4];
-        d0 = m.I[m.oBlockI + blkid * BLOCK_I + 2];
-        for (int b = w.cbody[i]; b > 0; b = m.I[m.oBodyI + b * BODY_I]) {
-          const int* bi = m.I + m.oBodyI + b * BODY_I; float c3[3];
-          if (bi[1] == JHINGE) { float rb[3] = {p[0] - w.xpos[b][0], p[1] - w.xpos[b][1], p[2] - w.xpos[b][2]}; cross3(c3, w.axw[b], rb); }
-          else { c3[0] = w.axw[b][0]; c3[1] = w.axw[b][1]; c3[2] = w.axw[b][2]; }
-          Jb[nbcol][0] = dot3(fr, c3); Jb[nbcol][1] = dot3(fr + 3, c3); Jb[nbcol][2] = dot3(fr + 6, c3); lb[nbcol] = bi[2] - d0; nbcol++;
+      for (int k = 0; k < 6; k++) Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.f;
+      for (int k = 0; k < C::BD; k++) Jb[k][0] = Jb[k][1] = Jb[k][2] = 0.f;
+      for (int side = 0; side < 2; side++) {
+        const int body = side == 0 ? w.cbodyA[i] : w.cbody[i]; const float sg = side == 0 ? -1.f : 1.f;
+        if (body == 0) {
+          has_cube = true;
+          float rr[3] = {p[0] - w.xpos[0][0], p[1] - w.xpos[0][1], p[2] - w.xpos[0][2]};
+          for (int k = 0; k < 3; k++) { Jc[k][0] += sg * fr[k]; Jc[k][1] += sg * fr[3 + k]; Jc[k][2] += sg * fr[6 + k]; }
+          for (int k = 0; k < 3; k++) { float ax[3], c3[3]; col3(ax, w.xR[0], k); cross3(c3, ax, rr); Jc[3 + k][0] += sg * dot3(fr, c3); Jc[3 + k][1] += sg * dot3(fr + 3, c3); Jc[3 + k][2] += sg * dot3(fr + 6, c3); }
+        } else if (body > 0) {
+          blkid = m.I[m.oBodyI + body * BODY_I + 4];
+          d0 = m.I[m.oBlockI + blkid * BLOCK_I + 2];
+          for (int bq = body; bq > 0; bq = m.I[m.oBodyI + bq * BODY_I]) {
+            const int* bi = m.I + m.oBodyI + bq * BODY_I; float c3[3];
+            if (bi[1] == JHINGE) { float rb[3] = {p[0] - w.xpos[bq][0], p[1] - w.xpos[bq][1], p[2] - w.xpos[bq][2]}; cross3(c3, w.axw[bq], rb); }
+            else { c3[0] = w.axw[bq][0]; c3[1] = w.axw[bq][1]; c3[2] = w.axw[bq][2]; }
+            int lq = bi[2] - d0;
+            Jb[lq][0] += sg * dot3(fr, c3); Jb[lq][1] += sg * dot3(fr + 3, c3); Jb[lq][2] += sg * dot3(fr + 6, c3);
+          }
         }
       }
       // G = W J ; H += J' G
       float Gc[6][3], Gb[C::BD][3];
       for (int k = 0; k < 6; k++) { const float* j = Jc[k]; Gc[k][0] = W[0] * j[0] + W[1] * j[1] + W[3] * j[2]; Gc[k][1] = W[1] * j[0] + W[2] * j[1] + W[4] * j[2]; Gc[k][2] = W[3] * j[0] + W[4] * j[1] + W[5] * j[2]; }
-      for (int k = 0; k < nbcol; k++) { const float* j = Jb[k]; Gb[k][0] = W[0] * j[0] + W[1] * j[1] + W[3] * j[2]; Gb[k][1] = W[1] * j[0] + W[2] * j[1] + W[4] * j[2]; Gb[k][2] = W[3] * j[0] + W[4] * j[1] + W[5] * j[2]; }
-      for (int u = 0; u < 6; u++) for (int v = 0; v <= u; v++) H.cc[tri(u, v)] += (hreal)(Jc[u][0] * Gc[v][0] + Jc[u][1] * Gc[v][1] + Jc[u][2] * Gc[v][2]);
-      for (int u = 0; u < nbcol; u++) {
-        for (int v = 0; v < nbcol; v++) if (lb[v] <= lb[u]) H.bb[blkid][tri(lb[u], lb[v])] += (hreal)(Jb[u][0] * Gb[v][0] + Jb[u][1] * Gb[v][1] + Jb[u][2] * Gb[v][2]);
-        for (int q = 0; q < 6; q++) H.cb[blkid][q * C::BD + lb[u]] += (hreal)(Jc[q][0] * Gb[u][0] + Jc[q][1] * Gb[u][1] + Jc[q][2] * Gb[u][2]);
+      if (has_cube) for (int u = 0; u < 6; u++) for (int v = 0; v <= u; v++) H.cc[tri(u, v)] += (hreal)(Jc[u][0] * Gc[v][0] + Jc[u][1] * Gc[v][1] + Jc[u][2] * Gc[v][2]);
+      if (blkid >= 0) {
+        const int nbk = m.I[m.oBlockI + blkid * BLOCK_I + 1];
+        for (int k = 0; k < nbk; k++) { const float* j = Jb[k]; Gb[k][0] = W[0] * j[0] + W[1] * j[1] + W[3] * j[2]; Gb[k][1] = W[1] * j[0] + W[2] * j[1] + W[4] * j[2]; Gb[k][2] = W[3] * j[0] + W[4] * j[1] + W[5] * j[2]; }
+        for (int u = 0; u < nbk; u++) {
+          for (int v = 0; v <= u; v++) H.bb[blkid][tri(u, v)] += (hreal)(Jb[u][0] * Gb[v][0] + Jb[u][1] * Gb[v][1] + Jb[u][2] * Gb[v][2]);
+          if (has_cube) for (int q = 0; q < 6; q++) H.cb[blkid][q * C::BD + u] += (hreal)(Jc[q][0] * Gb[u][0] + Jc[q][1] * Gb[u][1] + Jc[q][2] * Gb[u][2]);
+        }
       }
+    }
+    for (int e = 0; e < m.NEQ && e < 2; e++) {  // joint equality: quadratic row over two dofs of one block
+      const int* ei = m.I + m.oEqI + e * EQ_I; const float a1 = F[m.oEqF + e * EQ_F + EF_A1];
+      float Dx = w.eD[e] * r.ej[e];
+      g[ei[0]] += Dx; g[ei[1]] -= a1 * Dx;
+      int l1 = ei[3], l2 = ei[4], bk = ei[2];
+      H.bb[bk][tri(l1, l1)] += (hreal)w.eD[e]; H.bb[bk][tri(l2, l2)] += (hreal)(a1 * a1 * w.eD[e]);
+      H.bb[bk][l1 > l2 ? tri(l1, l2) : tri(l2, l1)] -= (hreal)(a1 * w.eD[e]);
     }
     for (int c = 0; c < C::NBLK; c++) {
       const int* blk = m.I + m.oBlockI + c * BLOCK_I; const int nb = blk[1], d0 = blk[2];
@@ -697,26 +780,74 @@ __device__ void engine_forward(const EngineModel& m, Work<C>& w, const float* ct
   JH_TICK(4)
 }
 
-// sensors of the forward pass (position stage): framepos of sites/bodies, jointpos, framezaxis
+// signed box-box distance = largest separation over the 15 SAT axes (exact when a face or an edge pair is closest; see the oracle)
+__device__ float box_box_distance(const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
+  float A[3][3], B[3][3], dv[3], best = -1e30f;
+  for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
+  for (int i = 0; i < 3; i++) {
+    float ra = h1[i], rb = 0.f; for (int k = 0; k < 3; k++) rb += h2[k] * fabsf(dot3(B[k], A[i]));
+    float sA = fabsf(dot3(dv, A[i])) - ra - rb; if (sA > best) best = sA;
+    ra = 0.f; rb = h2[i]; for (int k = 0; k < 3; k++) ra += h1[k] * fabsf(dot3(A[k], B[i]));
+    float sB = fabsf(dot3(dv, B[i])) - ra - rb; if (sB > best) best = sB;
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float L[3]; cross3(L, A[i], B[j]); float l2 = dot3(L, L);
+      if (l2 < 1e-12f) continue;
+      float il = rsqrtf(l2); L[0] *= il; L[1] *= il; L[2] *= il;
+      float ra = 0.f, rb = 0.f; for (int k = 0; k < 3; k++) { ra += h1[k] * fabsf(dot3(A[k], L)); rb += h2[k] * fabsf(dot3(B[k], L)); }
+      float sE = fabsf(dot3(dv, L)) - ra - rb; if (sE > best) best = sE;
+    }
+  return best;
+}
+
+// sensors of the forward pass (position stage): framepos of sites/bodies, jointpos, frame z axes, geom distances
 template <class C>
 __device__ void engine_sensors(const EngineModel& m, const Work<C>& w, float* y) {
-  for (int s = 0; s < m.NSENS; s++) {
-    const int* si = m.I + m.oSensI + s * SENS_I; int tp = si[0], obj = si[1], adr = si[2];
-    if (tp == 0) { int b = m.I[m.oSiteI + obj]; float p[3]; mulMV(p, w.xR[b], m.F + m.oSiteF + obj * SITE_F); for (int k = 0; k < 3; k++) y[adr + k] = p[k] + w.xpos[b][k]; }
+  for (int s = 0; s < m.NGS; s++) {
+    const int* si = m.I + m.oSensG + s * 4; int tp = si[0], obj = si[1], adr = si[3];
+    if (tp == 0 || tp == 5) {  // site frame: position / z axis
+      int b = m.I[m.oFrameI + obj]; const float* ff = m.F + m.oFrameF + obj * FRAME_F;
+      if (tp == 0) { float p[3]; mulMV(p, w.xR[b], ff); for (int k = 0; k < 3; k++) y[adr + k] = p[k] + w.xpos[b][k]; }
+      else { float zl[3] = {ff[3 + 2], ff[3 + 5], ff[3 + 8]}, z[3]; mulMV(z, w.xR[b], zl); for (int k = 0; k < 3; k++) y[adr + k] = z[k]; }
+    }
     else if (tp == 1) { for (int k = 0; k < 3; k++) y[adr + k] = w.xpos[obj][k]; }
     else if (tp == 2) y[adr] = w.qpos[obj];
     else if (tp == 3) { float z[3]; col3(z, w.xR[obj], 2); for (int k = 0; k < 3; k++) y[adr + k] = z[k]; }
-    else y[adr] = 0.f;
+    else {  // minimum signed distance between the box geoms of two bodies, clipped at the cutoff
+      const int* di = m.I + m.oDistI + obj * 4; float best = m.F[m.oDistF + obj];
+      for (int a = 0; a < di[1]; a++) {
+        int ga = m.I[m.oGlist + di[0] + a]; float pa[3], Ra[9]; geom_pose(m, w, ga, pa, Ra, true);
+        for (int bq = 0; bq < di[3]; bq++) {
+          int gb = m.I[m.oGlist + di[2] + bq]; float pb[3], Rb[9]; geom_pose(m, w, gb, pb, Rb, true);
+          float dd = box_box_distance(pa, Ra, m.F + m.oAGF + ga * GEOM_F + GF_SIZE, pb, Rb, m.F + m.oAGF + gb * GEOM_F + GF_SIZE);
+          if (dd < best) best = dd;
+        }
+      }
+      y[adr] = best;
+    }
   }
 }
 
+// task costs: one struct per task
+struct LeapCost {
+  static constexpr bool needs_sensors = false;
+  __device__ static float step(const float* tp, int, const float* qpos, const float*, const float*, float) { return leap_step_cost(tp, qpos); }
+  __device__ static float finish(float acc, int H) { return acc / (float)H; }  // mean over time
+};
+struct Fr3Cost {
+  static constexpr bool needs_sensors = true;
+  __device__ static float step(const float* tp, int phase, const float* qpos, const float* qvel, const float* y, float decay) { return fr3_step_cost(tp, phase, qpos, qvel, 15, y, decay); }
+  __device__ static float finish(float acc, int) { return acc; }  // sum over time
+};
+
 // ------------------------------------------------------------------------------------------------ kernels
-template <class C>
+template <class C, class TC>
 __global__ __launch_bounds__(kBlock) void k_engine_cost(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI,
                                                         const float* __restrict__ x0, const float* __restrict__ nominal,
                                                         const float* __restrict__ noise, int ldn, const float* __restrict__ sigma,
                                                         const float* __restrict__ W, const float* __restrict__ lohi, const float* __restrict__ tp,
-                                                        int ntp, int N, int n_offset, int H, int K, float* __restrict__ costs,
+                                                        int ntp, int phase, int N, int n_offset, int H, int K, float* __restrict__ costs,
                                                         float* __restrict__ knots_out, int* __restrict__ overflow) {
   extern __shared__ float lds[];
   float* sF = lds; int* sI = (int*)(sF + nF);
@@ -752,15 +883,17 @@ __global__ __launch_bounds__(kBlock) void k_engine_cost(const float* __restrict_
     for (int j = 0; j < C::NU; j++) u[j] = 0.f;
     for (int k = 0; k < K; k++) { float wk = sW[h * K + k]; for (int j = 0; j < C::NU; j++) u[j] = fmaf(wk, sKn[(k * C::NU + j) * kBlock + lane], u[j]); }
     engine_forward(m, w, u);
+    float y[C::NS];
+    if (TC::needs_sensors) engine_sensors(m, w, y);
     engine_step(m, w, u);
     JH_TICK(5)
-    acc += leap_step_cost(sTp, w.qpos);
+    acc += TC::step(sTp, phase, w.qpos, w.qvel, y, H > 1 ? 1.f - (float)h / (float)(H - 1) : 1.f);
   }
 #ifdef JH_ENGINE_PROFILE
   if (lane == 0 && overflow) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(overflow + 4) + k, (unsigned long long)w.cyc[k]);
 #endif
   if (live) {
-    costs[n] = acc / (float)H;
+    costs[n] = TC::finish(acc, H);
     if (overflow) { if (w.overflow) atomicAdd(overflow, w.overflow); if (w.maxed) atomicAdd(overflow + 1, w.maxed); atomicAdd(overflow + 2, w.iters); atomicAdd(overflow + 3, H); }
   }
 }
@@ -814,30 +947,41 @@ __global__ __launch_bounds__(kBlock) void k_leap_reward(const float* __restrict_
   rewards[n] = -acc / (float)H;
 }
 
-bool model_matches_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 12 && m->h_i[0] == 17 && m->h_i[1] == 4; }
+__global__ __launch_bounds__(kBlock) void k_fr3_reward(const float* __restrict__ states, const float* __restrict__ sensors, const float* __restrict__ tp,
+                                                       int phase, int N, int H, float* __restrict__ rewards) {
+  __shared__ float sTp[22];
+  if (threadIdx.x < 22) sTp[threadIdx.x] = tp[threadIdx.x];
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int h = 0; h < H; h++) {
+    float x[31], y[14];
+    for (int i = 0; i < 31; i++) x[i] = states[((size_t)n * H + h) * 31 + i];
+    for (int i = 0; i < 14; i++) y[i] = sensors[((size_t)n * H + h) * 14 + i];
+    acc += fr3_step_cost(sTp, phase, x, x + 16, 15, y, H > 1 ? 1.f - (float)h / (float)(H - 1) : 1.f);
+  }
+  rewards[n] = -acc;
+}
 
-}  // namespace
+bool model_matches_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 14 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[13] > 0; }
+bool model_matches_fr3(const jh_model* m) { return m->kind == JH_TASK_FR3_PICK && m->nq == 16 && m->nv == 15 && m->nu == 8 && m->ns == 14 && m->h_i.size() > 14 && m->h_i[0] == 10 && m->h_i[1] == 1 && m->h_i[13] > 0; }
 
-int jh_engine_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
-                           const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
-                           float* knots_out, hipStream_t st) {
-  (void)phase;
-  if (!model_matches_leap(m)) { jh_set_error("rollout_cost: the articulated engine is instantiated for leap_cube only (fr3_pick: next round)"); return JH_ERR_UNSUPPORTED; }
-  using C = LeapCfg;
+template <class C, class TC>
+int launch_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W, const float* lohi,
+                const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
   size_t lds = 4 * (m->nf + m->ni + (size_t)H * K + (size_t)K * C::NU * kBlock + JH_MAX_TASK_PARAMS);
   JH_REQUIRE(lds <= 64 * 1024, "rollout_cost: LDS staging needs %zu bytes (> 64 KiB)", lds);
   int grid = (N + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_engine_cost<C>, dim3(grid), dim3(kBlock), lds, st, m->d_f, m->d_i, (int)m->nf, (int)m->ni, x0, nominal, noise, ldn, sigma, W, lohi,
-                     tp, m->ntaskparam, N, n_offset, H, K, costs, knots_out, m->d_stats);
+  hipLaunchKernelGGL((k_engine_cost<C, TC>), dim3(grid), dim3(kBlock), lds, st, m->d_f, m->d_i, (int)m->nf, (int)m->ni, x0, nominal, noise, ldn, sigma, W, lohi,
+                     tp, m->ntaskparam, phase, N, n_offset, H, K, costs, knots_out, m->d_stats);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
-
-int jh_engine_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
-                          hipStream_t st) {
-  if (!model_matches_leap(m)) { jh_set_error("rollout_materialize: the articulated engine is instantiated for leap_cube only (fr3_pick: next round)"); return JH_ERR_UNSUPPORTED; }
-  using C = LeapCfg;
+template <class C>
+int launch_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors, hipStream_t st) {
   size_t lds = 4 * (m->nf + m->ni);
+  JH_REQUIRE(lds <= 64 * 1024, "rollout_materialize: LDS staging needs %zu bytes (> 64 KiB)", lds);
   int grid = (N + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(k_engine_materialize<C>, dim3(grid), dim3(kBlock), lds, st, m->d_f, m->d_i, (int)m->nf, (int)m->ni, x0, x0_batched, controls, N, H, states,
                      sensors, m->d_stats);
@@ -845,12 +989,38 @@ int jh_engine_materialize(const jh_model* m, const float* x0, int x0_batched, co
   return JH_OK;
 }
 
+}  // namespace
+
+int jh_engine_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                           const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
+                           float* knots_out, hipStream_t st) {
+  if (model_matches_leap(m)) return launch_cost<LeapCfg, LeapCost>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
+  if (model_matches_fr3(m)) {
+    JH_REQUIRE(phase >= 0 && phase <= 3, "rollout_cost: fr3_pick phase must be 0..3 (got %d)", phase);
+    return launch_cost<Fr3Cfg, Fr3Cost>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
+  }
+  jh_set_error("rollout_cost: the articulated engine is instantiated for leap_cube and fr3_pick");
+  return JH_ERR_UNSUPPORTED;
+}
+
+int jh_engine_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                          hipStream_t st) {
+  if (model_matches_leap(m)) return launch_materialize<LeapCfg>(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (model_matches_fr3(m)) return launch_materialize<Fr3Cfg>(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  jh_set_error("rollout_materialize: the articulated engine is instantiated for leap_cube and fr3_pick");
+  return JH_ERR_UNSUPPORTED;
+}
+
 int jh_engine_reward(const jh_model* m, const float* states, const float* sensors, const float* controls, const float* tp, int phase, int N, int H,
                      float* rewards, hipStream_t st) {
-  (void)sensors; (void)controls; (void)phase;
-  if (m->kind != JH_TASK_LEAP_CUBE) { jh_set_error("task_reward: fr3_pick reward kernel lands with its engine instantiation (next round)"); return JH_ERR_UNSUPPORTED; }
+  (void)controls;
   int grid = (N + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_leap_reward, dim3(grid), dim3(kBlock), 0, st, states, tp, N, H, m->nq + m->nv, rewards);
+  if (m->kind == JH_TASK_LEAP_CUBE) hipLaunchKernelGGL(k_leap_reward, dim3(grid), dim3(kBlock), 0, st, states, tp, N, H, m->nq + m->nv, rewards);
+  else if (m->kind == JH_TASK_FR3_PICK) {
+    JH_REQUIRE(sensors != nullptr, "task_reward: fr3_pick needs the sensor array");
+    JH_REQUIRE(phase >= 0 && phase <= 3, "task_reward: fr3_pick phase must be 0..3 (got %d)", phase);
+    hipLaunchKernelGGL(k_fr3_reward, dim3(grid), dim3(kBlock), 0, st, states, sensors, tp, phase, N, H, rewards);
+  } else { jh_set_error("task_reward: unknown articulated task"); return JH_ERR_UNSUPPORTED; }
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -11,6 +11,8 @@ constexpr int GBOX = 6, GSPHERE = 2;
 constexpr int HEADER_I = 24, HEADER_F = 24;
 constexpr int BODY_I = 6, GEOM_I = 2, ACT_I = 2, BLOCK_I = 4, SENS_I = 3;
 constexpr int BODY_F = 32, DOF_F = 20, ACT_F = 8, GEOM_F = 20, SITE_F = 3;
+constexpr int EQ_I = 5, EQ_F = 12, FRAME_F = 12, GP_F = 8;  // GP: solref[2], solimp[5], pad
+enum { EF_A0 = 0, EF_A1, EF_K, EF_B, EF_SOLIMP, EF_INVW = 9 };
 // header floats
 enum { HF_DT = 0, HF_IMPRATIO = 1, HF_TOL = 2, HF_MAXITER = 22, HF_LSTOL = 23, HF_GRAV = 3, HF_CK = 6, HF_CB = 7, HF_SOLIMP = 8, HF_CMASS = 13, HF_CINERTIA = 14, HF_CSIZE = 17, HF_CRBOUND = 20, HF_CTRAN = 21 };
 // body floats
@@ -28,12 +30,21 @@ struct EngineModel {  // views into the LDS copy of the blob
   int NM, NBLK, NV, NQ, NU, NG, NSITE, NS, NSENS;
   int oBodyI, oBlockI, oActI, oGeomI, oSiteI, oSensI;
   int oBodyF, oDofF, oActF, oGeomF, oSiteF;
+  // generic sections (reference kernel): all geoms incl. the cube, explicit pairs, equalities, frames, distance sensors
+  int NAG, NPAIR, NEQ, NFRAME, NDIST, NGS, cone;
+  int oAGI, oPairI, oEqI, oFrameI, oDistI, oSensG, oGlist, oAGF, oGPF, oEqF, oFrameF, oDistF;
   __device__ void init(const float* f, const int* i) {
     F = f; I = i;
     NM = i[0]; NBLK = i[1]; NV = i[2]; NQ = i[3]; NU = i[4]; NG = i[5]; NSITE = i[6]; NS = i[7]; NSENS = i[10];
     oBodyI = HEADER_I; oBlockI = oBodyI + NM * BODY_I; oActI = oBlockI + NBLK * BLOCK_I; oGeomI = oActI + NU * ACT_I;
     oSiteI = oGeomI + NG * GEOM_I; oSensI = oSiteI + NSITE;
     oBodyF = HEADER_F; oDofF = oBodyF + NM * BODY_F; oActF = oDofF + NV * DOF_F; oGeomF = oActF + NU * ACT_F; oSiteF = oGeomF + NG * GEOM_F;
+    cone = i[9];
+    const int gi = i[13], gf = i[14];
+    NAG = i[gi]; NPAIR = i[gi + 1]; NEQ = i[gi + 2]; NFRAME = i[gi + 3]; NDIST = i[gi + 4]; NGS = i[gi + 5];
+    oAGI = gi + 8; oPairI = oAGI + NAG * GEOM_I; oEqI = oPairI + NPAIR * 2; oFrameI = oEqI + NEQ * EQ_I; oDistI = oFrameI + NFRAME;
+    oSensG = oDistI + NDIST * 4; oGlist = oSensG + NGS * 4;
+    oAGF = gf; oGPF = oAGF + NAG * GEOM_F; oEqF = oGPF + NAG * GP_F; oFrameF = oEqF + NEQ * EQ_F; oDistF = oFrameF + NFRAME * FRAME_F;
   }
 };
 
@@ -43,6 +54,7 @@ struct Cfg {
   static constexpr int TRI = BD_ * (BD_ + 1) / 2;
 };
 using LeapCfg = Cfg<17, 22, 23, 16, 4, 4, 32, 31>;
+using Fr3Cfg = Cfg<10, 15, 16, 8, 1, 9, 64, 14>;
 
 // ------------------------------------------------------------------------------------------------ small vector helpers
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -122,6 +134,29 @@ __device__ __forceinline__ float cone_eval(const float* jar, const float* D, flo
   return 0.5f * Dm * NT * NT;
 }
 
+
+// pyramidal-cone contact (condim 3): four one-sided rows  jar_n +- mu*jar_t1, jar_n +- mu*jar_t2, all with the same D.
+// Expressed in the contact-frame 3-vector jar = J a - aref it returns the frame force f = -ds/djar and the 3x3 weight W.
+__device__ __forceinline__ float pyramid_eval(const float* jar, float D, float mu, float* f, float* W) {
+  float cs = 0.f, fn = 0.f, f1 = 0.f, f2 = 0.f, w00 = 0.f, w01 = 0.f, w02 = 0.f, w11 = 0.f, w22 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float sg = (k & 1) ? -mu : mu;
+    const float x = jar[0] + sg * (k < 2 ? jar[1] : jar[2]);
+    if (x < 0.f) {
+      cs += 0.5f * D * x * x; const float fk = -D * x;
+      fn += fk; w00 += D;
+      if (k < 2) { f1 += sg * fk; w01 += sg * D; w11 += sg * sg * D; } else { f2 += sg * fk; w02 += sg * D; w22 += sg * sg * D; }
+    }
+  }
+  f[0] = fn; f[1] = f1; f[2] = f2;
+  W[0] = w00; W[1] = w01; W[2] = w11; W[3] = w02; W[4] = 0.f; W[5] = w22;
+  return cs;
+}
+__device__ __forceinline__ float contact_eval(int cone, const float* jar, const float* D, float mu, float fri, float* f, float* W) {
+  return cone == 1 ? cone_eval(jar, D, mu, fri, f, W) : pyramid_eval(jar, D[0], fri, f, W);
+}
+
 // ------------------------------------------------------------------------------------------------ task costs
 // leap_cube (judo/tasks/leap_cube.py:63-88): tp = (w_pos, w_rot, goal_pos[3], goal_quat[4]); MEAN over time
 __device__ __forceinline__ float leap_step_cost(const float* tp, const float* qpos) {
@@ -139,5 +174,26 @@ __device__ __forceinline__ float leap_step_cost(const float* tp, const float* qp
   return tp[0] * 0.5f * (d0 * d0 + d1 * d1 + d2 * d2) + tp[1] * 0.5f * speed * speed;
 }
 
+
+// fr3_pick (judo/tasks/fr3_pick.py:225-311): one step's contribution.  tp = (w_lift_close, w_lift_height, w_move_goal, w_move_close,
+// w_place_table, w_place_goal, w_upright, w_coll, w_qvel, w_open, goal_x, goal_y, pick_height, arm_home[9]).  `y` = sensordata of the forward
+// pass that produced the state (it lags the state by one step, as in the reference); `decay` = linspace(1,0,H)[h].
+__device__ __forceinline__ float fr3_step_cost(const float* tp, int phase, const float* qpos, const float* qvel, int nv, const float* y, float decay) {
+  const float* gs = y + 11; const float* ez = y + 5;
+  float gd = (gs[0] - qpos[0]) * (gs[0] - qpos[0]) + (gs[1] - qpos[1]) * (gs[1] - qpos[1]) + (gs[2] - qpos[2]) * (gs[2] - qpos[2]);
+  float he = (qpos[2] - tp[12]) * (qpos[2] - tp[12]);
+  float og = sqrtf((qpos[0] - tp[10]) * (qpos[0] - tp[10]) + (qpos[1] - tp[11]) * (qpos[1] - tp[11]));
+  float c;
+  if (phase == 0) c = tp[0] * gd + tp[1] * he;
+  else if (phase == 1) c = tp[2] * og + tp[3] * gd;
+  else if (phase == 2) c = tp[4] * y[4] + tp[5] * og;
+  else { float hd = 0.f; for (int k = 0; k < 9; k++) hd += (qpos[7 + k] - tp[13 + k]) * (qpos[7 + k] - tp[13 + k]); c = sqrtf(hd); }
+  float up = sqrtf(ez[0] * ez[0] + ez[1] * ez[1] + (ez[2] + 1.f) * (ez[2] + 1.f));
+  float touching = (y[2] <= 0.f || y[3] <= 0.f) ? 1.f : 0.f;
+  float qn = 0.f; for (int k = 0; k < nv; k++) qn += qvel[k] * qvel[k];
+  float op = (qpos[15] - 0.04f) * (qpos[15] - 0.04f);
+  // reward = -(phase terms) + w_upright*(-up) + w_coll*(1-touching) + w_qvel*(-decay*|qvel|) + w_open*(-op); cost = -reward
+  return c + tp[6] * up - tp[7] * (1.f - touching) + tp[8] * decay * sqrtf(qn) + tp[9] * op;
+}
 
 }  // namespace jh_eng

@@ -97,11 +97,146 @@ def engine_structure(desc: dict) -> dict:
     return dict(layout=lay, is_static=is_static, moving=moving, midx=midx, blocks=blocks, block_of=block_of, free=free[0])
 
 
+def _mat_to_quat(R: np.ndarray) -> np.ndarray:
+    """Rotation matrix -> unit quaternion (w, x, y, z)."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def fuse_fixed_bodies(desc: dict) -> dict:
+    """Merge every joint-less body whose parent moves into that parent (fr3_pick: `hand` is welded to `fr3_link7`).
+
+    MuJoCo keeps such bodies and lets them ride on the parent; the engine wants exactly one joint per moving body, so the
+    child's inertia is added to the parent (parallel-axis, re-diagonalised), its children / geoms / sites are re-expressed
+    in the parent frame, and sensors that referenced the body frame get an equivalent site.  Geoms remember the body
+    they came from (`orig_body`) because contact regularisation and distance sensors are defined per original body."""
+    import copy
+
+    d = copy.deepcopy(desc)
+    for g in d["geoms"]:
+        g.setdefault("orig_body", g["body"])
+    lay = layout(d)
+    nb = len(d["bodies"])
+    static = [True] + [False] * (nb - 1)
+    for b in range(1, nb):
+        static[b] = (len(lay.body_joints[b]) == 0) and static[d["bodies"][b]["parent"]]
+    victims = [b for b in range(1, nb) if len(lay.body_joints[b]) == 0 and not static[b]]
+    if not victims:
+        return d
+    b = victims[0]
+    body = d["bodies"][b]
+    p = body["parent"]
+    par = d["bodies"][p]
+    Rb, pb = quat_to_mat(body["quat"]), np.array(body["pos"])
+    # inertia merge in the parent frame
+    m1, m2 = par["mass"], body["mass"]
+    c1, c2 = np.array(par["ipos"]), pb + Rb @ np.array(body["ipos"])
+    R1 = quat_to_mat(par["iquat"])
+    R2 = Rb @ quat_to_mat(body["iquat"])
+    I1, I2 = R1 @ np.diag(par["inertia"]) @ R1.T, R2 @ np.diag(body["inertia"]) @ R2.T
+    m = m1 + m2
+    c = (m1 * c1 + m2 * c2) / m if m > 0 else c1
+    shift = lambda mm, r: mm * (r @ r * np.eye(3) - np.outer(r, r))  # noqa: E731
+    I = I1 + shift(m1, c1 - c) + I2 + shift(m2, c2 - c)
+    w, V = np.linalg.eigh(I)
+    if np.linalg.det(V) < 0:
+        V[:, 2] = -V[:, 2]
+    par.update(mass=m, ipos=c.tolist(), iquat=_mat_to_quat(V).tolist(), inertia=w.tolist())
+    for ch in d["bodies"]:
+        if ch.get("parent") == b:
+            ch["pos"] = (pb + Rb @ np.array(ch["pos"])).tolist()
+            ch["quat"] = quat_mul(body["quat"], ch["quat"]).tolist()
+            ch["parent"] = p
+    for coll in (d["geoms"], d["sites"]):
+        for g in coll:
+            if g["body"] == b:
+                g["pos"] = (pb + Rb @ np.array(g["pos"])).tolist()
+                g["quat"] = quat_mul(body["quat"], g.get("quat", [1, 0, 0, 0])).tolist()
+                g["body"] = p
+    # sensors on the body frame -> an equivalent site on the parent
+    for sn in d["sensors"]:
+        if sn["type"] in ("framepos", "framezaxis") and sn.get("objtype") == "body" and sn["obj"] == b:
+            d["sites"].append(dict(name=f"{body['name']}_frame", body=p, pos=pb.tolist(), quat=list(body["quat"])))
+            sn["objtype"], sn["obj"] = "site", len(d["sites"]) - 1
+    # drop body b, renumber
+    remap = {i: (i if i < b else i - 1) for i in range(nb) if i != b}
+    del d["bodies"][b]
+    for ch in d["bodies"]:
+        if ch["parent"] >= 0:
+            ch["parent"] = remap[ch["parent"]]
+    for coll in (d["geoms"], d["sites"], d["joints"]):
+        for g in coll:
+            g["body"] = remap[g["body"]]
+    for sn in d["sensors"]:
+        if sn["type"] in ("framepos", "framezaxis") and sn.get("objtype") == "body":
+            sn["obj"] = remap[sn["obj"]]
+    d["excludes"] = [[remap[a], remap[c2]] for a, c2 in d["excludes"] if a != b and c2 != b]
+    d.setdefault("fused", []).append(body["name"])
+    return fuse_fixed_bodies(d)
+
+
+def generic_pairs(desc: dict, fused: dict, st: dict) -> list[tuple[int, int]]:
+    """Candidate box-box / box-sphere pairs for the generic (reference-kernel) contact path, MuJoCo's static filters
+    applied on the ORIGINAL bodies: same welded body, parent-child (unless the parent is welded to the world), excludes.
+    leap_cube: restricted to pairs that involve the cube (hand self-collision is out of scope this round)."""
+    bodies = desc["bodies"]
+    njnt = [0] * len(bodies)
+    for j in desc["joints"]:
+        njnt[j["body"]] += 1
+
+    def weld(b):
+        while b > 0 and njnt[b] == 0:
+            b = bodies[b]["parent"]
+        return b
+
+    def weld_parent(b):
+        w = weld(b)
+        return weld(bodies[w]["parent"]) if w > 0 else 0
+
+    excl = {tuple(sorted(e)) for e in desc["excludes"]}
+    geoms = fused["geoms"]
+    free_fused = st["free"]
+    out = []
+    for a in range(len(geoms)):
+        for b in range(a + 1, len(geoms)):
+            ga, gb = geoms[a], geoms[b]
+            ta, tb = ga["type"], gb["type"]
+            if not ((ta == "box" and tb in ("box", "sphere")) or (ta == "sphere" and tb == "box")):
+                continue
+            ba, bb = ga["orig_body"], gb["orig_body"]
+            wa, wb = weld(ba), weld(bb)
+            if wa == wb or tuple(sorted((ba, bb))) in excl:
+                continue
+            if (weld_parent(ba) == wb and wb != 0) or (weld_parent(bb) == wa and wa != 0):
+                continue
+            if desc["task"] == "leap_cube" and free_fused not in (ga["body"], gb["body"]):
+                continue
+            out.append((a, b))
+    return out
+
+
 def pack_engine_model(desc: dict) -> bytes:
+    orig = desc
+    dofw_o, bodyw_o = inverse_weights(orig)
+    desc = fuse_fixed_bodies(orig)
     st = engine_structure(desc)
     lay, moving, midx, blocks = st["layout"], st["moving"], st["midx"], st["blocks"]
     o = desc["option"]
-    dofw, bodyw = inverse_weights(desc)
+    dofw = dofw_o  # dof order is unchanged by fusing
+    bodyw_geom = lambda g: bodyw_o[g.get("orig_body", g["body"])][0]  # noqa: E731  (contact diagApprox uses the geom's ORIGINAL body)
+    _, bodyw = inverse_weights(desc)
     NM, NBLK = len(moving), len(blocks)
     if NM > MAX_MOVING or lay.nv > MAX_DOF or NBLK > MAX_BLOCKS or max(len(b) for b in blocks) > MAX_BLOCK_DOF:
         raise NotImplementedError("model exceeds the engine's compile-time limits")
@@ -121,15 +256,16 @@ def pack_engine_model(desc: dict) -> bytes:
     F: list[float] = [0.0] * HEADER_F
     integ = {"euler": 0, "implicitfast": 3}[o["integrator"]]
     cone = {"pyramidal": 0, "elliptic": 1}[o["cone"]]
-    if cone != 1 or integ != 3:
-        raise NotImplementedError("engine kernels implement implicitfast + elliptic cones (leap_cube / fr3_pick)")
+    if integ != 3:
+        raise NotImplementedError("engine kernels implement the implicitfast integrator (leap_cube / fr3_pick)")
     sites = desc["sites"]
     sens = desc["sensors"]
     I[0:12] = [NM, NBLK, lay.nv, lay.nq, lay.nu, len(others), len(sites), lay.ns, integ, cone, len(sens), 0]
     # contact solver parameters are shared by all geoms in these models (checked)
+    uniform = all(g["solref"] == cube["solref"] and g["solimp"] == cube["solimp"] for g in others)
     for g in others:
-        if g["solref"] != cube["solref"] or g["solimp"] != cube["solimp"] or g["condim"] != 3 or g["margin"] != 0 or g["gap"] != 0:
-            raise NotImplementedError("engine assumes uniform geom solref/solimp, condim 3, zero margin/gap")
+        if g["condim"] != 3 or g["margin"] != 0 or g["gap"] != 0:
+            raise NotImplementedError("engine assumes condim 3 and zero margin/gap")
     cK, cB = solref_to_kb(cube["solref"], cube["solimp"], o["timestep"])
     F[0:3] = [o["timestep"], o["impratio"], SOLVER_TOL]
     F[3:6] = o["gravity"]
@@ -139,7 +275,7 @@ def pack_engine_model(desc: dict) -> bytes:
     F[13:17] = [fbody["mass"], *fbody["inertia"]]
     F[17:20] = cube["size"]
     F[20] = float(np.linalg.norm(cube["size"]))
-    F[21] = bodyw[st["free"]][0]
+    F[21] = bodyw_geom(cube)
     F[22] = float(SOLVER_MAX_ITER)
     F[23] = float(SOLVER_LS_TOL)
 
@@ -209,7 +345,7 @@ def pack_engine_model(desc: dict) -> bytes:
         rb = size[0] if g["type"] == "sphere" else float(np.linalg.norm(size))
         mu = max(MINMU, max(g["friction"][0], mu_cube))
         I += [mb, GBOX if g["type"] == "box" else GSPHERE]
-        F += [*size, *pos, *R.reshape(-1), rb, mu, bodyw[b][0], 0, 0]
+        F += [*size, *pos, *R.reshape(-1), rb, mu, bodyw_geom(g), 0, 0]
     # ---- sites + sensors
     for s in sites:
         b = s["body"]
@@ -224,13 +360,15 @@ def pack_engine_model(desc: dict) -> bytes:
             I += [1, midx[s["obj"]], s["adr"]]
         elif s["type"] == "jointpos":
             I += [2, lay.jnt_qposadr[s["obj"]], s["adr"]]
-        elif s["type"] == "framezaxis":
+        elif s["type"] == "framezaxis" and s.get("objtype") == "body":
             I += [3, midx[s["obj"]], s["adr"]]
+        elif s["type"] == "framezaxis":
+            I += [5, s["obj"], s["adr"]]  # z axis of a site frame (generic section carries the rotation)
         else:
-            I += [4, 0, s["adr"]]  # geom distance: not produced by the engine yet (fr3_pick, next round)
+            I += [4, 0, s["adr"]]  # geom distance: generic section
     # ---- cooperative kernel (16 lanes per rollout, one lane per finger link): per-lane list of geoms to broad-phase.
     # lane l tests the geoms of moving body 1+l; static geoms are dealt greedily to the least-loaded lanes.
-    if NM - 1 <= 16:
+    if NM - 1 == 16 and NBLK == 4 and uniform:  # leap_cube layout of the cooperative kernel (needs uniform contact parameters)
         lists: list[list[int]] = [[] for _ in range(16)]
         for gi, g in enumerate(others):
             b = g["body"]
@@ -243,6 +381,71 @@ def pack_engine_model(desc: dict) -> bytes:
         I[11], I[12] = len(I), lgm
         for x in lists:
             I += x + [-1] * (lgm - len(x))
+    # ---- generic sections (reference kernel): every collision geom incl. the cube, explicit candidate pairs, joint
+    # equalities, sensor frames with orientation, geom-distance sensors
+    allg = [g for g in desc["geoms"] if g["type"] in ("box", "sphere")]
+    gidx = {id(g): i for i, g in enumerate(allg)}
+    pairs_all = generic_pairs(orig, dict(desc, geoms=allg), st)
+    frames = [dict(body=midx[sx["body"]], pos=sx["pos"], quat=sx.get("quat", [1, 0, 0, 0])) for sx in sites]
+    dists = [sx for sx in sens if sx["type"] == "distance"]
+    eqs = desc["equalities"]
+    I[13], I[14] = len(I), len(F)
+    I += [len(allg), len(pairs_all), len(eqs), len(frames), len(dists), len(sens), 0, 0]
+    for g in allg:
+        b = g["body"]
+        if st["is_static"][b]:
+            bpos, bquat = _static_world_pose(desc, b)
+            pos = bpos + quat_to_mat(bquat) @ np.array(g["pos"])
+            R = quat_to_mat(quat_mul(bquat, g["quat"]))
+            mb = -1
+        else:
+            pos, R, mb = np.array(g["pos"]), quat_to_mat(g["quat"]), midx[b]
+        size = (list(g["size"]) + [0, 0, 0])[:3]
+        rb = size[0] if g["type"] == "sphere" else float(np.linalg.norm(size))
+        I += [mb, GBOX if g["type"] == "box" else GSPHERE]
+        F += [*size, *pos, *R.reshape(-1), rb, max(MINMU, g["friction"][0]), bodyw_geom(g), 0, 0]
+    for g in allg:  # per-geom solver parameters, mixed per contact (solref/solimp averaged, friction max)
+        F += [*g["solref"], *clamp_solimp(g["solimp"]), 0.0]
+    for a, b in pairs_all:
+        I += [a, b]
+    for e in eqs:
+        j1, j2 = e["joint1"], e["joint2"]
+        d1, d2 = lay.jnt_dofadr[j1], lay.jnt_dofadr[j2]
+        if any(abs(x) > 0 for x in e["polycoef"][2:]):
+            raise NotImplementedError("joint equality: only linear coupling")
+        eK, eB = solref_to_kb(e["solref"], e["solimp"], o["timestep"])
+        blk1 = st["block_of"][desc["joints"][j1]["body"]]
+        if blk1 != st["block_of"][desc["joints"][j2]["body"]]:
+            raise NotImplementedError("joint equality across blocks")
+        d0 = lay.jnt_dofadr[lay.body_joints[blocks[blk1][0]][0]]
+        I += [d1, d2, blk1, d1 - d0, d2 - d0]
+        F += [e["polycoef"][0], e["polycoef"][1], eK, eB, *clamp_solimp(e["solimp"]), dofw[d1] + dofw[d2], 0, 0]
+    for fr in frames:
+        I += [fr["body"]]
+        F += [*fr["pos"], *quat_to_mat(fr["quat"]).reshape(-1)]
+    glists: list[int] = []
+    for sx in dists:
+        la = [gidx[id(g)] for g in allg if g["orig_body"] == sx["body1"] and g["type"] == "box"]
+        lb = [gidx[id(g)] for g in allg if g["orig_body"] == sx["body2"] and g["type"] == "box"]
+        I += [len(glists), len(la), len(glists) + len(la), len(lb)]
+        glists += la + lb
+        F += [sx["cutoff"]]
+    idist = 0
+    for sx in sens:  # generic sensor table: (type, object, aux, address)
+        if sx["type"] == "framepos" and sx.get("objtype") == "site":
+            I += [0, sx["obj"], 0, sx["adr"]]
+        elif sx["type"] == "framepos":
+            I += [1, midx[sx["obj"]], 0, sx["adr"]]
+        elif sx["type"] == "jointpos":
+            I += [2, lay.jnt_qposadr[sx["obj"]], 0, sx["adr"]]
+        elif sx["type"] == "framezaxis" and sx.get("objtype") == "site":
+            I += [5, sx["obj"], 0, sx["adr"]]
+        elif sx["type"] == "framezaxis":
+            I += [3, midx[sx["obj"]], 0, sx["adr"]]
+        else:
+            I += [4, idist, 0, sx["adr"]]
+            idist += 1
+    I += glists
     ntp = 9 if desc["task"] == "leap_cube" else 22
     return _pack(TASK_KIND[desc["task"]], lay, ntp, F, I)
 

@@ -486,6 +486,30 @@ static int collide_cyl_cyl_parallel(const double* p1, const double* R1, const do
   return 1;
 }
 
+/* Signed distance between two boxes as the largest separation over the 15 SAT axes: exact whenever the closest
+ * features involve a face or an edge pair (all finger-pad / cube / table configurations of fr3_pick), a lower bound for
+ * vertex-vertex and vertex-edge pairs; equals -penetration depth when the boxes overlap (what MuJoCo's geom-distance
+ * sensor reports, `fr3_components/params_and_default.xml:58-68`). */
+static double box_box_distance(const double* p1, const double* R1, const double* h1, const double* p2, const double* R2, const double* h2) {
+  double A[3][3], B[3][3], dv[3], best = -1e30;
+  for (int k = 0; k < 3; k++) { col(A[k], R1, k); col(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
+  for (int i = 0; i < 3; i++) {
+    double ra = h1[i], rb = 0; for (int k = 0; k < 3; k++) rb += h2[k] * fabs(dot3(B[k], A[i]));
+    double s = fabs(dot3(dv, A[i])) - ra - rb; if (s > best) best = s;
+    ra = 0; rb = h2[i]; for (int k = 0; k < 3; k++) ra += h1[k] * fabs(dot3(A[k], B[i]));
+    s = fabs(dot3(dv, B[i])) - ra - rb; if (s > best) best = s;
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double L[3]; cross3(L, A[i], B[j]); double l = norm3(L);
+      if (l < 1e-6) continue;
+      L[0] /= l; L[1] /= l; L[2] /= l;
+      double ra = 0, rb = 0; for (int k = 0; k < 3; k++) { ra += h1[k] * fabs(dot3(A[k], L)); rb += h2[k] * fabs(dot3(B[k], L)); }
+      double s = fabs(dot3(dv, L)) - ra - rb; if (s > best) best = s;
+    }
+  return best;
+}
+
 static void collision(const jo_model* m, jo_data* d) {
   d->ncon = 0;
   if (!m->contact_enabled) return;
@@ -655,7 +679,7 @@ static void make_constraint(const jo_model* m, jo_data* d) {
     jo_contact* con = &d->con[c]; int id = con->efc_adr;
     if (id < 0 || con->dim < 2) continue;
     if (m->cone == JO_CONE_PYRAMIDAL) {
-      con->mu = con->friction[0];
+      con->mu = con->friction[0] * sqrt(1 / fmax(MINVAL, m->impratio)); /* regularised cone: impratio divides Rpy */
       double Rpy = 2 * con->mu * con->mu * d->efc_R[id];
       for (int r = id; r < id + 2 * (con->dim - 1); r++) d->efc_R[r] = fmax(MINVAL, Rpy);
     } else {
@@ -804,7 +828,15 @@ static void sensors(const jo_model* m, jo_data* d) {
       case JO_SENS_FRAMEPOS_BODY: copy3(o, d->xpos[obj]); break;
       case JO_SENS_JOINTPOS: o[0] = d->qpos[m->jnt_qposadr[obj]]; break;
       case JO_SENS_FRAMEZAXIS_BODY: col(o, d->xmat[obj], 2); break;
-      case JO_SENS_DISTANCE: o[0] = m->sensor_cutoff[s]; break; /* geom distance: filled by the fr3 extension */
+      case JO_SENS_DISTANCE: { /* min over the box geoms of body obj and body obj2, clipped at the cutoff */
+        double best = m->sensor_cutoff[s]; int b2 = m->sensor_obj2[s];
+        for (int g1 = 0; g1 < m->ngeom; g1++) if (m->geom_body[g1] == obj && m->geom_type[g1] == JO_GEOM_BOX)
+          for (int g2 = 0; g2 < m->ngeom; g2++) if (m->geom_body[g2] == b2 && m->geom_type[g2] == JO_GEOM_BOX) {
+            double dd = box_box_distance(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2]);
+            if (dd < best) best = dd;
+          }
+        o[0] = best;
+      } break;
     }
   }
 }

@@ -107,7 +107,7 @@ def test_blob_packing():
 
     from judo_amd import models as M
 
-    for task, kind in (("cartpole", 0), ("cylinder_push", 1), ("leap_cube", 2)):
+    for task, kind in (("cartpole", 0), ("cylinder_push", 1), ("leap_cube", 2), ("fr3_pick", 3)):
         blob = M.pack_model(M.load_description(task))
         head = struct.unpack("<16I", blob[:64])
         assert head[0] == M.BLOB_MAGIC and head[2] == kind
@@ -116,6 +116,33 @@ def test_blob_packing():
 
     st = engine_structure(M.load_description("leap_cube"))
     assert len(st["moving"]) == 17 and [len(b) for b in st["blocks"]] == [4, 4, 4, 4]
+
+
+def test_fused_fixed_bodies_preserve_the_dynamics():
+    """fr3_pick: `hand` (no joint, welded to link7) is merged into its parent for the engine; the joint-space inertia of the
+    merged tree equals that of the original at arbitrary configurations, and the candidate contact pairs match the oracle's."""
+    from judo_amd import models as M
+    from judo_amd.engine_model import engine_structure, fuse_fixed_bodies, generic_pairs
+    from oracle import oracle as O
+
+    d = M.load_description("fr3_pick")
+    f = fuse_fixed_bodies(d)
+    assert f["fused"] == ["hand"] and len(f["bodies"]) == len(d["bodies"]) - 1
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        q = M.qpos0(d)
+        q[7:] = rng.uniform(-1.5, 1.5, 9)
+        M1, _ = M.mass_matrix(d, q)
+        M2, _ = M.mass_matrix(f, q)
+        np.testing.assert_allclose(M1, M2, rtol=1e-12, atol=1e-14)
+    st = engine_structure(f)
+    assert len(st["moving"]) == 10 and [len(b) for b in st["blocks"]] == [9]
+    allg = [g for g in f["geoms"] if g["type"] in ("box", "sphere")]
+    pairs = generic_pairs(d, dict(f, geoms=allg), st)
+    names = {tuple(sorted((allg[a]["name"], allg[b]["name"]))) for a, b in pairs}
+    om = O.Model("fr3_pick")
+    onames = {tuple(sorted((om.desc["geoms"][a]["name"], om.desc["geoms"][b]["name"]))) for a, b in om.pairs}
+    assert names == onames and len(names) == 63
 
 
 def test_c_abi_library_exports_every_declared_symbol():
