@@ -226,9 +226,16 @@ def test_compute_requires_gpu_and_never_falls_back():
 
 
 def test_product_never_imports_the_oracle():
+    """No product source imports, includes, links or loads anything under oracle/ (comments may cite it)."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "judo_amd")):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
-                assert "libjudo_oracle" not in src and "jo_engine" not in src.replace("oracle/jo_engine.c for the fp64 checker", ""), f
+                if f.endswith(".py"):
+                    code = re.sub(r'"""[\s\S]*?"""', "", src)
+                    code = re.sub(r"#.*", "", code)
+                else:
+                    code = re.sub(r"//.*", "", src)
+                    code = re.sub(r"/\*[\s\S]*?\*/", "", code)
+                assert not re.search(r"^\s*(from|import)\s+oracle", code, re.M), f
+                assert "libjudo_oracle" not in code and "jo_engine" not in code and "jo_plan" not in code and "oracle/" not in code, f
