@@ -235,3 +235,40 @@ def test_argument_errors_raise_like_the_reference(gpu):
         opt.sample_control_knots(np.zeros((5, 1)))
     with pytest.raises(ValueError):
         opt.update_nominal_knots(np.zeros((8, 4, 1)), np.zeros(7))
+
+
+def test_min_max_normaliser_is_equivalent_to_scaled_sigma(gpu):
+    """action_normalizer="min_max": the reference samples `nominal_n + sigma*eps` in [-1,1] units, clips to [-1,1] and
+    denormalises (controller.py:222,252-258; normalization.py:94-138).  The fused path folds that into sigma*(hi-lo)/2 in raw
+    units; compared here with the reference arithmetic done in numpy on the same noise."""
+    import torch
+
+    from judo_amd.controller import make_controller
+
+    rng = np.random.default_rng(21)
+    ctrl = make_controller("cylinder_push", "mppi")
+    N, K = 64, 4
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.action_normalizer = "min_max"
+    ctrl.controller_cfg.horizon = 0.64
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.nominal_knots = rng.uniform(-2, 2, (K, 2))
+    ctrl.update_spline(ctrl.times, ctrl.nominal_knots)
+    noise = rng.standard_normal((N - 1, K, 2)).astype(np.float32)
+    ctrl.optimizer.injected_noise = noise
+    ctrl.keep_candidates = True
+    nominal0 = ctrl.nominal_knots.copy()
+    ctrl.update_action()
+    torch.cuda.synchronize()
+    lo, hi = ctrl.task.actuator_ctrlrange[:, 0], ctrl.task.actuator_ctrlrange[:, 1]
+    norm = lambda x: 2 * (x - lo) / (hi - lo) - 1  # noqa: E731
+    denorm = lambda x: (x + 1) * (hi - lo) / 2 + lo  # noqa: E731
+    sigma = ctrl.optimizer.knot_sigma()
+    cand_n = np.concatenate([norm(nominal0)[None], norm(nominal0)[None] + sigma[None] * noise.astype(np.float64)])
+    cand = denorm(np.clip(cand_n, -1, 1))
+    got = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
+    np.testing.assert_allclose(got, cand, rtol=1e-5, atol=1e-5)
+    ctrl.controller_cfg.action_normalizer = "running"
+    with pytest.raises(NotImplementedError):
+        ctrl.update_action()
