@@ -57,7 +57,8 @@ def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
         ctrl.optimizer.config.num_rollouts = n
         noise = rng.standard_normal((n - 1, K, nu))
         t0 = time.perf_counter()
-        oracle_plan_step(om, ctrl, nom, noise, nthread=cores)
+        cem_sigma = ctrl.optimizer.sigma.copy() if hasattr(ctrl.optimizer, "sigma_min") else None
+        oracle_plan_step(om, ctrl, nom, noise, cem_sigma=cem_sigma, nthread=cores)
         dt = time.perf_counter() - t0
         total_rollouts, total_t = n, dt
         if dt > seconds_target / 4 or n >= 65536:
