@@ -221,7 +221,7 @@ def generic_pairs(desc: dict, fused: dict, st: dict) -> list[tuple[int, int]]:
                 continue
             if (weld_parent(ba) == wb and wb != 0) or (weld_parent(bb) == wa and wa != 0):
                 continue
-            if desc["task"] == "leap_cube" and free_fused not in (ga["body"], gb["body"]):
+            if desc.get("family", desc["task"]) == "leap_cube" and free_fused not in (ga["body"], gb["body"]):
                 continue
             out.append((a, b))
     return out
@@ -446,8 +446,8 @@ def pack_engine_model(desc: dict) -> bytes:
             I += [4, idist, 0, sx["adr"]]
             idist += 1
     I += glists
-    ntp = 9 if desc["task"] == "leap_cube" else 22
-    return _pack(TASK_KIND[desc["task"]], lay, ntp, F, I)
+    ntp = 9 if desc.get("family", desc["task"]) == "leap_cube" else 22
+    return _pack(TASK_KIND[desc.get("family", desc["task"])], lay, ntp, F, I)
 
 
 def geom_order(desc: dict) -> list[str]:

@@ -275,7 +275,7 @@ def _pack_cylinder(desc: dict) -> bytes:
 
 
 def pack_model(desc: dict) -> bytes:
-    task = desc["task"]
+    task = desc.get("family", desc["task"])
     if task == "cartpole":
         return _pack_cartpole(desc)
     if task == "cylinder_push":

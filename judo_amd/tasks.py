@@ -265,6 +265,35 @@ class LeapCube(Task[LeapCubeConfig]):
         return np.concatenate([LEAP_QPOS_HOME, np.zeros(22)])
 
 
+LEAP_DOWN_QPOS_HOME = np.array(
+    [-0.04, -0.035, -0.065, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.8, 0.8, 1.0, 0.0, 0.8, 0.8, 1.0, 0.0, 0.8, 0.8, 1.0, 1.0, 0.4, 0.9]
+)  # judo/tasks/leap_cube_down.py:14-22
+
+
+@dataclass
+class LeapCubeDownConfig(LeapCubeConfig):
+    w_rot: float = 0.05
+
+
+class LeapCubeDown(LeapCube):
+    """Palm-down variant (judo/tasks/leap_cube_down.py:33-53): same hand and cube, identity hand orientation, different home
+    pose and goal position; runs on the leap_cube kernels with its own model constants."""
+
+    name = "leap_cube_down"
+    config_t = LeapCubeDownConfig
+
+    def __init__(self) -> None:
+        Task.__init__(self)
+        self.goal_pos = np.array([-0.04, -0.035, -0.065])
+        self.goal_quat = np.array([1.0, 0.0, 0.0, 0.0])
+        self.qpos_home = LEAP_DOWN_QPOS_HOME
+        self.reset_command = LEAP_DOWN_QPOS_HOME[7:].copy()
+        self.reset()
+
+    def default_state(self) -> np.ndarray:
+        return np.concatenate([LEAP_DOWN_QPOS_HOME, np.zeros(22)])
+
+
 # ------------------------------------------------------------------------------------------------ fr3_pick
 FR3_QPOS_HOME = np.array([0.7, 0, 0.02, 1, 0, 0, 0, 0, -0.7854, 0.0, -2.3562, 0.0, 1.5708, 0.7854, 0.04, 0.04])  # fr3_pick.py:16-22
 
@@ -369,6 +398,7 @@ _registered_tasks: dict[str, tuple[type, type]] = {
     Cartpole.name: (Cartpole, CartpoleConfig),
     CylinderPush.name: (CylinderPush, CylinderPushConfig),
     LeapCube.name: (LeapCube, LeapCubeConfig),
+    LeapCubeDown.name: (LeapCubeDown, LeapCubeDownConfig),
     FR3Pick.name: (FR3Pick, FR3PickConfig),
 }
 

@@ -131,7 +131,7 @@ def collision_pairs(desc: dict, scope: str = "task") -> list[tuple[int, int]]:
                 continue
             if (geoms[g1]["type"], geoms[g2]["type"]) not in supported:
                 continue
-            if desc["task"] == "leap_cube" and scope == "task":
+            if desc.get("family", desc["task"]) == "leap_cube" and scope == "task":
                 cube = next(i for i, g in enumerate(geoms) if g["name"] == "cube")
                 if cube not in (g1, g2):
                     continue

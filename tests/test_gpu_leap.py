@@ -195,3 +195,31 @@ def test_leap_two_kernel_generations_agree(gpu):
     assert np.median(e) < 1e-6 and np.percentile(e[:, -1, :3], 95) < 5e-3
     with pytest.raises(ValueError):
         b1.model.set_kernel(3)
+
+
+def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):
+    """leap_cube_down (judo/tasks/leap_cube_down.py): same components, palm-down hand pose, different home pose and goal --
+    only the model constants change.  Rollouts of both kernel generations against the oracle."""
+    from judo_amd.controller import make_controller
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.tasks import LeapCubeDown
+    from oracle import oracle as O
+
+    t = LeapCubeDown()
+    om = O.Model("leap_cube_down")
+    rng = np.random.default_rng(3)
+    N, H = 64, 48
+    U = t.reset_command[None, None] + 0.3 * np.repeat(rng.standard_normal((N, 4, 16)), H // 4, axis=1)
+    x0 = t.default_state()
+    rs, rsens = om.rollout(x0, U)
+    for gen in (2, 1):
+        be = GpuRolloutBackend(t.gpu_model(), N)
+        be.model.set_kernel(gen)
+        gs, gsens, _ = be.rollout(x0, U)
+        e = np.abs(gs - rs)
+        assert np.median(e) < 1e-5 and np.percentile(e[:, -1, :3], 95) < 5e-3, gen
+        np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=1e-4)
+    ctrl = make_controller("leap_cube_down", "mppi")
+    assert ctrl.optimizer.config.num_rollouts == 64 and ctrl.task.config.w_rot == 0.05
+    ctrl.update_action()
+    assert np.isfinite(ctrl.nominal_knots).all()

@@ -353,8 +353,11 @@ def compile_model(xml_name: str, task: str) -> dict:
 
 def main() -> None:
     os.makedirs(OUT_DIR, exist_ok=True)
-    for xml_name, task in (("cartpole.xml", "cartpole"), ("cylinder_push.xml", "cylinder_push"), ("leap_cube.xml", "leap_cube"), ("fr3_pick.xml", "fr3_pick")):
+    for xml_name, task in (("cartpole.xml", "cartpole"), ("cylinder_push.xml", "cylinder_push"), ("leap_cube.xml", "leap_cube"), ("fr3_pick.xml", "fr3_pick"),
+                           ("leap_cube_palm_down.xml", "leap_cube_down")):
         m = compile_model(xml_name, task)
+        if task == "leap_cube_down":
+            m["family"] = "leap_cube"  # same components, palm-down hand pose: runs on the leap_cube kernels
         path = os.path.join(OUT_DIR, task + ".json")
         with open(path, "w") as f:
             json.dump(m, f, indent=None, separators=(",", ":"))
