@@ -21,7 +21,11 @@ namespace {
 
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NCH = 4, NLK = 4;
-constexpr int NCP = 32;     // contact pool per rollout = 2 slots per lane
+#ifndef JH_V2_NSLOT
+#define JH_V2_NSLOT 2
+#endif
+constexpr int NSLOT = JH_V2_NSLOT;
+constexpr int NCP = 16 * NSLOT;  // contact pool per rollout = NSLOT slots per lane
 constexpr int MAXHIT = 32;  // broad-phase survivors per rollout
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
 constexpr int MAXG = 72, MAXLG = 8;  // collision geoms / broad-phase list length per lane staged in LDS
@@ -228,7 +232,7 @@ struct DofRows { float fl, fD, faref, lims, laref, lD, jf, jl, pf, pl; };
 __device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr, float al, bool with_dir, float* cost, float* d1, float* d2) {
   float cs = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < NSLOT; k++) {
     if (!sl[k].valid) continue;
     float jar[3], f[3], W[6];
     const float* jp = sl[k].jp;
@@ -529,9 +533,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
     V2_TICK(2)
     // ================================================================ constraint rows: <= 2 contacts per lane + the own dof's friction-loss / limit rows
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
-    Slot sl[2];
+    Slot sl[NSLOT];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NSLOT; k++) {
       int idx = l + 16 * k;
       sl[k].valid = idx < ncon;
       sl[k].chain = -1;
@@ -584,7 +588,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       for (int i = 0; i < NLK; i++) if (i == s) v = Mc[i >= j ? tri(i, j) : tri(j, i)];
       Mrow[j] = v; }
     const float snorm = gsum(fs_own * fs_own / Mdiag_own + (l < 3 ? fsc[l] * fsc[l] / cmass : (l < 6 ? fsc[l] * fsc[l] / cI[l - 3] : 0.f)));
-    const bool has_rows = gor((int)(sl[0].valid || sl[1].valid || dr.fl > 0.f || dr.lims != 0.f)) != 0;
+    bool anyslot = false;
+    for (int k = 0; k < NSLOT; k++) anyslot |= sl[k].valid;
+    const bool has_rows = gor((int)(anyslot || dr.fl > 0.f || dr.lims != 0.f)) != 0;
     int iters_this = 0;
     if (!has_rows) { a_own = a0_own; for (int k = 0; k < 6; k++) ac[k] = a0c[k]; }
     else {
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         S.p[6 + l] = qws; if (l < 6) S.p[l] = wsc[l];
         __syncthreads();
         float cs, d1, d2, jx[3];
-        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], wsc, S.p, jx); for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; }
+        for (int k = 0; k < NSLOT; k++) if (sl[k].valid) { slot_Jx(sl[k], wsc, S.p, jx); for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; }
         dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
         lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
         float dws = qws - a0_own, md = 0.f;
@@ -606,8 +612,8 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         __syncthreads();
         S.p[6 + l] = a0_own; if (l < 6) S.p[l] = a0c[l];
         __syncthreads();
-        float jar0[2][3];
-        for (int k = 0; k < 2; k++) if (sl[k].valid) { slot_Jx(sl[k], a0c, S.p, jx); for (int rw = 0; rw < 3; rw++) { jar0[k][rw] = sl[k].jar[rw]; sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; } }
+        float jar0[NSLOT][3];
+        for (int k = 0; k < NSLOT; k++) if (sl[k].valid) { slot_Jx(sl[k], a0c, S.p, jx); for (int rw = 0; rw < 3; rw++) { jar0[k][rw] = sl[k].jar[rw]; sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; } }
         float jf_ws = dr.jf, jl_ws = dr.jl;
         dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
         lane_rows_eval(sl, dr, 0.f, false, &cs, &d1, &d2);
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         const bool use_ws = cost_ws < cost_0;
         if (use_ws) {
           a_own = qws; for (int k = 0; k < 6; k++) ac[k] = wsc[k];
-          for (int k = 0; k < 2; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar0[k][rw];
+          for (int k = 0; k < NSLOT; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar0[k][rw];
           dr.jf = jf_ws; dr.jl = jl_ws;
         } else { a_own = a0_own; for (int k = 0; k < 6; k++) ac[k] = a0c[k]; }
         __syncthreads();
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         for (int e = 0; e < 21; e++) hcp[e] = 0.f;
         if (act) {
 #pragma unroll
-          for (int k = 0; k < 2; k++) if (sl[k].valid) {
+          for (int k = 0; k < NSLOT; k++) if (sl[k].valid) {
             float f[3], Wm[6];
             cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wm);
             const Slot& t = sl[k];
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         float pMd = gsum(Mp_own * da_own + mck * xcl * dcl);
         float gp = gsum(g_own * p_own + gcl * xcl);
         if (act && !(gp < 0.f)) act = false;
-        for (int k = 0; k < 2; k++) if (sl[k].valid) slot_Jx(sl[k], xc6, S.p, sl[k].jp);
+        for (int k = 0; k < NSLOT; k++) if (sl[k].valid) slot_Jx(sl[k], xc6, S.p, sl[k].jp);
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
         for (int ls = 0; ls < 12 && __any(lsact); ls++) {
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         // ---- (6) step
         if (act) {
           a_own += alpha * p_own; for (int k = 0; k < 6; k++) ac[k] += alpha * xc6[k];
-          for (int k = 0; k < 2; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
+          for (int k = 0; k < NSLOT; k++) if (sl[k].valid) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
           dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         }

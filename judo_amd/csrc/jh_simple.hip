@@ -202,34 +202,49 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
   if (live) costs[n] = T::finish(acc, H);
 }
 
-template <class T>
+// Drop-in RolloutBackend.rollout: this path IS bound by HBM (it streams 4*H*(nx+ns+nu) bytes per rollout), so the row-major
+// (N,H,.) arrays the interface prescribes are moved in tiles: a wave owns 64 rollouts, stages TS time steps of controls /
+// states / sensors in LDS (row stride padded to an odd number of words: conflict-free for the per-lane accesses) and moves each
+// rollout's TS*width contiguous floats with lane-consecutive addresses.
+template <class T, int TS>
 __global__ __launch_bounds__(kBlock) void k_materialize(const float* __restrict__ P, const float* __restrict__ x0, int x0_batched,
                                                         const float* __restrict__ controls, int N, int H, float* __restrict__ states,
                                                         float* __restrict__ sensors) {
+  constexpr int SU = (TS * T::NU) | 1, SX = (TS * T::NX) | 1, SY = (TS * T::NS) | 1;
   __shared__ float sP[T::NP];
-  for (int i = threadIdx.x; i < T::NP; i += kBlock) sP[i] = P[i];
-  __syncthreads();
-  const int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float sU[kBlock * SU], sXo[kBlock * SX], sYo[kBlock * SY];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < T::NP; i += kBlock) sP[i] = P[i];
+  const int n0 = blockIdx.x * kBlock, n = n0 + lane;
+  const int nvalid = min(kBlock, N - n0);
   float xi[T::NX];
 #pragma unroll
-  for (int i = 0; i < T::NX; i++) xi[i] = x0[(x0_batched ? (size_t)n * T::NX : 0) + i];
+  for (int i = 0; i < T::NX; i++) xi[i] = x0[(x0_batched ? (size_t)min(n, N - 1) * T::NX : 0) + i];
   T s; s.load(xi);
-  for (int h = 0; h < H; h++) {
-    float u[T::NU], o[T::NX], y[T::NS];
+  __syncthreads();
+  for (int h0 = 0; h0 < H; h0 += TS) {
+    const int ts = min(TS, H - h0);
+    // controls tile: rollout r's ts*NU floats are contiguous in global memory
+    for (int f = lane; f < nvalid * ts * T::NU; f += kBlock) { int r = f / (ts * T::NU), i = f - r * (ts * T::NU); sU[r * SU + i] = controls[((size_t)(n0 + r) * H + h0) * T::NU + i]; }
+    __syncthreads();
+    if (n < N) {
+      for (int t = 0; t < ts; t++) {
+        float u[T::NU], o[T::NX], y[T::NS];
 #pragma unroll
-    for (int j = 0; j < T::NU; j++) u[j] = controls[((size_t)n * H + h) * T::NU + j];
-    s.sensors(sP, y);  // sensor values belong to the forward pass at the start of the step
-    s.step(sP, u);
-    s.store(o);
-    if (states) {
+        for (int j = 0; j < T::NU; j++) u[j] = sU[lane * SU + t * T::NU + j];
+        s.sensors(sP, y);  // sensor values belong to the forward pass at the start of the step
+        s.step(sP, u);
+        s.store(o);
 #pragma unroll
-      for (int i = 0; i < T::NX; i++) states[((size_t)n * H + h) * T::NX + i] = o[i];
+        for (int i = 0; i < T::NX; i++) sXo[lane * SX + t * T::NX + i] = o[i];
+#pragma unroll
+        for (int i = 0; i < T::NS; i++) sYo[lane * SY + t * T::NS + i] = y[i];
+      }
     }
-    if (sensors) {
-#pragma unroll
-      for (int i = 0; i < T::NS; i++) sensors[((size_t)n * H + h) * T::NS + i] = y[i];
-    }
+    __syncthreads();
+    if (states) for (int f = lane; f < nvalid * ts * T::NX; f += kBlock) { int r = f / (ts * T::NX), i = f - r * (ts * T::NX); states[((size_t)(n0 + r) * H + h0) * T::NX + i] = sXo[r * SX + i]; }
+    if (sensors) for (int f = lane; f < nvalid * ts * T::NS; f += kBlock) { int r = f / (ts * T::NS), i = f - r * (ts * T::NS); sensors[((size_t)(n0 + r) * H + h0) * T::NS + i] = sYo[r * SY + i]; }
+    __syncthreads();
   }
 }
 
@@ -279,9 +294,9 @@ int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, co
                           float* sensors, hipStream_t st) {
   int grid = (N + kBlock - 1) / kBlock;
   if (m->kind == JH_TASK_CARTPOLE)
-    hipLaunchKernelGGL(k_materialize<Cartpole>, dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
+    hipLaunchKernelGGL((k_materialize<Cartpole, 4>), dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
   else
-    hipLaunchKernelGGL(k_materialize<CylinderPush>, dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
+    hipLaunchKernelGGL((k_materialize<CylinderPush, 4>), dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -26,10 +26,10 @@ def run(tol, lstol, cap, N=8192, ref=None):
     print(out)
     return ctrl, noise, nominal0
 
-N = 2048
+N = 16384
 ctrl, noise, nominal0 = run(1e-4, 1e-6, 20, N)
 om = O.Model('leap_cube')
 r = oracle_plan_step(om, ctrl, nominal0, noise, 'mppi')
 ref = {"c": -r["rewards"], "nom": r["nominal"]}
-for tol, lstol, cap in [(1e-4, 1e-6, 20), (1e-4, 1e-3, 20), (1e-4, 1e-2, 20), (1e-3, 1e-3, 20), (1e-3, 1e-2, 12), (3e-3, 1e-2, 8), (1e-2, 1e-2, 8), (1e-5, 1e-6, 40)]:
+for tol, lstol, cap in [(1e-4, 1e-3, 20), (1e-4, 1e-2, 20), (1e-4, 5e-2, 20), (1e-4, 0.2, 20), (1e-4, 0.5, 20), (3e-4, 0.1, 20), (1e-3, 0.1, 20)]:
     run(tol, lstol, cap, N, ref)
