@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjudo_amd.so")
+LIB_PATH = os.environ.get("JUDO_AMD_LIB") or os.path.join(_HERE, "libjudo_amd.so")  # JUDO_AMD_LIB: alternative build of the same C ABI
 
 _lib: C.CDLL | None = None
 

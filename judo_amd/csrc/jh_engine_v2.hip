@@ -21,6 +21,12 @@ namespace {
 
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NCH = 4, NLK = 4;
+#ifndef JH_V2_LSMAX
+#define JH_V2_LSMAX 12
+#endif
+#ifndef JH_V2_LSBRACKET
+#define JH_V2_LSBRACKET 0.f
+#endif
 #ifndef JH_V2_NSLOT
 #define JH_V2_NSLOT 2
 #endif
@@ -507,7 +513,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       }
       nh = nh < MAXHIT ? nh : MAXHIT;
 #ifdef JH_ENGINE_PROFILE
+#ifndef JH_V2_LSHIST
       if (l == 0 && live && stats) atomicAdd(stats + 48 + (nh < 15 ? nh : 15), 1);
+#endif
 #endif
       __syncthreads();
       PoolCtx pc{&S, stats};
@@ -763,22 +771,40 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         if (act && !(gp < 0.f)) act = false;
         for (int k = 0; k < NSLOT; k++) if (sl[k].valid) slot_Jx(sl[k], xc6, S.p, sl[k].jp);
         dr.pf = p_own; dr.pl = dr.lims * p_own;
-        float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
-        for (int ls = 0; ls < 12 && __any(lsact); ls++) {
+        float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
+#if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
+        int ls_evals = 0;
+#endif
+        for (int ls = 0; ls < JH_V2_LSMAX && __any(lsact); ls++) {
           float cs, d1, d2;
+#if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
+          if (lsact) ls_evals++;
+#endif
           lane_rows_eval(sl, dr, alpha, true, &cs, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
-              if (d1 < 0.f) lo = alpha; else hi = alpha;
+              // bracket [lo, hi] with the slopes at both ends; Newton step from the current point, else Illinois secant, else bisection
+              if (d1 < 0.f) { lo = alpha; dlo = d1; if (side < 0) dhi *= 0.5f; side = -1; } else { hi = alpha; dhi = d1; if (side > 0) dlo *= 0.5f; side = 1; }
               float nx = alpha - d1 * __frcp_rn(d2);
               if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
-              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
-              alpha = nx;
+              else if (nx <= lo || nx >= hi) {
+#ifdef JH_V2_LSSECANT
+                nx = (lo * dhi - hi * dlo) * __frcp_rn(dhi - dlo);
+                if (!(nx > lo && nx < hi)) nx = 0.5f * (lo + hi);
+#else
+                nx = 0.5f * (lo + hi);
+#endif
+              }
+              if (hi > 0.f && hi - lo <= JH_V2_LSBRACKET * hi) lsact = false;  // step length known to the bracket tolerance
+              else alpha = nx;
             }
           }
         }
+#if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
+        if (l == 0 && live && stats && act) atomicAdd(stats + 48 + (ls_evals < 15 ? ls_evals : 15), 1);
+#endif
         // ---- (6) step
         if (act) {
           a_own += alpha * p_own; for (int k = 0; k < 6; k++) ac[k] += alpha * xc6[k];

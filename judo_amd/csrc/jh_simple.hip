@@ -14,6 +14,7 @@
 // Physics = MuJoCo's Euler step with implicit joint damping, restated in closed form for these two models
 // (derivation in DESIGN.md section 4): semi-implicit update  v += h*a ; q += h*v  with
 // a = (M + h*diag(damping))^-1 (qfrc_smooth + qfrc_constraint); soft constraints by solref/solimp.
+#include <cstdint>
 #include "jh_internal.h"
 
 namespace {
@@ -205,12 +206,35 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
 // Drop-in RolloutBackend.rollout: this path IS bound by HBM (it streams 4*H*(nx+ns+nu) bytes per rollout), so the row-major
 // (N,H,.) arrays the interface prescribes are moved in tiles: a wave owns 64 rollouts, stages TS time steps of controls /
 // states / sensors in LDS (row stride padded to an odd number of words: conflict-free for the per-lane accesses) and moves each
-// rollout's TS*width contiguous floats with lane-consecutive addresses.
+// rollout's TS*width contiguous floats with lane-consecutive addresses.  Full tiles (64 live rollouts, TS steps, 16-byte aligned
+// rows) move as float4 with compile-time index arithmetic; ragged tiles take the scalar path.
+#ifndef JH_MAT_TS
+#define JH_MAT_TS 8  // time steps per LDS tile (measured on MI355X, 1M rollouts: 2 -> 1.3/2.1, 4 -> 2.5/2.9, 8 -> 5.0/5.0, 16 -> 3.8/2.6 TB/s)
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int CH, int STRIDE, bool TO_LDS>
+__device__ __forceinline__ void tile_move_full(float* __restrict__ g, size_t pitch, float* __restrict__ sm, int lane) {
+  static_assert(CH % 4 == 0, "vector tile path needs a multiple of 4 floats per rollout chunk");
+  constexpr int V = CH / 4;
+#pragma unroll
+  for (int f0 = 0; f0 < kBlock * V; f0 += kBlock) {
+    const int f = f0 + lane, r = f / V, i = f - r * V;
+    v4f* gp = reinterpret_cast<v4f*>(g + (size_t)r * pitch) + i;
+    float* sp = sm + r * STRIDE + 4 * i;
+    if (TO_LDS) { v4f v = *gp; sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w; }
+    else {
+      v4f v = {sp[0], sp[1], sp[2], sp[3]};
+      __builtin_nontemporal_store(v, gp);  // written once, never re-read by this kernel (+35 % over a cached store at TS=8)
+    }
+  }
+}
+
 template <class T, int TS>
 __global__ __launch_bounds__(kBlock) void k_materialize(const float* __restrict__ P, const float* __restrict__ x0, int x0_batched,
                                                         const float* __restrict__ controls, int N, int H, float* __restrict__ states,
-                                                        float* __restrict__ sensors) {
+                                                        float* __restrict__ sensors, int vec_ok) {
   constexpr int SU = (TS * T::NU) | 1, SX = (TS * T::NX) | 1, SY = (TS * T::NS) | 1;
+  constexpr bool kVec = (TS * T::NU) % 4 == 0 && (TS * T::NX) % 4 == 0 && (TS * T::NS) % 4 == 0;
   __shared__ float sP[T::NP];
   __shared__ float sU[kBlock * SU], sXo[kBlock * SX], sYo[kBlock * SY];
   const int lane = threadIdx.x;
@@ -224,8 +248,12 @@ __global__ __launch_bounds__(kBlock) void k_materialize(const float* __restrict_
   __syncthreads();
   for (int h0 = 0; h0 < H; h0 += TS) {
     const int ts = min(TS, H - h0);
+    const bool full = kVec && vec_ok && nvalid == kBlock && ts == TS;  // block-uniform
     // controls tile: rollout r's ts*NU floats are contiguous in global memory
-    for (int f = lane; f < nvalid * ts * T::NU; f += kBlock) { int r = f / (ts * T::NU), i = f - r * (ts * T::NU); sU[r * SU + i] = controls[((size_t)(n0 + r) * H + h0) * T::NU + i]; }
+    if constexpr (kVec) {
+      if (full) tile_move_full<TS * T::NU, SU, true>(const_cast<float*>(controls) + ((size_t)n0 * H + h0) * T::NU, (size_t)H * T::NU, sU, lane);
+    }
+    if (!full) for (int f = lane; f < nvalid * ts * T::NU; f += kBlock) { int r = f / (ts * T::NU), i = f - r * (ts * T::NU); sU[r * SU + i] = controls[((size_t)(n0 + r) * H + h0) * T::NU + i]; }
     __syncthreads();
     if (n < N) {
       for (int t = 0; t < ts; t++) {
@@ -242,8 +270,18 @@ __global__ __launch_bounds__(kBlock) void k_materialize(const float* __restrict_
       }
     }
     __syncthreads();
-    if (states) for (int f = lane; f < nvalid * ts * T::NX; f += kBlock) { int r = f / (ts * T::NX), i = f - r * (ts * T::NX); states[((size_t)(n0 + r) * H + h0) * T::NX + i] = sXo[r * SX + i]; }
-    if (sensors) for (int f = lane; f < nvalid * ts * T::NS; f += kBlock) { int r = f / (ts * T::NS), i = f - r * (ts * T::NS); sensors[((size_t)(n0 + r) * H + h0) * T::NS + i] = sYo[r * SY + i]; }
+    bool done = false;
+    if constexpr (kVec) {
+      if (full) {
+        if (states) tile_move_full<TS * T::NX, SX, false>(states + ((size_t)n0 * H + h0) * T::NX, (size_t)H * T::NX, sXo, lane);
+        if (sensors) tile_move_full<TS * T::NS, SY, false>(sensors + ((size_t)n0 * H + h0) * T::NS, (size_t)H * T::NS, sYo, lane);
+        done = true;
+      }
+    }
+    if (!done) {
+      if (states) for (int f = lane; f < nvalid * ts * T::NX; f += kBlock) { int r = f / (ts * T::NX), i = f - r * (ts * T::NX); states[((size_t)(n0 + r) * H + h0) * T::NX + i] = sXo[r * SX + i]; }
+      if (sensors) for (int f = lane; f < nvalid * ts * T::NS; f += kBlock) { int r = f / (ts * T::NS), i = f - r * (ts * T::NS); sensors[((size_t)(n0 + r) * H + h0) * T::NS + i] = sYo[r * SY + i]; }
+    }
     __syncthreads();
   }
 }
@@ -293,10 +331,12 @@ int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nomi
 int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
                           float* sensors, hipStream_t st) {
   int grid = (N + kBlock - 1) / kBlock;
+  // float4 tile moves need 16-byte aligned rows: aligned base pointers and H a multiple of the tile length
+  const int vec_ok = (H % JH_MAT_TS == 0) && ((reinterpret_cast<uintptr_t>(controls) | reinterpret_cast<uintptr_t>(states) | reinterpret_cast<uintptr_t>(sensors)) & 15) == 0;
   if (m->kind == JH_TASK_CARTPOLE)
-    hipLaunchKernelGGL((k_materialize<Cartpole, 4>), dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
+    hipLaunchKernelGGL((k_materialize<Cartpole, JH_MAT_TS>), dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors, vec_ok);
   else
-    hipLaunchKernelGGL((k_materialize<CylinderPush, 4>), dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors);
+    hipLaunchKernelGGL((k_materialize<CylinderPush, JH_MAT_TS>), dim3(grid), dim3(kBlock), 0, st, m->d_f, x0, x0_batched, controls, N, H, states, sensors, vec_ok);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

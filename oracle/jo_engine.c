@@ -762,6 +762,11 @@ static double total_cost(const jo_model* m, jo_data* d, const double* a, double*
 }
 
 /* ------------------------------------------------------------------ primal Newton solver with exact line search (mj_solNewton) */
+/* diagnostics for the tests/tools: Newton iterations per solve, over all threads */
+static long g_iter_hist[32];
+void jo_solver_histogram(long* out32, int reset) { for (int i = 0; i < 32; i++) { out32[i] = g_iter_hist[i]; if (reset) g_iter_hist[i] = 0; } }
+void jo_set_solver(jo_model* m, double tol, int maxiter) { m->solver_tol = tol; m->solver_maxiter = maxiter; }
+
 static void solve_constraints(const jo_model* m, jo_data* d) {
   int nv = m->nv, ne = d->nefc;
   if (ne == 0) { memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv); memset(d->qfrc_constraint, 0, sizeof(double) * nv); d->solver_iter = 0; return; }
@@ -814,6 +819,7 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
     for (int i = 0; i < nv; i++) a[i] += al * p[i];
   }
   d->solver_iter = it;
+  __atomic_fetch_add(&g_iter_hist[it < 31 ? it : 31], 1, __ATOMIC_RELAXED);
   total_cost(m, d, a, grad, jar, NULL, NULL, NULL);
   memcpy(d->qacc, a, sizeof(double) * nv);
   for (int i = 0; i < nv; i++) { double s = 0; for (int r = 0; r < ne; r++) s += d->efc_J[r][i] * d->efc_force[r]; d->qfrc_constraint[i] = s; }

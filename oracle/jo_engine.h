@@ -166,6 +166,10 @@ void jo_rollout(const jo_model* m, jo_data* d, const double* x0, const double* c
 void jo_rollout_batch(const jo_model* m, const double* x0, int x0_batched, const double* controls, int N, int H, double* states,
                       double* sensors, int nthread);
 
+/* diagnostics (tools/): Newton iterations per solve over all threads; solver tolerance / iteration cap override */
+void jo_solver_histogram(long* out32, int reset);
+void jo_set_solver(jo_model* m, double tol, int maxiter);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,23 @@ def test_rollout_backend_matches_oracle(gpu, task_name, scale, x0):
     np.testing.assert_allclose(sb, rb, rtol=0, atol=3e-3)
 
 
+@pytest.mark.parametrize("task_name", ["cartpole", "cylinder_push"])
+@pytest.mark.parametrize("N,H", [(1, 1), (70, 13), (64, 61), (129, 8)])
+def test_rollout_backend_ragged_tiles(gpu, task_name, N, H):
+    """Materialise mode moves full tiles (64 rollouts x 8 steps) as float4 and everything else element-wise: both paths, same answer."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(11)
+    om = O.Model(task_name)
+    U = np.repeat(rng.standard_normal((N, (H + 3) // 4, om.nu)) * 1.5, 4, axis=1)[:, :H]
+    x0 = np.array([1.0, np.pi, 0.0, 0.0] if task_name == "cartpole" else [1.0, 0.0, 2 * np.cos(1.0), 2 * np.sin(1.0), 0, 0, 0, 0])
+    states, sensors, _ = GpuRolloutBackend(task_name, N).rollout(x0, U)
+    rs, rsens = om.rollout(x0, U)
+    np.testing.assert_allclose(states, rs, rtol=0, atol=3e-3)
+    np.testing.assert_allclose(sensors, rsens, rtol=0, atol=3e-3)
+
+
 @pytest.mark.parametrize("task_name,opt_name,N,K", [
     ("cartpole", "mppi", 4096, 4), ("cartpole", "ps", 32, 4), ("cartpole", "cem", 257, 4), ("cylinder_push", "mppi", 1000, 4),
     ("cylinder_push", "cem", 64, 8), ("cartpole", "mppi", 1, 4),
