@@ -69,6 +69,58 @@ def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
             "sample": f"{total_rollouts} rollouts x H={H} of the same plan step (fp64 oracle engine, {cores} pthreads), {total_t:.1f} s"}
 
 
+def materialize_line(args, torch, world: int, rank: int) -> None:
+    """One step = one `rollout` of N rollouts x H steps with controls resident in HBM; states and sensors are written once."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.distributed import shard_rollouts
+
+    N = args.rollouts or (65536 if args.task in ("leap_cube", "fr3_pick") else 1 << 20)
+    H = args.horizon_steps or WORKLOADS[args.task][2]
+    n_local = shard_rollouts(N, world, rank).count
+    be = GpuRolloutBackend(args.task, n_local)
+    gm = be.model
+    from judo_amd.tasks import get_registered_tasks
+
+    task = get_registered_tasks()[args.task][0]()
+    x0 = torch.as_tensor(np.asarray(task.default_state(), dtype=np.float32), device=gm.device)
+    # controls = the task's warm-start command + N(0, 0.5^2) per step
+    U = 0.5 * torch.randn((n_local, H, gm.nu), device=gm.device, generator=torch.Generator(device=gm.device).manual_seed(1234 + rank))
+    U += torch.as_tensor(np.asarray(task.optimizer_warm_start(), dtype=np.float32), device=gm.device)
+    for _ in range(args.warmup):
+        be.rollout_device(x0, U)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        be.rollout_device(x0, U)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    alg = 4 * n_local * H * (gm.nx + gm.ns + gm.nu)
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"rollouts/sec, {args.task} materialise mode (RolloutBackend.rollout)", "value": N * args.steps / elapsed, "unit": "rollouts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.task} materialise {N} rollouts x H={H} (nx={gm.nx}, ns={gm.ns}, nu={gm.nu})", "rollouts": N, "horizon_steps": H,
+                       "parallelism": f"rollout-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rollout materialise", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +131,8 @@ def main() -> None:
     ap.add_argument("--rollouts", type=int, default=None)
     ap.add_argument("--horizon-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
+                    help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
     args = ap.parse_args()
 
     import torch
@@ -94,6 +148,9 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    if args.mode == "materialize":
+        return materialize_line(args, torch, world, rank)
 
     from judo_amd.controller import make_controller
 
