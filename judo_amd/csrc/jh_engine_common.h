@@ -134,6 +134,26 @@ __device__ __forceinline__ float cone_eval(const float* jar, const float* D, flo
   return 0.5f * Dm * NT * NT;
 }
 
+// directional derivatives of one elliptic-cone contact's cost along jp at jar (the exact line search needs only these two scalars):
+// middle zone s = 1/2 Dm e^2 with e = N - mu T  =>  s' = Dm e e',  s'' = Dm (e'^2 + e e''),  T' = (U.V)/T,  T'' = (|V|^2 - T'^2)/T
+__device__ __forceinline__ void cone_dir(const float* jar, const float* jp, const float* D, float mu, float fri, float* d1, float* d2) {
+  float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
+  float N = U0, T2 = U1 * U1 + U2 * U2;
+  float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
+  if (N >= mu * T || (T <= 0.f && N >= 0.f)) return;
+  if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+    *d1 += D[0] * jar[0] * jp[0] + D[1] * jar[1] * jp[1] + D[2] * jar[2] * jp[2];
+    *d2 += D[0] * jp[0] * jp[0] + D[1] * jp[1] * jp[1] + D[2] * jp[2] * jp[2];
+    return;
+  }
+  float V0 = jp[0] * mu, V1 = jp[1] * fri, V2 = jp[2] * fri;
+  float Dm = D[0] * __frcp_rn(mu * mu * (1.f + mu * mu)), e = N - mu * T;
+  float Tp = (U1 * V1 + U2 * V2) * iT, Tpp = (V1 * V1 + V2 * V2 - Tp * Tp) * iT;
+  float ep = V0 - mu * Tp;
+  *d1 += Dm * e * ep;
+  *d2 += Dm * (ep * ep - e * mu * Tpp);
+}
+
 
 // pyramidal-cone contact (condim 3): four one-sided rows  jar_n +- mu*jar_t1, jar_n +- mu*jar_t2, all with the same D.
 // Expressed in the contact-frame 3-vector jar = J a - aref it returns the frame force f = -ds/djar and the 3x3 weight W.

@@ -233,7 +233,7 @@ __device__ __forceinline__ void slot_Jx(const Slot& s, const float* xc, const fl
 }
 
 // cost / derivative / curvature of this lane's rows at jar + al*jp (contacts in both slots + own dof friction/limit rows)
-struct DofRows { float fl, fD, faref, lims, laref, lD, jf, jl, pf, pl; };
+struct DofRows { float fl, fD, fR, faref, lims, laref, lD, jf, jl, pf, pl; };  // fR = 1/fD
 
 __device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr, float al, bool with_dir, float* cost, float* d1, float* d2) {
   float cs = 0.f, g1 = 0.f, g2 = 0.f;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr
     }
   }
   if (dr.fl > 0.f) {
-    float D = dr.fD, R = 1.f / D, jp = dr.pf, x = dr.jf + (with_dir ? al * jp : 0.f), fl = dr.fl;
+    float D = dr.fD, R = dr.fR, jp = dr.pf, x = dr.jf + (with_dir ? al * jp : 0.f), fl = dr.fl;
     if (x <= -R * fl) { cs += -0.5f * R * fl * fl - fl * x; g1 -= fl * jp; }
     else if (x >= R * fl) { cs += -0.5f * R * fl * fl + fl * x; g1 += fl * jp; }
     else { cs += 0.5f * D * x * x; g1 += D * x * jp; g2 += D * jp * jp; }
@@ -260,6 +260,29 @@ __device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr
     if (x < 0.f) { cs += 0.5f * dr.lD * x * x; g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; }
   }
   *cost = cs; *d1 = g1; *d2 = g2;
+}
+
+// slope and curvature of the lane's rows along the search direction at step al (line search)
+__device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr, float al, float* d1, float* d2) {
+  float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NSLOT; k++) {
+    if (!sl[k].valid) continue;
+    const float* jp = sl[k].jp;
+    float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
+    cone_dir(jar, jp, sl[k].D, sl[k].mu, sl[k].fri, &g1, &g2);
+  }
+  if (dr.fl > 0.f) {
+    float D = dr.fD, jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
+    if (x <= -lim) g1 -= fl * jp;
+    else if (x >= lim) g1 += fl * jp;
+    else { g1 += D * x * jp; g2 += D * jp * jp; }
+  }
+  if (dr.lims != 0.f) {
+    float jp = dr.pl, x = fmaf(al, jp, dr.jl);
+    if (x < 0.f) { g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; }
+  }
+  *d1 = g1; *d2 = g2;
 }
 
 // 4x4 Cholesky (packed lower) + triangular solves on registers; the diagonal is kept as its reciprocal (one v_rsq per
@@ -364,6 +387,16 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
   }
   int n_overflow = 0, n_iters = 0, n_maxed = 0;
   float acc = 0.f;
+  // JH_V2_ABLATE (tools/time_ablate.py): repeat one phase gI[21] times (gI[20] selects it) to measure its share of the step;
+  // the repeated work is idempotent, V2_OPAQUE keeps the compiler from hoisting it out of the repeat loop
+#ifdef JH_V2_ABLATE
+  const int ab_phase = gI[20], ab_reps = gI[21] > 0 ? gI[21] : 1;
+#define V2_REPEAT(phase) for (int rep__ = 0, nrep__ = (ab_phase == (phase) ? ab_reps : 1); rep__ < nrep__; rep__++)
+#define V2_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define V2_REPEAT(phase)
+#define V2_OPAQUE(x)
+#endif
 #ifdef JH_ENGINE_PROFILE
   long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
 #define V2_TICK(slot) { long long t__ = clock64(); cyc[slot] += t__ - t0; t0 = t__; }
@@ -379,6 +412,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
     else { u = 0.f; for (int k = 0; k < K && k < 8; k++) u = fmaf(W[hh * K + k], kn[k], u); }
     // ================================================================ kinematics (each lane walks its chain up to its own link)
     float ax[NLK][3], og[NLK][3], Rown[9], pown[3], Rc[9];
+    float Mc[10], fs_own, a0_own, fsc[6], a0c[6];
+    V2_REPEAT(5) {
+    V2_OPAQUE(q); V2_OPAQUE(qd);
     {
       float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
       qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
@@ -417,7 +453,6 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
     }
     V2_TICK(0)
     // ================================================================ chain dynamics: inertia block, bias, smooth force
-    float Mc[10], fs_own, a0_own, fsc[6], a0c[6];
     {
       const float* bf = sBody + (4 * c + s) * BODY_F;
       float Rk[9], rr[3], cs3[3]; mulMM(Rk, Rown, bf + BF_IR); mulMV(rr, Rown, bf + BF_IPOS);
@@ -480,10 +515,15 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
       for (int k = 0; k < 3; k++) { fsc[k] = cmass * grav[k]; a0c[k] = grav[k]; fsc[3 + k] = -gc[k]; a0c[3 + k] = -gc[k] / cI[k]; }
     }
+    }  // V2_REPEAT(5)
     __syncthreads();
     V2_TICK(1)
     // ================================================================ collision: broad phase on the lane's geoms, balanced narrow phase
-    {
+    V2_REPEAT(4) {
+#ifdef JH_V2_ABLATE
+      if (rep__ > 0) { __syncthreads(); if (l == 0) S.ncon = 0; __syncthreads(); }
+      V2_OPAQUE(qc[0]);
+#endif
       int nh = 0;
       for (int i = 0; i < lgm; i++) {
         int gid = sLaneG[l * lgm + i];
@@ -575,7 +615,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       }
     }
     DofRows dr;
-    dr.fl = lc.fl; dr.fD = lc.fD; dr.faref = -lc.fB * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
+    dr.fl = lc.fl; dr.fD = lc.fD; dr.fR = lc.fD > 0.f ? 1.f / lc.fD : 0.f; dr.faref = -lc.fB * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
     if (lc.limited != 0.f) {
       float dlo = q - lc.lo, dhi = lc.hi - q, dist = fminf(dlo, dhi);
       if (dist < 0.f) {
@@ -635,61 +675,109 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         __syncthreads();
       }
       bool act = true;
+      const float mck = (l < 3 ? cmass : (l < 6 ? cI[l < 3 ? 0 : l - 3] : 0.f)), imck = l < 6 ? 1.f / mck : 0.f, iMd = 1.f / Mdiag_own;
       V2_TICK(3)
       for (int it = 0; it < cap && __any(act); it++) {
-        // ---- (1) owner lanes: M (a - a0) rows, dof-row forces and weights, Hessian initialised with M
+#ifdef JH_V2_ABLATE
+        for (int rep__ = 0, nrep__ = (ab_phase == 1 || ab_phase == 2) ? ab_reps : 1; rep__ < nrep__; rep__++) {
+        for (int k = 0; k < NSLOT; k++) { V2_OPAQUE(sl[k].jar[0]); V2_OPAQUE(sl[k].jar[1]); V2_OPAQUE(sl[k].jar[2]); }
+        V2_OPAQUE(a_own);
+#endif
+        // ---- (1) gradient.  Owner lanes: M (a - a0) rows + dof-row forces; contacts: -J'f (chain part: LDS float atomics, cube part: row sums)
         float da_own = a_own - a0_own, g_own = 0.f, hd = 0.f, dac[NLK];
 #pragma unroll
         for (int j = 0; j < NLK; j++) { dac[j] = quad_get(da_own, j); g_own += Mrow[j] * dac[j]; }
         if (dr.fl > 0.f) {
-          float D = dr.fD, R = 1.f / D, x = dr.jf, fl = dr.fl;
-          if (x <= -R * fl) g_own -= fl; else if (x >= R * fl) g_own += fl; else { g_own += D * x; hd += D; }
+          float D = dr.fD, x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+          if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += D * x; hd += D; }
         }
         if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
+        if (act) S.g[6 + l] = g_own;
+        __syncthreads();
+        float gcp[6] = {0, 0, 0, 0, 0, 0};
+#ifdef JH_V2_KEEPW
+        float Wm[NSLOT][6];
+#endif
         if (act) {
-          S.g[6 + l] = g_own;
-          if (l < 6) { S.g[l] = (l < 3 ? cmass : cI[l < 3 ? 0 : l - 3]) * (ac[l] - a0c[l]); }
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) if (sl[k].valid) {
+            float f[3];
+#ifdef JH_V2_KEEPW
+            cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wm[k]);
+#else
+            float Wtmp[6]; cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wtmp);
+#endif
+            const Slot& t = sl[k];
+            for (int q3 = 0; q3 < 3; q3++) {  // cube columns: translation q3 -> -fr[row][q3]; rotation -> Jr[q3][row]
+              gcp[q3] += t.fr[q3] * f[0] + t.fr[3 + q3] * f[1] + t.fr[6 + q3] * f[2];
+              gcp[3 + q3] -= t.Jr[q3][0] * f[0] + t.Jr[q3][1] * f[1] + t.Jr[q3][2] * f[2];
+            }
+            if (t.chain >= 0) for (int j = 0; j < NLK; j++) atomicAdd(&S.g[6 + 4 * t.chain + j], -(t.Jb[j][0] * f[0] + t.Jb[j][1] * f[1] + t.Jb[j][2] * f[2]));
+          }
+        }
+        float gcl = 0.f;
+#pragma unroll
+        for (int q6 = 0; q6 < 6; q6++) { float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
+        float dcl = 0.f;  // own cube dof's (a - a0); lanes 6..15 carry zeros (mck = 0)
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k == l) dcl = ac[k] - a0c[k];
+        gcl = fmaf(mck, dcl, gcl);
+        __syncthreads();
+        V2_TICK(4)
+        // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
+        g_own = S.g[6 + l];
+        float gn = gsum(g_own * g_own * iMd + gcl * gcl * imck);
+        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        if (!__any(act)) break;
+        if (act) iters_this++;
+        // ---- (3) Hessian: M + dof rows on the chain diagonals, J'WJ of the contacts into the arrow blocks
+        if (act) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
         }
         __syncthreads();
-        // ---- (2) contacts: -J'f into g, J'WJ into the arrow Hessian (chain parts: LDS float atomics; cube parts: row sums)
-        float gcp[6] = {0, 0, 0, 0, 0, 0}, hcp[21];
+        float hcp[21];
         for (int e = 0; e < 21; e++) hcp[e] = 0.f;
         if (act) {
 #pragma unroll
           for (int k = 0; k < NSLOT; k++) if (sl[k].valid) {
-            float f[3], Wm[6];
-            cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wm);
             const Slot& t = sl[k];
-            // cube columns: translation k3 -> -fr[row][k3]; rotation -> Jr[k3][row]
-            float Jc[6][3];
-            for (int q3 = 0; q3 < 3; q3++) { Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3]; Jc[3 + q3][0] = t.Jr[q3][0]; Jc[3 + q3][1] = t.Jr[q3][1]; Jc[3 + q3][2] = t.Jr[q3][2]; }
-            for (int q6 = 0; q6 < 6; q6++) gcp[q6] -= Jc[q6][0] * f[0] + Jc[q6][1] * f[1] + Jc[q6][2] * f[2];
-            if (t.chain >= 0) for (int j = 0; j < NLK; j++) atomicAdd(&S.g[6 + 4 * t.chain + j], -(t.Jb[j][0] * f[0] + t.Jb[j][1] * f[1] + t.Jb[j][2] * f[2]));
-            if (!(Wm[0] == 0.f && Wm[2] == 0.f && Wm[5] == 0.f)) {
-              float Gc[6][3], Gb[NLK][3];
-              for (int q6 = 0; q6 < 6; q6++) { const float* j3 = Jc[q6]; Gc[q6][0] = Wm[0] * j3[0] + Wm[1] * j3[1] + Wm[3] * j3[2]; Gc[q6][1] = Wm[1] * j3[0] + Wm[2] * j3[1] + Wm[4] * j3[2]; Gc[q6][2] = Wm[3] * j3[0] + Wm[4] * j3[1] + Wm[5] * j3[2]; }
-              for (int u6 = 0; u6 < 6; u6++) for (int v6 = 0; v6 <= u6; v6++) hcp[tri(u6, v6)] += Jc[u6][0] * Gc[v6][0] + Jc[u6][1] * Gc[v6][1] + Jc[u6][2] * Gc[v6][2];
+#ifdef JH_V2_KEEPW
+            const float* Wk = Wm[k];
+#else
+            float Wk[6], ftmp[3]; cone_eval(t.jar, t.D, t.mu, t.fri, ftmp, Wk);  // recomputed: cheaper than 12 registers live across the convergence test
+#endif
+            if (!(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f)) {
+              // column by column (one 3-vector W J_v live at a time keeps the register pressure of this block low)
+              float Jc[6][3];
+              for (int q3 = 0; q3 < 3; q3++) { Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3]; Jc[3 + q3][0] = t.Jr[q3][0]; Jc[3 + q3][1] = t.Jr[q3][1]; Jc[3 + q3][2] = t.Jr[q3][2]; }
+#pragma unroll
+              for (int v6 = 0; v6 < 6; v6++) {
+                const float* j3 = Jc[v6];
+                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                for (int u6 = v6; u6 < 6; u6++) hcp[tri(u6, v6)] += Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2;
+              }
               if (t.chain >= 0) {
-                for (int j = 0; j < NLK; j++) { const float* j3 = t.Jb[j]; Gb[j][0] = Wm[0] * j3[0] + Wm[1] * j3[1] + Wm[3] * j3[2]; Gb[j][1] = Wm[1] * j3[0] + Wm[2] * j3[1] + Wm[4] * j3[2]; Gb[j][2] = Wm[3] * j3[0] + Wm[4] * j3[1] + Wm[5] * j3[2]; }
+#pragma unroll
                 for (int u4 = 0; u4 < NLK; u4++) {
-                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[t.chain][tri(u4, v4)], t.Jb[u4][0] * Gb[v4][0] + t.Jb[u4][1] * Gb[v4][1] + t.Jb[u4][2] * Gb[v4][2]);
-                  for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[t.chain][u4 * 6 + q6], Jc[q6][0] * Gb[u4][0] + Jc[q6][1] * Gb[u4][1] + Jc[q6][2] * Gb[u4][2]);
+                  const float* j3 = t.Jb[u4];
+                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[t.chain][tri(u4, v4)], t.Jb[v4][0] * G0 + t.Jb[v4][1] * G1 + t.Jb[v4][2] * G2);
+#pragma unroll
+                  for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[t.chain][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
                 }
               }
             }
           }
         }
-        {  // every lane ends up with the full cube gradient and cube Hessian block; lanes write their share to LDS
-          float gsel = 0.f, hsel0 = 0.f, hsel1 = 0.f;
-#pragma unroll
-          for (int q6 = 0; q6 < 6; q6++) { float v = gsum(gcp[q6]); if (q6 == l) gsel = v; }
+        {  // every lane ends up with the full cube Hessian block; lanes write their share to LDS
+          float hsel0 = 0.f, hsel1 = 0.f;
 #pragma unroll
           for (int e = 0; e < 21; e++) { float v = gsum(hcp[e]); if (e == l) hsel0 = v; if (e == l + 16) hsel1 = v; }
           if (act) {
-            if (l < 6) S.g[l] += gsel;
             bool d0 = (l == 0 || l == 2 || l == 5 || l == 9 || l == 14), d1 = (l + 16 == 20);  // packed indices of the diagonal
             int k0 = l == 0 ? 0 : (l == 2 ? 1 : (l == 5 ? 2 : (l == 9 ? 3 : 4)));
             S.Hcc[l] = hsel0 + (d0 ? (k0 < 3 ? cmass : cI[k0 - 3]) : 0.f);
@@ -697,13 +785,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
           }
         }
         __syncthreads();
-        V2_TICK(4)
-        // ---- (3) convergence on the scaled gradient
-        g_own = S.g[6 + l];
-        float gcl = l < 6 ? S.g[l] : 0.f;
-        float gn = gsum(g_own * g_own / Mdiag_own + (l < 3 ? gcl * gcl / cmass : (l < 6 ? gcl * gcl / cI[l - 3] : 0.f)));
-        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
-        if (act) iters_this++;
+#ifdef JH_V2_ABLATE
+        if (ab_phase == 1 && rep__ + 1 < nrep__) continue;
+#endif
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly), 6x6 Schur complement on the cube
         float L[10], Linv[4], Y[6][NLK], zb[NLK], xc6[6], pc4[NLK];
         {
@@ -757,30 +841,35 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         if (act) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xc6[l]; }
         __syncthreads();
         V2_TICK(5)
+#ifdef JH_V2_ABLATE
+        if (ab_phase == 2 && rep__ + 1 < nrep__) continue;
+#endif
         // ---- (5) exact line search along p
         float Mp_own = 0.f;
 #pragma unroll
         for (int j = 0; j < NLK; j++) Mp_own += Mrow[j] * pc4[j];
-        float mck = (l < 3 ? cmass : (l < 6 ? cI[l < 3 ? 0 : l - 3] : 0.f));
-        float xcl = 0.f, dcl = 0.f;
+        float xcl = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (k == l) { xcl = xc6[k]; dcl = ac[k] - a0c[k]; }
+        for (int k = 0; k < 6; k++) if (k == l) xcl = xc6[k];
         float pMp = gsum(p_own * Mp_own + mck * xcl * xcl);
         float pMd = gsum(Mp_own * da_own + mck * xcl * dcl);
         float gp = gsum(g_own * p_own + gcl * xcl);
         if (act && !(gp < 0.f)) act = false;
         for (int k = 0; k < NSLOT; k++) if (sl[k].valid) slot_Jx(sl[k], xc6, S.p, sl[k].jp);
         dr.pf = p_own; dr.pl = dr.lims * p_own;
-        float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
+        float lo, hi, alpha, dlo, dhi; int side; bool lsact;
 #if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
         int ls_evals = 0;
 #endif
+        V2_REPEAT(3) {
+        lo = 0.f; hi = -1.f; alpha = 1.f; dlo = gp; dhi = 0.f; side = 0; lsact = act;
+        V2_OPAQUE(alpha);
         for (int ls = 0; ls < JH_V2_LSMAX && __any(lsact); ls++) {
-          float cs, d1, d2;
+          float d1, d2;
 #if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
           if (lsact) ls_evals++;
 #endif
-          lane_rows_eval(sl, dr, alpha, true, &cs, &d1, &d2);
+          lane_rows_dir(sl, dr, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
@@ -802,6 +891,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
             }
           }
         }
+        }  // V2_REPEAT(3)
 #if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
         if (l == 0 && live && stats && act) atomicAdd(stats + 48 + (ls_evals < 15 ? ls_evals : 15), 1);
 #endif
@@ -814,6 +904,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         }
         __syncthreads();
         V2_TICK(6)
+#ifdef JH_V2_ABLATE
+        }
+#endif
       }
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
 #ifdef JH_ENGINE_PROFILE

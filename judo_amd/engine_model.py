@@ -41,6 +41,8 @@ HEADER_I, HEADER_F = 24, 24
 # Newton termination on the GPU: |grad|_Minv <= tol * |qfrc_smooth|_Minv (or the expected decrease of a step falls below
 # tol^2 of the same scale), at most SOLVER_MAX_ITER iterations (MuJoCo: tolerance 1e-8 in fp64, 100 iterations)
 SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-3
+# diagnostics: (phase, repeats) read only by -DJH_V2_ABLATE builds of the cooperative kernel (tools/time_ablate.py)
+ABLATE = (0, 1)
 
 
 def _static_world_pose(desc: dict, b: int) -> tuple[np.ndarray, np.ndarray]:
@@ -390,6 +392,7 @@ def pack_engine_model(desc: dict) -> bytes:
     dists = [sx for sx in sens if sx["type"] == "distance"]
     eqs = desc["equalities"]
     I[13], I[14] = len(I), len(F)
+    I[20], I[21] = ABLATE
     I += [len(allg), len(pairs_all), len(eqs), len(frames), len(dists), len(sens), 0, 0]
     for g in allg:
         b = g["body"]

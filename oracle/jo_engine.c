@@ -764,6 +764,8 @@ static double total_cost(const jo_model* m, jo_data* d, const double* a, double*
 /* ------------------------------------------------------------------ primal Newton solver with exact line search (mj_solNewton) */
 /* diagnostics for the tests/tools: Newton iterations per solve, over all threads */
 static long g_iter_hist[32];
+static int g_trace = 0;
+void jo_set_trace(int on) { g_trace = on; }
 void jo_solver_histogram(long* out32, int reset) { for (int i = 0; i < 32; i++) { out32[i] = g_iter_hist[i]; if (reset) g_iter_hist[i] = 0; } }
 void jo_set_solver(jo_model* m, double tol, int maxiter) { m->solver_tol = tol; m->solver_maxiter = maxiter; }
 
@@ -816,8 +818,13 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
       if (fabs(nx - al) <= 1e-15 * fabs(al)) { al = nx; break; }
       al = nx;
     }
+    if (g_trace) {
+      int nz[3] = {0, 0, 0}; for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0) nz[cz[c] ? 1 : (d->efc_force[d->con[c].efc_adr] == 0 ? 0 : 2)]++;
+      fprintf(stderr, "  it %2d cost %.6e |g|s %.3e alpha %.4g  ncon %d nefc %d zones top(free)/middle/bottom(stick) %d/%d/%d\n", it, cost, gn * scale, al, d->ncon, ne, nz[0], nz[1], nz[2]);
+    }
     for (int i = 0; i < nv; i++) a[i] += al * p[i];
   }
+  if (g_trace) fprintf(stderr, "solve done: %d iterations (warm start %s)\n", it, cw < cs ? "used" : "not used");
   d->solver_iter = it;
   __atomic_fetch_add(&g_iter_hist[it < 31 ? it : 31], 1, __ATOMIC_RELAXED);
   total_cost(m, d, a, grad, jar, NULL, NULL, NULL);
