@@ -115,7 +115,7 @@ __device__ __forceinline__ void inertia_mul(float* r, const float* Rk, const flo
 }
 
 // elliptic-cone contact: force = -ds/djar, cost s, Hessian block W (sym 3x3: 00,10,11,20,21,22)
-__device__ __forceinline__ float cone_eval(const float* jar, const float* D, float mu, float fri, float* f, float* W) {
+__device__ __forceinline__ float cone_eval(const float* jar, const float* D, float Dm, float mu, float fri, float* f, float* W) {
   float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
   float N = U0, T2 = U1 * U1 + U2 * U2;
   float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
@@ -125,35 +125,33 @@ __device__ __forceinline__ float cone_eval(const float* jar, const float* D, flo
     W[0] = D[0]; W[1] = 0.f; W[2] = D[1]; W[3] = 0.f; W[4] = 0.f; W[5] = D[2];
     return 0.5f * (D[0] * jar[0] * jar[0] + D[1] * jar[1] * jar[1] + D[2] * jar[2] * jar[2]);
   }
-  float Dm = D[0] * __frcp_rn(mu * mu * (1.f + mu * mu)), NT = N - mu * T;
-  f[0] = -Dm * NT * mu; f[1] = -f[0] * iT * U1 * fri; f[2] = -f[0] * iT * U2 * fri;
-  float h00 = Dm, h01 = -Dm * mu * U1 * iT, h02 = -Dm * mu * U2 * iT;
-  float k1 = Dm * mu * mu * iT * iT, k2 = Dm * NT * mu * iT;
-  float h11 = k1 * U1 * U1 - k2 * (1.f - U1 * U1 * iT * iT), h12 = k1 * U1 * U2 + k2 * U1 * U2 * iT * iT, h22 = k1 * U2 * U2 - k2 * (1.f - U2 * U2 * iT * iT);
-  W[0] = mu * h00 * mu; W[1] = fri * h01 * mu; W[2] = fri * h11 * fri; W[3] = fri * h02 * mu; W[4] = fri * h12 * fri; W[5] = fri * h22 * fri;
+  // middle zone: distance to the cone; a = unit tangential direction (a branch-free variant of this function measured slower)
+  const float NT = N - mu * T, a1 = U1 * iT, a2 = U2 * iT;
+  f[0] = -Dm * NT * mu; f[1] = -f[0] * a1 * fri; f[2] = -f[0] * a2 * fri;
+  const float k1 = Dm * mu * mu, k2 = Dm * NT * mu * iT;
+  const float h01 = -Dm * mu * a1, h02 = -Dm * mu * a2;
+  const float h11 = k1 * a1 * a1 - k2 * (1.f - a1 * a1), h12 = (k1 + k2) * a1 * a2, h22 = k1 * a2 * a2 - k2 * (1.f - a2 * a2);
+  W[0] = mu * Dm * mu; W[1] = fri * h01 * mu; W[2] = fri * h11 * fri; W[3] = fri * h02 * mu; W[4] = fri * h12 * fri; W[5] = fri * h22 * fri;
   return 0.5f * Dm * NT * NT;
 }
 
 // directional derivatives of one elliptic-cone contact's cost along jp at jar (the exact line search needs only these two scalars):
-// middle zone s = 1/2 Dm e^2 with e = N - mu T  =>  s' = Dm e e',  s'' = Dm (e'^2 + e e''),  T' = (U.V)/T,  T'' = (|V|^2 - T'^2)/T
-__device__ __forceinline__ void cone_dir(const float* jar, const float* jp, const float* D, float mu, float fri, float* d1, float* d2) {
-  float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
-  float N = U0, T2 = U1 * U1 + U2 * U2;
-  float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
-  if (N >= mu * T || (T <= 0.f && N >= 0.f)) return;
-  if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
-    *d1 += D[0] * jar[0] * jp[0] + D[1] * jar[1] * jp[1] + D[2] * jar[2] * jp[2];
-    *d2 += D[0] * jp[0] * jp[0] + D[1] * jp[1] * jp[1] + D[2] * jp[2] * jp[2];
-    return;
-  }
-  float V0 = jp[0] * mu, V1 = jp[1] * fri, V2 = jp[2] * fri;
-  float Dm = D[0] * __frcp_rn(mu * mu * (1.f + mu * mu)), e = N - mu * T;
-  float Tp = (U1 * V1 + U2 * V2) * iT, Tpp = (V1 * V1 + V2 * V2 - Tp * Tp) * iT;
-  float ep = V0 - mu * Tp;
-  *d1 += Dm * e * ep;
-  *d2 += Dm * (ep * ep - e * mu * Tpp);
+// middle zone s = 1/2 Dm e^2 with e = N - mu T  =>  s' = Dm e e',  s'' = Dm (e'^2 + e e''),  T' = (U.V)/T,  T'' = (|V|^2 - T'^2)/T.
+// Branch-free: the three zones are evaluated side by side and selected (lanes of a wave sit in different zones anyway);
+// Dm = D0 / (mu^2 (1 + mu^2)) is a per-contact constant supplied by the caller.
+__device__ __forceinline__ void cone_dir(const float* jar, const float* jp, const float* D, float Dm, float mu, float fri, float* d1, float* d2) {
+  const float U1 = jar[1] * fri, U2 = jar[2] * fri, N = jar[0] * mu, T2 = U1 * U1 + U2 * U2;
+  const float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
+  const bool top = N >= mu * T || (T <= 0.f && N >= 0.f);
+  const bool bottom = mu * N + T <= 0.f || (T <= 0.f && N < 0.f);
+  const float b1 = D[0] * jar[0] * jp[0] + D[1] * jar[1] * jp[1] + D[2] * jar[2] * jp[2];
+  const float b2 = D[0] * jp[0] * jp[0] + D[1] * jp[1] * jp[1] + D[2] * jp[2] * jp[2];
+  const float V0 = jp[0] * mu, V1 = jp[1] * fri, V2 = jp[2] * fri, e = N - mu * T;
+  const float Tp = (U1 * V1 + U2 * V2) * iT, Tpp = (V1 * V1 + V2 * V2 - Tp * Tp) * iT, ep = V0 - mu * Tp;
+  const float m1 = Dm * e * ep, m2 = Dm * (ep * ep - e * mu * Tpp);
+  *d1 += top ? 0.f : (bottom ? b1 : m1);
+  *d2 += top ? 0.f : (bottom ? b2 : m2);
 }
-
 
 // pyramidal-cone contact (condim 3): four one-sided rows  jar_n +- mu*jar_t1, jar_n +- mu*jar_t2, all with the same D.
 // Expressed in the contact-frame 3-vector jar = J a - aref it returns the frame force f = -ds/djar and the 3x3 weight W.
@@ -174,7 +172,7 @@ __device__ __forceinline__ float pyramid_eval(const float* jar, float D, float m
   return cs;
 }
 __device__ __forceinline__ float contact_eval(int cone, const float* jar, const float* D, float mu, float fri, float* f, float* W) {
-  return cone == 1 ? cone_eval(jar, D, mu, fri, f, W) : pyramid_eval(jar, D[0], fri, f, W);
+  return cone == 1 ? cone_eval(jar, D, D[0] * __frcp_rn(mu * mu * (1.f + mu * mu)), mu, fri, f, W) : pyramid_eval(jar, D[0], fri, f, W);
 }
 
 // ------------------------------------------------------------------------------------------------ task costs

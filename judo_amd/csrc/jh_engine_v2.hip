@@ -214,7 +214,7 @@ struct Slot {
   float fr[9];       // contact frame rows (normal, t1, t2)
   float Jr[3][3];    // cube rotational columns (negated), Jr[k][row]
   float Jb[NLK][3];  // chain columns, Jb[j][row] (0 beyond the body's depth)
-  float aref[3], D[3], mu, fri;
+  float aref[3], D[3], Dm, mu, fri;  // Dm = D0 / (mu^2 (1 + mu^2)): middle-zone weight of the elliptic cone
   float jar[3], jp[3];
 };
 
@@ -243,7 +243,7 @@ __device__ __forceinline__ void lane_rows_eval(const Slot* sl, const DofRows& dr
     float jar[3], f[3], W[6];
     const float* jp = sl[k].jp;
     for (int r = 0; r < 3; r++) jar[r] = sl[k].jar[r] + (with_dir ? al * jp[r] : 0.f);
-    cs += cone_eval(jar, sl[k].D, sl[k].mu, sl[k].fri, f, W);
+    cs += cone_eval(jar, sl[k].D, sl[k].Dm, sl[k].mu, sl[k].fri, f, W);
     if (with_dir) {
       g1 -= f[0] * jp[0] + f[1] * jp[1] + f[2] * jp[2];
       g2 += W[0] * jp[0] * jp[0] + W[2] * jp[1] * jp[1] + W[5] * jp[2] * jp[2] + 2.f * (W[1] * jp[0] * jp[1] + W[3] * jp[0] * jp[2] + W[4] * jp[1] * jp[2]);
@@ -270,7 +270,7 @@ __device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr,
     if (!sl[k].valid) continue;
     const float* jp = sl[k].jp;
     float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
-    cone_dir(jar, jp, sl[k].D, sl[k].mu, sl[k].fri, &g1, &g2);
+    cone_dir(jar, jp, sl[k].D, sl[k].Dm, sl[k].mu, sl[k].fri, &g1, &g2);
   }
   if (dr.fl > 0.f) {
     float D = dr.fD, jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
         sl[k].D[0] = 1.f / R0; sl[k].D[1] = 1.f / R1; sl[k].D[2] = 1.f / R1;
         sl[k].fri = mu; sl[k].mu = mu * sqrtf(R1 / R0);
+        { float m2 = sl[k].mu * sl[k].mu; sl[k].Dm = sl[k].D[0] / (m2 * (1.f + m2)); }
         float vel[3]; slot_Jx(sl[k], vc, S.qv, vel);
         sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
       }
@@ -703,9 +704,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
           for (int k = 0; k < NSLOT; k++) if (sl[k].valid) {
             float f[3];
 #ifdef JH_V2_KEEPW
-            cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wm[k]);
+            cone_eval(sl[k].jar, sl[k].D, sl[k].Dm, sl[k].mu, sl[k].fri, f, Wm[k]);
 #else
-            float Wtmp[6]; cone_eval(sl[k].jar, sl[k].D, sl[k].mu, sl[k].fri, f, Wtmp);
+            float Wtmp[6]; cone_eval(sl[k].jar, sl[k].D, sl[k].Dm, sl[k].mu, sl[k].fri, f, Wtmp);
 #endif
             const Slot& t = sl[k];
             for (int q3 = 0; q3 < 3; q3++) {  // cube columns: translation q3 -> -fr[row][q3]; rotation -> Jr[q3][row]
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
 #ifdef JH_V2_KEEPW
             const float* Wk = Wm[k];
 #else
-            float Wk[6], ftmp[3]; cone_eval(t.jar, t.D, t.mu, t.fri, ftmp, Wk);  // recomputed: cheaper than 12 registers live across the convergence test
+            float Wk[6], ftmp[3]; cone_eval(t.jar, t.D, t.Dm, t.mu, t.fri, ftmp, Wk);  // recomputed: cheaper than 12 registers live across the convergence test
 #endif
             if (!(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f)) {
               // column by column (one 3-vector W J_v live at a time keeps the register pressure of this block low)
