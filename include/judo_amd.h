@@ -95,6 +95,13 @@ int jh_task_reward(const jh_model* m, const float* states, const float* sensors,
 int jh_sample_knots(const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi /* NULL = no clip */,
                     int N, int n_offset, int K, int nu, float* knots_nku, void* stream);
 
+/* Candidate control trajectories of the materialise path (judo/controller/controller.py:239-249: the candidate splines evaluated at
+ * the rollout times): controls[n,h,u] = sum_k W[h,k] * knot(n,k,u), (N,H,nu) row-major, ready for jh_rollout_materialize.
+ * W is the (H,K) interpolation matrix of the spline kind (linear in the knots for zero/linear/cubic interp1d); knots come from
+ * `knots_nku` or, when it is NULL, are recomputed as clip(nominal + sigma*noise) exactly like jh_rollout_cost does. */
+int jh_spline_controls(const float* W, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
+                       const float* ctrl_lo_hi, int N, int n_offset, int H, int K, int nu, float* controls, void* stream);
+
 /* MPPI.update_nominal_knots (judo/optimizers/mppi.py:61-82), shard-local part.
  * Writes one record rec[0] = beta = min cost, rec[1] = S = sum exp(-(c-beta)/lambda), rec[2..2+K*nu) = sum w*knots.
  * Knots come either from `knots_nku` ((N,K,nu) row-major, the drop-in path) or, when it is NULL, are recomputed as

@@ -49,6 +49,8 @@ class Controller:
         self._w_cache: dict[tuple, torch.Tensor] = {}
         self._lohi_dev: torch.Tensor | None = None
         self.keep_candidates = False
+        self.force_materialize = False  # True: always take the materialise path (rollout arrays + Task.reward), e.g. to inspect trajectories
+        self.last_rollout = None  # (states, sensors, controls) device tensors of the last materialised iteration
         self.record_kernel_events = False  # bench.py: HIP events around the rollout kernel on the launch stream
         self.kernel_events: list[tuple[torch.cuda.Event, torch.cuda.Event]] = []
         self.candidate_knots_device: torch.Tensor | None = None
@@ -133,10 +135,20 @@ class Controller:
         self.update_spline(self.times, self.nominal_knots)
         self.current_state = np.concatenate([self.task.data.qpos, self.task.data.qvel])
 
-    def update_states(self, qpos: np.ndarray, qvel: np.ndarray, time: float, sim_metadata: dict | None = None) -> None:
-        self.current_state = np.concatenate([qpos, qvel])
-        self.time = time
+    def update_states(self, qpos, qvel: np.ndarray | None = None, time: float | None = None, sim_metadata: dict | None = None) -> None:
+        """Either the reference's call `update_states(MujocoState)` (judo/controller/controller.py:188-194) or the unpacked fields."""
+        if qvel is None and hasattr(qpos, "qpos"):
+            qpos, qvel, time, sim_metadata = qpos.qpos, qpos.qvel, qpos.time, qpos.sim_metadata
+        self.current_state = np.concatenate([np.asarray(qpos, dtype=np.float64), np.asarray(qvel, dtype=np.float64)])
+        self.time = float(time)
         self.system_metadata = sim_metadata or {}
+
+    @property
+    def spline_data(self):
+        """The plan as the record the plant consumes (judo/controller/controller.py:175-178)."""
+        from judo_amd.structs import SplineData
+
+        return SplineData(self._spline_times, self._spline_knots, self._spline_kind)
 
     # ---- device-side constants ---------------------------------------------------------------------------------
     def _weights(self, K: int, H: int) -> torch.Tensor:
@@ -212,10 +224,13 @@ class Controller:
             if self.record_kernel_events:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(x0_d), _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(W),
-                                     _lib.ptr(lohi_d), _lib.ptr(tp_d), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(costs),
-                                     _lib.ptr(knots_out), stream)
-            _lib.check(st, "jh_rollout_cost")
+            if self.uses_fused_cost:
+                st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(x0_d), _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(W),
+                                         _lib.ptr(lohi_d), _lib.ptr(tp_d), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(costs),
+                                         _lib.ptr(knots_out), stream)
+                _lib.check(st, "jh_rollout_cost")
+            else:
+                costs = self._materialised_costs(x0_d, nom_d, noise, sig_d, lohi_d, W, shard, H, K, stream)
             if self.record_kernel_events:
                 ev1.record()
                 self.kernel_events.append((ev0, ev1))
@@ -234,6 +249,34 @@ class Controller:
         self.nominal_knots = nominal_knots
         self.times = new_times
         self.update_spline(self.times, self.nominal_knots)
+
+    @property
+    def uses_fused_cost(self) -> bool:
+        """True when the task's cost is the one fused into the rollout kernel.  A task that overrides `Task.reward` (a plugin
+        registered through `register_task` with its own reward on one of the shipped models) is served by the materialise path:
+        candidate controls -> full state/sensor trajectories -> the task's own `reward`, all on device arrays."""
+        return not self.force_materialize and type(self.task).reward is Task.reward
+
+    def _materialised_costs(self, x0_d, nom_d, noise, sig_d, lohi_d, W, shard: Shard, H: int, K: int, stream) -> torch.Tensor:
+        """judo/controller/controller.py:239-262 on the device: candidate splines at the rollout times, RolloutBackend.rollout,
+        Task.reward, Task.post_rollout.  Returns costs = -rewards (fp32, device)."""
+        lib, task, nu = _lib.lib(), self.task, self.nu
+        controls = torch.empty((shard.count, H, nu), dtype=torch.float32, device=self.device)
+        st = lib.jh_spline_controls(_lib.ptr(W), None, _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(lohi_d), shard.count,
+                                    shard.offset, H, K, nu, _lib.ptr(controls), stream)
+        _lib.check(st, "jh_spline_controls")
+        states, sensors = self.rollout_backend.rollout_device(x0_d, controls)
+        if getattr(task, "reward_accepts_torch", True):
+            args = (states, sensors, controls)
+        else:  # numpy-only plugin reward: one host round trip of the trajectories
+            args = tuple(a.cpu().numpy().astype(np.float64) for a in (states, sensors, controls))
+        rewards = task.reward(*args, self.system_metadata)
+        task.post_rollout(*args, self.system_metadata)
+        rewards = torch.as_tensor(rewards, device=self.device).to(torch.float32).reshape(-1)
+        if rewards.shape[0] != shard.count:
+            raise ValueError(f"Task.reward must return ({shard.count},) rewards, got {tuple(rewards.shape)}")
+        self.last_rollout = (states, sensors, controls)
+        return (-rewards).contiguous()
 
     @property
     def rewards_local(self) -> np.ndarray:

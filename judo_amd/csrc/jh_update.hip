@@ -45,6 +45,27 @@ __global__ __launch_bounds__(kUB) void k_sample_knots(KnotSrc src, int N, float*
   out[i] = src.get(n, idx);
 }
 
+// Candidate control trajectories for the materialise path (judo/controller/controller.py:239-249: candidate splines evaluated
+// at the rollout times): controls[n,h,u] = sum_k W[h,k] * knot(n,k,u).  A wave owns 64 rollouts: their K*nu knots go to LDS
+// (lane-fastest noise reads, odd row stride), then each rollout's contiguous H*nu floats are written with lane-consecutive addresses.
+__global__ __launch_bounds__(64) void k_spline_controls(KnotSrc src, const float* __restrict__ W, int N, int H, int K, float* __restrict__ out) {
+  extern __shared__ float sm[];
+  const int KU = src.KU, nu = src.nu, SK = KU | 1;
+  float* sW = sm;            // H*K
+  float* sK = sm + H * K;    // 64 * SK
+  const int lane = threadIdx.x, n0 = blockIdx.x * 64, nvalid = min(64, N - n0);
+  for (int i = lane; i < H * K; i += 64) sW[i] = W[i];
+  if (lane < nvalid) for (int idx = 0; idx < KU; idx++) sK[lane * SK + idx] = src.get(n0 + lane, idx);
+  __syncthreads();
+  const int row = H * nu;
+  for (int f = lane; f < nvalid * row; f += 64) {
+    const int r = f / row, i = f - r * row, h = i / nu, u = i - h * nu;
+    float v = 0.f;
+    for (int k = 0; k < K; k++) v = fmaf(sW[h * K + k], sK[r * SK + k * nu + u], v);
+    out[(size_t)(n0 + r) * row + i] = v;
+  }
+}
+
 // ---------------------------------------------------------------- MPPI
 __global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ costs, KnotSrc src, int N, float inv_lambda,
                                                    float* __restrict__ scratch) {
@@ -223,6 +244,21 @@ extern "C" int jh_sample_knots(const float* nominal, const float* noise, int ldn
   KnotSrc src{nullptr, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
   size_t total = (size_t)N * K * nu;
   hipLaunchKernelGGL(k_sample_knots, dim3((unsigned)((total + kUB - 1) / kUB)), dim3(kUB), 0, (hipStream_t)stream, src, N, knots_nku);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_spline_controls(const float* W, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
+                                 const float* lohi, int N, int n_offset, int H, int K, int nu, float* controls, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(W && controls, "spline_controls: null pointer");
+  JH_REQUIRE(knots_nku || (nominal && noise && sigma), "spline_controls: need either knots_nku or nominal+noise+sigma");
+  JH_REQUIRE(knots_nku || ldn >= N, "spline_controls: ldn (%d) < N (%d)", ldn, N);
+  JH_REQUIRE(H > 0, "spline_controls: H must be positive");
+  size_t lds = sizeof(float) * ((size_t)H * K + 64 * (size_t)((K * nu) | 1));
+  JH_REQUIRE(lds <= 64 * 1024, "spline_controls: H*K too large for the LDS staging (%zu bytes)", lds);
+  KnotSrc src{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
+  hipLaunchKernelGGL(k_spline_controls, dim3((N + 63) / 64), dim3(64), lds, (hipStream_t)stream, src, W, N, H, K, controls);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

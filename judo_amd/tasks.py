@@ -41,6 +41,7 @@ class TaskData:
 class Task(ABC, Generic[ConfigT]):
     name: str
     config_t: type
+    reward_accepts_torch: bool = True  # a plugin whose overridden `reward` is numpy-only sets this to False
 
     def __init__(self) -> None:
         self.desc = load_description(self.name)

@@ -289,3 +289,94 @@ def test_min_max_normaliser_is_equivalent_to_scaled_sigma(gpu):
     ctrl.controller_cfg.action_normalizer = "running"
     with pytest.raises(NotImplementedError):
         ctrl.update_action()
+
+
+def test_plugin_task_with_its_own_reward_runs_on_the_materialise_path(gpu):
+    """A task registered through `register_task` that overrides `Task.reward` (torch, on device) is served by
+    spline-controls -> RolloutBackend.rollout -> reward -> update; with the reference's cartpole reward restated in torch the
+    new nominal must equal the fused kernel's."""
+    import torch
+    from judo_amd import tasks as T
+    from judo_amd.controller import Controller, make_controller
+    from judo_amd.config import ControllerConfig
+
+    class TorchCartpole(T.Cartpole):
+        name = "cartpole"
+
+        def reward(self, states, sensors, controls, system_metadata=None):  # judo/tasks/cartpole.py:54-76, in torch on device tensors
+            c = self.config
+            assert states.is_cuda and sensors.is_cuda and controls.is_cuda
+            sl1 = lambda z, p: torch.sqrt(z * z + p * p) - p  # noqa: E731  smooth L1
+            x, th, v, w = states[..., 0], states[..., 1], states[..., 2], states[..., 3]
+            per_step = (c.w_vertical * sl1(torch.cos(th) - 1, c.p_vertical) + c.w_centered * sl1(x, c.p_centered)
+                        + c.w_velocity * 0.5 * (v * v + w * w) + c.w_control * 0.5 * controls[..., 0] ** 2)
+            return -per_step.sum(-1)
+
+    T.register_task("torch_cartpole", TorchCartpole, T.CartpoleConfig)
+    rng = np.random.default_rng(5)
+    N, K = 512, 4
+    noise = rng.standard_normal((N - 1, K, 1)).astype(np.float32)  # reference layout: sample n uses row n-1
+    outs = []
+    for name in ("cartpole", "torch_cartpole"):
+        ctrl = make_controller(name, "mppi")
+        if name != "cartpole":  # the shipped per-task overrides are keyed by the task name: give the plugin the same settings
+            import copy
+            ref_ctrl = make_controller("cartpole", "mppi")
+            ctrl.optimizer.config = copy.deepcopy(ref_ctrl.optimizer.config)
+            ctrl.controller_cfg = copy.deepcopy(ref_ctrl.controller_cfg)
+        ctrl.optimizer.config.num_rollouts = N
+        ctrl.controller_cfg.horizon = 64 * ctrl.task.dt
+        ctrl.reset()
+        ctrl.current_state = np.array([1.0, np.pi, 0.0, 0.0])
+        ctrl.optimizer.injected_noise = noise
+        assert ctrl.uses_fused_cost == (name == "cartpole")
+        ctrl.update_action()
+        outs.append((ctrl.nominal_knots.copy(), ctrl.rewards_local.copy()))
+    # the torch reward is checked against the fused cost first (same formula), then the update
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("kind,K,nu,N,H", [("zero", 4, 1, 70, 50), ("linear", 5, 2, 129, 64), ("cubic", 4, 16, 33, 64), ("cubic", 8, 8, 1, 7)])
+def test_spline_controls_kernel_matches_reference_splines(gpu, kind, K, nu, N, H):
+    """jh_spline_controls == clip(nominal + sigma*eps) pushed through the reference's interp1d (restated in oracle.spline_weights,
+    itself pinned by tests/golden/spline.npz), for both knot sources."""
+    import torch
+    from judo_amd import _lib
+    from judo_amd.device import current_stream_ptr
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(K * 100 + nu)
+    dev = torch.device("cuda", 0)
+    nominal, sigma = rng.standard_normal((K, nu)), 0.3 * rng.random((K, nu)) + 0.05
+    noise = rng.standard_normal((K, nu, N)).astype(np.float32)
+    lo, hi = -0.8 * np.ones(nu), 0.9 * np.ones(nu)
+    W = O.spline_weights(kind, np.linspace(0, 1.0, K), np.linspace(0, 1.0, H, endpoint=False))
+    knots = nominal[None] + sigma[None] * np.transpose(noise, (2, 0, 1)).astype(np.float64)
+    knots[0] = nominal
+    knots = np.clip(knots, lo, hi)
+    want = np.einsum("hk,nku->nhu", W, knots)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)  # noqa: E731
+    Wd, nd, sd, ed, lh = t(W), t(nominal), t(sigma), t(noise), t(np.concatenate([lo, hi]))
+    out = torch.empty((N, H, nu), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    _lib.check(L.jh_spline_controls(_lib.ptr(Wd), None, _lib.ptr(nd), _lib.ptr(ed), N, _lib.ptr(sd), _lib.ptr(lh), N, 0, H, K, nu, _lib.ptr(out), current_stream_ptr()), "spline")
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=5e-6)  # fp32 accumulation of K terms of O(1)
+    kd = t(knots)
+    out2 = torch.empty_like(out)
+    _lib.check(L.jh_spline_controls(_lib.ptr(Wd), _lib.ptr(kd), None, None, 0, None, None, N, 0, H, K, nu, _lib.ptr(out2), current_stream_ptr()), "spline")
+    np.testing.assert_allclose(out2.cpu().numpy(), want, rtol=0, atol=5e-6)
+    with pytest.raises(ValueError):
+        _lib.check(L.jh_spline_controls(_lib.ptr(Wd), None, None, None, 0, None, None, N, 0, H, K, nu, _lib.ptr(out2), current_stream_ptr()), "spline")
+
+
+def test_benchmark_sweep_reports_every_pair(gpu):
+    """`python -m judo_amd.benchmark` (judo/app/benchmark.py): statistics for every task x optimizer pair."""
+    from judo_amd import benchmark
+
+    res = benchmark.main(["--num-samples", "3", "--warmup", "1", "--tasks", "cartpole", "cylinder_push", "--json"])
+    assert set(res) == {"cartpole", "cylinder_push"}
+    for per_opt in res.values():
+        assert set(per_opt) == {"cem", "mppi", "ps"}
+        for r in per_opt.values():
+            assert 0 < r["min"] <= r["median"] <= r["max"] and r["iqr25"] <= r["iqr75"]

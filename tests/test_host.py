@@ -239,3 +239,39 @@ def test_product_never_imports_the_oracle():
                     code = re.sub(r"/\*[\s\S]*?\*/", "", code)
                 assert not re.search(r"^\s*(from|import)\s+oracle", code, re.M), f
                 assert "libjudo_oracle" not in code and "jo_engine" not in code and "jo_plan" not in code and "oracle/" not in code, f
+
+
+def test_wire_records_round_trip_through_arrow():
+    """SplineData / MujocoState (judo/app/structs.py:30-84): Arrow form and back; SplineData.spline() holds the end knots."""
+    from judo_amd.structs import MujocoState, SplineData, from_arrow, to_arrow
+
+    rng = np.random.default_rng(0)
+    st = MujocoState(time=1.25, qpos=rng.standard_normal(23), qvel=rng.standard_normal(22), xpos=rng.standard_normal((5, 3)),
+                     xquat=rng.standard_normal((5, 4)), sim_metadata={"goal_quat": np.array([0.0, 1.0, 0.0, 0.0]), "phase": 2})
+    arr, meta = to_arrow(st)
+    assert all(isinstance(v, str) for v in meta.values())
+    back = from_arrow(arr, meta, MujocoState)
+    assert back.time == 1.25 and back.sim_metadata == {"goal_quat": [0.0, 1.0, 0.0, 0.0], "phase": 2}
+    for f in ("qpos", "qvel", "xpos", "xquat", "mocap_pos", "mocap_quat"):
+        np.testing.assert_array_equal(getattr(back, f), getattr(st, f))
+        assert getattr(back, f).shape == getattr(st, f).shape
+    with pytest.raises(ValueError):
+        from_arrow(arr, meta, SplineData)
+
+    g = np.load(os.path.join(GOLDEN, "spline.npz"))
+    for key in [k[: -len("_cfg")] for k in g.files if k.endswith("_cfg")]:
+        kind, K, H, dt, hor, t0 = g[key + "_cfg"]
+        kind = {0: "zero", 1: "linear", 3: "cubic"}[int(kind)]
+        sp = SplineData(t0 + np.linspace(0, hor, int(K)), g[key + "_knots"], kind)  # batched knots (N, K, nu)
+        f = sp.spline()
+        np.testing.assert_allclose(f(t0 + dt * np.arange(int(H))), g[key + "_U"], atol=1e-12)  # the reference's make_spline(...)(q)
+        np.testing.assert_allclose(f(np.array([t0 - 1.0, t0 + hor + 2.0]))[0], g[key + "_far"], atol=1e-14)  # held end values
+        a2, m2 = to_arrow(sp)
+        sp2 = from_arrow(a2, m2, SplineData)
+        assert sp2.kind == kind and sp2.extrapolate is True
+        np.testing.assert_array_equal(sp2.x, sp.x)
+        np.testing.assert_array_equal(sp2.t, sp.t)
+    with pytest.raises(ValueError):
+        SplineData(np.arange(4.0), np.zeros((4, 2)), "quintic")
+    with pytest.raises(ValueError):
+        SplineData(np.arange(4.0), np.zeros((4, 2)), "linear", extrapolate=False).spline()(5.0)
