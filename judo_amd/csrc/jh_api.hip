@@ -102,6 +102,7 @@ extern "C" int jh_rollout_cost(const jh_model* m, const float* x0, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH)
     return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 2) return jh_engine3_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
   return jh_engine_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
 }
@@ -113,6 +114,7 @@ extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0
   JH_REQUIRE(N > 0 && H > 0, "rollout_materialize: N and H must be positive (N=%d H=%d)", N, H);
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) return jh_simple_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 2) return jh_engine3_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   return jh_engine_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
 }

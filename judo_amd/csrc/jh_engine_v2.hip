@@ -13,9 +13,10 @@
 //
 // The arithmetic is the same restatement of MuJoCo's step as jh_engine.hip / oracle/jo_engine.c;
 // fp32 throughout (an fp32 Hessian was measured to need the same number of Newton iterations as fp64).
-#include "jh_engine_common.h"
+#include "jh_coop.h"
 
 using namespace jh_eng;
+using namespace jh_coop;
 
 namespace {
 
@@ -49,34 +50,6 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   int ncon, nhit;
 };
 
-// Cross-lane traffic stays inside one DPP row (the 16 lanes of a rollout): row-local DPP modifiers instead of
-// ds_bpermute.  A sum butterfly only needs each step to pair a lane with one from the "other half" of the group that is
-// already uniform: quad_perm xor 1, quad_perm xor 2, row_half_mirror (i <-> 7-i), row_mirror (i <-> 15-i).
-template <int CTRL>
-__device__ __forceinline__ float dppf(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
-
-__device__ __forceinline__ float csum(float v) {  // sum over the 4 lanes of a chain (= one quad)
-  v += dppf<DPP_XOR1>(v); v += dppf<DPP_XOR2>(v);
-  return v;
-}
-__device__ __forceinline__ float gsum(float v) {  // sum over the 16 lanes of a rollout (= one DPP row)
-  v = csum(v); v += dppf<DPP_HALF_MIRROR>(v); v += dppf<DPP_MIRROR>(v);
-  return v;
-}
-__device__ __forceinline__ int gor(int v) {
-  v |= dppi<DPP_XOR1>(v); v |= dppi<DPP_XOR2>(v); v |= dppi<DPP_HALF_MIRROR>(v); v |= dppi<DPP_MIRROR>(v);
-  return v;
-}
-// value held by lane j of the caller's quad (j is a compile-time constant after unrolling)
-__device__ __forceinline__ float quad_get(float v, int j) {
-  switch (j) { case 0: return dppf<0x00>(v); case 1: return dppf<0x55>(v); case 2: return dppf<0xAA>(v); default: return dppf<0xFF>(v); }
-}
-
 // ------------------------------------------------------------------------------------------------ collision into the LDS pool
 struct PoolCtx { RS* S; int* overflow; };
 
@@ -87,125 +60,10 @@ __device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos
   e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = dist; e[7] = mu; e[8] = __int_as_float(body); e[9] = tran;
 }
 
-// box 1 = the cube (geom 1), box 2 = hand geom; normal from box 1 to box 2 (same algorithm as jh_engine.hip / the oracle)
-__device__ void collide_box_box(const PoolCtx& pc, const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2, int body, float mu, float tran) {
-  float A[3][3], B[3][3], dv[3], Cm[3][3], AC[3][3], dA[3], dB[3];
-  for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
-  for (int i = 0; i < 3; i++) { dA[i] = dot3(dv, A[i]); dB[i] = dot3(dv, B[i]); for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); AC[i][j] = fabsf(Cm[i][j]); } }
-  float best = -1e30f; int btype = -1, bi = 0, bj = 0;
-  for (int i = 0; i < 3; i++) {
-    float s = fabsf(dA[i]) - (h1[i] + h2[0] * AC[i][0] + h2[1] * AC[i][1] + h2[2] * AC[i][2]);
-    if (s > 0.f) return;
-    if (s > best) { best = s; btype = 0; bi = i; }
-  }
-  for (int j = 0; j < 3; j++) {
-    float s = fabsf(dB[j]) - (h2[j] + h1[0] * AC[0][j] + h1[1] * AC[1][j] + h1[2] * AC[2][j]);
-    if (s > 0.f) return;
-    if (s > best) { best = s; btype = 1; bj = j; }
-  }
-  float ebest = -1e30f, eL[3] = {0, 0, 0}; int ei = -1, ej = -1;
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      float L[3]; cross3(L, A[i], B[j]);
-      float l2 = dot3(L, L);
-      if (l2 < 1e-12f) continue;
-      float il = rsqrtf(l2); L[0] *= il; L[1] *= il; L[2] *= il;
-      float ra = 0.f, rb = 0.f;
-      for (int k = 0; k < 3; k++) { ra += h1[k] * fabsf(dot3(A[k], L)); rb += h2[k] * fabsf(dot3(B[k], L)); }
-      float s = fabsf(dot3(dv, L)) - (ra + rb);
-      if (s > 0.f) return;
-      if (s > ebest) { ebest = s; ei = i; ej = j; eL[0] = L[0]; eL[1] = L[1]; eL[2] = L[2]; }
-    }
-  bool use_edge = ei >= 0 && (best < 0.f ? ebest > best / 1.05f + 1e-12f : ebest > best * 1.05f + 1e-12f);
-  if (use_edge) {
-    float n[3] = {eL[0], eL[1], eL[2]};
-    if (dot3(n, dv) < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-    float pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
-    for (int k = 0; k < 3; k++) {
-      if (k != ei) { float s = (dot3(n, A[k]) > 0.f ? 1.f : -1.f) * h1[k]; pa[0] += A[k][0] * s; pa[1] += A[k][1] * s; pa[2] += A[k][2] * s; }
-      if (k != ej) { float s = (dot3(n, B[k]) > 0.f ? -1.f : 1.f) * h2[k]; pb[0] += B[k][0] * s; pb[1] += B[k][1] * s; pb[2] += B[k][2] * s; }
-    }
-    float wv[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-    float b = Cm[ei][ej], dd = dot3(A[ei], wv), e = dot3(B[ej], wv), den = 1.f - b * b;
-    float s = den > 1e-12f ? (b * e - dd) / den : 0.f, t = den > 1e-12f ? (e - b * dd) / den : 0.f;
-    s = jh_clampf(s, -h1[ei], h1[ei]); t = jh_clampf(t, -h2[ej], h2[ej]);
-    float pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + A[ei][k] * s) + (pb[k] + B[ej][k] * t));
-    push_contact(pc, pos, n, ebest, body, mu, tran);
-    return;
-  }
-  const float *pr, *pi, *hr, *hi; float (*Ar)[3], (*Ai)[3]; int ri; float n[3];
-  if (btype == 0) { pr = p1; pi = p2; hr = h1; hi = h2; Ar = A; Ai = B; ri = bi; float sg = dA[bi] >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = sg * A[bi][k]; }
-  else { pr = p2; pi = p1; hr = h2; hi = h1; Ar = B; Ai = A; ri = bj; float sg = dB[bj] >= 0.f ? -1.f : 1.f; for (int k = 0; k < 3; k++) n[k] = sg * B[bj][k]; }
-  int mi = 0; float mb = -1.f;
-  for (int k = 0; k < 3; k++) { float v = fabsf(dot3(n, Ai[k])); if (v > mb) { mb = v; mi = k; } }
-  float sgi = dot3(n, Ai[mi]) > 0.f ? -1.f : 1.f;
-  int u = (mi + 1) % 3, v = (mi + 2) % 3;
-  // Face manifold without polygon buffers: the vertices of (incident quad) n (reference rectangle) are exactly
-  //   (a) incident vertices inside the rectangle, (b) incident-edge x rectangle-edge crossings, (c) rectangle corners inside the quad;
-  // contact order is irrelevant, so they are emitted as found (same point set as Sutherland-Hodgman clipping).
-  const int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
-  const float ha = hr[ra], hb = hr[rb];
-  float ci[3], e1[3], e2[3];
-  for (int k = 0; k < 3; k++) { ci[k] = pi[k] + sgi * hi[mi] * Ai[mi][k] - pr[k]; e1[k] = hi[u] * Ai[u][k]; e2[k] = hi[v] * Ai[v][k]; }
-  const float ca = dot3(ci, Ar[ra]), cbb = dot3(ci, Ar[rb]), cg = dot3(ci, n);
-  const float e1a = dot3(e1, Ar[ra]), e1b = dot3(e1, Ar[rb]), e1g = dot3(e1, n), e2a = dot3(e2, Ar[ra]), e2b = dot3(e2, Ar[rb]), e2g = dot3(e2, n);
-  const float href = hr[ri];
-  auto emit = [&](float al, float be, float ga) {
-    float depth = href - ga;
-    if (depth <= 0.f) return;
-    float pos[3], nn[3], gm = ga + 0.5f * depth;
-    for (int k = 0; k < 3; k++) { pos[k] = pr[k] + al * Ar[ra][k] + be * Ar[rb][k] + gm * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
-    push_contact(pc, pos, nn, -depth, body, mu, tran);
-  };
-  const float s1[4] = {1, -1, -1, 1}, s2[4] = {1, 1, -1, -1};
-  float va[4], vb[4], vg[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) { va[q] = ca + s1[q] * e1a + s2[q] * e2a; vb[q] = cbb + s1[q] * e1b + s2[q] * e2b; vg[q] = cg + s1[q] * e1g + s2[q] * e2g; }
-#pragma unroll
-  for (int q = 0; q < 4; q++) if (fabsf(va[q]) <= ha && fabsf(vb[q]) <= hb) emit(va[q], vb[q], vg[q]);   // (a)
-#pragma unroll
-  for (int q = 0; q < 4; q++) {                                                                        // (b)
-    const int qn = (q + 1) & 3;
-    const float da = va[qn] - va[q], db = vb[qn] - vb[q], dg = vg[qn] - vg[q];
-#pragma unroll
-    for (int sgn = -1; sgn <= 1; sgn += 2) {
-      if (da != 0.f) { float t = (sgn * ha - va[q]) / da; float bb2 = vb[q] + t * db; if (t > 0.f && t < 1.f && fabsf(bb2) < hb) emit(sgn * ha, bb2, vg[q] + t * dg); }
-      if (db != 0.f) { float t = (sgn * hb - vb[q]) / db; float aa2 = va[q] + t * da; if (t > 0.f && t < 1.f && fabsf(aa2) < ha) emit(aa2, sgn * hb, vg[q] + t * dg); }
-    }
-  }
-  const float det = e1a * e2b - e1b * e2a;                                                               // (c)
-  if (fabsf(det) > 1e-12f) {
-    const float idet = 1.f / det;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const float pa = s1[q] * ha - ca, pb2 = s2[q] * hb - cbb;
-      const float t1 = (pa * e2b - pb2 * e2a) * idet, t2 = (e1a * pb2 - e1b * pa) * idet;
-      if (fabsf(t1) < 1.f && fabsf(t2) < 1.f) emit(s1[q] * ha, s2[q] * hb, cg + t1 * e1g + t2 * e2g);
-    }
-  }
-}
-
-__device__ void collide_box_sphere(const PoolCtx& pc, const float* pb, const float* Rb, const float* hb, const float* c, float r, int body, float mu, float tran) {
-  float dl[3] = {c[0] - pb[0], c[1] - pb[1], c[2] - pb[2]}, cl[3], q[3]; bool outside = false;
-  mulMTV(cl, Rb, dl);
-  for (int k = 0; k < 3; k++) { q[k] = cl[k]; if (q[k] > hb[k]) { q[k] = hb[k]; outside = true; } else if (q[k] < -hb[k]) { q[k] = -hb[k]; outside = true; } }
-  float nl[3], dist;
-  if (outside) {
-    float df[3] = {cl[0] - q[0], cl[1] - q[1], cl[2] - q[2]}; float l = sqrtf(dot3(df, df));
-    if (l - r >= 0.f) return;
-    nl[0] = df[0] / l; nl[1] = df[1] / l; nl[2] = df[2] / l; dist = l - r;
-  } else {
-    int kb = 0; float mn = 1e30f;
-    for (int k = 0; k < 3; k++) { float s = hb[k] - fabsf(cl[k]); if (s < mn) { mn = s; kb = k; } }
-    nl[0] = nl[1] = nl[2] = 0.f; nl[kb] = cl[kb] >= 0.f ? 1.f : -1.f;
-    q[kb] = nl[kb] * hb[kb]; dist = -mn - r;
-  }
-  float ql[3] = {q[0] + 0.5f * dist * nl[0], q[1] + 0.5f * dist * nl[1], q[2] + 0.5f * dist * nl[2]}, pos[3], n[3];
-  mulMV(pos, Rb, ql); for (int k = 0; k < 3; k++) pos[k] += pb[k];
-  mulMV(n, Rb, nl);
-  push_contact(pc, pos, n, dist, body, mu, tran);
-}
+struct LeapSink {  // contact sink of the narrow phase: cube (geom 1) against one hand geom
+  PoolCtx pc; int body; float mu, tran;
+  __device__ __forceinline__ void push(const float* pos, const float* n, float dist) { push_contact(pc, pos, n, dist, body, mu, tran); }
+};
 
 // ------------------------------------------------------------------------------------------------ per-lane contact slot
 struct Slot {
@@ -572,8 +430,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
             mulMM(gR, bR, gf + GF_R);
           }
           float tran = ctran + gf[GF_TRAN];
-          if (gtype == GBOX) collide_box_box(pc, qc, Rc, chs, gp, gR, gf + GF_SIZE, body, gf[GF_MU], tran);
-          else collide_box_sphere(pc, qc, Rc, chs, gp, gf[GF_SIZE], body, gf[GF_MU], tran);
+          LeapSink sk{pc, body, gf[GF_MU], tran};
+          if (gtype == GBOX) collide_box_box(sk, qc, Rc, chs, gp, gR, gf + GF_SIZE);
+          else collide_box_sphere(sk, qc, Rc, chs, gp, gf[GF_SIZE]);
         }
       }
     }

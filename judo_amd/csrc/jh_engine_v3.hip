@@ -1,0 +1,955 @@
+// jh_engine_v3.hip -- fr3_pick cooperative kernel (gfx950): 16 lanes (one DPP row) per rollout, 4 rollouts per wave64.
+//
+// Model structure (judo/models/xml/fr3_pick.xml as compiled by tools/compile_mjcf.py + judo_amd/engine_model.py): one free box,
+// one serial arm of 7 hinges that forks into two finger slides (9 dofs, dense 9x9 inertia), 15 box collision geoms with 63
+// candidate pairs whose two sides may be static / the free box / an arm link, pyramidal friction cones with per-pair solver
+// parameters, dof friction loss + joint limits on all 9 arm dofs, one joint equality (finger coupling), position servos with
+// joint-level force clamps, 5 box-box distance sensors.  Same semantics as the one-lane generic kernel (jh_engine.hip) and the
+// fp64 oracle; what changes is the decomposition:
+//
+//   lane l < 6      owns free-body dof l        (row l of the Newton Hessian)
+//   lane 6..14      owns arm dof l-6: joint state, actuator, spline knots, friction-loss / limit rows, its link's inertia
+//   lane 15         carries the right-hand side as a 16th matrix row, so the forward solve rides along with the factorisation
+//   every lane      up to 2 contacts (slots l, l+16): pyramid evaluation, aref, jar, line-search terms
+//
+// The contact Jacobian (3 x 15 per contact) lives in LDS and is built column-per-lane once per step.  The dense 15x15 Hessian
+// is assembled row-per-lane (no atomics, no cross-lane sums), factorised by a left-looking row Cholesky in which lane k
+// publishes row k through LDS (15 dependent steps of k FMAs instead of a redundant 560-FMA factorisation per lane), and the
+// backward solve is done redundantly from the published rows so that every lane ends up with the whole search direction.
+// The 9x9 inertia is summed from per-link contributions with DPP row sums.  Model constants are read from the global image
+// (uniform indices become scalar loads); LDS holds only per-rollout state (37.8 KB per workgroup of one wave).
+#include "jh_coop.h"
+
+using namespace jh_eng;
+using namespace jh_coop;
+
+namespace {
+
+constexpr int G = 16, RPW = 4, WAVE = 64;
+constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, NMB = 10;
+constexpr int NCP = 32, NSL = NCP / G, MAXHIT = 32, RAW_F = 8, JW = NVT * 3;
+constexpr int MAXDT = 32;  // box pairs behind the distance sensors
+constexpr int NFS = 3, NFF = NFS * G;  // finger-finger contacts: kept in registers of their owner lanes (3 per lane), never in the LDS Jacobian
+constexpr int LF = 8, RF = 9;       // moving-body indices of the two fingers (arm dofs 7 / 8 = lanes 13 / 14)
+
+struct __attribute__((aligned(16))) RS3 {  // per-rollout shared state
+  float xpos[NMB][3], xR[NMB][9], axw[NMB][3];  // moving bodies: 0 = free box, 1..9 = arm links / fingers
+  float q[16], qd[16];                          // arm joint positions / velocities by arm index
+  float M[NA][NA];
+  float vec[3][16];
+  union {                                       // the raw contact pool is dead once the Jacobian and the slots are built
+    float raw[NCP][RAW_F];                      // pos3, normal3, dist, pair
+    float Lrow[16][16];                         // Cholesky rows (row 15 = transformed right-hand side); diagonal holds 1/L_kk
+  };
+  float J[NCP][JW];                             // J[c][3 r + w]: contact-frame row w, dof r
+  float fW[NCP][9];                             // frame (while rows are built), then f[3], W[6] of the current Newton iterate
+  float y[16];                                  // sensordata of the forward pass
+  int hits[MAXHIT];
+  int ncon, nhit, nff;
+};
+
+struct Sink3 {  // contact sink of the narrow phase
+  RS3* S; int* overflow; int pair; bool ff;
+  __device__ __forceinline__ void push(const float* pos, const float* n, float dist) {
+    float* e;
+    if (ff) {  // finger against finger: parked in the (still unused) Jacobian area until the owner lanes have taken them into registers
+      int i = atomicAdd(&S->nff, 1);
+      if (i >= NFF) { if (overflow) atomicAdd(overflow, 1); return; }
+      e = &S->J[0][0] + i * RAW_F;
+    } else {
+      int i = atomicAdd(&S->ncon, 1);
+      if (i >= NCP) { if (overflow) atomicAdd(overflow, 1); return; }
+      e = S->raw[i];
+    }
+    e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = dist; e[7] = __int_as_float(pair);
+  }
+};
+
+struct Slot3 { bool valid; float D, mu, aref[3], jar[3], jp[3]; };
+struct SlotF : Slot3 { float J13[3], J14[3]; };  // finger-finger contact: the only non-zero Jacobian columns are the two finger slides
+struct DofRows3 { float fl, fD, fR, faref, lims, laref, lD, jf, jl, pf, pl; };
+
+// four one-sided rows x_k = jar_n +- mu jar_t1, jar_n +- mu jar_t2: slope and curvature along jp
+__device__ __forceinline__ void pyramid_dir(const float* jar, const float* jp, float D, float mu, float* d1, float* d2) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float sg = (k & 1) ? -mu : mu;
+    const float x = jar[0] + sg * (k < 2 ? jar[1] : jar[2]), xp = jp[0] + sg * (k < 2 ? jp[1] : jp[2]);
+    if (x < 0.f) { *d1 += D * x * xp; *d2 += D * xp * xp; }
+  }
+}
+
+// J x for contact c: free-body part from registers, arm part from an LDS vector indexed by arm dof
+__device__ __forceinline__ void contact_Jx(const RS3& S, int c, const float* xc, const float* xa, float* out) {
+  const float* Jc = S.J[c];
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; r++) { o0 = fmaf(Jc[3 * r], xc[r], o0); o1 = fmaf(Jc[3 * r + 1], xc[r], o1); o2 = fmaf(Jc[3 * r + 2], xc[r], o2); }
+#pragma unroll
+  for (int r = 0; r < NA; r++) { float x = xa[r]; o0 = fmaf(Jc[18 + 3 * r], x, o0); o1 = fmaf(Jc[18 + 3 * r + 1], x, o1); o2 = fmaf(Jc[18 + 3 * r + 2], x, o2); }
+  out[0] = o0; out[1] = o1; out[2] = o2;
+}
+
+__device__ __forceinline__ float lane_rows_cost(const Slot3* sl, const SlotF* sf, const DofRows3& dr, bool eq_lane, float eD, float ejar) {
+  float cs = 0.f;
+#pragma unroll
+  for (int k = 0; k < NFS; k++) if (sf[k].valid) { float f[3], W[6]; cs += pyramid_eval(sf[k].jar, sf[k].D, sf[k].mu, f, W); }
+#pragma unroll
+  for (int k = 0; k < NSL; k++) if (sl[k].valid) { float f[3], W[6]; cs += pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, W); }
+  if (dr.fl > 0.f) {
+    float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+    if (x <= -lim) cs += -0.5f * dr.fR * fl * fl - fl * x; else if (x >= lim) cs += -0.5f * dr.fR * fl * fl + fl * x; else cs += 0.5f * dr.fD * x * x;
+  }
+  if (dr.lims != 0.f && dr.jl < 0.f) cs += 0.5f * dr.lD * dr.jl * dr.jl;
+  if (eq_lane) cs += 0.5f * eD * ejar * ejar;
+  return cs;
+}
+
+__device__ __forceinline__ void lane_rows_dir(const Slot3* sl, const SlotF* sf, const DofRows3& dr, bool eq_lane, float eD, float ejar, float ejp, float al, float* d1, float* d2) {
+  float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NFS; k++) if (sf[k].valid) {
+    const float* jp = sf[k].jp;
+    float jar[3] = {fmaf(al, jp[0], sf[k].jar[0]), fmaf(al, jp[1], sf[k].jar[1]), fmaf(al, jp[2], sf[k].jar[2])};
+    pyramid_dir(jar, jp, sf[k].D, sf[k].mu, &g1, &g2);
+  }
+#pragma unroll
+  for (int k = 0; k < NSL; k++) if (sl[k].valid) {
+    const float* jp = sl[k].jp;
+    float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
+    pyramid_dir(jar, jp, sl[k].D, sl[k].mu, &g1, &g2);
+  }
+  if (dr.fl > 0.f) {
+    float jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
+    if (x <= -lim) g1 -= fl * jp; else if (x >= lim) g1 += fl * jp; else { g1 += dr.fD * x * jp; g2 += dr.fD * jp * jp; }
+  }
+  if (dr.lims != 0.f) { float jp = dr.pl, x = fmaf(al, jp, dr.jl); if (x < 0.f) { g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; } }
+  if (eq_lane) { float x = fmaf(al, ejp, ejar); g1 += eD * x * ejp; g2 += eD * ejp * ejp; }
+  *d1 = g1; *d2 = g2;
+}
+
+// dense Cholesky + solve of an n x n system held in registers (packed lower L, reciprocal diagonal), redundantly per lane
+template <int N_>
+__device__ __forceinline__ void chol_solve(float* L, float* x) {
+  float inv[N_];
+#pragma unroll
+  for (int i = 0; i < N_; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = L[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { float rr = __frsqrt_rn(fmaxf(s, 1e-30f)); inv[i] = rr; L[tri(i, i)] = s * rr; }
+      else L[tri(i, j)] = s * inv[j];
+    }
+#pragma unroll
+  for (int i = 0; i < N_; i++) { float s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
+    x[i] = s * inv[i]; }
+#pragma unroll
+  for (int i = N_ - 1; i >= 0; i--) { float s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < N_; k++) s -= L[tri(k, i)] * x[k];
+    x[i] = s * inv[i]; }
+}
+
+__device__ __forceinline__ void rodrigues(float* Rq, const float* al, float q) {
+  float sn, cs; sincosf(q, &sn, &cs); float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
+  Rq[0] = t * x * x + cs; Rq[1] = t * x * y - sn * z; Rq[2] = t * x * z + sn * y;
+  Rq[3] = t * x * y + sn * z; Rq[4] = t * y * y + cs; Rq[5] = t * y * z - sn * x;
+  Rq[6] = t * x * z - sn * y; Rq[7] = t * y * z + sn * x; Rq[8] = t * z * z + cs;
+}
+
+// world pose of collision geom g (all fr3 collision geoms are boxes); body -1 = static (pose stored in world coordinates)
+__device__ __forceinline__ void geom_pose3(const RS3& S, const float* gf, int body, float* gp, float* gR, bool want_R) {
+  if (body < 0) { for (int k = 0; k < 3; k++) gp[k] = gf[GF_POS + k]; if (want_R) for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; }
+  else {
+    float bR[9]; for (int k = 0; k < 9; k++) bR[k] = S.xR[body][k];
+    mulMV(gp, bR, gf + GF_POS); for (int k = 0; k < 3; k++) gp[k] += S.xpos[body][k];
+    if (want_R) mulMM(gR, bR, gf + GF_R);
+  }
+}
+
+template <bool MATERIALIZE>
+__global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
+                                                    const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
+                                                    const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
+                                                    const float* __restrict__ tp, int phase, int N, int n_offset, int H, int K,
+                                                    float* __restrict__ costs, float* __restrict__ knots_out, const float* __restrict__ controls,
+                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats) {
+  __shared__ RS3 sRS[RPW];
+  __shared__ int sDT[MAXDT][3];  // distance-sensor tasks: sensordata address, geom a, geom b
+  __shared__ int sNDT, sDadr[8];
+  __shared__ float sTp[24];
+  const int lane = threadIdx.x, l = lane & 15, r = lane >> 4;
+  RS3& S = sRS[r];
+  EngineModel m; m.init(gF, gI);
+  const bool isarm = l >= 6 && l < 15, iscube = l < 6, hasdof = l < 15;
+  const int ai = isarm ? l - 6 : 0;        // arm dof index 0..8 (7, 8 = finger slides)
+  const bool isfinger = isarm && ai >= NCHAIN;
+  const int n = blockIdx.x * RPW + r;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  if (lane == 0) {  // flatten the distance sensors into (address, geom, geom) tasks
+    int nt = 0;
+    for (int s = 0; s < m.NGS; s++) {
+      const int* si = gI + m.oSensG + s * 4;
+      if (si[0] != 4) continue;
+      if (si[1] < 8) sDadr[si[1]] = si[3];
+      const int* di = gI + m.oDistI + si[1] * 4;
+      for (int a = 0; a < di[1]; a++) for (int b = 0; b < di[3]; b++) if (nt < MAXDT) { sDT[nt][0] = si[3]; sDT[nt][1] = gI[m.oGlist + di[0] + a]; sDT[nt][2] = gI[m.oGlist + di[2] + b]; nt++; }
+    }
+    sNDT = nt;
+  }
+  if (!MATERIALIZE && lane < 22) sTp[lane] = tp[lane];
+  // ---- per-lane constants: own dof rows, own actuator
+  const int dofc = hasdof ? l : 14;
+  const float* df = gF + m.oDofF + dofc * DOF_F;
+  const float en = hasdof ? 1.f : 0.f;
+  const float c_damp = df[DF_DAMP] * en, c_kvd = df[DF_KV] * en, c_fl = df[DF_FL] * en, c_fB = df[DF_FB], c_fD = df[DF_FD], c_invw = df[DF_INVW];
+  const float c_limited = df[DF_LIMITED] * en, c_lo = df[DF_LO], c_hi = df[DF_HI], c_lK = df[DF_LK], c_lB = df[DF_LB];
+  float c_si[5]; for (int k = 0; k < 5; k++) c_si[k] = df[DF_SOLIMP + k];
+  const float c_frclim = df[DF_FRCLIM] * en, c_frclo = df[DF_FRCLO], c_frchi = df[DF_FRCHI];
+  const bool hasact = l >= 6 && l < 6 + NU;
+  const float* af = gF + m.oActF + (hasact ? l - 6 : 0) * ACT_F;
+  const float c_kp = hasact ? af[AF_KP] : 0.f, c_kv = hasact ? af[AF_KV] : 0.f, c_clim = af[AF_CLIM], c_clo = af[AF_CLO], c_chi = af[AF_CHI];
+  const float h = gF[HF_DT], impratio = gF[HF_IMPRATIO], tol = gF[HF_TOL], lstol = gF[HF_LSTOL]; const int cap = (int)gF[HF_MAXITER];
+  const float grav[3] = {gF[HF_GRAV], gF[HF_GRAV + 1], gF[HF_GRAV + 2]};
+  const float cmass = gF[HF_CMASS], cI[3] = {gF[HF_CINERTIA], gF[HF_CINERTIA + 1], gF[HF_CINERTIA + 2]};
+  // joint equality (finger coupling), rows live in lanes 13 / 14 (dofs ei0 / ei1)
+  const bool has_eq = m.NEQ > 0;
+  const float* ef = gF + m.oEqF;
+  const float e_a0 = has_eq ? ef[EF_A0] : 0.f, e_a1 = has_eq ? ef[EF_A1] : 0.f, e_K = ef[EF_K], e_B = ef[EF_B], e_invw = ef[EF_INVW];
+  float e_si[5]; for (int k = 0; k < 5; k++) e_si[k] = ef[EF_SOLIMP + k];
+  const bool eq_lane = has_eq && l == 13;  // the lane that accounts for the row's cost / line-search terms
+  // ---- state: replicated free body + own joint
+  float q = 0.f, qd = 0.f, qws = 0.f, qc[7], vc[6];
+  {
+    const float* xi = x0 + ((MATERIALIZE && x0_batched) ? (size_t)nc * NX : 0);
+    for (int k = 0; k < 7; k++) qc[k] = xi[k];
+    for (int k = 0; k < 6; k++) vc[k] = xi[NQ + k];
+    if (isarm) { q = xi[7 + ai]; qd = xi[NQ + 6 + ai]; }
+  }
+  // ---- own actuator's spline knots (fused mode)
+  float kn[8];
+  if (!MATERIALIZE) {
+    for (int k = 0; k < 8; k++) kn[k] = 0.f;
+    if (hasact) {
+      const int u = l - 6;
+      for (int k = 0; k < K && k < 8; k++) {
+        int i = k * NU + u;
+        float v = nominal[i];
+        if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
+        v = jh_clampf(v, lohi[u], lohi[NU + u]);
+        kn[k] = v;
+        if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
+      }
+    }
+  }
+  int n_iters = 0, n_maxed = 0;
+#ifdef JH_V3_EXITSTATS
+  int n_x[4] = {0, 0, 0, 0};  // solver exits: gradient / not a descent direction / expected decrease / iteration cap
+#endif
+  float acc = 0.f;
+#ifdef JH_V3_DEBUG
+  float dbg[12] = {0}, dit[8][8] = {{0}}, dls[6][4] = {{0}};
+#endif
+  __syncthreads();
+  const int ndt = sNDT;
+
+  for (int hh = 0; hh < H; hh++) {
+    // ================================================================ controls
+    float u = 0.f;
+    if (hasact) {
+      if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + (l - 6)];
+      else for (int k = 0; k < K && k < 8; k++) u = fmaf(W[hh * K + k], kn[k], u);
+    }
+    if (isarm) { S.q[ai] = q; S.qd[ai] = qd; }
+    if (l == 0) { S.ncon = 0; S.nhit = 0; S.nff = 0; }
+    __syncthreads();
+    // ================================================================ kinematics: every lane walks the 7-hinge chain (uniform records -> scalar loads)
+    float ax[8][3], og[8][3], Rown[9], pown[3], axown[3], Rc[9];
+    {
+      float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
+      qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+      quat2mat(Rc, qc + 3);
+      float P[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      for (int k = 0; k < 9; k++) Rown[k] = R[k];
+      for (int k = 0; k < 3; k++) { pown[k] = 0.f; axown[k] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < NCHAIN; j++) {
+        const float* bf = gF + m.oBodyF + (1 + j) * BODY_F;
+        float P2[3], R0[9];
+        if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
+        else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
+        mulMV(ax[j], R0, bf + BF_AXIS);
+        for (int k = 0; k < 3; k++) { og[j][k] = P2[k]; P[k] = P2[k]; }
+        float Rq[9]; rodrigues(Rq, bf + BF_AXIS, S.q[j]);
+        mulMM(R, R0, Rq);
+        if (j == ai) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = ax[j][k]; } for (int k = 0; k < 9; k++) Rown[k] = R[k]; }
+      }
+      {  // finger slide hanging off link 7 (lanes that are not a finger compute finger 7 and ignore it)
+        const int fi = isfinger ? ai : NCHAIN;
+        const float* bf = gF + m.oBodyF + (1 + fi) * BODY_F;
+        float P2[3], R0[9], lp[3] = {bf[BF_LPOS], bf[BF_LPOS + 1], bf[BF_LPOS + 2]}, lr[9], la[3] = {bf[BF_AXIS], bf[BF_AXIS + 1], bf[BF_AXIS + 2]};
+        for (int k = 0; k < 9; k++) lr[k] = bf[BF_LR + k];
+        mulMV(P2, R, lp); mulMM(R0, R, lr);
+        mulMV(ax[7], R0, la);
+        const float qf = S.q[fi];
+        for (int k = 0; k < 3; k++) { P2[k] += P[k] + ax[7][k] * qf; og[7][k] = P2[k]; }
+        if (isfinger) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = ax[7][k]; } for (int k = 0; k < 9; k++) Rown[k] = R0[k]; }
+      }
+      if (isarm) {
+        for (int k = 0; k < 3; k++) { S.xpos[1 + ai][k] = pown[k]; S.axw[1 + ai][k] = axown[k]; }
+        for (int k = 0; k < 9; k++) S.xR[1 + ai][k] = Rown[k];
+      }
+      if (l == 0) { for (int k = 0; k < 3; k++) S.xpos[0][k] = qc[k]; for (int k = 0; k < 9; k++) S.xR[0][k] = Rc[k]; }
+    }
+    __syncthreads();
+    // ================================================================ sensors of this forward pass
+    {
+      if (l < m.NGS) {
+        const int* si = gI + m.oSensG + l * 4; const int st = si[0], obj = si[1], adr = si[3];
+        if (st == 0 || st == 5) {
+          int b = gI[m.oFrameI + obj]; const float* ff = gF + m.oFrameF + obj * FRAME_F;
+          float bR[9]; for (int k = 0; k < 9; k++) bR[k] = S.xR[b][k];
+          if (st == 0) { float lp[3] = {ff[0], ff[1], ff[2]}, p3[3]; mulMV(p3, bR, lp); for (int k = 0; k < 3; k++) S.y[adr + k] = p3[k] + S.xpos[b][k]; }
+          else { float zl[3] = {ff[3 + 2], ff[3 + 5], ff[3 + 8]}, z[3]; mulMV(z, bR, zl); for (int k = 0; k < 3; k++) S.y[adr + k] = z[k]; }
+        } else if (st == 1) { for (int k = 0; k < 3; k++) S.y[adr + k] = S.xpos[obj][k]; }
+        else if (st == 3) { for (int k = 0; k < 3; k++) S.y[adr + k] = S.xR[obj][3 * k + 2]; }
+      }
+      float dmin[2] = {3.0e38f, 3.0e38f}; int dadr[2] = {-1, -1};
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int t = l + 16 * k;
+        if (t < ndt) {
+          const int ga = sDT[t][1], gb = sDT[t][2];
+          const float* fa = gF + m.oAGF + ga * GEOM_F; const float* fb = gF + m.oAGF + gb * GEOM_F;
+          float pa[3], Ra[9], pb[3], Rb[9], ha[3] = {fa[GF_SIZE], fa[GF_SIZE + 1], fa[GF_SIZE + 2]}, hb[3] = {fb[GF_SIZE], fb[GF_SIZE + 1], fb[GF_SIZE + 2]};
+          geom_pose3(S, fa, gI[m.oAGI + ga * GEOM_I], pa, Ra, true); geom_pose3(S, fb, gI[m.oAGI + gb * GEOM_I], pb, Rb, true);
+          dmin[k] = box_box_distance(pa, Ra, ha, pb, Rb, hb); dadr[k] = sDT[t][0];
+        }
+      }
+      for (int s = 0; s < m.NDIST; s++) {  // per sensor: minimum over its box pairs, clipped at the cutoff
+        const int adr = sDadr[s < 8 ? s : 7];
+        float v = fminf(dadr[0] == adr ? dmin[0] : 3.0e38f, dadr[1] == adr ? dmin[1] : 3.0e38f);
+        v = fminf(gmin(v), gF[m.oDistF + s]);
+        if (l == 0 && adr >= 0) S.y[adr] = v;
+      }
+      __syncthreads();
+      if (MATERIALIZE && sensors && live && l < NS) sensors[((size_t)nc * H + hh) * NS + l] = S.y[l];
+    }
+    // ================================================================ arm dynamics: 9x9 inertia and bias from per-link contributions
+    float Mrow[NA], a0_own, fs_own, Md_own, fsc[6], a0c[6];
+    {
+      // own link (lanes that own no arm dof contribute a massless link 1)
+      const float* bo = gF + m.oBodyF + (1 + ai) * BODY_F;
+      const float mass = isarm ? bo[BF_MASS] : 0.f;
+      float di[3] = {bo[BF_INERTIA] * (isarm ? 1.f : 0.f), bo[BF_INERTIA + 1] * (isarm ? 1.f : 0.f), bo[BF_INERTIA + 2] * (isarm ? 1.f : 0.f)};
+      float lip[3] = {bo[BF_IPOS], bo[BF_IPOS + 1], bo[BF_IPOS + 2]}, lir[9]; for (int k = 0; k < 9; k++) lir[k] = bo[BF_IR + k];
+      float Rk[9], rr[3], com[3]; mulMM(Rk, Rown, lir); mulMV(rr, Rown, lip);
+      for (int k = 0; k < 3; k++) com[k] = pown[k] + rr[k];
+      const int depth = isfinger ? NCHAIN - 1 : ai;  // deepest chain hinge above (or at) the own link
+      // velocity-product accelerations down the chain (gravity as base acceleration)
+      float wv[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao[3] = {-grav[0], -grav[1], -grav[2]};
+#pragma unroll
+      for (int j = 0; j < NCHAIN; j++) {
+        const float qdj = S.qd[j];
+        if (j <= depth) {
+          if (j > 0) {
+            float d[3] = {og[j][0] - og[j - 1][0], og[j][1] - og[j - 1][1], og[j][2] - og[j - 1][2]}, t1[3], t2[3], t3[3];
+            cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d);
+            for (int k = 0; k < 3; k++) ao[k] += t3[k] + t2[k];
+          }
+          float wxa[3]; cross3(wxa, wv, ax[j]);
+          for (int k = 0; k < 3; k++) { al[k] += wxa[k] * qdj; wv[k] += ax[j][k] * qdj; }
+        }
+      }
+      if (isfinger) {  // slide joint: the origin moves with the parent, plus the Coriolis term of the sliding rate
+        float d[3] = {og[7][0] - og[6][0], og[7][1] - og[6][1], og[7][2] - og[6][2]}, t1[3], t2[3], t3[3], wxa[3];
+        cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d); cross3(wxa, wv, ax[7]);
+        for (int k = 0; k < 3; k++) ao[k] += t3[k] + t2[k] + 2.f * wxa[k] * qd;
+      }
+      float t1[3], t2[3], t3[3], ac[3];
+      cross3(t1, wv, rr); cross3(t2, wv, t1); cross3(t3, al, rr);
+      for (int k = 0; k < 3; k++) ac[k] = ao[k] + t3[k] + t2[k];
+      float Iw[3], Ia[3], gy[3]; inertia_mul(Iw, Rk, di, wv); inertia_mul(Ia, Rk, di, al); cross3(gy, wv, Iw);
+      float Fk[3] = {mass * ac[0], mass * ac[1], mass * ac[2]}, Nk[3] = {Ia[0] + gy[0], Ia[1] + gy[1], Ia[2] + gy[2]};
+      // projections on the own link's ancestors: entries 0..6 = chain hinges, entry 7 = own finger slide
+      float Jv[8][3], bias[8], Mc[28], Mf[8];
+#pragma unroll
+      for (int e = 0; e < NCHAIN; e++) {
+        const bool val = e <= depth;
+        float ri[3] = {com[0] - og[e][0], com[1] - og[e][1], com[2] - og[e][2]}, rxF[3];
+        cross3(Jv[e], ax[e], ri); cross3(rxF, ri, Fk);
+        bias[e] = val ? ax[e][0] * (Nk[0] + rxF[0]) + ax[e][1] * (Nk[1] + rxF[1]) + ax[e][2] * (Nk[2] + rxF[2]) : 0.f;
+        if (!val) Jv[e][0] = Jv[e][1] = Jv[e][2] = 0.f;
+      }
+      for (int k = 0; k < 3; k++) Jv[7][k] = isfinger ? ax[7][k] : 0.f;
+      bias[7] = isfinger ? dot3(ax[7], Fk) : 0.f;
+#pragma unroll
+      for (int a = 0; a < NCHAIN; a++) {
+        float tB[3]; inertia_mul(tB, Rk, di, ax[a]);
+        const bool va = a <= depth;
+#pragma unroll
+        for (int b = 0; b <= a; b++) Mc[tri(a, b)] = va ? mass * dot3(Jv[a], Jv[b]) + dot3(tB, ax[b]) : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < NCHAIN; b++) Mf[b] = mass * dot3(Jv[7], Jv[b]);  // slide row: translational coupling only
+      Mf[7] = mass * dot3(Jv[7], Jv[7]);
+      // sums over the links: chain block (all lanes), finger rows (only the finger's own link contributes)
+      for (int k = 0; k < 28; k++) Mc[k] = gsum(Mc[k]);
+      float M7[8], M8[8];
+#pragma unroll
+      for (int b = 0; b < 8; b++) { M7[b] = gsum(ai == 7 && isarm ? Mf[b] : 0.f); M8[b] = gsum(ai == 8 && isarm ? Mf[b] : 0.f); }
+      float bown = isfinger ? bias[7] : 0.f;
+#pragma unroll
+      for (int e = 0; e < NCHAIN; e++) { float b = gsum(bias[e]); if (e == ai && isarm) bown = b; }
+      // full 9x9 (packed lower) with armature on the diagonal, shared through LDS so that each lane can fetch its row
+      float Lm[45];
+#pragma unroll
+      for (int a = 0; a < NCHAIN; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) Lm[tri(a, b)] = Mc[tri(a, b)];
+#pragma unroll
+      for (int b = 0; b < NCHAIN; b++) { Lm[tri(7, b)] = M7[b]; Lm[tri(8, b)] = M8[b]; }
+      Lm[tri(7, 7)] = M7[7]; Lm[tri(8, 7)] = 0.f; Lm[tri(8, 8)] = M8[7];
+#pragma unroll
+      for (int a = 0; a < NA; a++) Lm[tri(a, a)] += gF[m.oDofF + (6 + a) * DOF_F + DF_ARM];
+      if (l == 0) {
+#pragma unroll
+        for (int a = 0; a < NA; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) { S.M[a][b] = Lm[tri(a, b)]; S.M[b][a] = Lm[tri(a, b)]; }
+      }
+      // position servo, joint-level actuator force clamp
+      float cc = u; if (c_clim != 0.f) cc = jh_clampf(cc, c_clo, c_chi);
+      float fa = c_kp * (cc - q) - c_kv * qd;
+      if (c_frclim != 0.f) fa = jh_clampf(fa, c_frclo, c_frchi);
+      fs_own = -c_damp * qd - bown + fa;
+      if (isarm) S.vec[0][ai] = fs_own;
+      __syncthreads();
+      float x9[NA];
+#pragma unroll
+      for (int a = 0; a < NA; a++) { x9[a] = S.vec[0][a]; Mrow[a] = S.M[ai][a]; }
+      chol_solve<NA>(Lm, x9);
+      a0_own = 0.f;
+#pragma unroll
+      for (int a = 0; a < NA; a++) if (a == ai) a0_own = x9[a];
+      Md_own = Mrow[0];
+#pragma unroll
+      for (int a = 1; a < NA; a++) if (a == ai) Md_own = Mrow[a];
+      // free body: M = diag(m, m, m, I)
+      float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
+      for (int k = 0; k < 3; k++) { fsc[k] = cmass * grav[k]; a0c[k] = grav[k]; fsc[3 + k] = -gc[k]; a0c[3 + k] = -gc[k] / cI[k]; }
+      if (iscube) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k == l) { fs_own = fsc[k]; a0_own = a0c[k]; }
+        Md_own = l < 3 ? cmass : cI[l < 3 ? 0 : l - 3];
+      }
+      if (!hasdof) { fs_own = 0.f; a0_own = 0.f; Md_own = 1.f; }
+    }
+    __syncthreads();
+    // ================================================================ collision: 63 candidate pairs over the lanes, balanced narrow phase
+    {
+      int nh = 0;
+      for (int base = 0; base < m.NPAIR; base += G) {
+        const int p = base + l;
+        bool hit = false;
+        if (p < m.NPAIR) {
+          const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
+          const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
+          float p1[3], p2[3];
+          geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, nullptr, false); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, nullptr, false);
+          float dc[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, rs = f1[GF_RBOUND] + f2[GF_RBOUND];
+          hit = dot3(dc, dc) <= rs * rs;
+        }
+        unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+        int pos = nh + __popc(m16 & ((1u << l) - 1u));
+        if (hit && pos < MAXHIT) S.hits[pos] = p;
+        nh += __popc(m16);
+      }
+      nh = nh < MAXHIT ? nh : MAXHIT;
+      __syncthreads();
+      for (int base = 0; __any(base < nh); base += G) {
+        const int idx = base + l;
+        if (idx < nh) {
+          const int p = S.hits[idx];
+          const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
+          const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
+          float p1[3], R1[9], p2[3], R2[9], h1[3] = {f1[GF_SIZE], f1[GF_SIZE + 1], f1[GF_SIZE + 2]}, h2[3] = {f2[GF_SIZE], f2[GF_SIZE + 1], f2[GF_SIZE + 2]};
+          geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, R1, true); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, R2, true);
+          const int sbA = gI[m.oAGI + g1 * GEOM_I], sbB = gI[m.oAGI + g2 * GEOM_I];
+          Sink3 sk{&S, stats, p, sbA >= 1 && sbB >= 1};
+          collide_box_box(sk, p1, R1, h1, p2, R2, h2);
+        }
+      }
+    }
+    __syncthreads();
+    // ================================================================ constraint rows
+    const int ncon = S.ncon < NCP ? S.ncon : NCP;
+    const int nff = S.nff < NFF ? S.nff : NFF;
+    SlotF sf[NFS];
+#pragma unroll
+    for (int k = 0; k < NFS; k++) {  // finger-finger contacts go straight into registers of their owner lane
+      const int c = l + 16 * k;
+      sf[k].valid = c < nff;
+      sf[k].D = 0.f; sf[k].mu = 0.f;
+      for (int w = 0; w < 3; w++) sf[k].aref[w] = sf[k].jar[w] = sf[k].jp[w] = sf[k].J13[w] = sf[k].J14[w] = 0.f;
+      if (sf[k].valid) {
+        const float* e = &S.J[0][0] + c * RAW_F;
+        float fr[9]; fr[0] = e[3]; fr[1] = e[4]; fr[2] = e[5];
+        make_frame(fr);
+        const float dist = e[6]; const int p = __float_as_int(e[7]);
+        const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
+        const int bA = gI[m.oAGI + g1 * GEOM_I], bB = gI[m.oAGI + g2 * GEOM_I];
+        const float s13 = (bB == LF ? 1.f : 0.f) - (bA == LF ? 1.f : 0.f), s14 = (bB == RF ? 1.f : 0.f) - (bA == RF ? 1.f : 0.f);
+        const float a13[3] = {S.axw[LF][0], S.axw[LF][1], S.axw[LF][2]}, a14[3] = {S.axw[RF][0], S.axw[RF][1], S.axw[RF][2]};
+        for (int w = 0; w < 3; w++) { sf[k].J13[w] = s13 * dot3(fr + 3 * w, a13); sf[k].J14[w] = s14 * dot3(fr + 3 * w, a14); }
+        const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
+        const float* q1 = gF + m.oGPF + g1 * GP_F; const float* q2 = gF + m.oGPF + g2 * GP_F;
+        const float mu = fmaxf(f1[GF_MU], f2[GF_MU]), tran = f1[GF_TRAN] + f2[GF_TRAN];
+        float si[5]; for (int w = 0; w < 5; w++) si[w] = 0.5f * (q1[2 + w] + q2[2 + w]);
+        const float tc = fmaxf(0.5f * (q1[0] + q2[0]), 2.f * h), dr_ = 0.5f * (q1[1] + q2[1]);
+        const float cK = 1.f / fmaxf(1e-15f, si[1] * si[1] * tc * tc * dr_ * dr_), cB = 2.f / fmaxf(1e-15f, si[1] * tc);
+        const float imp = impedance(si, dist);
+        const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran * (1.f + mu * mu));
+        const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
+        sf[k].D = 1.f / Rpy; sf[k].mu = mu;
+        const float v13 = S.qd[LF - 1], v14 = S.qd[RF - 1];
+        for (int w = 0; w < 3; w++) { const float vel = sf[k].J13[w] * v13 + sf[k].J14[w] * v14; sf[k].aref[w] = -cB * vel - (w == 0 ? cK * imp * dist : 0.f); }
+      }
+    }
+    __syncthreads();
+    Slot3 sl[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; k++) {  // owner lanes: contact frame (parked in fW until the Jacobian is built)
+      const int c = l + 16 * k;
+      sl[k].valid = c < ncon;
+      if (sl[k].valid) {
+        float fr[9]; fr[0] = S.raw[c][3]; fr[1] = S.raw[c][4]; fr[2] = S.raw[c][5];
+        make_frame(fr);
+        for (int w = 0; w < 9; w++) S.fW[c][w] = fr[w];
+      }
+    }
+    __syncthreads();
+    for (int c = 0; __any(c < ncon); c++) {  // Jacobian: lane r computes column r of every contact
+      if (c < ncon && hasdof) {
+        const float* e = S.raw[c];
+        const float pos[3] = {e[0], e[1], e[2]};
+        float fr[9]; for (int w = 0; w < 9; w++) fr[w] = S.fW[c][w];
+        const int p = __float_as_int(e[7]);
+        const int bA = gI[m.oAGI + gI[m.oPairI + 2 * p] * GEOM_I], bB = gI[m.oAGI + gI[m.oPairI + 2 * p + 1] * GEOM_I];
+        float col[3] = {0.f, 0.f, 0.f};
+        if (iscube) {
+          const float sg = (bB == 0 ? 1.f : 0.f) - (bA == 0 ? 1.f : 0.f);
+          if (l < 3) { col[0] = sg * fr[l]; col[1] = sg * fr[3 + l]; col[2] = sg * fr[6 + l]; }
+          else {
+            float axc[3], rc3[3] = {pos[0] - qc[0], pos[1] - qc[1], pos[2] - qc[2]}, c3[3];
+            col3(axc, Rc, l - 3); cross3(c3, axc, rc3);
+            col[0] = sg * dot3(fr, c3); col[1] = sg * dot3(fr + 3, c3); col[2] = sg * dot3(fr + 6, c3);
+          }
+        } else {
+          // is the side's body in the subtree of the own joint?  chain hinge i: links i..9; finger slide: the finger itself
+          const int kA = bA - 1, kB = bB - 1;
+          const bool inA = bA >= 1 && (isfinger ? kA == ai : kA >= ai), inB = bB >= 1 && (isfinger ? kB == ai : kB >= ai);
+          const float sg = (inB ? 1.f : 0.f) - (inA ? 1.f : 0.f);
+          float c3[3];
+          if (isfinger) { c3[0] = axown[0]; c3[1] = axown[1]; c3[2] = axown[2]; }
+          else { float rb[3] = {pos[0] - pown[0], pos[1] - pown[1], pos[2] - pown[2]}; cross3(c3, axown, rb); }
+          col[0] = sg * dot3(fr, c3); col[1] = sg * dot3(fr + 3, c3); col[2] = sg * dot3(fr + 6, c3);
+        }
+        S.J[c][3 * l] = col[0]; S.J[c][3 * l + 1] = col[1]; S.J[c][3 * l + 2] = col[2];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NSL; k++) {  // owner lanes: per-pair solver parameters, reference acceleration
+      const int c = l + 16 * k;
+      if (sl[k].valid) {
+        const float dist = S.raw[c][6]; const int p = __float_as_int(S.raw[c][7]);
+        const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
+        const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
+        const float* q1 = gF + m.oGPF + g1 * GP_F; const float* q2 = gF + m.oGPF + g2 * GP_F;
+        const float mu = fmaxf(f1[GF_MU], f2[GF_MU]), tran = f1[GF_TRAN] + f2[GF_TRAN];
+        float si[5]; for (int w = 0; w < 5; w++) si[w] = 0.5f * (q1[2 + w] + q2[2 + w]);
+        const float tc = fmaxf(0.5f * (q1[0] + q2[0]), 2.f * h), dr_ = 0.5f * (q1[1] + q2[1]);
+        const float cK = 1.f / fmaxf(1e-15f, si[1] * si[1] * tc * tc * dr_ * dr_), cB = 2.f / fmaxf(1e-15f, si[1] * tc);
+        const float imp = impedance(si, dist);
+        const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran * (1.f + mu * mu));
+        const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
+        sl[k].D = 1.f / Rpy; sl[k].mu = mu;
+        float vel[3]; contact_Jx(S, c, vc, S.qd, vel);
+        sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
+      } else { sl[k].D = 0.f; sl[k].mu = 0.f; for (int w = 0; w < 3; w++) sl[k].aref[w] = sl[k].jar[w] = sl[k].jp[w] = 0.f; }
+    }
+    DofRows3 dr;
+    dr.fl = c_fl; dr.fD = c_fD; dr.fR = c_fD > 0.f ? 1.f / c_fD : 0.f; dr.faref = -c_fB * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
+    if (c_limited != 0.f) {
+      float dlo = q - c_lo, dhi = c_hi - q, dist = fminf(dlo, dhi);
+      if (dist < 0.f) {
+        float sg = dlo < dhi ? 1.f : -1.f, imp = impedance(c_si, dist), R = fmaxf(1e-15f, (1.f - imp) / imp * c_invw);
+        dr.lims = sg; dr.lD = 1.f / R; dr.laref = -c_lB * (sg * qd) - c_lK * imp * dist;
+      }
+    }
+    // joint equality (q13 - a0 - a1 q14 = 0): both finger lanes hold the row; quad 3 = lanes 12..15
+    float eD = 0.f, earef = 0.f, ejar = 0.f, ejp = 0.f;
+    if (has_eq) {
+      const float q13 = quad_get(q, 1), q14 = quad_get(q, 2), v13 = quad_get(qd, 1), v14 = quad_get(qd, 2);
+      const float pos = q13 - e_a0 - e_a1 * q14, vel = v13 - e_a1 * v14;
+      const float imp = impedance(e_si, pos), R = fmaxf(1e-15f, (1.f - imp) / imp * e_invw);
+      eD = 1.f / R; earef = -e_B * vel - e_K * imp * pos;
+    }
+    // ================================================================ Newton solver
+    float a_own;
+    const float iMd = 1.f / Md_own;
+    const float snorm = gsum(hasdof ? fs_own * fs_own * iMd : 0.f);
+    int iters_this = 0;
+    {
+      // ---- warm start: the better of last step's acceleration and the unconstrained one
+      {
+        if (hasdof) { S.vec[0][l] = qws; S.vec[1][l] = a0_own; S.vec[2][l] = qws - a0_own; }
+        __syncthreads();
+        float xc[6], jar_ws[NSL][3];
+        for (int k = 0; k < 6; k++) xc[k] = S.vec[0][k];
+        for (int k = 0; k < NSL; k++) if (sl[k].valid) { float jx[3]; contact_Jx(S, l + 16 * k, xc, S.vec[0] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
+        for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jar[w] = sf[k].J13[w] * S.vec[0][13] + sf[k].J14[w] * S.vec[0][14] - sf[k].aref[w];
+        dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
+        ejar = has_eq ? quad_get(qws, 1) - e_a1 * quad_get(qws, 2) - earef : 0.f;
+        float mdw = 0.f;
+        if (isarm) { for (int a = 0; a < NA; a++) mdw += Mrow[a] * S.vec[2][6 + a]; } else if (iscube) mdw = Md_own * (qws - a0_own);
+        const float cost_ws = gsum(lane_rows_cost(sl, sf, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
+        for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) jar_ws[k][w] = sl[k].jar[w];
+        float jarf_ws[NFS][3];
+        for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) { jarf_ws[k][w] = sf[k].jar[w]; sf[k].jar[w] = sf[k].J13[w] * S.vec[1][13] + sf[k].J14[w] * S.vec[1][14] - sf[k].aref[w]; }
+        const float jf_ws = dr.jf, jl_ws = dr.jl, ej_ws = ejar;
+        for (int k = 0; k < 6; k++) xc[k] = S.vec[1][k];
+        for (int k = 0; k < NSL; k++) if (sl[k].valid) { float jx[3]; contact_Jx(S, l + 16 * k, xc, S.vec[1] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
+        dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
+        ejar = has_eq ? quad_get(a0_own, 1) - e_a1 * quad_get(a0_own, 2) - earef : 0.f;
+        const float cost_0 = gsum(lane_rows_cost(sl, sf, dr, eq_lane, eD, ejar));
+        if (cost_ws < cost_0) {
+          a_own = qws;
+          for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] = jar_ws[k][w];
+          for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jar[w] = jarf_ws[k][w];
+          dr.jf = jf_ws; dr.jl = jl_ws; ejar = ej_ws;
+        } else a_own = a0_own;
+        __syncthreads();
+      }
+      bool has_rows_l = dr.fl > 0.f || dr.lims != 0.f || has_eq;
+      for (int k = 0; k < NSL; k++) has_rows_l |= sl[k].valid;
+      for (int k = 0; k < NFS; k++) has_rows_l |= sf[k].valid;
+      bool act = gor((int)has_rows_l) != 0;
+      if (!act) a_own = a0_own;
+      for (int it = 0; it < cap && __any(act); it++) {
+        // ---- (1) gradient row: M (a - a0) + dof rows + equality - J' f
+        const float da_own = a_own - a0_own;
+        if (hasdof) S.vec[0][l] = da_own;
+#pragma unroll
+        for (int k = 0; k < NSL; k++) if (sl[k].valid) {
+          float f[3], Wm[6]; pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, Wm);
+          float* o = S.fW[l + 16 * k];
+          o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[3 + w] = Wm[w];
+        }
+        __syncthreads();
+        float g_own = 0.f, hd = 0.f;
+        if (isarm) { for (int a = 0; a < NA; a++) g_own += Mrow[a] * S.vec[0][6 + a]; } else if (iscube) g_own = Md_own * da_own;
+        if (dr.fl > 0.f) {
+          float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+          if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += dr.fD * x; hd += dr.fD; }
+        }
+        if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
+        if (has_eq) { if (l == 13) g_own += eD * ejar; if (l == 14) g_own -= e_a1 * eD * ejar; }
+        if (hasdof) for (int c = 0; c < ncon; c++) {
+          const float* jc = S.J[c] + 3 * l; const float* fc = S.fW[c];
+          g_own -= jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2];
+        }
+        float ffg13 = 0.f, ffg14 = 0.f, ffh0 = 0.f, ffh1 = 0.f, ffh2 = 0.f;  // finger-finger contacts: -J'f and J'WJ on the two finger dofs
+#pragma unroll
+        for (int k = 0; k < NFS; k++) if (sf[k].valid) {
+          float f[3], Wm[6]; pyramid_eval(sf[k].jar, sf[k].D, sf[k].mu, f, Wm);
+          const float* j13 = sf[k].J13; const float* j14 = sf[k].J14;
+          ffg13 -= j13[0] * f[0] + j13[1] * f[1] + j13[2] * f[2]; ffg14 -= j14[0] * f[0] + j14[1] * f[1] + j14[2] * f[2];
+          const float G0 = Wm[0] * j13[0] + Wm[1] * j13[1] + Wm[3] * j13[2], G1 = Wm[1] * j13[0] + Wm[2] * j13[1] + Wm[4] * j13[2], G2 = Wm[3] * j13[0] + Wm[4] * j13[1] + Wm[5] * j13[2];
+          const float K0 = Wm[0] * j14[0] + Wm[1] * j14[1] + Wm[3] * j14[2], K1 = Wm[1] * j14[0] + Wm[2] * j14[1] + Wm[4] * j14[2], K2 = Wm[3] * j14[0] + Wm[4] * j14[1] + Wm[5] * j14[2];
+          ffh0 += j13[0] * G0 + j13[1] * G1 + j13[2] * G2; ffh1 += j14[0] * G0 + j14[1] * G1 + j14[2] * G2; ffh2 += j14[0] * K0 + j14[1] * K1 + j14[2] * K2;
+        }
+        if (__any(nff > 0)) {
+          ffg13 = gsum(ffg13); ffg14 = gsum(ffg14); ffh0 = gsum(ffh0); ffh1 = gsum(ffh1); ffh2 = gsum(ffh2);
+          if (l == 13) g_own += ffg13;
+          if (l == 14) g_own += ffg14;
+        }
+        // ---- (2) convergence on the scaled gradient; leave before any Hessian work once every rollout of the wave is done
+        const float gn = gsum(hasdof ? g_own * g_own * iMd : 0.f);
+#ifdef JH_V3_EXITSTATS
+        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) n_x[0]++;
+#endif
+        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        if (!__any(act)) break;
+        if (act) iters_this++;
+        // ---- (3) Hessian row r (columns 0..r): M + dof rows + equality + sum_c J_c[:,r]' W_c J_c[:,0..r]; lane 15 holds -g
+        if (hasdof) S.vec[1][l] = -g_own;
+        float Hrow[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) Hrow[j] = 0.f;
+        if (isarm) {
+#pragma unroll
+          for (int a = 0; a < NA; a++) Hrow[6 + a] = Mrow[a];
+        }
+#pragma unroll
+        for (int j = 0; j < NVT; j++) if (j == l) Hrow[j] = (iscube ? Md_own : Hrow[j]) + hd;
+        if (has_eq) {
+          if (l == 13) Hrow[13] += eD;
+          if (l == 14) { Hrow[14] += e_a1 * e_a1 * eD; Hrow[13] -= e_a1 * eD; }
+        }
+        if (l == 13) Hrow[13] += ffh0;
+        if (l == 14) { Hrow[13] += ffh1; Hrow[14] += ffh2; }
+        if (hasdof) for (int c = 0; c < ncon; c++) {
+          const float* fc = S.fW[c];
+          if (fc[3] == 0.f && fc[5] == 0.f && fc[8] == 0.f) continue;  // no active pyramid row
+          const float* Jc = S.J[c];
+          const float j0 = Jc[3 * l], j1 = Jc[3 * l + 1], j2 = Jc[3 * l + 2];
+          const float G0 = fc[3] * j0 + fc[4] * j1 + fc[6] * j2, G1 = fc[4] * j0 + fc[5] * j1 + fc[7] * j2, G2 = fc[6] * j0 + fc[7] * j1 + fc[8] * j2;
+#pragma unroll
+          for (int j = 0; j < NVT; j++) Hrow[j] += Jc[3 * j] * G0 + Jc[3 * j + 1] * G1 + Jc[3 * j + 2] * G2;
+        }
+        __syncthreads();
+        if (l == 15) {
+#pragma unroll
+          for (int j = 0; j < NVT; j++) Hrow[j] = S.vec[1][j];
+        }
+        // ---- (4) left-looking row Cholesky through LDS: at step k lane k finishes and publishes row k, rows below take column k
+#pragma unroll
+        for (int k = 0; k < NVT; k++) {
+          if (l == k) {
+            float d = Hrow[k];
+#pragma unroll
+            for (int j = 0; j < k; j++) d -= Hrow[j] * Hrow[j];
+            const float rinv = __frsqrt_rn(fmaxf(d, 1e-30f));
+#pragma unroll
+            for (int j = 0; j < k; j++) S.Lrow[k][j] = Hrow[j];
+            S.Lrow[k][k] = rinv;
+          }
+          __syncthreads();
+          if (l > k) {
+            float s = Hrow[k];
+#pragma unroll
+            for (int j = 0; j < k; j++) s -= Hrow[j] * S.Lrow[k][j];
+            Hrow[k] = s * S.Lrow[k][k];
+          }
+        }
+        if (l == 15) {
+#pragma unroll
+          for (int j = 0; j < NVT; j++) S.Lrow[15][j] = Hrow[j];
+        }
+        __syncthreads();
+        // ---- (5) backward solve, redundantly: every lane gets the whole direction p
+        float p[NVT];
+#pragma unroll
+        for (int k = NVT - 1; k >= 0; k--) {
+          float s = S.Lrow[15][k];
+#pragma unroll
+          for (int j = k + 1; j < NVT; j++) s -= S.Lrow[j][k] * p[j];
+          p[k] = s * S.Lrow[k][k];
+        }
+        float p_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
+        // ---- (6) exact line search along p
+        float Mp_own = 0.f;
+        if (isarm) {
+#pragma unroll
+          for (int a = 0; a < NA; a++) Mp_own += Mrow[a] * p[6 + a];
+        } else if (iscube) Mp_own = Md_own * p_own;
+        const float pMp = gsum(p_own * Mp_own), pMd = gsum(Mp_own * da_own), gp = gsum(g_own * p_own);
+#ifdef JH_V3_EXITSTATS
+        if (act && !(gp < 0.f)) n_x[1]++;
+#endif
+        if (act && !(gp < 0.f)) act = false;
+#pragma unroll
+        for (int k = 0; k < NSL; k++) if (sl[k].valid) {
+          const float* Jc = S.J[l + 16 * k];
+          float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < NVT; j++) { o0 = fmaf(Jc[3 * j], p[j], o0); o1 = fmaf(Jc[3 * j + 1], p[j], o1); o2 = fmaf(Jc[3 * j + 2], p[j], o2); }
+          sl[k].jp[0] = o0; sl[k].jp[1] = o1; sl[k].jp[2] = o2;
+        }
+        for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jp[w] = sf[k].J13[w] * p[13] + sf[k].J14[w] * p[14];
+        dr.pf = p_own; dr.pl = dr.lims * p_own;
+        ejp = has_eq ? p[13] - e_a1 * p[14] : 0.f;
+        float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
+        for (int ls = 0; ls < 12 && __any(lsact); ls++) {
+          float d1, d2;
+          lane_rows_dir(sl, sf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
+#ifdef JH_V3_DEBUG
+          const float d1raw = d1, d2raw = d2;
+#endif
+          d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
+#ifdef JH_V3_DEBUG
+          if (hh == 0 && it == 2 && ls < 6) { dls[ls][0] = d1; dls[ls][1] = d2; dls[ls][2] = alpha; dls[ls][3] = d1raw; }
+#endif
+          if (lsact) {
+            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
+            else {
+              if (d1 < 0.f) lo = alpha; else hi = alpha;
+              float nx = alpha - d1 * __frcp_rn(d2);
+              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
+              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
+              alpha = nx;
+            }
+          }
+        }
+#ifdef JH_V3_DEBUG
+        if (hh == 0 && it < 8) { dit[it][0] = gn; dit[it][1] = gp; dit[it][2] = alpha; dit[it][3] = g_own; dit[it][4] = p_own; dit[it][5] = a_own; dit[it][6] = act ? 1.f : 0.f; dit[it][7] = snorm; }
+#endif
+        // ---- (7) step
+        if (act) {
+          a_own += alpha * p_own;
+          for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] += alpha * sl[k].jp[w];
+          for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jar[w] += alpha * sf[k].jp[w];
+          dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl; ejar += alpha * ejp;
+#ifdef JH_V3_EXITSTATS
+          if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) n_x[2]++;
+#endif
+          if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        }
+        __syncthreads();
+      }
+      if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
+#ifdef JH_V3_EXITSTATS
+      if (act) n_x[3]++;
+#endif
+    }
+    // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
+    {
+      __syncthreads();
+      const float da_own = a_own - a0_own;
+      if (hasdof) S.vec[0][l] = da_own;
+      __syncthreads();
+      float rhs_own = fs_own;
+      if (isarm) { for (int a = 0; a < NA; a++) rhs_own += Mrow[a] * S.vec[0][6 + a]; } else if (iscube) rhs_own += Md_own * da_own;
+      if (hasdof) S.vec[1][l] = rhs_own;
+      __syncthreads();
+      float Lm[45], x9[NA];
+#pragma unroll
+      for (int a = 0; a < NA; a++) {
+#pragma unroll
+        for (int b = 0; b <= a; b++) Lm[tri(a, b)] = S.M[a][b];
+        Lm[tri(a, a)] += h * (gF[m.oDofF + (6 + a) * DOF_F + DF_DAMP] + gF[m.oDofF + (6 + a) * DOF_F + DF_KV]);
+        x9[a] = S.vec[1][6 + a];
+      }
+      chol_solve<NA>(Lm, x9);
+      float qacc = 0.f;
+#pragma unroll
+      for (int a = 0; a < NA; a++) if (a == ai) qacc = x9[a];
+      if (isarm) { qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); }
+      qws = a_own;
+#ifdef JH_V3_DEBUG
+      if (hh == 0) { dbg[0] = fs_own; dbg[1] = a0_own; dbg[2] = a_own; dbg[3] = qacc; dbg[4] = eD; dbg[5] = earef; dbg[6] = ejar; dbg[7] = dr.jf; dbg[8] = dr.fD; dbg[9] = dr.fl; dbg[10] = dr.lims; dbg[11] = (float)iters_this; }
+#endif
+      for (int k = 0; k < 3; k++) {  // free body: every lane integrates the replicated state from the published right-hand side
+        const float al = S.vec[1][k] / cmass, aw = S.vec[1][3 + k] / cI[k];
+        vc[k] = fmaf(h, al, vc[k]); vc[3 + k] = fmaf(h, aw, vc[3 + k]);
+      }
+      for (int k = 0; k < 3; k++) qc[k] = fmaf(h, vc[k], qc[k]);
+      const float wn = sqrtf(vc[3] * vc[3] + vc[4] * vc[4] + vc[5] * vc[5]), ang = wn * h;
+      if (ang > 0.f) {
+        float sn, cs; sincosf(0.5f * ang, &sn, &cs); const float kk = sn / wn;
+        float dq[4] = {cs, vc[3] * kk, vc[4] * kk, vc[5] * kk}, *qq = qc + 3;
+        float r0 = qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2] - qq[3] * dq[3];
+        float r1 = qq[0] * dq[1] + qq[1] * dq[0] + qq[2] * dq[3] - qq[3] * dq[2];
+        float r2 = qq[0] * dq[2] - qq[1] * dq[3] + qq[2] * dq[0] + qq[3] * dq[1];
+        float r3 = qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1] + qq[3] * dq[0];
+        qq[0] = r0; qq[1] = r1; qq[2] = r2; qq[3] = r3;
+      }
+      const float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
+      qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+    }
+    if (MATERIALIZE) {
+      if (states && live) {
+        float* o = states + ((size_t)nc * H + hh) * NX;
+        if (isarm) { o[7 + ai] = q; o[NQ + 6 + ai] = qd; }
+        if (l < 7) o[l] = qc[l];
+        if (l < 6) o[NQ + l] = vc[l];
+      }
+      __syncthreads();
+    } else {
+      // running cost: the state after the step with the sensors of the forward pass that produced it (judo/tasks/fr3_pick.py:225-311)
+      __syncthreads();
+      if (isarm) { S.vec[0][ai] = q; S.vec[1][ai] = qd; }
+      __syncthreads();
+      float qpos[NQ], qvel[NVT], y[NS];
+      for (int k = 0; k < 7; k++) qpos[k] = qc[k];
+      for (int k = 0; k < 6; k++) qvel[k] = vc[k];
+      for (int a = 0; a < NA; a++) { qpos[7 + a] = S.vec[0][a]; qvel[6 + a] = S.vec[1][a]; }
+      for (int k = 0; k < NS; k++) y[k] = S.y[k];
+      acc += fr3_step_cost(sTp, phase, qpos, qvel, NVT, y, H > 1 ? 1.f - (float)hh / (float)(H - 1) : 1.f);
+      __syncthreads();
+    }
+  }
+#ifdef JH_V3_DEBUG
+  __syncthreads();
+  if (MATERIALIZE && states && N == 4 && n == 0) {  // debug dump (tools/debug_fr3_m.py), one wave: step-0 quantities into the other rollouts' output rows
+    float* o = states + (size_t)H * NX;
+    for (int k = 0; k < 12; k++) o[16 * k + l] = dbg[k];
+    for (int it = 0; it < 8; it++) for (int k = 0; k < 8; k++) o[192 + (it * 8 + k) * 16 + l] = dit[it][k];
+    for (int e = 0; e < 6; e++) for (int k = 0; k < 4; k++) o[192 + 1024 + (e * 4 + k) * 16 + l] = dls[e][k];
+  }
+#endif
+  if (!MATERIALIZE && live && l == 0) costs[n] = acc;
+#ifdef JH_V3_EXITSTATS
+  if (stats && live && l == 0) for (int k = 0; k < 4; k++) atomicAdd(stats + 24 + k, n_x[k]);
+#endif
+  if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
+}
+
+}  // namespace
+
+bool jh_model_is_fr3(const jh_model* m) {
+  if (!(m->kind == JH_TASK_FR3_PICK && m->nq == NQ && m->nv == NVT && m->nu == NU && m->ns == NS && m->h_i.size() > 24 && m->h_i[0] == NMB && m->h_i[9] == 0)) return false;
+  const int gi = m->h_i[13];
+  // 7 hinges in a chain welded to the world, two slides on the last link; boxes only; at most one joint equality on the fingers
+  for (int b = 1; b <= 9; b++) {
+    const int* bi = m->h_i.data() + jh_eng::HEADER_I + b * jh_eng::BODY_I;
+    const int par = bi[0], jt = bi[1], dof = bi[2];
+    if (dof != 5 + b) return false;
+    if (b <= 7) { if (jt != jh_eng::JHINGE || par != (b == 1 ? -1 : b - 1)) return false; }
+    else if (jt != jh_eng::JSLIDE || par != 7) return false;
+  }
+  const int nag = m->h_i[gi], npair = m->h_i[gi + 1], neq = m->h_i[gi + 2], ngs = m->h_i[gi + 5];
+  if (neq > 1 || ngs > G || m->h_i[gi + 4] > 8) return false;
+  for (int s = 0; s < ngs; s++) if (m->h_i[gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3] + m->h_i[gi + 4] * 4 + s * 4] == 2) return false;  // no jointpos sensors
+  { int nt = 0; const int* di = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3]; for (int s = 0; s < m->h_i[gi + 4]; s++) nt += di[4 * s + 1] * di[4 * s + 3]; if (nt > MAXDT) return false; }
+  for (int g = 0; g < nag; g++) if (m->h_i[gi + 8 + g * jh_eng::GEOM_I + 1] != jh_eng::GBOX) return false;
+  for (int p = 0; p < npair; p++) {  // pairs between two articulated bodies are kept as finger-finger contacts: nothing else qualifies
+    const int* pi = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + 2 * p;
+    const int b1 = m->h_i[gi + 8 + pi[0] * jh_eng::GEOM_I], b2 = m->h_i[gi + 8 + pi[1] * jh_eng::GEOM_I];
+    if (b1 >= 1 && b2 >= 1 && !((b1 == LF && b2 == RF) || (b1 == RF && b2 == LF))) return false;
+  }
+  if (neq == 1) { const int* ei = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2; if (ei[0] != 13 || ei[1] != 14) return false; }
+  for (int u = 0; u < NU; u++) if (m->h_i[jh_eng::HEADER_I + NMB * jh_eng::BODY_I + m->h_i[1] * jh_eng::BLOCK_I + u * jh_eng::ACT_I] != 6 + u) return false;
+  return true;
+}
+
+int jh_engine3_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                            const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+  if (!jh_model_is_fr3(m)) { jh_set_error("rollout_cost: the cooperative arm kernel is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }
+  JH_REQUIRE(K <= 8, "rollout_cost: the cooperative arm kernel keeps at most 8 knots per actuator in registers (K=%d)", K);
+  int grid = (N + RPW - 1) / RPW;
+  hipLaunchKernelGGL(k_fr3_v3<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
+                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+int jh_engine3_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                           hipStream_t st) {
+  if (!jh_model_is_fr3(m)) { jh_set_error("rollout_materialize: the cooperative arm kernel is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }
+  int grid = (N + RPW - 1) / RPW;
+  hipLaunchKernelGGL(k_fr3_v3<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
+                     (float*)nullptr, controls, states, sensors, m->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

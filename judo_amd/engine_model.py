@@ -226,6 +226,14 @@ def generic_pairs(desc: dict, fused: dict, st: dict) -> list[tuple[int, int]]:
             if desc.get("family", desc["task"]) == "leap_cube" and free_fused not in (ga["body"], gb["body"]):
                 continue
             out.append((a, b))
+    # order by importance for the fixed-capacity contact pools: pairs with the free body first, then pairs against static
+    # geometry, pairs between two articulated bodies (e.g. the two fingers' pad stacks) last -- those are the ones dropped on overflow
+    def rank(pr):
+        ba, bb = geoms[pr[0]]["body"], geoms[pr[1]]["body"]
+        if free_fused in (ba, bb):
+            return 0
+        return 1 if (st["is_static"][ba] or st["is_static"][bb]) else 2
+    out.sort(key=rank)  # stable: original order within a class
     return out
 
 

@@ -1,0 +1,34 @@
+"""Scratch diagnostic (GPU box): fused fr3 costs of both kernel generations vs the oracle, per rollout."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from judo_amd.controller import make_controller
+from oracle import oracle as O
+from tests.harness import oracle_plan_step
+np.set_printoptions(precision=5, suppress=True, linewidth=200)
+phase = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+N = 256
+res = {}
+for gen in (2, 1):
+    rng = np.random.default_rng(10 + phase)
+    ctrl = make_controller("fr3_pick", "cem"); ctrl.optimizer.config.num_rollouts = N; ctrl.controller_cfg.horizon = 40 * ctrl.task.dt
+    ctrl.reset(); ctrl.model.set_kernel(gen)
+    x0 = ctrl.task.default_state()
+    if phase == 1: x0[2] = 0.05
+    elif phase == 2: x0[0:3] = [0.6, 0.4, 0.05]
+    elif phase == 3: x0[0:3] = [0.6, 0.4, 0.02]
+    ctrl.current_state = x0
+    noise = rng.standard_normal((N - 1, 4, 8)).astype(np.float32)
+    ctrl.optimizer.injected_noise = noise; ctrl.keep_candidates = True
+    nominal0 = ctrl.nominal_knots.copy(); sigma0 = ctrl.optimizer.sigma.copy()
+    ctrl.update_action(); torch.cuda.synchronize()
+    res[gen] = -ctrl.rewards_local
+    if gen == 2:
+        ref = oracle_plan_step(O.Model("fr3_pick"), ctrl, nominal0, noise, "cem", sigma0)
+    print('gen', gen, ctrl.model.stats())
+r = -ref["rewards"]
+for gen in (2, 1):
+    d = np.abs(res[gen] - r)
+    print('gen', gen, 'median', np.median(d), 'p95', np.percentile(d, 95), 'max', d.max(), 'n>0.01:', (d > 0.01).sum())
+bad = np.argsort(-np.abs(res[2] - r))[:12]
+print('worst rollouts', bad); print('oracle', r[bad]); print('gen2  ', res[2][bad]); print('gen1  ', res[1][bad])
