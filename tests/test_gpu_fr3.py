@@ -1,5 +1,5 @@
-"""GPU parity tests for fr3_pick (BASELINE config 4: CEM, 7-DoF arm + gripper + cube + table) on the generic articulated
-engine kernel, against the fp64 oracle.  Collision scope on both sides: box geoms (cube, table, hand and finger boxes);
+"""GPU parity tests for fr3_pick (BASELINE config 4: CEM, 7-DoF arm + gripper + cube + table) on the cooperative arm kernel
+(default; the generic one-lane kernel is cross-checked at the end), against the fp64 oracle.  Collision scope on both sides: box geoms (cube, table, hand and finger boxes);
 the capsule stand-ins for the arm links' collision meshes are not collided."""
 
 import os
@@ -60,7 +60,7 @@ def test_fr3_rollout_backend_matches_oracle(gpu, x0_kind):
     assert np.median(es) < 1e-5 and np.percentile(es, 99) < 5e-3
     st = be.model.stats()
     # closing the empty gripper slams the two pad stacks together: for 1-2 steps the oracle itself sees up to 72 contacts (36 box
-    # pairs), above the kernel capacity of 64; the dropped points are redundant pad-pad contacts (parity above is unaffected)
+    # pairs), above the kernel capacity (48 finger-finger + 32 other contacts); the dropped points are redundant pad-pad contacts (parity above is unaffected)
     assert st["contact_overflow"] < 4 * st["steps"]
 
 
@@ -108,3 +108,25 @@ def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
     gap = np.sort(ref["rewards"])[::-1]
     if gap[2] - gap[3] > 5 * np.percentile(d, 99):
         np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], atol=1e-5)
+
+
+def test_fr3_two_kernel_generations_agree(gpu):
+    """The cooperative kernel (16 lanes per rollout, dense row-per-lane Hessian) and the one-lane-per-rollout generic kernel are
+    independent implementations of the same step: on identical inputs their rollouts and sensors agree to solver tolerance over
+    the first steps (contact-rich trajectories decorrelate later, each still tracking the oracle as the tests above require)."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+
+    N, H = 96, 40
+    om, task, knots, U = _controls(N, H, seed=4)
+    x0 = task.default_state().copy()
+    x0[7:14] = [0.0, 0.55, 0.0, -2.05, 0.0, 2.6, 0.785]
+    x0[14:16] = [0.03, 0.025]
+    b2 = GpuRolloutBackend("fr3_pick", N)
+    s2, y2, _ = b2.rollout(x0, U)
+    b1 = GpuRolloutBackend("fr3_pick", N)
+    b1.model.set_kernel(1)
+    s1, y1, _ = b1.rollout(x0, U)
+    np.testing.assert_allclose(s2[:, :3], s1[:, :3], atol=2e-4)
+    np.testing.assert_allclose(y2[:, :3], y1[:, :3], atol=2e-4)
+    e = np.abs(s2 - s1)
+    assert np.median(e) < 2e-6 and np.percentile(e[:, -1, :3], 90) < 5e-3
