@@ -45,8 +45,30 @@ __device__ __forceinline__ float gmin(float v) {  // min over the 16 lanes of a 
 }
 
 // box-box contacts, normal from box 1 to box 2 (same algorithm as jh_engine.hip / the oracle); every contact goes to sk.push(pos, normal, dist)
+// element / row i (0..2, a run-time value) of a register array, and the triple rotated to start at i: compare-and-select instead of
+// an indexed read, so that the arrays stay in registers (an indexed read, or picking between two arrays through a pointer, puts them
+// in scratch memory: one lane's box-box call then costs a round trip through memory per operand)
+// (the empty asm pins the candidates in registers first: otherwise the compiler folds the select of three loads back into one load
+// from a computed address, which is exactly the indexed scratch access this is meant to avoid)
+__device__ __forceinline__ float pick(const float* a, int i) {
+  float a0 = a[0], a1 = a[1], a2 = a[2];
+#ifndef JH_PICK_NOASM
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+#endif
+  return i == 0 ? a0 : (i == 1 ? a1 : a2);
+}
+__device__ __forceinline__ void pick_row(float* o, const float (*M)[3], int i) {
+  for (int k = 0; k < 3; k++) {
+    float m0 = M[0][k], m1 = M[1][k], m2 = M[2][k];
+#ifndef JH_PICK_NOASM
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2));
+#endif
+    o[k] = i == 0 ? m0 : (i == 1 ? m1 : m2);
+  }
+}
+
 template <class Sink>
-__device__ void collide_box_box(Sink& sk, const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
+__device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
   float A[3][3], B[3][3], dv[3], Cm[3][3], AC[3][3], dA[3], dB[3];
   for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
   for (int i = 0; i < 3; i++) { dA[i] = dot3(dv, A[i]); dB[i] = dot3(dv, B[i]); for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); AC[i][j] = fabsf(Cm[i][j]); } }
@@ -84,36 +106,51 @@ __device__ void collide_box_box(Sink& sk, const float* p1, const float* R1, cons
       if (k != ej) { float s = (dot3(n, B[k]) > 0.f ? -1.f : 1.f) * h2[k]; pb[0] += B[k][0] * s; pb[1] += B[k][1] * s; pb[2] += B[k][2] * s; }
     }
     float wv[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-    float b = Cm[ei][ej], dd = dot3(A[ei], wv), e = dot3(B[ej], wv), den = 1.f - b * b;
+    float Ae[3], Be[3], Cme[3]; pick_row(Ae, A, ei); pick_row(Be, B, ej); pick_row(Cme, Cm, ei);
+    const float h1e = pick(h1, ei), h2e = pick(h2, ej);
+    float b = pick(Cme, ej), dd = dot3(Ae, wv), e = dot3(Be, wv), den = 1.f - b * b;
     float s = den > 1e-12f ? (b * e - dd) / den : 0.f, t = den > 1e-12f ? (e - b * dd) / den : 0.f;
-    s = jh_clampf(s, -h1[ei], h1[ei]); t = jh_clampf(t, -h2[ej], h2[ej]);
+    s = jh_clampf(s, -h1e, h1e); t = jh_clampf(t, -h2e, h2e);
     float pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + A[ei][k] * s) + (pb[k] + B[ej][k] * t));
+    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + Ae[k] * s) + (pb[k] + Be[k] * t));
     sk.push(pos, n, ebest);
     return;
   }
-  const float *pr, *pi, *hr, *hi; float (*Ar)[3], (*Ai)[3]; int ri; float n[3];
-  if (btype == 0) { pr = p1; pi = p2; hr = h1; hi = h2; Ar = A; Ai = B; ri = bi; float sg = dA[bi] >= 0.f ? 1.f : -1.f; for (int k = 0; k < 3; k++) n[k] = sg * A[bi][k]; }
-  else { pr = p2; pi = p1; hr = h2; hi = h1; Ar = B; Ai = A; ri = bj; float sg = dB[bj] >= 0.f ? -1.f : 1.f; for (int k = 0; k < 3; k++) n[k] = sg * B[bj][k]; }
+  // reference box (owns the separating face) and incident box: values selected into registers
+  const bool f0 = btype == 0;
+  const int ri = f0 ? bi : bj;
+  float pr[3], pi[3], hr[3], hi[3], Ar[3][3], Ai[3][3], n[3];
+  for (int k = 0; k < 3; k++) {
+    pr[k] = f0 ? p1[k] : p2[k]; pi[k] = f0 ? p2[k] : p1[k]; hr[k] = f0 ? h1[k] : h2[k]; hi[k] = f0 ? h2[k] : h1[k];
+    for (int j = 0; j < 3; j++) { Ar[k][j] = f0 ? A[k][j] : B[k][j]; Ai[k][j] = f0 ? B[k][j] : A[k][j]; }
+  }
+  {
+    float Arr[3]; pick_row(Arr, Ar, ri);
+    const float dref = f0 ? pick(dA, bi) : pick(dB, bj);
+    const float sg = f0 ? (dref >= 0.f ? 1.f : -1.f) : (dref >= 0.f ? -1.f : 1.f);
+    for (int k = 0; k < 3; k++) n[k] = sg * Arr[k];
+  }
   int mi = 0; float mb = -1.f;
   for (int k = 0; k < 3; k++) { float v = fabsf(dot3(n, Ai[k])); if (v > mb) { mb = v; mi = k; } }
-  float sgi = dot3(n, Ai[mi]) > 0.f ? -1.f : 1.f;
-  int u = (mi + 1) % 3, v = (mi + 2) % 3;
   // Face manifold without polygon buffers: the vertices of (incident quad) n (reference rectangle) are exactly
   //   (a) incident vertices inside the rectangle, (b) incident-edge x rectangle-edge crossings, (c) rectangle corners inside the quad;
   // contact order is irrelevant, so they are emitted as found (same point set as Sutherland-Hodgman clipping).
-  const int ra = (ri + 1) % 3, rb = (ri + 2) % 3;
-  const float ha = hr[ra], hb = hr[rb];
+  const int u = mi == 2 ? 0 : mi + 1, v = mi == 0 ? 2 : mi - 1, ra = ri == 2 ? 0 : ri + 1, rb = ri == 0 ? 2 : ri - 1;
+  float Aim[3], Aiu[3], Aiv[3], Ara[3], Arb[3];
+  pick_row(Aim, Ai, mi); pick_row(Aiu, Ai, u); pick_row(Aiv, Ai, v); pick_row(Ara, Ar, ra); pick_row(Arb, Ar, rb);
+  const float him = pick(hi, mi), hiu = pick(hi, u), hiv = pick(hi, v);
+  const float sgi = dot3(n, Aim) > 0.f ? -1.f : 1.f;
+  const float ha = pick(hr, ra), hb = pick(hr, rb);
   float ci[3], e1[3], e2[3];
-  for (int k = 0; k < 3; k++) { ci[k] = pi[k] + sgi * hi[mi] * Ai[mi][k] - pr[k]; e1[k] = hi[u] * Ai[u][k]; e2[k] = hi[v] * Ai[v][k]; }
-  const float ca = dot3(ci, Ar[ra]), cbb = dot3(ci, Ar[rb]), cg = dot3(ci, n);
-  const float e1a = dot3(e1, Ar[ra]), e1b = dot3(e1, Ar[rb]), e1g = dot3(e1, n), e2a = dot3(e2, Ar[ra]), e2b = dot3(e2, Ar[rb]), e2g = dot3(e2, n);
-  const float href = hr[ri];
-  auto emit = [&](float al, float be, float ga) {
+  for (int k = 0; k < 3; k++) { ci[k] = pi[k] + sgi * him * Aim[k] - pr[k]; e1[k] = hiu * Aiu[k]; e2[k] = hiv * Aiv[k]; }
+  const float ca = dot3(ci, Ara), cbb = dot3(ci, Arb), cg = dot3(ci, n);
+  const float e1a = dot3(e1, Ara), e1b = dot3(e1, Arb), e1g = dot3(e1, n), e2a = dot3(e2, Ara), e2b = dot3(e2, Arb), e2g = dot3(e2, n);
+  const float href = pick(hr, ri);
+  auto emit = [&](float al, float be, float ga) __attribute__((always_inline)) {
     float depth = href - ga;
     if (depth <= 0.f) return;
     float pos[3], nn[3], gm = ga + 0.5f * depth;
-    for (int k = 0; k < 3; k++) { pos[k] = pr[k] + al * Ar[ra][k] + be * Ar[rb][k] + gm * n[k]; nn[k] = btype == 0 ? n[k] : -n[k]; }
+    for (int k = 0; k < 3; k++) { pos[k] = pr[k] + al * Ara[k] + be * Arb[k] + gm * n[k]; nn[k] = f0 ? n[k] : -n[k]; }
     sk.push(pos, nn, -depth);
   };
   const float s1[4] = {1, -1, -1, 1}, s2[4] = {1, 1, -1, -1};
@@ -145,7 +182,7 @@ __device__ void collide_box_box(Sink& sk, const float* p1, const float* R1, cons
 }
 
 template <class Sink>
-__device__ void collide_box_sphere(Sink& sk, const float* pb, const float* Rb, const float* hb, const float* c, float r) {
+__device__ __forceinline__ void collide_box_sphere(Sink& sk, const float* pb, const float* Rb, const float* hb, const float* c, float r) {
   float dl[3] = {c[0] - pb[0], c[1] - pb[1], c[2] - pb[2]}, cl[3], q[3]; bool outside = false;
   mulMTV(cl, Rb, dl);
   for (int k = 0; k < 3; k++) { q[k] = cl[k]; if (q[k] > hb[k]) { q[k] = hb[k]; outside = true; } else if (q[k] < -hb[k]) { q[k] = -hb[k]; outside = true; } }
@@ -157,8 +194,8 @@ __device__ void collide_box_sphere(Sink& sk, const float* pb, const float* Rb, c
   } else {
     int kb = 0; float mn = 1e30f;
     for (int k = 0; k < 3; k++) { float s = hb[k] - fabsf(cl[k]); if (s < mn) { mn = s; kb = k; } }
-    nl[0] = nl[1] = nl[2] = 0.f; nl[kb] = cl[kb] >= 0.f ? 1.f : -1.f;
-    q[kb] = nl[kb] * hb[kb]; dist = -mn - r;
+    for (int k = 0; k < 3; k++) { nl[k] = k == kb ? (cl[k] >= 0.f ? 1.f : -1.f) : 0.f; if (k == kb) q[k] = nl[k] * hb[k]; }  // no run-time array index: stays in registers
+    dist = -mn - r;
   }
   float ql[3] = {q[0] + 0.5f * dist * nl[0], q[1] + 0.5f * dist * nl[1], q[2] + 0.5f * dist * nl[2]}, pos[3], n[3];
   mulMV(pos, Rb, ql); for (int k = 0; k < 3; k++) pos[k] += pb[k];
@@ -168,7 +205,7 @@ __device__ void collide_box_sphere(Sink& sk, const float* pb, const float* Rb, c
 
 
 // signed box-box distance = largest separation over the 15 SAT axes (exact when a face or an edge pair is closest; see the oracle)
-__device__ inline float box_box_distance(const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
+__device__ __forceinline__ float box_box_distance(const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
   float A[3][3], B[3][3], dv[3], best = -1e30f;
   for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
   for (int i = 0; i < 3; i++) {

@@ -29,7 +29,10 @@ constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, NMB = 10;
 constexpr int NCP = 32, NSL = NCP / G, MAXHIT = 32, RAW_F = 8, JW = NVT * 3;
 constexpr int MAXDT = 32;  // box pairs behind the distance sensors
-constexpr int NFS = 3, NFF = NFS * G;  // finger-finger contacts: kept in registers of their owner lanes (3 per lane), never in the LDS Jacobian
+#ifndef JH_V3_NFS
+#define JH_V3_NFS 3
+#endif
+constexpr int NFS = JH_V3_NFS, NFF = NFS * G;  // finger-finger contacts: kept in registers of their owner lanes (3 per lane), never in the LDS Jacobian
 constexpr int LF = 8, RF = 9;       // moving-body indices of the two fingers (arm dofs 7 / 8 = lanes 13 / 14)
 
 struct __attribute__((aligned(16))) RS3 {  // per-rollout shared state
@@ -44,6 +47,7 @@ struct __attribute__((aligned(16))) RS3 {  // per-rollout shared state
   float J[NCP][JW];                             // J[c][3 r + w]: contact-frame row w, dof r
   float fW[NCP][9];                             // frame (while rows are built), then f[3], W[6] of the current Newton iterate
   float y[16];                                  // sensordata of the forward pass
+  float kn[NU][8];                              // spline knots per actuator (kept out of the register file: they are read once per step)
   int hits[MAXHIT];
   int ncon, nhit, nff;
 };
@@ -232,9 +236,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
     if (isarm) { q = xi[7 + ai]; qd = xi[NQ + 6 + ai]; }
   }
   // ---- own actuator's spline knots (fused mode)
-  float kn[8];
   if (!MATERIALIZE) {
-    for (int k = 0; k < 8; k++) kn[k] = 0.f;
     if (hasact) {
       const int u = l - 6;
       for (int k = 0; k < K && k < 8; k++) {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         float v = nominal[i];
         if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
         v = jh_clampf(v, lohi[u], lohi[NU + u]);
-        kn[k] = v;
+        S.kn[u][k] = v;
         if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
       }
     }
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
     float u = 0.f;
     if (hasact) {
       if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + (l - 6)];
-      else for (int k = 0; k < K && k < 8; k++) u = fmaf(W[hh * K + k], kn[k], u);
+      else for (int k = 0; k < K && k < 8; k++) u = fmaf(W[hh * K + k], S.kn[l - 6][k], u);
     }
     if (isarm) { S.q[ai] = q; S.qd[ai] = qd; }
     if (l == 0) { S.ncon = 0; S.nhit = 0; S.nff = 0; }
