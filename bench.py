@@ -204,10 +204,11 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
     # measurement of this exact launch (profiles/, separate --pmc passes) is reported when the workload matches.
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_v2_leap_traffic.json")
-    if args.task == "leap_cube" and N == 65536 and H == 64 and world == 1 and os.path.exists(tfile):
-        t = json.load(open(tfile))
-        traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r01_v2_leap_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    tfile = os.path.join(ROOT, "profiles", "r01b_traffic.json")
+    if world == 1 and (N, H) == WORKLOADS[args.task][1:] and os.path.exists(tfile):
+        t = json.load(open(tfile)).get(args.task)
+        if t:
+            traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r01b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
     if rank == 0:
         ms = np.array(per_step) * 1e3
@@ -232,7 +233,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused rollout+cost", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_source": traffic_src,
-                         "note": "VALU-issue-bound by construction (64 serial physics steps, ~1e5 flop per 260 algorithmic bytes); see DESIGN.md section 6"},
+                         "note": "latency/VALU-issue-bound by construction (H serial physics steps, ~1e5 flop per step against a few hundred algorithmic bytes per rollout); see DESIGN.md section 6"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.task, ctrl)
