@@ -48,6 +48,12 @@ def all_gather_records(rec: torch.Tensor, group=None) -> torch.Tensor:
     world, _ = world_info(group)
     if world == 1:
         return rec
+    if rec.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: stage the (<= few KB) record through the host.  This is the rendezvous used when several
+        # ranks share one GPU (tests); on a multi-GPU node the backend is nccl (RCCL) and the branch below runs on the device.
+        host = torch.empty(world * rec.numel(), dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.detach().cpu().contiguous(), group=group)
+        return host.to(rec.device)
     out = torch.empty(world * rec.numel(), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
     return out

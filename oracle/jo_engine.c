@@ -764,7 +764,8 @@ static double total_cost(const jo_model* m, jo_data* d, const double* a, double*
 /* ------------------------------------------------------------------ primal Newton solver with exact line search (mj_solNewton) */
 /* diagnostics for the tests/tools: Newton iterations per solve, over all threads */
 static long g_iter_hist[32];
-static int g_trace = 0;
+static int g_trace = 0, g_wsmode = 0;
+void jo_set_warmstart_mode(int mode) { g_wsmode = mode; }
 void jo_set_trace(int on) { g_trace = on; }
 void jo_solver_histogram(long* out32, int reset) { for (int i = 0; i < 32; i++) { out32[i] = g_iter_hist[i]; if (reset) g_iter_hist[i] = 0; } }
 void jo_set_solver(jo_model* m, double tol, int maxiter) { m->solver_tol = tol; m->solver_maxiter = maxiter; }
@@ -780,6 +781,11 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
   double cw = total_cost(m, d, d->qacc_warmstart, NULL, jar, NULL, NULL, NULL);
   double cs = total_cost(m, d, d->qacc_smooth, NULL, jar, NULL, NULL, NULL);
   memcpy(a, cw < cs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
+  if (g_wsmode == 1) { /* experiment: keep last step's constraint acceleration on top of the new smooth acceleration */
+    double a3[JO_MAXDOF]; for (int i = 0; i < nv; i++) a3[i] = d->qacc_smooth[i] + d->qacc_con_prev[i];
+    double c3 = total_cost(m, d, a3, NULL, jar, NULL, NULL, NULL);
+    if (c3 < fmin(cw, cs)) memcpy(a, a3, sizeof(double) * nv);
+  }
   double scale = 0; for (int i = 0; i < nv; i++) scale += d->M[i][i]; scale = 1.0 / fmax(MINVAL, scale);
   int it;
   for (it = 0; it < m->solver_maxiter; it++) {
@@ -911,6 +917,7 @@ static void integrate(const jo_model* m, jo_data* d) {
     } else d->qpos[qa] += h * d->qvel[da];
   }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  for (int i = 0; i < nv; i++) d->qacc_con_prev[i] = d->qacc[i] - d->qacc_smooth[i];
 }
 
 void jo_step(const jo_model* m, jo_data* d) { jo_forward(m, d); integrate(m, d); }
@@ -996,7 +1003,7 @@ int jo_model_finalize(jo_model* m) {
 void jo_rollout(const jo_model* m, jo_data* d, const double* x0, const double* controls, int H, double* states, double* sensors_out) {
   int nq = m->nq, nv = m->nv, nu = m->nact, ns = m->nsensordata;
   memcpy(d->qpos, x0, sizeof(double) * nq); memcpy(d->qvel, x0 + nq, sizeof(double) * nv);
-  memset(d->qacc_warmstart, 0, sizeof(double) * nv);
+  memset(d->qacc_warmstart, 0, sizeof(double) * nv); memset(d->qacc_con_prev, 0, sizeof(double) * nv);
   for (int t = 0; t < H; t++) {
     memcpy(d->ctrl, controls + (size_t)t * nu, sizeof(double) * nu);
     jo_step(m, d);

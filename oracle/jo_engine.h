@@ -107,6 +107,7 @@ typedef struct jo_contact {
 typedef struct jo_data {
   double qpos[JO_MAXQ], qvel[JO_MAXDOF], ctrl[JO_MAXACT];
   double qacc[JO_MAXDOF], qacc_warmstart[JO_MAXDOF], qacc_smooth[JO_MAXDOF];
+  double qacc_con_prev[JO_MAXDOF]; /* diagnostics: last step's constraint acceleration qacc - qacc_smooth (third warm-start candidate, off by default) */
   double qfrc_bias[JO_MAXDOF], qfrc_passive[JO_MAXDOF], qfrc_actuator[JO_MAXDOF], qfrc_smooth[JO_MAXDOF], qfrc_constraint[JO_MAXDOF];
   double act_force[JO_MAXACT];
   double xpos[JO_MAXBODY][3], xquat[JO_MAXBODY][4], xmat[JO_MAXBODY][9], xipos[JO_MAXBODY][3], ximat[JO_MAXBODY][9];
@@ -169,6 +170,7 @@ void jo_rollout_batch(const jo_model* m, const double* x0, int x0_batched, const
 /* diagnostics (tools/): Newton iterations per solve over all threads; solver tolerance / iteration cap override */
 void jo_solver_histogram(long* out32, int reset);
 void jo_set_solver(jo_model* m, double tol, int maxiter);
+void jo_set_warmstart_mode(int mode); /* 0 = MuJoCo (better of previous qacc and qacc_smooth); 1 = also try qacc_smooth + previous constraint acceleration */
 
 #ifdef __cplusplus
 }

@@ -18,9 +18,9 @@ knots = np.clip(knots, lo, hi)
 W = O.spline_weights('cubic', np.linspace(0, 0.64, K), np.arange(H) * 0.01)
 ctrl = np.einsum('hk,nku->nhu', W, knots)
 x0 = task.default_state() if hasattr(task, 'default_state') else None
-for tol in [float(a) for a in sys.argv[1:]] or [1e-10, 1e-8, 1e-6]:
-    L.jo_set_solver(om.ptr, tol, 100)
+for mode, tol in [(0, 1e-8), (1, 1e-8), (0, 1e-5), (1, 1e-5)]:
+    L.jo_set_warmstart_mode(mode); L.jo_set_solver(om.ptr, tol, 100)
     h = (C.c_long * 32)(); L.jo_solver_histogram(h, 1)
     st, se = om.rollout(np.asarray(x0, float), ctrl)
     L.jo_solver_histogram(h, 1); h = np.array(list(h), float)
-    print(f'tol {tol:g}: mean {np.sum(h * np.arange(32)) / h.sum():.2f}  hist%', ' '.join(f'{i}:{100 * v / h.sum():.0f}' for i, v in enumerate(h) if v), ' final cube z', st[:3, -1, 2])
+    print(f'warm-start mode {mode} tol {tol:g}: mean {np.sum(h * np.arange(32)) / h.sum():.2f}  hist%', ' '.join(f'{i}:{100 * v / h.sum():.0f}' for i, v in enumerate(h) if v), ' final cube z', st[:3, -1, 2])
