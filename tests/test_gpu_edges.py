@@ -1,0 +1,68 @@
+"""Edge sizes of the two cooperative engine kernels through the whole plan step: a single rollout, a ragged last wave (N not a
+multiple of the 4 rollouts a wave holds), a one-step horizon, the maximum knot count the kernels keep in registers / LDS (K = 8), and the
+argument errors the C ABI reports.  Oracle = the fp64 engine on the same candidates."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(task, opt, N, H, K, seed):
+    import torch
+    from judo_amd.controller import make_controller
+    from oracle import oracle as O
+    from tests.harness import oracle_plan_step
+
+    ctrl = make_controller(task, opt)
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.horizon = H * ctrl.task.dt
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
+    nu = ctrl.task.nu
+    sigma0 = None
+    if opt == "cem":
+        sigma0 = np.full((K, nu), ctrl.optimizer.sigma[0, 0])  # constant in time: the node-count change re-interpolates it to itself
+    # the node count changes between two plan steps, as a GUI slider would (the previous plan is resampled onto the new knot grid)
+    ctrl.optimizer.config.num_nodes = K
+    nominal0 = np.atleast_2d(ctrl.spline(ctrl.time + ctrl.spline_timesteps))
+    noise = np.random.default_rng(seed).standard_normal((max(N - 1, 0), K, nu)).astype(np.float32)
+    ctrl.optimizer.injected_noise = noise
+    ctrl.keep_candidates = True
+    ctrl.update_action()
+    torch.cuda.synchronize()
+    ref = oracle_plan_step(O.Model(task), ctrl, nominal0, noise, opt, sigma0)
+    return ctrl, ref
+
+
+@pytest.mark.parametrize("task,opt,N,H,K", [
+    ("leap_cube", "mppi", 1, 16, 4), ("leap_cube", "ps", 5, 1, 4), ("leap_cube", "mppi", 7, 9, 8), ("leap_cube", "cem", 3, 12, 4),
+    ("fr3_pick", "cem", 3, 10, 4), ("fr3_pick", "mppi", 1, 1, 4), ("fr3_pick", "ps", 6, 7, 8), ("fr3_pick", "cem", 9, 25, 5),
+])
+def test_small_and_ragged_plan_steps_match_oracle(gpu, task, opt, N, H, K):
+    ctrl, ref = _plan(task, opt, N, H, K, seed=N * 100 + H)
+    assert ctrl.num_timesteps == H and ctrl.optimizer.num_nodes == K
+    cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
+    np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
+    costs = -ctrl.rewards_local
+    assert costs.shape == (N,) and np.isfinite(costs).all()
+    # few steps from the home pose: fp32 vs fp64 engine, costs are sums / means of O(1) terms
+    np.testing.assert_allclose(costs, -ref["rewards"], rtol=2e-4, atol=2e-3)
+    if N == 1:  # the only sample is the unperturbed nominal: every optimiser returns it
+        np.testing.assert_allclose(ctrl.nominal_knots, ref["knots"][0], rtol=0, atol=1e-6)
+
+
+def test_engine_kernels_reject_more_knots_than_they_hold(gpu):
+    from judo_amd.controller import make_controller
+
+    for task in ("leap_cube", "fr3_pick"):
+        ctrl = make_controller(task, "mppi")
+        ctrl.optimizer.config.num_rollouts = 8
+        ctrl.optimizer.config.num_nodes = 9
+        ctrl.controller_cfg.horizon = 8 * ctrl.task.dt
+        ctrl.reset()
+        ctrl.current_state = ctrl.task.default_state()
+        ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
+        with pytest.raises(ValueError, match="at most 8 knots|exceeds"):
+            ctrl.update_action()
