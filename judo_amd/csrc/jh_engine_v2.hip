@@ -278,17 +278,17 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
       quat2mat(Rc, qc + 3);
       float P[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      float sn_own, cs_own; sincosf(q, &sn_own, &cs_own);  // each lane evaluates its own joint once; the chain-mates fetch it with a quad broadcast
 #pragma unroll
       for (int j = 0; j < NLK; j++) {
         const float* bf = sBody + (4 * c + j) * BODY_F;
-        float qj = quad_get(q, j);
         float P2[3], R0[9];
         if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
         else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
         const float* al = bf + BF_AXIS;
         mulMV(ax[j], R0, al);
         for (int k = 0; k < 3; k++) { og[j][k] = P2[k]; P[k] = P2[k]; }
-        float sn, cs; sincosf(qj, &sn, &cs); float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
+        const float sn = quad_get(sn_own, j), cs = quad_get(cs_own, j), t = 1.f - cs, x = al[0], y = al[1], z = al[2];
         float Rq[9] = {t * x * x + cs, t * x * y - sn * z, t * x * z + sn * y, t * x * y + sn * z, t * y * y + cs, t * y * z - sn * x, t * x * z - sn * y, t * y * z + sn * x, t * z * z + cs};
         mulMM(R, R0, Rq);
         if (j == s) { for (int k = 0; k < 3; k++) pown[k] = P2[k]; for (int k = 0; k < 9; k++) Rown[k] = R[k]; }

@@ -38,6 +38,7 @@ constexpr int LF = 8, RF = 9;       // moving-body indices of the two fingers (a
 struct __attribute__((aligned(16))) RS3 {  // per-rollout shared state
   float xpos[NMB][3], xR[NMB][9], axw[NMB][3];  // moving bodies: 0 = free box, 1..9 = arm links / fingers
   float q[16], qd[16];                          // arm joint positions / velocities by arm index
+  float sn[16], cs[16];                         // sin / cos of the hinge angles (each evaluated once, by its owner lane)
   float M[NA][NA];
   float vec[3][16];
   union {                                       // the raw contact pool is dead once the Jacobian and the slots are built
@@ -158,8 +159,8 @@ __device__ __forceinline__ void chol_solve(float* L, float* x) {
     x[i] = s * inv[i]; }
 }
 
-__device__ __forceinline__ void rodrigues(float* Rq, const float* al, float q) {
-  float sn, cs; sincosf(q, &sn, &cs); float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
+__device__ __forceinline__ void rodrigues(float* Rq, const float* al, float sn, float cs) {
+  float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
   Rq[0] = t * x * x + cs; Rq[1] = t * x * y - sn * z; Rq[2] = t * x * z + sn * y;
   Rq[3] = t * x * y + sn * z; Rq[4] = t * y * y + cs; Rq[5] = t * y * z - sn * x;
   Rq[6] = t * x * z - sn * y; Rq[7] = t * y * z + sn * x; Rq[8] = t * z * z + cs;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + (l - 6)];
       else for (int k = 0; k < K && k < 8; k++) u = fmaf(W[hh * K + k], S.kn[l - 6][k], u);
     }
-    if (isarm) { S.q[ai] = q; S.qd[ai] = qd; }
+    if (isarm) { S.q[ai] = q; S.qd[ai] = qd; float sn_, cs_; sincosf(q, &sn_, &cs_); S.sn[ai] = sn_; S.cs[ai] = cs_; }
     if (l == 0) { S.ncon = 0; S.nhit = 0; S.nff = 0; }
     __syncthreads();
     // ================================================================ kinematics: every lane walks the 7-hinge chain (uniform records -> scalar loads)
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
         mulMV(ax[j], R0, bf + BF_AXIS);
         for (int k = 0; k < 3; k++) { og[j][k] = P2[k]; P[k] = P2[k]; }
-        float Rq[9]; rodrigues(Rq, bf + BF_AXIS, S.q[j]);
+        float Rq[9]; rodrigues(Rq, bf + BF_AXIS, S.sn[j], S.cs[j]);
         mulMM(R, R0, Rq);
         if (j == ai) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = ax[j][k]; } for (int k = 0; k < 9; k++) Rown[k] = R[k]; }
       }
