@@ -102,6 +102,12 @@ int jh_sample_knots(const float* nominal, const float* noise, int ldn, const flo
 int jh_spline_controls(const float* W, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
                        const float* ctrl_lo_hi, int N, int n_offset, int H, int K, int nu, float* controls, void* stream);
 
+/* Moments of this shard's candidate knots for the "running" action normaliser (RunningMeanStdNormalizer.update on candidate_knots,
+ * judo/utils/normalization.py:176-200, judo/controller/controller.py:290-291): out[u] = sum over rollouts and knots of (x - center[u]),
+ * out[nu+u] = sum of (x - center[u])^2, x = knot of actuator u (same knot sources as jh_spline_controls).  `out` (2*nu floats) is zeroed first. */
+int jh_knot_moments(const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi,
+                    const float* center, int N, int n_offset, int K, int nu, float* out, void* stream);
+
 /* MPPI.update_nominal_knots (judo/optimizers/mppi.py:61-82), shard-local part.
  * Writes one record rec[0] = beta = min cost, rec[1] = S = sum exp(-(c-beta)/lambda), rec[2..2+K*nu) = sum w*knots.
  * Knots come either from `knots_nku` ((N,K,nu) row-major, the drop-in path) or, when it is NULL, are recomputed as

@@ -20,6 +20,7 @@ from judo_amd import _lib
 from judo_amd.config import ControllerConfig, OptimizerConfig
 from judo_amd.device import current_stream_ptr, require_gpu
 from judo_amd.distributed import Shard, all_gather_records, shard_rollouts, world_info
+from judo_amd.normalization import Normalizer, make_normalizer, normalizer_registry
 from judo_amd.optimizers import Optimizer, get_registered_optimizers
 from judo_amd.rollout_backend import GpuRolloutBackend
 from judo_amd.spline import SPLINE_KINDS, evaluate, spline_weights
@@ -134,6 +135,7 @@ class Controller:
         self.times = self.task.data.time + self.spline_timesteps
         self.update_spline(self.times, self.nominal_knots)
         self.current_state = np.concatenate([self.task.data.qpos, self.task.data.qvel])
+        self.action_normalizer = self._init_action_normalizer()  # judo/controller/controller.py:208
 
     def update_states(self, qpos, qvel: np.ndarray | None = None, time: float | None = None, sim_metadata: dict | None = None) -> None:
         """Either the reference's call `update_states(MujocoState)` (judo/controller/controller.py:188-194) or the unpacked fields."""
@@ -160,18 +162,23 @@ class Controller:
             self._w_cache = {key: W}
         return W
 
-    def _normaliser_scale(self) -> np.ndarray:
-        """action_normalizer: "none" -> 1; "min_max" -> (hi-lo)/2 per finite-range actuator, i.e. sampling
-        `nominal_n + sigma*eps` in [-1,1]-normalised units equals `nominal + sigma*scale*eps` in raw units
-        (judo/utils/normalization.py:94-138).  The running-statistics normaliser is not offered on the GPU path."""
+    def _init_action_normalizer(self) -> Normalizer:
+        """judo/controller/controller.py:226-239: min_max over the actuator ctrlranges, running statistics, or none."""
         kind = self.controller_cfg.action_normalizer
-        if kind == "none":
-            return np.ones(self.nu)
         if kind == "min_max":
             r = self.task.actuator_ctrlrange
-            finite = np.isfinite(r[:, 0]) & np.isfinite(r[:, 1])
-            return np.where(finite, (r[:, 1] - r[:, 0]) / 2, 1.0)
-        raise NotImplementedError(f"action_normalizer {kind!r} is host-side state in the reference and is not supported by the fused GPU path")
+            return make_normalizer("min_max", self.nu, min=r[:, 0], max=r[:, 1])
+        if kind in normalizer_registry:
+            return make_normalizer(kind, self.nu)
+        warnings.warn(f"Invalid action normalizer type {kind!r}. Available types: {list(normalizer_registry)}. Falling back to 'none' normalizer.", stacklevel=3)
+        return make_normalizer("none", self.nu)
+
+    def _current_normalizer(self) -> Normalizer:
+        """Re-initialised when the configured type changes (controller.py:240-243)."""
+        cls = normalizer_registry.get(self.controller_cfg.action_normalizer, normalizer_registry["none"])
+        if getattr(self, "action_normalizer", None) is None or type(self.action_normalizer) is not cls:
+            self.action_normalizer = self._init_action_normalizer()
+        return self.action_normalizer
 
     # ---- the plan step -------------------------------------------------------------------------------------------
     def update_action(self) -> None:
@@ -191,12 +198,13 @@ class Controller:
         nominal_knots = self.spline(new_times)
         if self.rollout_backend.num_threads != N:
             self.rollout_backend.update(N)
-        scale = self._normaliser_scale()
+        nrm = self._current_normalizer()
+        nominal_n = nrm.normalize(nominal_knots)  # the optimiser's state lives in normalised units (controller.py:222)
         opt.pre_optimization(self.times, new_times)
 
         W = self._weights(K, H)
-        lohi_np = np.concatenate([task.actuator_ctrlrange[:, 0], task.actuator_ctrlrange[:, 1]]).astype(np.float32)
-        lohi_np = np.nan_to_num(lohi_np, posinf=3.0e38, neginf=-3.0e38)
+        ctrl_lo, ctrl_hi = task.actuator_ctrlrange[:, 0], task.actuator_ctrlrange[:, 1]
+        mom = torch.empty(2 * nu, dtype=torch.float32, device=dev) if nrm.needs_moments else None
         nx, ntp = task.nq + task.nv, len(task.task_params(self.system_metadata))
         host = np.empty(nx + 2 * K * nu + ntp + 2 * nu, dtype=np.float32)
         costs = torch.empty(shard.count, dtype=torch.float32, device=dev)
@@ -209,6 +217,12 @@ class Controller:
         i = 0
         while i < self.max_opt_iters and not opt.stop_cond():
             sigma_n = np.asarray(opt.knot_sigma(), dtype=np.float64)  # normalised units; may advance CEM state
+            # every shipped normaliser is affine per actuator: raw = center + scale * normalised (judo_amd/normalization.py)
+            scale, center = nrm.noise_scale(), nrm.denormalize(np.zeros(nu))
+            nominal_knots = nrm.denormalize(nominal_n)
+            with np.errstate(invalid="ignore"):
+                lohi_np = np.concatenate([nrm.denormalize(nrm.normalize(ctrl_lo)), nrm.denormalize(nrm.normalize(ctrl_hi))])
+            lohi_np = np.nan_to_num(np.where(np.isnan(lohi_np), np.concatenate([ctrl_lo, ctrl_hi]), lohi_np).astype(np.float32), posinf=3.0e38, neginf=-3.0e38)
             task.pre_rollout(self.current_state)
             # one small H2D transfer: x0 | nominal | sigma | task params | ctrl bounds
             o = 0
@@ -236,17 +250,29 @@ class Controller:
                 self.kernel_events.append((ev0, ev1))
             opt.device_partial(costs, None, nom_d, noise, sig_d, lohi_d, shard.count, shard.offset, scratch, rec)
             recs = all_gather_records(rec, self.group)
-            opt.device_merge(recs, world, out[: K * nu], out[K * nu :])
+            opt.device_merge(recs, world, out[: K * nu], out[K * nu :], clip_sigma=False)
             res = out.cpu().numpy().astype(np.float64)  # the only sync of the iteration
-            nominal_knots = res[: K * nu].reshape(K, nu)
+            nominal_n = (res[: K * nu].reshape(K, nu) - center[None, :]) / scale[None, :]  # the update acted on the normalised candidates
             if hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray):  # CEM: refit in normalised units
                 opt.sigma = np.clip(res[K * nu :].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
+            if nrm.needs_moments:  # running statistics over this iteration's raw candidates, all ranks (controller.py:290-291)
+                ctr = torch.from_numpy(np.asarray(nrm.mean, dtype=np.float32)).to(dev)
+                st = lib.jh_knot_moments(None, _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(lohi_d), _lib.ptr(ctr),
+                                         shard.count, shard.offset, K, nu, _lib.ptr(mom), stream)
+                _lib.check(st, "jh_knot_moments")
+                m = all_gather_records(mom, self.group).cpu().numpy().astype(np.float64).reshape(world, 2, nu).sum(0)
+                # the kernel centred on the fp32 image of the mean: shift the moments to the fp64 mean
+                dm = np.asarray(nrm.mean, dtype=np.float32).astype(np.float64) - nrm.mean
+                cnt = N * K
+                s1 = m[0] + cnt * dm
+                s2 = m[1] + 2 * dm * m[0] + cnt * dm * dm
+                nrm.update_from_moments(cnt, s1, s2)
             i += 1
 
         self.costs_device = costs
         self.candidate_knots_device = knots_out
         self.last_shard = shard
-        self.nominal_knots = nominal_knots
+        self.nominal_knots = nrm.denormalize(nominal_n)  # with the statistics as updated in the loop (controller.py:296)
         self.times = new_times
         self.update_spline(self.times, self.nominal_knots)
 

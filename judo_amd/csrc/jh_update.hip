@@ -66,6 +66,20 @@ __global__ __launch_bounds__(64) void k_spline_controls(KnotSrc src, const float
   }
 }
 
+// Moments of the candidate knots per actuator for the running action normaliser (judo/utils/normalization.py:176-200 on
+// `candidate_knots`): out[u] += sum_{n,k} (x - center[u]), out[nu+u] += sum_{n,k} (x - center[u])^2.  One wave per 64 rollouts, wave
+// butterflies, one atomic per (block, actuator, moment).
+__global__ __launch_bounds__(64) void k_knot_moments(KnotSrc src, const float* __restrict__ center, int N, int K, float* __restrict__ out) {
+  const int n = blockIdx.x * 64 + threadIdx.x, nu = src.nu;
+  const bool live = n < N;
+  for (int u = 0; u < nu; u++) {
+    float s1 = 0.f, s2 = 0.f;
+    if (live) for (int k = 0; k < K; k++) { float d = src.get(n, k * nu + u) - center[u]; s1 += d; s2 = fmaf(d, d, s2); }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (threadIdx.x == 0) { atomicAdd(out + u, s1); atomicAdd(out + nu + u, s2); }
+  }
+}
+
 // ---------------------------------------------------------------- MPPI
 __global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ costs, KnotSrc src, int N, float inv_lambda,
                                                    float* __restrict__ scratch) {
@@ -259,6 +273,20 @@ extern "C" int jh_spline_controls(const float* W, const float* knots_nku, const 
   JH_REQUIRE(lds <= 64 * 1024, "spline_controls: H*K too large for the LDS staging (%zu bytes)", lds);
   KnotSrc src{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
   hipLaunchKernelGGL(k_spline_controls, dim3((N + 63) / 64), dim3(64), lds, (hipStream_t)stream, src, W, N, H, K, controls);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_knot_moments(const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* lohi,
+                               const float* center, int N, int n_offset, int K, int nu, float* out, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(center && out, "knot_moments: null pointer");
+  JH_REQUIRE(knots_nku || (nominal && noise && sigma), "knot_moments: need either knots_nku or nominal+noise+sigma");
+  JH_REQUIRE(knots_nku || ldn >= N, "knot_moments: ldn (%d) < N (%d)", ldn, N);
+  KnotSrc src{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu};
+  hipStream_t st = (hipStream_t)stream;
+  JH_HIP(hipMemsetAsync(out, 0, sizeof(float) * 2 * nu, st));
+  hipLaunchKernelGGL(k_knot_moments, dim3((N + 63) / 64), dim3(64), 0, st, src, center, N, K, out);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -130,7 +130,7 @@ class Optimizer(ABC, Generic[OptimizerConfigT]):
         ...
 
     @abstractmethod
-    def device_merge(self, recs, G, nominal_out, sigma_out) -> None:
+    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True) -> None:
         ...
 
     def _check_update_args(self, sampled_knots, rewards):
@@ -195,7 +195,7 @@ class GpuMPPI(Optimizer[MPPIConfig]):
                                         n_local, n_offset, K, self.nu, float(self.temperature), _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr())
         _lib.check(st, "jh_mppi_partial")
 
-    def device_merge(self, recs, G, nominal_out, sigma_out, K=None) -> None:
+    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True) -> None:
         K = K or self.num_nodes
         st = _lib.lib().jh_mppi_merge(_lib.ptr(recs), G, K, self.nu, float(self.temperature), _lib.ptr(nominal_out), current_stream_ptr())
         _lib.check(st, "jh_mppi_merge")
@@ -225,9 +225,11 @@ class _EliteOptimizer(Optimizer[OptimizerConfigT]):
                                         n_local, n_offset, K, self.nu, self.num_keep(), self.tie_high, _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr())
         _lib.check(st, "jh_topk_partial")
 
-    def device_merge(self, recs, G, nominal_out, sigma_out, K=None) -> None:
+    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True) -> None:
+        """clip_sigma=False returns the raw population std: the controller clips it after mapping it back to the action normaliser's
+        units (cem.py:91 clips the std of the NORMALISED elites)."""
         K = K or self.num_nodes
-        smin, smax = self.sigma_bounds()
+        smin, smax = self.sigma_bounds() if clip_sigma else (0.0, float("inf"))
         st = _lib.lib().jh_elite_merge(_lib.ptr(recs), G, self.num_keep(), K, self.nu, self.tie_high, smin, min(smax, 3.0e38), _lib.ptr(nominal_out),
                                        _lib.ptr(sigma_out), current_stream_ptr())
         _lib.check(st, "jh_elite_merge")

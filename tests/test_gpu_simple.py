@@ -286,9 +286,6 @@ def test_min_max_normaliser_is_equivalent_to_scaled_sigma(gpu):
     cand = denorm(np.clip(cand_n, -1, 1))
     got = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
     np.testing.assert_allclose(got, cand, rtol=1e-5, atol=1e-5)
-    ctrl.controller_cfg.action_normalizer = "running"
-    with pytest.raises(NotImplementedError):
-        ctrl.update_action()
 
 
 def test_plugin_task_with_its_own_reward_runs_on_the_materialise_path(gpu):
@@ -380,3 +377,103 @@ def test_benchmark_sweep_reports_every_pair(gpu):
         assert set(per_opt) == {"cem", "mppi", "ps"}
         for r in per_opt.values():
             assert 0 < r["min"] <= r["median"] <= r["max"] and r["iqr25"] <= r["iqr75"]
+
+
+@pytest.mark.parametrize("nu,K,N", [(1, 4, 70), (2, 5, 129), (16, 4, 33)])
+def test_knot_moments_kernel(gpu, nu, K, N):
+    """jh_knot_moments: sum and sum of squares of (candidate knot - center) per actuator, from the recomputed or the explicit knots."""
+    import torch
+    from judo_amd import _lib
+    from judo_amd.device import current_stream_ptr
+
+    rng = np.random.default_rng(nu * 7 + K)
+    dev = torch.device("cuda", 0)
+    nominal, sigma, center = rng.standard_normal((K, nu)), 0.2 + 0.3 * rng.random((K, nu)), rng.standard_normal(nu)
+    noise = rng.standard_normal((K, nu, N)).astype(np.float32)
+    lo, hi = -1.2 * np.ones(nu), 1.1 * np.ones(nu)
+    knots = nominal[None] + sigma[None] * np.transpose(noise, (2, 0, 1)).astype(np.float64)
+    knots[0] = nominal
+    knots = np.clip(knots, lo, hi)
+    d = knots.reshape(-1, nu) - center
+    want = np.concatenate([d.sum(0), (d * d).sum(0)])
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)  # noqa: E731
+    nd, sd, ed, lh, cd = t(nominal), t(sigma), t(noise), t(np.concatenate([lo, hi])), t(center)
+    out = torch.full((2 * nu,), 7.0, dtype=torch.float32, device=dev)  # the call zeroes it
+    L = _lib.lib()
+    _lib.check(L.jh_knot_moments(None, _lib.ptr(nd), _lib.ptr(ed), N, _lib.ptr(sd), _lib.ptr(lh), _lib.ptr(cd), N, 0, K, nu, _lib.ptr(out), current_stream_ptr()), "moments")
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-4)  # fp32 sums of N*K terms of O(1)
+    kd = t(knots)
+    _lib.check(L.jh_knot_moments(_lib.ptr(kd), None, None, 0, None, None, _lib.ptr(cd), N, 0, K, nu, _lib.ptr(out), current_stream_ptr()), "moments")
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("opt_name", ["mppi", "cem"])
+def test_running_normaliser_plan_steps_match_the_reference_loop(gpu, opt_name):
+    """action_normalizer="running" through two plan steps of two optimiser iterations each: the controller's nominal, its normaliser
+    statistics and (CEM) sigma against the reference loop (controller.py:222-296) restated with the host classes that
+    tests/test_host.py pins to the reference golden, the oracle engine providing the rewards."""
+    import torch
+    from judo_amd.controller import make_controller
+    from judo_amd.normalization import RunningMeanStdNormalizer
+    from oracle import oracle as O
+    from tests.harness import oracle_knot_sigma, oracle_reward
+
+    N, K, nu = 96, 4, 2
+    ctrl = make_controller("cylinder_push", opt_name)
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.action_normalizer = "running"
+    ctrl.controller_cfg.max_opt_iters = 2
+    ctrl.controller_cfg.horizon = 32 * ctrl.task.dt
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    assert type(ctrl.action_normalizer).__name__ == "RunningMeanStdNormalizer"
+    rng = np.random.default_rng(33)
+    om = O.Model("cylinder_push")
+    nrm = RunningMeanStdNormalizer(nu)
+    cem_sigma = ctrl.optimizer.sigma.copy() if opt_name == "cem" else None
+    lo, hi = ctrl.task.actuator_ctrlrange[:, 0], ctrl.task.actuator_ctrlrange[:, 1]
+    for step in range(2):
+        ctrl.time = 0.05 * step
+        noises = [rng.standard_normal((N - 1, K, nu)).astype(np.float32) for _ in range(2)]
+        it_box = {"i": 0}
+        orig_draw = ctrl.optimizer.draw_noise
+
+        def draw(n_local, n_offset, device, _noises=noises, _box=it_box, _orig=orig_draw):  # a fresh noise block per optimiser iteration
+            ctrl.optimizer.injected_noise = _noises[_box["i"]]
+            _box["i"] += 1
+            return _orig(n_local, n_offset, device)
+
+        ctrl.optimizer.draw_noise = draw
+        new_times = ctrl.time + ctrl.spline_timesteps
+        nominal = ctrl.spline(new_times)
+        ctrl.update_action()
+        torch.cuda.synchronize()
+        ctrl.optimizer.draw_noise = orig_draw
+        # ---- the reference loop
+        W = O.spline_weights(ctrl.spline_order, new_times, ctrl.time + ctrl.task.dt * np.arange(ctrl.num_timesteps))
+        nominal_n = nrm.normalize(nominal)
+        for it in range(2):
+            if opt_name == "cem":
+                sig_n = O.cem_sigma_ramp(cem_sigma, ctrl.optimizer.use_noise_ramp, ctrl.optimizer.noise_ramp, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
+                cem_sigma = sig_n
+            else:
+                sig_n = oracle_knot_sigma("mppi", ctrl.optimizer.config, nu, None)
+            cand_n = np.concatenate([nominal_n[None], nominal_n[None] + sig_n[None] * noises[it].astype(np.float64)])
+            cand_n = np.clip(cand_n, nrm.normalize(lo), nrm.normalize(hi))
+            cand = nrm.denormalize(cand_n)
+            states, sensors = om.rollout(ctrl.current_state, O.spline_eval(W, cand))
+            rewards = oracle_reward(ctrl.task, states, sensors, O.spline_eval(W, cand), {})
+            if opt_name == "mppi":
+                nominal_n = O.mppi_update(cand_n, rewards, ctrl.optimizer.config.temperature)
+            else:
+                nominal_n, cem_sigma, _ = O.cem_update(cand_n, rewards, ctrl.optimizer.num_elites, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
+            nrm.update(cand)
+        want = nrm.denormalize(nominal_n)
+        got = ctrl.action_normalizer
+        assert got.count == nrm.count == (step + 1) * 2 * N * K
+        np.testing.assert_allclose(got.mean, nrm.mean, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got.std, nrm.std, rtol=2e-5, atol=2e-6)
+        # costs are fp32: the MPPI average moves by ~1e-4 relative, the CEM elite mean is exact unless two candidates tie
+        np.testing.assert_allclose(ctrl.nominal_knots, want, rtol=0, atol=5e-4)
+        if opt_name == "cem":
+            np.testing.assert_allclose(ctrl.optimizer.sigma, cem_sigma, rtol=1e-4, atol=1e-6)

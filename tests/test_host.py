@@ -275,3 +275,39 @@ def test_wire_records_round_trip_through_arrow():
         SplineData(np.arange(4.0), np.zeros((4, 2)), "quintic")
     with pytest.raises(ValueError):
         SplineData(np.arange(4.0), np.zeros((4, 2)), "linear", extrapolate=False).spline()(5.0)
+
+
+def test_running_normaliser_loop_matches_reference_golden():
+    """The optimiser loop of Controller.update_action with the "running" action normaliser (judo/controller/controller.py:222-296),
+    restated the way the GPU path runs it: the kernels see raw knots (nominal_eff, sigma_eff, bounds_eff), the update returns the
+    weighted mean of RAW candidates, the statistics are updated from two moments per actuator.  The golden sequence was produced by the
+    reference's RunningMeanStdNormalizer + MPPI with a stand-in reward (tools/gen_golden.py::gen_normalizer)."""
+    from judo_amd.normalization import RunningMeanStdNormalizer
+    from oracle import oracle as O
+
+    g = np.load(os.path.join(GOLDEN, "normalizer.npz"))
+    N, K, nu, iters, sigma, lam, ramp = g["running_cfg"]
+    N, K, nu, iters = int(N), int(K), int(nu), int(iters)
+    lo, hi, target = g["running_lo"], g["running_hi"], g["running_target"]
+    nrm = RunningMeanStdNormalizer(nu)
+    sig_n = O.mppi_sigma(sigma, True, ramp, K, nu)
+    nominal_n = nrm.normalize(g["running_nominal_in"])
+    for it in range(iters):
+        scale, center = nrm.noise_scale(), nrm.denormalize(np.zeros(nu))
+        np.testing.assert_allclose(scale, nrm.std, rtol=1e-15)
+        nominal_eff, sigma_eff = nrm.denormalize(nominal_n), sig_n * scale[None, :]
+        lo_eff, hi_eff = nrm.denormalize(nrm.normalize(lo)), nrm.denormalize(nrm.normalize(hi))
+        # what jh_rollout_cost / jh_knot_moments compute from the effective inputs
+        cand = O.clip_knots(O.sample_knots(nominal_eff, g[f"running_it{it}_noise"], sigma_eff), lo_eff, hi_eff)
+        np.testing.assert_allclose(cand, g[f"running_it{it}_candidates"], rtol=1e-12, atol=1e-12)
+        rewards = -np.sum((cand - target) ** 2, axis=(1, 2))
+        np.testing.assert_allclose(rewards, g[f"running_it{it}_rewards"], rtol=1e-12)
+        wmean_raw = O.mppi_update(cand, rewards, lam)           # the device update acts on raw candidates ...
+        nominal_n = (wmean_raw - center[None, :]) / scale[None, :]  # ... which is the update in normalised units
+        np.testing.assert_allclose(nominal_n, g[f"running_it{it}_nominal_normalized"], rtol=1e-9, atol=1e-12)
+        d = cand.reshape(-1, nu) - nrm.mean
+        nrm.update_from_moments(N * K, d.sum(0), (d * d).sum(0))
+        st = g[f"running_it{it}_state"]
+        assert nrm.count == st[0]
+        np.testing.assert_allclose(np.concatenate([nrm.mean, nrm.std, nrm.M2]), st[1:], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(nrm.denormalize(nominal_n), g["running_nominal_out"], rtol=1e-9, atol=1e-12)

@@ -47,7 +47,7 @@ from judo.tasks.cylinder_push import CylinderPush, CylinderPushConfig  # noqa: E
 from judo.tasks.fr3_pick import QPOS_HOME as FR3_QPOS_HOME  # noqa: E402
 from judo.tasks.fr3_pick import FR3Pick, FR3PickConfig, Phase  # noqa: E402
 from judo.tasks.leap_cube import LeapCube, LeapCubeConfig  # noqa: E402
-from judo.utils.normalization import MinMaxNormalizer  # noqa: E402
+from judo.utils.normalization import MinMaxNormalizer, RunningMeanStdNormalizer  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 META = {
@@ -311,7 +311,38 @@ def gen_normalizer() -> dict[str, np.ndarray]:
         warnings.simplefilter("ignore")
         nrm = MinMaxNormalizer(4, lo, hi)
     x = rng.standard_normal((6, 3, 4))
-    return {"minmax_lo": lo, "minmax_hi": hi, "minmax_x": x, "minmax_norm": nrm.normalize(x), "minmax_denorm": nrm.denormalize(x)}
+    out = {"minmax_lo": lo, "minmax_hi": hi, "minmax_x": x, "minmax_norm": nrm.normalize(x), "minmax_denorm": nrm.denormalize(x)}
+    # "running" action normaliser inside the optimiser loop of Controller.update_action (judo/controller/controller.py:222-296):
+    # normalise the nominal, sample + clip in normalised units, denormalise the candidates, update on the normalised candidates,
+    # update the running statistics with the raw candidates, denormalise the result with the UPDATED statistics.
+    # The rollout + Task.reward in the middle is replaced by a deterministic stand-in reward so that the sequence needs no simulator.
+    N, K, nu, iters = 24, 4, 3, 3
+    rlo, rhi = np.array([-1.0, -np.inf, 0.0]), np.array([1.0, np.inf, 0.5])
+    run = RunningMeanStdNormalizer(nu)
+    out["running_defaults"] = np.array([1.0, run.min_std, run.max_std, run.eps])
+    opt = MPPI(MPPIConfig(num_rollouts=N, num_nodes=K, sigma=0.3, temperature=0.05, use_noise_ramp=True, noise_ramp=2.0), nu)
+    nominal = rng.standard_normal((K, nu)) * 0.3 + np.array([0.2, 1.5, 0.25])
+    target = np.array([0.5, 1.0, 0.1])
+    out["running_nominal_in"] = nominal.copy()
+    out["running_lo"], out["running_hi"], out["running_target"] = rlo, rhi, target
+    out["running_cfg"] = np.array([N, K, nu, iters, 0.3, 0.05, 2.0])
+    nominal_n = run.normalize(nominal)
+    for it in range(iters):
+        seed = 900 + it
+        out[f"running_it{it}_noise"] = _draw(seed, (N - 1, K, nu))
+        np.random.seed(seed)
+        cand_n = opt.sample_control_knots(nominal_n)
+        cand_n = np.clip(cand_n, run.normalize(rlo), run.normalize(rhi))
+        cand = run.denormalize(cand_n)
+        rewards = -np.sum((cand - target) ** 2, axis=(1, 2))
+        nominal_n = opt.update_nominal_knots(cand_n, rewards)
+        run.update(cand)
+        out[f"running_it{it}_candidates"] = cand
+        out[f"running_it{it}_rewards"] = rewards
+        out[f"running_it{it}_nominal_normalized"] = nominal_n.copy()
+        out[f"running_it{it}_state"] = np.concatenate([[run.count], run.mean, run.std, run.M2])
+    out["running_nominal_out"] = run.denormalize(nominal_n)
+    return out
 
 
 def main() -> None:
