@@ -61,24 +61,8 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
         # the shards cover the rollouts of the single-process run: same noise rows -> same costs, rank-major
         costs2 = np.concatenate([r0["costs"], r1["costs"]])
         assert costs2.shape == costs1.shape
-        exact = task in ("cartpole", "cylinder_push")  # closed-form kernels are bit-reproducible; the contact engines sum LDS atomics in arrival order
-        np.testing.assert_allclose(costs2, costs1, rtol=0, atol=0 if exact else 2e-2)
-        assert np.median(np.abs(costs2 - costs1)) <= (0 if exact else 1e-5)
-        if exact:  # vs one process only the reduction is regrouped (two block records instead of one): fp32 summation order
-            np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=5e-6 if opt == "mppi" else 0)
-            np.testing.assert_allclose(r0["sig"], sig1, rtol=1e-6, atol=1e-7)
-        else:  # the update applied to the gathered costs reproduces what the ranks computed
-            from oracle import oracle as O
-            from judo_amd.controller import make_controller
-            c = make_controller(task, opt); c.optimizer.config.num_rollouts = N
-            sig_k = np.asarray(c.optimizer.knot_sigma(), dtype=np.float64)
-            nominal0 = np.tile(c.task.optimizer_warm_start(), (4, 1))
-            knots = np.concatenate([nominal0[None], nominal0[None] + sig_k[None] * noise.astype(np.float64)])
-            lo, hi = c.task.actuator_ctrlrange[:, 0], c.task.actuator_ctrlrange[:, 1]
-            knots = np.clip(knots, lo, hi)
-            if opt == "mppi":
-                want = O.mppi_update(knots, -costs2.astype(np.float64), c.optimizer.config.temperature)
-                np.testing.assert_allclose(r0["nom"], want, rtol=0, atol=2e-3)
-            else:
-                want, wsig, _ = O.cem_update(knots, -costs2.astype(np.float64), c.optimizer.config.num_elites, c.optimizer.sigma_min, c.optimizer.sigma_max)
-                np.testing.assert_allclose(r0["nom"], want, rtol=1e-5, atol=1e-6)
+        # every kernel is bit-reproducible and independent of where a rollout sits in its wave (test_gpu_edges.py): the costs are identical
+        np.testing.assert_array_equal(costs2, costs1)
+        # vs one process only the reduction is regrouped (two block records instead of one): fp32 summation order in the MPPI average
+        np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=5e-6 if opt == "mppi" else 0)
+        np.testing.assert_allclose(r0["sig"], sig1, rtol=1e-6, atol=1e-7)
