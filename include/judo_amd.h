@@ -131,6 +131,20 @@ int jh_topk_partial(const float* costs, const float* knots_nku, const float* nom
 int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float sigma_min, float sigma_max, float* nominal_out,
                    float* sigma_out, void* stream);
 
+/* ---- policy half of the Spot policy rollout (mujoco_extensions/system/system_class.cpp:125-238; pybind entry
+ * mujoco_extensions/policy_rollout/pybind/policy_rollout.cpp).  One call = System::setObservation + System::policyInference for N rollouts:
+ * the 84-d observation from each rollout's state (row stride ld, qpos at 0, qvel at nq; free base at base_qpos / base_qvel, the 19 joints at
+ * leg_qpos / leg_qvel), its 25-d command and its previous policy output; the actor 84-512-256-128-12 (Gemm + Elu of spot_locomotion.onnx, weights
+ * passed in ONNX layout [out, in]) on exact-f32 MFMA tiles; the mapping to the 19 joint targets.  policy_out (N x 12) is read as the previous output
+ * and overwritten with the new one; control is (N x 19); scratch holds jh_policy_scratch_floats(N) floats.  The physics substeps between two policy
+ * steps are not part of this call. */
+typedef struct jh_policy jh_policy;
+int jh_policy_create(const float* const* weights, const float* const* biases, jh_policy** out);
+void jh_policy_destroy(jh_policy* p);
+size_t jh_policy_scratch_floats(int N);
+int jh_policy_step(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel,
+                   const float* command, float* policy_out, float* control, float* scratch, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,171 @@
+// jh_policy.hip -- the policy half of the Spot policy rollout (mujoco_extensions/system/system_class.cpp:125-238), batched over rollouts:
+//   k_policy_obs      System::setObservation: 84-d observation per rollout from its state, its 25-d command and its previous policy output
+//   k_gemm_bias_act   the actor 84 -> 512 -> 256 -> 128 -> 12 (Gemm + Elu, spot_locomotion.onnx): exact-f32 MFMA tiles
+//                     (v_mfma_f32_32x32x2_f32; same arithmetic as an fmaf chain, at the f32 vector rate but one VGPR per operand)
+//   k_policy_control  System::policyInference's mapping of the 12 actions to the 19 joint targets, arm pass-through, leg override
+// This is the one dense contraction on the path: a batch of N rollouts is an (N x 84) x (84 x 512) ... GEMM chain,
+// 0.42 MFLOP per rollout and control step.  The physics substeps between two policy steps need the Spot model, which the engine kernels
+// do not cover yet; this file is the policy step only.
+#include "jh_internal.h"
+
+namespace {
+
+constexpr int OBS = 84, H0 = 512, H1 = 256, H2 = 128, ACT = 12, NJ = 19, NCMD = 25;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PolicyTables {  // system_class.cpp:103-123
+  int m2o[NJ];         // mujoco_to_orbit.indices(): (P v)[idx[i]] = v[i]
+  int o2m_legs[ACT];   // orbit_to_mujoco_legs.indices()
+  float default_pos[NJ];
+};
+
+__device__ __forceinline__ void rot_vec_quat(float* r, const float* v, const float* q) {  // mju_rotVecQuat
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  r[0] = (1 - 2 * (y * y + z * z)) * v[0] + 2 * (x * y - w * z) * v[1] + 2 * (x * z + w * y) * v[2];
+  r[1] = 2 * (x * y + w * z) * v[0] + (1 - 2 * (x * x + z * z)) * v[1] + 2 * (y * z - w * x) * v[2];
+  r[2] = 2 * (x * z - w * y) * v[0] + 2 * (y * z + w * x) * v[1] + (1 - 2 * (x * x + y * y)) * v[2];
+}
+
+// one thread per rollout; the row is assembled in registers and written as 84 consecutive floats
+__global__ __launch_bounds__(256) void k_policy_obs(PolicyTables T, const float* __restrict__ states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos,
+                                                    int leg_qvel, const float* __restrict__ command, const float* __restrict__ prev_out, int N,
+                                                    float* __restrict__ obs) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* qpos = states + (size_t)n * ld; const float* qvel = qpos + nq;
+  const float* cmd = command + (size_t)n * NCMD;
+  float* o = obs + (size_t)n * OBS;
+  const float inv[4] = {qpos[base_qpos + 3], -qpos[base_qpos + 4], -qpos[base_qpos + 5], -qpos[base_qpos + 6]};
+  const float lv[3] = {qvel[base_qvel], qvel[base_qvel + 1], qvel[base_qvel + 2]}, g0[3] = {0.f, 0.f, -1.f};
+  float lin[3], grav[3];
+  rot_vec_quat(lin, lv, inv); rot_vec_quat(grav, g0, inv);
+  for (int i = 0; i < 3; i++) { o[i] = lin[i]; o[3 + i] = qvel[base_qvel + 3 + i]; o[6 + i] = grav[i]; o[9 + i] = cmd[i]; o[31 + i] = cmd[22 + i]; }
+  for (int i = 0; i < 7; i++) o[12 + i] = cmd[3 + i];
+  for (int i = 0; i < 12; i++) { o[19 + i] = cmd[10 + i]; o[72 + i] = prev_out[(size_t)n * ACT + i]; }
+  for (int i = 0; i < NJ; i++) { o[34 + T.m2o[i]] = qpos[leg_qpos + i] - T.default_pos[i]; o[53 + T.m2o[i]] = qvel[leg_qvel + i]; }
+}
+
+// C (M x Nout) = act(A (M x K) * W^T + b), W is (Nout x K) row-major (the ONNX Gemm layout with transB = 1).
+// Workgroup = 4 waves, tile 128 x 128, K in chunks of 32 staged in LDS; each wave owns a 64 x 64 quadrant as 2 x 2 MFMA accumulators
+// (four independent accumulation chains keep the matrix pipe busy from a single wave per SIMD).
+// Operand map of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+// result register v of lane l is C[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31].
+template <bool ELU>
+__global__ __launch_bounds__(256) void k_gemm_bias_act(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
+                                                       int Nout, float* __restrict__ C) {
+  constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
+  __shared__ float sA[BM * LDT], sW[BN * LDT];
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int v = 0; v < 16; v++) acc[i][j][v] = 0.f;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    for (int e = tid; e < BM * (BK / 4); e += 256) {  // K is a multiple of 4 on every layer: 16-byte loads, 8 per row and chunk
+      const int r = e >> 3, c = (e & 7) * 4, k = k0 + c;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + r < M && k < K) va = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
+      if (n0 + r < Nout && k < K) vw = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
+      float* pa_ = sA + r * LDT + c; float* pw_ = sW + r * LDT + c;
+      pa_[0] = va.x; pa_[1] = va.y; pa_[2] = va.z; pa_[3] = va.w; pw_[0] = vw.x; pw_[1] = vw.y; pw_[2] = vw.z; pw_[3] = vw.w;
+    }
+    __syncthreads();
+    const float* pa = sA + (64 * wm + (l & 31)) * LDT + (l >> 5);
+    const float* pw = sW + (64 * wn + (l & 31)) * LDT + (l >> 5);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = pa[kk], a1 = pa[32 * LDT + kk], b0 = pw[kk], b1 = pw[32 * LDT + kk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int col = n0 + 64 * wn + 32 * j + (l & 31);
+    if (col >= Nout) continue;
+    const float b = bias[col];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int row = m0 + 64 * wm + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+        if (row < M) {
+          float x = acc[i][j][v] + b;
+          if (ELU) x = x > 0.f ? x : expm1f(x);
+          C[(size_t)row * Nout + col] = x;
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_policy_control(PolicyTables T, const float* __restrict__ obs, const float* __restrict__ actions, int N,
+                                                        float* __restrict__ policy_out, float* __restrict__ control) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* o = obs + (size_t)n * OBS; const float* a = actions + (size_t)n * ACT;
+  float c[NJ];
+  for (int i = 0; i < ACT; i++) { const float ai = a[i]; policy_out[(size_t)n * ACT + i] = ai; c[T.o2m_legs[i]] = 0.2f * ai; }
+  for (int i = 0; i < ACT; i++) c[i] += T.default_pos[i];
+  for (int i = 0; i < 7; i++) c[12 + i] = o[12 + i];
+  bool done = false;  // the first leg with a non-zero command overrides its three joint targets (if / else-if chain in the reference)
+  for (int leg = 0; leg < 4; leg++) {
+    const float x = o[19 + 3 * leg], y = o[20 + 3 * leg], z = o[21 + 3 * leg];
+    if (!done && x * x + y * y + z * z > 0.f) { c[3 * leg] = x; c[3 * leg + 1] = y; c[3 * leg + 2] = z; done = true; }
+  }
+  for (int i = 0; i < NJ; i++) control[(size_t)n * NJ + i] = c[i];
+}
+
+}  // namespace
+
+struct jh_policy { float* d_w[4]; float* d_b[4]; PolicyTables tab; };
+
+extern "C" int jh_policy_create(const float* const* weights /* W0..W3, (out,in) row-major */, const float* const* biases, jh_policy** out) {
+  JH_REQUIRE(weights && biases && out, "policy_create: null pointer");
+  const int dims[5] = {OBS, H0, H1, H2, ACT};
+  jh_policy* p = new jh_policy();
+  for (int i = 0; i < 4; i++) {
+    JH_REQUIRE(weights[i] && biases[i], "policy_create: null layer %d", i);
+    JH_HIP(hipMalloc(&p->d_w[i], sizeof(float) * dims[i] * dims[i + 1]));
+    JH_HIP(hipMalloc(&p->d_b[i], sizeof(float) * dims[i + 1]));
+    JH_HIP(hipMemcpy(p->d_w[i], weights[i], sizeof(float) * dims[i] * dims[i + 1], hipMemcpyHostToDevice));
+    JH_HIP(hipMemcpy(p->d_b[i], biases[i], sizeof(float) * dims[i + 1], hipMemcpyHostToDevice));
+  }
+  const int m2o[NJ] = {1, 6, 11, 2, 7, 12, 3, 8, 13, 4, 9, 14, 0, 5, 10, 15, 16, 17, 18};
+  const int o2m[ACT] = {0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11};
+  const float dpos[NJ] = {0.12f, 0.5f, -1.f, -0.12f, 0.5f, -1.f, 0.12f, 0.5f, -1.f, -0.12f, 0.5f, -1.f, 0.f, -0.9f, 1.8f, 0.f, -0.9f, 0.f, -1.54f};
+  for (int i = 0; i < NJ; i++) { p->tab.m2o[i] = m2o[i]; p->tab.default_pos[i] = dpos[i]; }
+  for (int i = 0; i < ACT; i++) p->tab.o2m_legs[i] = o2m[i];
+  *out = p;
+  return JH_OK;
+}
+
+extern "C" void jh_policy_destroy(jh_policy* p) {
+  if (!p) return;
+  for (int i = 0; i < 4; i++) { (void)hipFree(p->d_w[i]); (void)hipFree(p->d_b[i]); }
+  delete p;
+}
+
+extern "C" size_t jh_policy_scratch_floats(int N) { return (size_t)(N > 0 ? N : 0) * (OBS + H0 + H1 + H2 + ACT); }
+
+extern "C" int jh_policy_step(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel,
+                              const float* command, float* policy_out, float* control, float* scratch, int N, void* stream) {
+  JH_REQUIRE(p && states && command && policy_out && control && scratch, "policy_step: null pointer");
+  JH_REQUIRE(N > 0, "policy_step: need at least one rollout");
+  JH_REQUIRE(nq > 0 && ld >= nq + leg_qvel + NJ && base_qpos >= 0 && base_qpos + 7 <= nq && leg_qpos >= 0 && leg_qpos + NJ <= nq && base_qvel >= 0 && leg_qvel >= 0,
+             "policy_step: state layout (ld=%d nq=%d base %d/%d joints %d/%d) does not hold a free base and 19 joints", ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel);
+  hipStream_t st = (hipStream_t)stream;
+  float* obs = scratch; float* h0 = obs + (size_t)N * OBS; float* h1 = h0 + (size_t)N * H0; float* h2 = h1 + (size_t)N * H1; float* act = h2 + (size_t)N * H2;
+  const int nb = (N + 255) / 256;
+  hipLaunchKernelGGL(k_policy_obs, dim3(nb), dim3(256), 0, st, p->tab, states, ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, command, policy_out, N, obs);
+  const int mb = (N + 127) / 128;
+  hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H0 / 128), dim3(256), 0, st, obs, p->d_w[0], p->d_b[0], N, OBS, H0, h0);
+  hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H1 / 128), dim3(256), 0, st, h0, p->d_w[1], p->d_b[1], N, H0, H1, h1);
+  hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H2 / 128), dim3(256), 0, st, h1, p->d_w[2], p->d_b[2], N, H1, H2, h2);
+  hipLaunchKernelGGL(k_gemm_bias_act<false>, dim3(mb, 1), dim3(256), 0, st, h2, p->d_w[3], p->d_b[3], N, H2, ACT, act);
+  hipLaunchKernelGGL(k_policy_control, dim3(nb), dim3(256), 0, st, p->tab, obs, act, N, policy_out, control);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

@@ -260,3 +260,26 @@ def test_box_box_contacts_face_and_edge():
     q = np.array([1.0 + 0.03, 0.0, 0.1 + 0.0707 - 0.05, c, s, 0, 0])  # hanging over the x = 1 edge of the floor
     o3 = m.forward(q, np.zeros(6), np.zeros(0))
     assert o3["ncon"] >= 1
+
+
+def test_spot_policy_step_matches_golden():
+    """Policy half of the Spot policy rollout (system_class.cpp:125-238): the vectorised oracle against the vectors written by the
+    independent scalar restatement in tools/extract_spot_policy.py (which also verifies the ONNX graph: Gemm/Elu, alpha = beta = 1, transB = 1)."""
+    from oracle import policy as P
+
+    g = np.load(os.path.join(GOLDEN, "spot_policy.npz"))
+    Ws, bs = P.load_actor()
+    assert [w.shape for w in Ws] == [(512, 84), (256, 512), (128, 256), (12, 128)]
+    np.testing.assert_allclose(P.actor(Ws, bs, g["obs"]), g["actions"], rtol=1e-12, atol=1e-12)
+    nq, nv, bq, bv, lq, lv = (int(x) for x in g["step_layout"])
+    obs, ctrl, out = P.policy_step(Ws, bs, g["step_qpos"], g["step_qvel"], g["step_command"], g["step_prev"], base_qpos=bq, base_qvel=bv, leg_qpos=lq, leg_qvel=lv)
+    np.testing.assert_allclose(obs, g["step_obs"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(out, g["step_out"], rtol=0, atol=0)
+    np.testing.assert_allclose(ctrl, g["step_ctrl"], rtol=0, atol=1e-15)
+    # hand-checkable pieces: identity orientation leaves the base velocity alone and gravity points down; the leg override is exclusive
+    q = np.zeros((1, nq)); q[0, 3] = 1.0; v = np.zeros((1, nv)); v[0, :3] = [0.3, -0.2, 0.1]
+    o = P.observation(q, v, np.zeros((1, 25)), np.zeros((1, 12)), base_qpos=bq, base_qvel=bv, leg_qpos=lq, leg_qvel=lv)
+    np.testing.assert_allclose(o[0, :3], [0.3, -0.2, 0.1]); np.testing.assert_allclose(o[0, 6:9], [0, 0, -1])
+    both = g["step_command"][3].copy()[None]; assert np.any(both[0, 10:13]) and np.any(both[0, 13:16])
+    _, c, _ = P.policy_step(Ws, bs, g["step_qpos"][3:4], g["step_qvel"][3:4], both, g["step_prev"][3:4], base_qpos=bq, base_qvel=bv, leg_qpos=lq, leg_qvel=lv)
+    np.testing.assert_allclose(c[0, 0:3], both[0, 10:13]); assert not np.allclose(c[0, 3:6], both[0, 13:16])  # FL wins, FR keeps the policy's targets
