@@ -40,12 +40,31 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box reports 256 hardware threads
+    but runs the job under a 16-CPU quota; 256 oracle threads there are 3x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(round(float(quota) / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
     """Oracle rollouts (threaded C, fp64) on the host cores for a bounded sample of the same workload."""
     from oracle import oracle as O
     from tests.harness import oracle_plan_step
 
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     om = O.Model(task)
     K, nu, H = ctrl.optimizer.num_nodes, ctrl.nu, ctrl.num_timesteps
     rng = np.random.default_rng(0)
@@ -66,7 +85,7 @@ def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
         n = int(min(65536, max(2 * n, n * (seconds_target / 2) / max(dt, 1e-3))))
     ctrl.optimizer.config.num_rollouts = saved
     return {"value": total_rollouts / total_t, "unit": "rollouts/s", "cores": cores, "kind": "port",
-            "sample": f"{total_rollouts} rollouts x H={H} of the same plan step (fp64 oracle engine, {cores} pthreads), {total_t:.1f} s"}
+            "sample": f"{total_rollouts} rollouts x H={H} of the same plan step (fp64 oracle engine, {cores} pthreads = usable CPUs of {os.cpu_count()} hardware threads), {total_t:.1f} s"}
 
 
 def materialize_line(args, torch, world: int, rank: int) -> None:
