@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
   }
   int n_overflow = 0, n_iters = 0, n_maxed = 0;
   float acc = 0.f;
-  // JH_V2_ABLATE (tools/time_ablate.py): repeat one phase gI[21] times (gI[20] selects it) to measure its share of the step;
+  // JH_V2_ABLATE (tools/diag/time_ablate.py): repeat one phase gI[21] times (gI[20] selects it) to measure its share of the step;
   // the repeated work is idempotent, V2_OPAQUE keeps the compiler from hoisting it out of the repeat loop
 #ifdef JH_V2_ABLATE
   const int ab_phase = gI[20], ab_reps = gI[21] > 0 ? gI[21] : 1;

@@ -255,9 +255,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
   int n_x[4] = {0, 0, 0, 0};  // solver exits: gradient / not a descent direction / expected decrease / iteration cap
 #endif
   float acc = 0.f;
-#ifdef JH_V3_DEBUG
-  float dbg[12] = {0}, dit[8][8] = {{0}}, dls[6][4] = {{0}};
-#endif
   __syncthreads();
   const int ndt = sNDT;
 
@@ -785,13 +782,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         for (int ls = 0; ls < 12 && __any(lsact); ls++) {
           float d1, d2;
           lane_rows_dir(sl, sf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
-#ifdef JH_V3_DEBUG
-          const float d1raw = d1, d2raw = d2;
-#endif
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
-#ifdef JH_V3_DEBUG
-          if (hh == 0 && it == 2 && ls < 6) { dls[ls][0] = d1; dls[ls][1] = d2; dls[ls][2] = alpha; dls[ls][3] = d1raw; }
-#endif
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
@@ -803,9 +794,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
             }
           }
         }
-#ifdef JH_V3_DEBUG
-        if (hh == 0 && it < 8) { dit[it][0] = gn; dit[it][1] = gp; dit[it][2] = alpha; dit[it][3] = g_own; dit[it][4] = p_own; dit[it][5] = a_own; dit[it][6] = act ? 1.f : 0.f; dit[it][7] = snorm; }
-#endif
         // ---- (7) step
         if (act) {
           a_own += alpha * p_own;
@@ -848,9 +836,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       for (int a = 0; a < NA; a++) if (a == ai) qacc = x9[a];
       if (isarm) { qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); }
       qws = a_own;
-#ifdef JH_V3_DEBUG
-      if (hh == 0) { dbg[0] = fs_own; dbg[1] = a0_own; dbg[2] = a_own; dbg[3] = qacc; dbg[4] = eD; dbg[5] = earef; dbg[6] = ejar; dbg[7] = dr.jf; dbg[8] = dr.fD; dbg[9] = dr.fl; dbg[10] = dr.lims; dbg[11] = (float)iters_this; }
-#endif
       for (int k = 0; k < 3; k++) {  // free body: every lane integrates the replicated state from the published right-hand side
         const float al = S.vec[1][k] / cmass, aw = S.vec[1][3 + k] / cI[k];
         vc[k] = fmaf(h, al, vc[k]); vc[3 + k] = fmaf(h, aw, vc[3 + k]);
@@ -891,15 +876,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       __syncthreads();
     }
   }
-#ifdef JH_V3_DEBUG
-  __syncthreads();
-  if (MATERIALIZE && states && N == 4 && n == 0) {  // debug dump (tools/debug_fr3_m.py), one wave: step-0 quantities into the other rollouts' output rows
-    float* o = states + (size_t)H * NX;
-    for (int k = 0; k < 12; k++) o[16 * k + l] = dbg[k];
-    for (int it = 0; it < 8; it++) for (int k = 0; k < 8; k++) o[192 + (it * 8 + k) * 16 + l] = dit[it][k];
-    for (int e = 0; e < 6; e++) for (int k = 0; k < 4; k++) o[192 + 1024 + (e * 4 + k) * 16 + l] = dls[e][k];
-  }
-#endif
   if (!MATERIALIZE && live && l == 0) costs[n] = acc;
 #ifdef JH_V3_EXITSTATS
   if (stats && live && l == 0) for (int k = 0; k < 4; k++) atomicAdd(stats + 24 + k, n_x[k]);

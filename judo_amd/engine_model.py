@@ -41,7 +41,7 @@ HEADER_I, HEADER_F = 24, 24
 # Newton termination on the GPU: |grad|_Minv <= tol * |qfrc_smooth|_Minv (or the expected decrease of a step falls below
 # tol^2 of the same scale), at most SOLVER_MAX_ITER iterations (MuJoCo: tolerance 1e-8 in fp64, 100 iterations)
 SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-3
-# diagnostics: (phase, repeats) read only by -DJH_V2_ABLATE builds of the cooperative kernel (tools/time_ablate.py)
+# diagnostics: (phase, repeats) read only by -DJH_V2_ABLATE builds of the cooperative kernel (tools/diag/time_ablate.py)
 ABLATE = (0, 1)
 
 

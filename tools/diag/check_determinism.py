@@ -1,6 +1,6 @@
 """Scratch diagnostic (GPU box): are two identical materialise launches bit-identical?  (per task, both kernel generations)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd.rollout_backend import GpuRolloutBackend
 from judo_amd.tasks import get_registered_tasks

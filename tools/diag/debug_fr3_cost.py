@@ -1,6 +1,6 @@
 """Scratch diagnostic (GPU box): fused fr3 costs of both kernel generations vs the oracle, per rollout."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd.controller import make_controller
 from oracle import oracle as O

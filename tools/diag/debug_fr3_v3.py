@@ -1,6 +1,6 @@
 """Scratch diagnostic (GPU box): fr3_pick cooperative kernel vs oracle, per-step / per-column error report."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests.test_gpu_fr3 import _controls
 from judo_amd.rollout_backend import GpuRolloutBackend

@@ -1,6 +1,6 @@
 """Scratch diagnostic (GPU box): leap_cube engine vs oracle, per-step and per-rollout errors."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd import _lib
 if os.environ.get("JH_LIB"): _lib.LIB_PATH = os.environ["JH_LIB"]

@@ -1,6 +1,6 @@
 """Scratch diagnostic (CPU): Newton iterations per solve of the fp64 oracle on bench-like leap_cube rollouts, per tolerance."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O
 from judo_amd.tasks import LeapCube

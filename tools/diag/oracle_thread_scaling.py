@@ -1,6 +1,6 @@
 """Scratch diagnostic (any box): throughput of the oracle's threaded rollout against the thread count (the bench's cpu_baseline uses all hardware threads)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O
 from judo_amd.tasks import LeapCube

@@ -1,7 +1,7 @@
 """Scratch diagnostic (GPU box): per-phase shader-cycle totals of the leap_cube engine, from an instrumented build
 (build/libjudo_amd_prof.so, -DJH_ENGINE_PROFILE)."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), '..', 'build', 'libjudo_amd_prof.so')

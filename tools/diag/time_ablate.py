@@ -1,7 +1,7 @@
 """Scratch diagnostic (GPU box): share of each phase of the cooperative leap_cube kernel, measured by repeating one phase
 R times in a -DJH_V2_ABLATE build (tools/build_variant.sh ablate -DJH_V2_ABLATE) and differencing the plan-step times."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd import _lib, engine_model
 from judo_amd.controller import make_controller

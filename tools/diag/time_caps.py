@@ -1,6 +1,6 @@
 """Scratch diagnostic (GPU box): leap_cube plan-step time against the Newton iteration cap (fixed cost vs per-iteration cost)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd import engine_model
 from judo_amd.controller import make_controller

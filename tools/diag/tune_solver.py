@@ -1,6 +1,6 @@
 """Scratch diagnostic (GPU box): effect of the Newton / line-search tolerances on time, iterations and parity."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd import engine_model as EM
 from oracle import oracle as O
