@@ -116,8 +116,9 @@ int jo_add_geom(jo_model* m, int body, int type, const double* size, const doubl
   m->geom_type[g] = type; m->geom_body[g] = body; m->geom_condim[g] = condim;
   copy3(m->geom_size[g], size); copy3(m->geom_pos[g], pos); memcpy(m->geom_quat[g], quat, 4 * sizeof(double)); quat_normalize(m->geom_quat[g]);
   copy3(m->geom_friction[g], friction); memcpy(m->geom_solref[g], solref, 2 * sizeof(double)); memcpy(m->geom_solimp[g], solimp, 5 * sizeof(double));
-  m->geom_margin[g] = margin; m->geom_gap[g] = gap;
+  m->geom_margin[g] = margin; m->geom_gap[g] = gap; m->geom_priority[g] = 0;
   switch (type) { /* bounding-sphere radius (mjModel.geom_rbound) */
+    case JO_GEOM_PLANE: m->geom_rbound[g] = 0; break; /* infinite: the bounding-sphere filter skips planes */
     case JO_GEOM_SPHERE: m->geom_rbound[g] = size[0]; break;
     case JO_GEOM_CAPSULE: m->geom_rbound[g] = size[0] + size[1]; break;
     case JO_GEOM_CYLINDER: m->geom_rbound[g] = sqrt(size[0] * size[0] + size[1] * size[1]); break;
@@ -126,6 +127,7 @@ int jo_add_geom(jo_model* m, int body, int type, const double* size, const doubl
   }
   return g;
 }
+int jo_set_geom_priority(jo_model* m, int geom, int priority) { if (geom < 0 || geom >= m->ngeom) return -1; m->geom_priority[geom] = priority; return 0; }
 int jo_add_pair(jo_model* m, int g1, int g2) {
   if (m->npair >= JO_MAXPAIR || g1 < 0 || g2 < 0 || g1 >= m->ngeom || g2 >= m->ngeom || g1 == g2) return -1;
   if (g1 > g2) { int t = g1; g1 = g2; g2 = t; } /* MuJoCo orders a pair by geom id: geom1 < geom2 */
@@ -342,7 +344,7 @@ static void rne_bias(const jo_model* m, jo_data* d) {
 }
 
 /* ------------------------------------------------------------------ collision */
-typedef struct { double dist, pos[3], n[3]; } rawcon;
+typedef struct { double dist, pos[3], n[3], t[3]; int has_t; } rawcon; /* t: preferred first tangent (mju_makeFrame orthogonalises it) */
 
 /* frame = [normal; t1; t2], tangents as mju_makeFrame builds them */
 static void make_frame(double* frame) {
@@ -510,6 +512,44 @@ static double box_box_distance(const double* p1, const double* R1, const double*
   return best;
 }
 
+/* Plane (geom 1) against sphere / capsule / box (engine_collision_primitive.c: mjc_PlaneSphere, mjc_PlaneCapsule, mjc_PlaneBox).
+ * The plane's normal is its local z axis; contact normal = plane normal (from geom 1 to geom 2), position midway between the surfaces. */
+static int collide_plane_sphere(const double* pp, const double* Rp, const double* c, double r, double margin, rawcon* out) {
+  double n[3]; col(n, Rp, 2);
+  double dif[3] = {c[0] - pp[0], c[1] - pp[1], c[2] - pp[2]};
+  double dist = dot3(dif, n) - r;
+  if (dist > margin) return 0;
+  out->dist = dist; copy3(out->n, n); out->has_t = 0;
+  for (int k = 0; k < 3; k++) out->pos[k] = c[k] - n[k] * (r + 0.5 * dist);
+  return 1;
+}
+static int collide_plane_capsule(const double* pp, const double* Rp, const double* pc, const double* Rc, const double* size, double margin, rawcon* out) {
+  double axis[3]; col(axis, Rc, 2);
+  int n = 0;
+  for (int sgn = 1; sgn >= -1; sgn -= 2) { /* the two end spheres, + end first */
+    double c[3] = {pc[0] + sgn * size[1] * axis[0], pc[1] + sgn * size[1] * axis[1], pc[2] + sgn * size[1] * axis[2]};
+    int k = collide_plane_sphere(pp, Rp, c, size[0], margin, out + n);
+    if (k) { copy3(out[n].t, axis); out[n].has_t = 1; n++; } /* the second frame axis follows the capsule axis */
+  }
+  return n;
+}
+static int collide_plane_box(const double* pp, const double* Rp, const double* pb, const double* Rb, const double* h, double margin, rawcon* out) {
+  double n[3]; col(n, Rp, 2);
+  double dif[3] = {pb[0] - pp[0], pb[1] - pp[1], pb[2] - pp[2]};
+  double dist = dot3(dif, n);
+  int cnt = 0;
+  for (int i = 0; i < 8 && cnt < 4; i++) { /* corners in MuJoCo's order: bit 0 -> x, bit 1 -> y, bit 2 -> z; at most 4 contacts */
+    double vl[3] = {(i & 1 ? h[0] : -h[0]), (i & 2 ? h[1] : -h[1]), (i & 4 ? h[2] : -h[2])}, vec[3];
+    rot(vec, Rb, vl);
+    double ldist = dot3(n, vec);
+    if (dist + ldist > margin) continue;
+    out[cnt].dist = dist + ldist; copy3(out[cnt].n, n); out[cnt].has_t = 0;
+    for (int k = 0; k < 3; k++) out[cnt].pos[k] = pb[k] + vec[k] - n[k] * (0.5 * out[cnt].dist);
+    cnt++;
+  }
+  return cnt;
+}
+
 static void collision(const jo_model* m, jo_data* d) {
   d->ncon = 0;
   if (!m->contact_enabled) return;
@@ -517,9 +557,17 @@ static void collision(const jo_model* m, jo_data* d) {
     int g1 = m->pair_g1[p], g2 = m->pair_g2[p];
     double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
     double dc[3] = {d->geom_xpos[g2][0] - d->geom_xpos[g1][0], d->geom_xpos[g2][1] - d->geom_xpos[g1][1], d->geom_xpos[g2][2] - d->geom_xpos[g1][2]};
-    if (norm3(dc) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue; /* bounding-sphere filter */
-    rawcon rc[8]; int n = 0, flip = 0;
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    if (t1 != JO_GEOM_PLANE && t2 != JO_GEOM_PLANE && norm3(dc) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue; /* bounding-sphere filter */
+    rawcon rc[8]; int n = 0, flip = 0;
+    for (int i = 0; i < 8; i++) rc[i].has_t = 0;
+    if (t1 == JO_GEOM_PLANE || t2 == JO_GEOM_PLANE) {
+      int gp = t1 == JO_GEOM_PLANE ? g1 : g2, go = t1 == JO_GEOM_PLANE ? g2 : g1, to = m->geom_type[go];
+      flip = (gp != g1);
+      if (to == JO_GEOM_SPHERE) n = collide_plane_sphere(d->geom_xpos[gp], d->geom_xmat[gp], d->geom_xpos[go], m->geom_size[go][0], margin, rc);
+      else if (to == JO_GEOM_CAPSULE) n = collide_plane_capsule(d->geom_xpos[gp], d->geom_xmat[gp], d->geom_xpos[go], d->geom_xmat[go], m->geom_size[go], margin, rc);
+      else if (to == JO_GEOM_BOX) n = collide_plane_box(d->geom_xpos[gp], d->geom_xmat[gp], d->geom_xpos[go], d->geom_xmat[go], m->geom_size[go], margin, rc);
+    } else
     if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_BOX) n = collide_box_box(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
     else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_SPHERE) n = collide_box_sphere(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2][0], margin, rc);
     else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], d->geom_xpos[g1], m->geom_size[g1][0], margin, rc); flip = 1; }
@@ -530,16 +578,24 @@ static void collision(const jo_model* m, jo_data* d) {
       c->dist = rc[i].dist; copy3(c->pos, rc[i].pos);
       for (int k = 0; k < 3; k++) c->frame[k] = flip ? -rc[i].n[k] : rc[i].n[k];
       make_frame(c->frame);
+      if (rc[i].has_t) { /* mju_makeFrame with a given second axis: orthogonalise against the normal, keep it if it survives */
+        double y[3]; copy3(y, rc[i].t); double dp = dot3(c->frame, y); addscl3(y, c->frame, -dp);
+        double nn = norm3(y);
+        if (nn > 0.5 * 1e-3) { for (int k = 0; k < 3; k++) c->frame[3 + k] = y[k] / nn; cross3(c->frame + 6, c->frame, c->frame + 3); }
+      }
       c->g1 = g1; c->g2 = g2;
       /* contact parameter mixing (mj_contactParam, equal priority / solmix): condim max, friction max,
        * solref/solimp average, margin/gap max */
       c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
       double f[3]; for (int k = 0; k < 3; k++) f[k] = fmax(m->geom_friction[g1][k], m->geom_friction[g2][k]);
+      int gpri = m->geom_priority[g1] > m->geom_priority[g2] ? g1 : (m->geom_priority[g2] > m->geom_priority[g1] ? g2 : -1);
+      if (gpri >= 0) { c->dim = m->geom_condim[gpri]; for (int k = 0; k < 3; k++) f[k] = m->geom_friction[gpri][k]; } /* different priorities: the higher one decides */
       c->friction[0] = c->friction[1] = f[0]; c->friction[2] = f[1]; c->friction[3] = c->friction[4] = f[2];
       for (int k = 0; k < 5; k++) if (c->friction[k] < MINMU) c->friction[k] = MINMU;
       if (m->geom_solref[g1][0] > 0 && m->geom_solref[g2][0] > 0) for (int k = 0; k < 2; k++) c->solref[k] = 0.5 * (m->geom_solref[g1][k] + m->geom_solref[g2][k]);
       else for (int k = 0; k < 2; k++) c->solref[k] = fmin(m->geom_solref[g1][k], m->geom_solref[g2][k]);
       for (int k = 0; k < 5; k++) c->solimp[k] = 0.5 * (m->geom_solimp[g1][k] + m->geom_solimp[g2][k]);
+      if (gpri >= 0) { memcpy(c->solref, m->geom_solref[gpri], 2 * sizeof(double)); memcpy(c->solimp, m->geom_solimp[gpri], 5 * sizeof(double)); }
       c->includemargin = margin - fmax(m->geom_gap[g1], m->geom_gap[g2]);
       c->efc_adr = -1; c->mu = c->friction[0];
     }

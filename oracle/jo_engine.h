@@ -49,7 +49,7 @@ extern "C" {
 #define JO_MAXEFC 400
 
 enum { JO_JNT_FREE = 0, JO_JNT_SLIDE = 2, JO_JNT_HINGE = 3 };
-enum { JO_GEOM_SPHERE = 2, JO_GEOM_CAPSULE = 3, JO_GEOM_CYLINDER = 5, JO_GEOM_BOX = 6 };
+enum { JO_GEOM_PLANE = 0, JO_GEOM_SPHERE = 2, JO_GEOM_CAPSULE = 3, JO_GEOM_CYLINDER = 5, JO_GEOM_BOX = 6 };
 enum { JO_INT_EULER = 0, JO_INT_IMPLICITFAST = 3 };
 enum { JO_CONE_PYRAMIDAL = 0, JO_CONE_ELLIPTIC = 1 };
 enum { JO_SENS_FRAMEPOS_SITE = 0, JO_SENS_FRAMEPOS_BODY = 1, JO_SENS_JOINTPOS = 2, JO_SENS_FRAMEZAXIS_BODY = 3, JO_SENS_DISTANCE = 4 };
@@ -75,7 +75,7 @@ typedef struct jo_model {
   double dof_solref[JO_MAXDOF][2], dof_solimp[JO_MAXDOF][5], dof_frcrange[JO_MAXDOF][2];
   double qpos0[JO_MAXQ];
   /* geoms */
-  int geom_type[JO_MAXGEOM], geom_body[JO_MAXGEOM], geom_condim[JO_MAXGEOM];
+  int geom_type[JO_MAXGEOM], geom_body[JO_MAXGEOM], geom_condim[JO_MAXGEOM], geom_priority[JO_MAXGEOM];
   double geom_size[JO_MAXGEOM][3], geom_pos[JO_MAXGEOM][3], geom_quat[JO_MAXGEOM][4], geom_friction[JO_MAXGEOM][3];
   double geom_solref[JO_MAXGEOM][2], geom_solimp[JO_MAXGEOM][5], geom_margin[JO_MAXGEOM], geom_gap[JO_MAXGEOM], geom_rbound[JO_MAXGEOM];
   int pair_g1[JO_MAXPAIR], pair_g2[JO_MAXPAIR];
@@ -170,6 +170,8 @@ void jo_rollout_batch(const jo_model* m, const double* x0, int x0_batched, const
 /* diagnostics (tools/): Newton iterations per solve over all threads; solver tolerance / iteration cap override */
 void jo_solver_histogram(long* out32, int reset);
 void jo_set_solver(jo_model* m, double tol, int maxiter);
+/* contact-parameter priority of a geom (mjModel.geom_priority, default 0): the higher priority side supplies friction / solref / solimp / condim */
+int jo_set_geom_priority(jo_model* m, int geom, int priority);
 void jo_set_warmstart_mode(int mode); /* 0 = MuJoCo (better of previous qacc and qacc_smooth); 1 = also try qacc_smooth + previous constraint acceleration */
 
 #ifdef __cplusplus

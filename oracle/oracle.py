@@ -24,7 +24,7 @@ _MODELS = os.path.join(os.path.dirname(_HERE), "judo_amd", "models")
 _LIB = None
 
 JNT = {"free": 0, "slide": 2, "hinge": 3}
-GEOM = {"sphere": 2, "capsule": 3, "cylinder": 5, "box": 6}
+GEOM = {"plane": 0, "sphere": 2, "capsule": 3, "cylinder": 5, "box": 6}
 SENS = {"framepos_site": 0, "framepos_body": 1, "jointpos": 2, "framezaxis_body": 3, "distance": 4}
 
 dp = C.POINTER(C.c_double)
@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
         L.jo_add_joint.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_double, C.c_int, dp, dp, dp, dp, dp]
         L.jo_add_geom.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int]
         L.jo_add_pair.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.jo_set_geom_priority.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.jo_add_site.argtypes = [C.c_void_p, C.c_int, dp]
         L.jo_add_actuator.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, dp, C.c_int, dp]
         L.jo_add_sensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
@@ -116,7 +117,8 @@ def collision_pairs(desc: dict, scope: str = "task") -> list[tuple[int, int]]:
         return weld(bodies[w]["parent"]) if w > 0 else 0
 
     excl = {tuple(sorted(e)) for e in desc["excludes"]}
-    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("cylinder", "cylinder")}
+    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("cylinder", "cylinder"),
+                 ("plane", "sphere"), ("plane", "capsule"), ("plane", "box"), ("sphere", "plane"), ("capsule", "plane"), ("box", "plane")}
     pairs = []
     for g1 in range(len(geoms)):
         for g2 in range(g1 + 1, len(geoms)):
@@ -164,6 +166,8 @@ class Model:
             size = (list(g["size"]) + [0, 0, 0])[:3]
             r = L.jo_add_geom(self.ptr, g["body"], GEOM[g["type"]], _d(size), _d(g["pos"]), _d(g["quat"]), _d(g["friction"]), _d(g["solref"]), _d(g["solimp"]), g["margin"], g["gap"], g["condim"])
             assert r >= 0
+            if g.get("priority", 0):
+                assert L.jo_set_geom_priority(self.ptr, r, int(g["priority"])) == 0
         self.pairs = pairs if pairs is not None else collision_pairs(d)
         for g1, g2 in self.pairs:
             assert L.jo_add_pair(self.ptr, g1, g2) >= 0

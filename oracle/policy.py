@@ -65,3 +65,43 @@ def policy_step(Ws, bs, qpos, qvel, command, prev_out, **layout):
         m = first == leg
         ctrl[m, 3 * leg:3 * leg + 3] = lj[m, leg]
     return obs, ctrl, out
+
+
+# ------------------------------------------------------------------------------------------------ the rollout around the policy step
+LEGS_STANDING_POS_RL = np.array([0.12, 0.5, -1.0, -0.12, 0.5, -1.0, 0.12, 0.5, -1.0, -0.12, 0.5, -1.0])  # judo/tasks/spot/spot_constants.py:72-88
+ARM_STOWED_POS = np.array([0, -3.11, 3.13, 1.56, 0, -1.56, 0.0])                                         # :90
+STANDING_HEIGHT = 0.52                                                                                    # :95
+DEFAULT_POLICY_COMMAND = np.concatenate([[0, 0, 0], ARM_STOWED_POS, np.zeros(12), [0, 0, STANDING_HEIGHT]])  # judo/tasks/spot/spot_base.py:159-161
+
+
+def spot_model():
+    """The Spot model (judo/models/xml/spot_primitive/robot.xml) in the oracle engine.  Scope of this round: robot geoms against the ground
+    plane (sphere / capsule / box vs plane); robot self-collision pairs (capsule-capsule, capsule-box) are not generated; the model's
+    sensors (relative frame positions, frame axes) are not evaluated."""
+    from oracle import oracle as O
+
+    desc = dict(O.load_description("spot"), sensors=[])
+    plane = next(i for i, g in enumerate(desc["geoms"]) if g["type"] == "plane")
+    pairs = [(min(plane, i), max(plane, i)) for i, g in enumerate(desc["geoms"]) if i != plane]
+    return O.Model("spot", desc=desc, pairs=pairs)
+
+
+def spot_reset_state(arm=ARM_STOWED_POS):
+    """SpotBase.reset_pose (spot_base.py:421-435) with zero velocities: (nq + nv,) = (26 + 25,)."""
+    return np.concatenate([[0, 0, STANDING_HEIGHT, 1, 0, 0, 0], LEGS_STANDING_POS_RL, arm, np.zeros(25)])
+
+
+def policy_rollout(om, Ws, bs, state, commands, physics_substeps=2, last_policy_output=None):
+    """System::rollout (system_class.cpp:277-331) without the wall-clock cutoff: per command row one policy step, then
+    `physics_substeps` engine steps with that control held; the state is recorded at the end of the substeps."""
+    nq = om.nq
+    x = np.asarray(state, dtype=np.float64).copy()
+    out = np.zeros(12) if last_policy_output is None else np.asarray(last_policy_output, dtype=np.float64)
+    states = np.zeros((len(commands), om.nx))
+    for i, cmd in enumerate(np.asarray(commands, dtype=np.float64)):
+        _, ctrl, o = policy_step(Ws, bs, x[None, :nq], x[None, nq:], cmd[None], out[None])
+        out = o[0]
+        st, _ = om.rollout(x, np.repeat(ctrl, physics_substeps, axis=0)[None], nthread=1)
+        x = st[0, -1]
+        states[i] = x
+    return states, out

@@ -134,6 +134,24 @@ def quat_rot(q, v):
     return [sum(R[i][j] * v[j] for j in range(3)) for i in range(3)]
 
 
+def mat_to_quat(R):
+    """Rotation matrix (rows) -> unit quaternion (w, x, y, z)."""
+    t = R[0][0] + R[1][1] + R[2][2]
+    if t > 0:
+        s_ = math.sqrt(t + 1.0) * 2
+        q = [0.25 * s_, (R[2][1] - R[1][2]) / s_, (R[0][2] - R[2][0]) / s_, (R[1][0] - R[0][1]) / s_]
+    elif R[0][0] > R[1][1] and R[0][0] > R[2][2]:
+        s_ = math.sqrt(1.0 + R[0][0] - R[1][1] - R[2][2]) * 2
+        q = [(R[2][1] - R[1][2]) / s_, 0.25 * s_, (R[0][1] + R[1][0]) / s_, (R[0][2] + R[2][0]) / s_]
+    elif R[1][1] > R[2][2]:
+        s_ = math.sqrt(1.0 + R[1][1] - R[0][0] - R[2][2]) * 2
+        q = [(R[0][2] - R[2][0]) / s_, (R[0][1] + R[1][0]) / s_, 0.25 * s_, (R[1][2] + R[2][1]) / s_]
+    else:
+        s_ = math.sqrt(1.0 + R[2][2] - R[0][0] - R[1][1]) * 2
+        q = [(R[1][0] - R[0][1]) / s_, (R[0][2] + R[2][0]) / s_, (R[1][2] + R[2][1]) / s_, 0.25 * s_]
+    return qnorm(q)
+
+
 def qnorm(q):
     n = math.sqrt(sum(x * x for x in q))
     return [x / n for x in q]
@@ -155,6 +173,8 @@ def quat_z_to(vec):
 def geom_inertia(g: dict) -> tuple[float, list[float]]:
     """mass, diagonal inertia (in the geom frame, about its centre) of a primitive; MuJoCo formulas."""
     t, s = g["type"], g["size"]
+    if t == "plane":  # planes carry no mass
+        return 0.0, [0.0, 0.0, 0.0]
     if t == "box":
         vol = 8 * s[0] * s[1] * s[2]
     elif t == "sphere":
@@ -271,7 +291,18 @@ def compile_model(xml_name: str, task: str) -> dict:
             # inertial: explicit <inertial> wins; else sum of geoms with mass (single-geom bodies in these models)
             inert = b.find("inertial")
             if inert is not None:
-                rec.update(mass=float(inert.get("mass")), ipos=fl(inert.get("pos", "0 0 0")), iquat=qnorm(fl(inert.get("quat", "1 0 0 0"))), inertia=fl(inert.get("diaginertia")))
+                if inert.get("diaginertia") is not None:
+                    rec.update(mass=float(inert.get("mass")), ipos=fl(inert.get("pos", "0 0 0")), iquat=qnorm(fl(inert.get("quat", "1 0 0 0"))), inertia=fl(inert.get("diaginertia")))
+                else:  # fullinertia = Ixx Iyy Izz Ixy Ixz Iyz in the inertial frame: principal axes by eigen-decomposition (any right-handed principal frame is equivalent)
+                    import numpy as _np
+                    f = fl(inert.get("fullinertia"))
+                    I = _np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+                    w, V = _np.linalg.eigh(I)
+                    if _np.linalg.det(V) < 0:
+                        V[:, 2] = -V[:, 2]
+                    q_local = mat_to_quat(V.tolist())
+                    q0 = qnorm(fl(inert.get("quat", "1 0 0 0")))
+                    rec.update(mass=float(inert.get("mass")), ipos=fl(inert.get("pos", "0 0 0")), iquat=qnorm(quat_mul(q0, q_local)), inertia=[float(x) for x in w])
             else:
                 massive = []
                 for g in geoms_here:
@@ -305,6 +336,12 @@ def compile_model(xml_name: str, task: str) -> dict:
             walk(b, bid, cc)
 
     wb = root.find("worldbody")
+    direct = [ch for ch in list(wb) if ch.tag in ("geom", "site")]
+    if direct:  # geoms / sites attached to the world itself (e.g. a ground plane): carried by a jointless body at the origin
+        fixtures = ET.SubElement(wb, "body", dict(name="world_fixtures", pos="0 0 0"))
+        for ch in direct:
+            wb.remove(ch)
+            fixtures.append(ch)
     walk(wb, 0, None)
 
     joint_id = {j["name"]: i for i, j in enumerate(model["joints"])}
@@ -337,8 +374,10 @@ def compile_model(xml_name: str, task: str) -> dict:
     for sen in root.findall("sensor"):
         for s in sen:
             rec = dict(name=s.get("name"), type=s.tag, adr=adr)
-            if s.tag == "framepos" or s.tag == "framezaxis":
+            if s.tag in ("framepos", "framexaxis", "frameyaxis", "framezaxis"):
                 rec.update(objtype=s.get("objtype"), obj=(site_id if s.get("objtype") == "site" else body_id)[s.get("objname")], dim=3)
+                if s.get("refname") is not None:  # value expressed in the reference frame (framepos: R_ref' (p - p_ref))
+                    rec.update(reftype=s.get("reftype"), ref=(site_id if s.get("reftype") == "site" else body_id)[s.get("refname")])
             elif s.tag == "jointpos":
                 rec.update(obj=joint_id[s.get("joint")], dim=1)
             elif s.tag == "distance":
@@ -354,7 +393,7 @@ def compile_model(xml_name: str, task: str) -> dict:
 def main() -> None:
     os.makedirs(OUT_DIR, exist_ok=True)
     for xml_name, task in (("cartpole.xml", "cartpole"), ("cylinder_push.xml", "cylinder_push"), ("leap_cube.xml", "leap_cube"), ("fr3_pick.xml", "fr3_pick"),
-                           ("leap_cube_palm_down.xml", "leap_cube_down")):
+                           ("leap_cube_palm_down.xml", "leap_cube_down"), ("spot_primitive/robot.xml", "spot")):
         m = compile_model(xml_name, task)
         if task == "leap_cube_down":
             m["family"] = "leap_cube"  # same components, palm-down hand pose: runs on the leap_cube kernels
