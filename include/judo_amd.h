@@ -145,6 +145,18 @@ size_t jh_policy_scratch_floats(int N);
 int jh_policy_step(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel,
                    const float* command, float* policy_out, float* control, float* scratch, int N, void* stream);
 
+/* ---- physics half of the Spot policy rollout (System::rollout's inner mj_step loop, mujoco_extensions/system/system_class.cpp:300-318): advance
+ * N rollouts of a floating-base robot on a ground plane by `substeps` engine steps with the control held.  The model image is what
+ * judo_amd/tree_model.py packs (free base + 19 hinges in 5 chains, plane contacts, pyramidal cones, implicitfast).  state_in / state_out are
+ * (N x 51) rows [qpos(26), qvel(25)] and may alias; ctrl is (N x 19) joint position targets; warmstart (N x 25, may be NULL) is the solver's
+ * starting acceleration, read and overwritten with this call's last constraint-consistent acceleration (mjData.qacc_warmstart).
+ * jh_tree_stats: [contacts dropped over capacity, steps at the iteration cap, Newton iterations, steps]. */
+typedef struct jh_tree jh_tree;
+int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out);
+void jh_tree_destroy(jh_tree* t);
+int jh_tree_stats(jh_tree* t, int* out4, int reset);
+int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

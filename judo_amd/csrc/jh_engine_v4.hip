@@ -1,0 +1,617 @@
+// jh_engine_v4.hip -- cooperative kernel for a floating-base robot on a ground plane (Spot, judo/models/xml/spot_primitive/robot.xml):
+// the physics substeps of the policy rollout (mujoco_extensions/system/system_class.cpp:277-331 calls mj_step `physics_substeps` times per
+// command row with the control of the policy step held).  32 lanes (two DPP rows) per rollout, 2 rollouts per wave64.
+//
+//   lane l < 6    free-base dof l (world-frame translation, body-frame rotation: MuJoCo's free-joint convention)
+//   lane 6..24    joint dof l-6 (4 legs x 3 + arm x 7): joint state, servo, friction-loss / limit rows, its link's inertia and geoms
+//   lane 25       carries the right-hand side as an extra matrix row through the factorisations
+//   every lane    one contact slot (capacity 24 per rollout)
+//
+// Dynamics in spatial-vector form about the base origin (an inertial point at this instant; keeps fp32 magnitudes small however far the
+// robot has walked): each dof lane publishes its spatial axis, each body lane its spatial inertia (10 numbers), composite inertias and bias
+// projections are accumulated along the (short) ancestor chains with LDS float atomics, M rows are `S_j . (Ic_i S_i)` over the ancestors
+// (mj_crb / mj_rne restated; oracle/jo_engine.c crb(), rne_bias()).  The three dense solves of a step -- M^-1 f, the Newton systems,
+// (M + h D)^-1 -- all run through one left-looking row Cholesky in which lane k publishes row k through LDS (same scheme as jh_engine_v3.hip).
+// Contacts: sphere / capsule / box against the plane (mjc_PlaneSphere / PlaneCapsule / PlaneBox), pyramidal cones, parameters mixed on the host.
+#include "jh_coop.h"
+
+using namespace jh_eng;
+using namespace jh_coop;
+
+namespace {
+
+constexpr int G = 32, RPW = 2, WAVE = 64;
+constexpr int NJ = 19, NVT = 25, NQ = 26, NX = 51, NB = 20, MAXD = 7;
+constexpr int NCP = 24, JW = NVT * 3, RAW_F = 8, NR = NVT + 1;  // NR: matrix rows incl. the right-hand-side row
+constexpr int TH_F = 32, TH_I = 16, TD_F = 56, TD_I = 4, TG_F = 28, TG_I = 2;  // judo_amd/tree_model.py
+// header floats
+enum { TF_DT = 0, TF_IMPRATIO, TF_TOL, TF_MAXITER, TF_LSTOL, TF_GRAV, TF_PLANE_P = 8, TF_PLANE_N = 11, TF_BMASS = 14, TF_BIPOS = 15, TF_BIR = 18, TF_BINERTIA = 27 };
+// joint floats
+enum { JF_LPOS = 0, JF_LR = 3, JF_AXIS = 12, JF_MASS = 15, JF_IPOS = 16, JF_IR = 19, JF_INERTIA = 28, JF_DAMP = 31, JF_ARM, JF_FL, JF_FB, JF_FD, JF_INVW, JF_LIMITED, JF_LO, JF_HI,
+       JF_LK, JF_LB, JF_SOLIMP = 42, JF_KP = 47, JF_KV, JF_CLIM, JF_CLO, JF_CHI, JF_FLIM, JF_FLO, JF_FHI };
+// geom floats
+enum { GF4_SIZE = 0, GF4_POS = 3, GF4_R = 6, GF4_MU = 15, GF4_K, GF4_B, GF4_SOLIMP = 18, GF4_TRAN = 23 };
+
+struct __attribute__((aligned(16))) RS4 {  // per-rollout shared state; positions are relative to the base origin
+  float xpos[NB][3], xR[NB][9];           // body 0 = base, 1 + k = link of joint k
+  float Sax[NVT][6];                      // spatial axes (angular, linear)
+  float Ic[NB][10];                       // composite spatial inertia: mass, m c (3), rotational part (xx, xy, xz, yy, yz, zz)
+  float q[NJ + 1], qd[G];
+  float bias[G];
+  float vec[3][G];
+  union { float M[NVT][NVT]; float Lrow[NR][NR]; };  // the inertia lives in LDS only until every lane has its row in registers
+  float raw[NCP][RAW_F];                  // pos3 (relative), dist, geom, tangent hint 3
+  float J[NCP][JW];
+  float fW[NCP][9];
+  int ncon;
+};
+
+__device__ __forceinline__ float gsum32(float v) {  // sum over the 32 lanes of a rollout, bit-identical in every lane
+  v = gsum(v);
+  return v + __shfl_xor(v, 16, 64);
+}
+__device__ __forceinline__ int gor32(int v) { v = gor(v); return v | __shfl_xor(v, 16, 64); }
+
+__device__ __forceinline__ void rodrigues4(float* Rq, const float* al, float q) {
+  float sn, cs; sincosf(q, &sn, &cs); const float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
+  Rq[0] = t * x * x + cs; Rq[1] = t * x * y - sn * z; Rq[2] = t * x * z + sn * y;
+  Rq[3] = t * x * y + sn * z; Rq[4] = t * y * y + cs; Rq[5] = t * y * z - sn * x;
+  Rq[6] = t * x * z - sn * y; Rq[7] = t * y * z + sn * x; Rq[8] = t * z * z + cs;
+}
+// spatial inertia (mass, mc, rotational part about the reference point) applied to a motion vector (w, v)
+__device__ __forceinline__ void inertia6_mul(float* f, const float* I10, const float* s) {
+  const float m = I10[0]; const float* mc = I10 + 1; const float* R = I10 + 4;  // R: xx xy xz yy yz zz
+  const float* w = s; const float* v = s + 3;
+  float cxv[3], cxw[3]; cross3(cxv, mc, v); cross3(cxw, mc, w);
+  f[0] = R[0] * w[0] + R[1] * w[1] + R[2] * w[2] + cxv[0];
+  f[1] = R[1] * w[0] + R[3] * w[1] + R[4] * w[2] + cxv[1];
+  f[2] = R[2] * w[0] + R[4] * w[1] + R[5] * w[2] + cxv[2];
+  f[3] = m * v[0] - cxw[0]; f[4] = m * v[1] - cxw[1]; f[5] = m * v[2] - cxw[2];
+}
+__device__ __forceinline__ void crossm6(float* r, const float* v, const float* s) {  // motion cross product v x s
+  float a[3], b[3], c[3]; cross3(a, v, s); cross3(b, v, s + 3); cross3(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+__device__ __forceinline__ void crossf6(float* r, const float* v, const float* f) {  // force cross product v x* f
+  float a[3], b[3], c[3]; cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+__device__ __forceinline__ float dot6(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+
+struct Slot4 { bool valid; float D, mu, aref[3], jar[3], jp[3]; };
+struct DofRows4 { float fl, fD, fR, faref, lims, laref, lD, jf, jl, pf, pl; };
+
+__device__ __forceinline__ void pyramid_dir4(const float* jar, const float* jp, float D, float mu, float* d1, float* d2) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float sg = (k & 1) ? -mu : mu;
+    const float x = jar[0] + sg * (k < 2 ? jar[1] : jar[2]), xp = jp[0] + sg * (k < 2 ? jp[1] : jp[2]);
+    if (x < 0.f) { *d1 += D * x * xp; *d2 += D * xp * xp; }
+  }
+}
+__device__ __forceinline__ float lane_cost4(const Slot4& sl, const DofRows4& dr) {
+  float cs = 0.f;
+  if (sl.valid) { float f[3], W[6]; cs += pyramid_eval(sl.jar, sl.D, sl.mu, f, W); }
+  if (dr.fl > 0.f) {
+    const float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+    if (x <= -lim) cs += -0.5f * dr.fR * fl * fl - fl * x; else if (x >= lim) cs += -0.5f * dr.fR * fl * fl + fl * x; else cs += 0.5f * dr.fD * x * x;
+  }
+  if (dr.lims != 0.f && dr.jl < 0.f) cs += 0.5f * dr.lD * dr.jl * dr.jl;
+  return cs;
+}
+__device__ __forceinline__ void lane_dir4(const Slot4& sl, const DofRows4& dr, float al, float* d1, float* d2) {
+  float g1 = 0.f, g2 = 0.f;
+  if (sl.valid) {
+    float jar[3] = {fmaf(al, sl.jp[0], sl.jar[0]), fmaf(al, sl.jp[1], sl.jar[1]), fmaf(al, sl.jp[2], sl.jar[2])};
+    pyramid_dir4(jar, sl.jp, sl.D, sl.mu, &g1, &g2);
+  }
+  if (dr.fl > 0.f) {
+    const float jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
+    if (x <= -lim) g1 -= fl * jp; else if (x >= lim) g1 += fl * jp; else { g1 += dr.fD * x * jp; g2 += dr.fD * jp * jp; }
+  }
+  if (dr.lims != 0.f) { const float jp = dr.pl, x = fmaf(al, jp, dr.jl); if (x < 0.f) { g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; } }
+  *d1 = g1; *d2 = g2;
+}
+
+// Left-looking row Cholesky through LDS + redundant backward solve.  Lane r < NVT holds row r of the symmetric matrix in row[0..r], lane NVT
+// the right-hand side in row[0..NVT-1]; on return every lane holds the whole solution x.  (row is clobbered.)
+__device__ __forceinline__ void row_cholesky_solve(float* row, RS4& S, int l, float* x) {
+#pragma unroll
+  for (int k = 0; k < NVT; k++) {
+    if (l == k) {
+      float d = row[k];
+#pragma unroll
+      for (int j = 0; j < k; j++) d -= row[j] * row[j];
+      const float rinv = __frsqrt_rn(fmaxf(d, 1e-30f));
+#pragma unroll
+      for (int j = 0; j < k; j++) S.Lrow[k][j] = row[j];
+      S.Lrow[k][k] = rinv;
+    }
+    __syncthreads();
+    if (l > k && l <= NVT) {
+      float s = row[k];
+#pragma unroll
+      for (int j = 0; j < k; j++) s -= row[j] * S.Lrow[k][j];
+      row[k] = s * S.Lrow[k][k];
+    }
+  }
+  if (l == NVT) {
+#pragma unroll
+    for (int j = 0; j < NVT; j++) S.Lrow[NVT][j] = row[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = NVT - 1; k >= 0; k--) {
+    float s = S.Lrow[NVT][k];
+#pragma unroll
+    for (int j = k + 1; j < NVT; j++) s -= S.Lrow[j][k] * x[j];
+    x[k] = s * S.Lrow[k][k];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ state_in, const float* __restrict__ ctrl,
+                                                    float* __restrict__ warm, int N, int substeps, float* __restrict__ state_out, int* __restrict__ stats) {
+  __shared__ RS4 sRS[RPW];
+  const int lane = threadIdx.x, l = lane & 31, r = lane >> 5;
+  RS4& S = sRS[r];
+  const int n = blockIdx.x * RPW + r;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  const int nj = gI[0], ng = gI[1];
+  const bool isbase = l < 6, isjoint = l >= 6 && l < 6 + nj, hasdof = isbase || isjoint, isbody = l == 0 || isjoint;
+  const int k = isjoint ? l - 6 : 0;                   // own joint
+  const int bidx = isjoint ? 1 + k : 0;                // own body
+  const float* jf = gF + TH_F + k * TD_F;
+  const int* ji = gI + TH_I + k * TD_I;
+  const int cstart = isjoint ? ji[1] : 0, cdepth = isjoint ? ji[2] : -1;  // chain dofs cstart .. cstart + cdepth are the joint ancestors incl. self
+  const int oGF = TH_F + nj * TD_F, oGI = TH_I + nj * TD_I;
+  const float h = gF[TF_DT], impratio = gF[TF_IMPRATIO], tol = gF[TF_TOL], lstol = gF[TF_LSTOL]; const int cap = (int)gF[TF_MAXITER];
+  const float grav[3] = {gF[TF_GRAV], gF[TF_GRAV + 1], gF[TF_GRAV + 2]};
+  const float pln[3] = {gF[TF_PLANE_N], gF[TF_PLANE_N + 1], gF[TF_PLANE_N + 2]}, plp[3] = {gF[TF_PLANE_P], gF[TF_PLANE_P + 1], gF[TF_PLANE_P + 2]};
+  const float en = isjoint ? 1.f : 0.f;
+  const float c_damp = jf[JF_DAMP] * en, c_arm = jf[JF_ARM] * en, c_fl = jf[JF_FL] * en, c_fB = jf[JF_FB], c_fD = jf[JF_FD], c_invw = jf[JF_INVW];
+  const float c_limited = jf[JF_LIMITED] * en, c_lo = jf[JF_LO], c_hi = jf[JF_HI], c_lK = jf[JF_LK], c_lB = jf[JF_LB];
+  float c_si[5]; for (int i = 0; i < 5; i++) c_si[i] = jf[JF_SOLIMP + i];
+  const bool hasact = isjoint && ji[3] != 0;
+  const float c_kp = hasact ? jf[JF_KP] : 0.f, c_kv = hasact ? jf[JF_KV] : 0.f, c_clim = jf[JF_CLIM], c_clo = jf[JF_CLO], c_chi = jf[JF_CHI];
+  const float c_flim = hasact ? jf[JF_FLIM] : 0.f, c_flo = jf[JF_FLO], c_fhi = jf[JF_FHI];
+  // ---- state: replicated base + own joint
+  float qb[7], vb[6], q = 0.f, qd = 0.f, qws = 0.f;
+  {
+    const float* xi = state_in + (size_t)nc * NX;
+    for (int i = 0; i < 7; i++) qb[i] = xi[i];
+    for (int i = 0; i < 6; i++) vb[i] = xi[NQ + i];
+    if (isjoint) { q = xi[7 + k]; qd = xi[NQ + 6 + k]; }
+    if (hasdof && warm) qws = warm[(size_t)nc * NVT + l];
+  }
+  const float u = hasact ? ctrl[(size_t)nc * NJ + k] : 0.f;
+  int n_iters = 0, n_maxed = 0;
+
+  for (int step = 0; step < substeps; step++) {
+    // ================================================================ publish joint state, clear accumulators
+    if (isjoint) S.q[k] = q;
+    {
+      float myqd = qd;
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (i == l) myqd = vb[i];
+      if (hasdof) S.qd[l] = myqd;
+    }
+    if (l < NB) for (int i = 0; i < 10; i++) S.Ic[l][i] = 0.f;
+    if (l < NVT) { for (int j = 0; j < NVT; j++) S.M[l][j] = 0.f; S.bias[l] = 0.f; }
+    if (l == 0) S.ncon = 0;
+    __syncthreads();
+    // ================================================================ kinematics (positions relative to the base origin)
+    float Rb[9], Rown[9], pown[3] = {0.f, 0.f, 0.f}, Sown[6] = {0, 0, 0, 0, 0, 0};
+    {
+      const float nn = rsqrtf(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+      qb[3] *= nn; qb[4] *= nn; qb[5] *= nn; qb[6] *= nn;
+      quat2mat(Rb, qb + 3);
+      float P[3] = {0.f, 0.f, 0.f}, R[9];
+      for (int i = 0; i < 9; i++) { R[i] = Rb[i]; Rown[i] = Rb[i]; }
+      float axw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < MAXD; t++) {
+        if (t <= cdepth) {  // chain link t of the own chain (lane-dependent records: vector loads from the L1-resident image)
+          const float* f = gF + TH_F + (cstart + t) * TD_F;
+          float lp[3] = {f[JF_LPOS], f[JF_LPOS + 1], f[JF_LPOS + 2]}, lr[9], la[3] = {f[JF_AXIS], f[JF_AXIS + 1], f[JF_AXIS + 2]};
+          for (int i = 0; i < 9; i++) lr[i] = f[JF_LR + i];
+          float P2[3], R0[9], Rq[9];
+          mulMV(P2, R, lp); for (int i = 0; i < 3; i++) P2[i] += P[i];
+          mulMM(R0, R, lr);
+          mulMV(axw, R0, la);
+          rodrigues4(Rq, la, S.q[cstart + t]);
+          mulMM(R, R0, Rq);
+          for (int i = 0; i < 3; i++) P[i] = P2[i];
+        }
+      }
+      if (isjoint) {
+        for (int i = 0; i < 3; i++) pown[i] = P[i];
+        for (int i = 0; i < 9; i++) Rown[i] = R[i];
+        float lin[3]; cross3(lin, pown, axw);  // velocity of the reference point under unit joint rate: anchor x axis
+        for (int i = 0; i < 3; i++) { Sown[i] = axw[i]; Sown[3 + i] = lin[i]; }
+      } else if (l < 3) Sown[3 + l] = 1.f;
+      else if (l < 6) { Sown[0] = Rb[l - 3]; Sown[1] = Rb[3 + l - 3]; Sown[2] = Rb[6 + l - 3]; }
+      if (hasdof) for (int i = 0; i < 6; i++) S.Sax[l][i] = Sown[i];
+      if (isbody) { for (int i = 0; i < 3; i++) S.xpos[bidx][i] = pown[i]; for (int i = 0; i < 9; i++) S.xR[bidx][i] = Rown[i]; }
+    }
+    // ================================================================ body spatial inertia, composite inertias along the ancestor chains
+    float Ib[10];
+    {
+      const float* bm = isjoint ? jf + JF_MASS : gF + TF_BMASS;  // mass, ipos(3), iR(9), inertia(3) in both records
+      const float mass = isbody ? bm[0] : 0.f;
+      float lip[3] = {bm[1], bm[2], bm[3]}, lir[9], di[3] = {bm[13], bm[14], bm[15]};
+      for (int i = 0; i < 9; i++) lir[i] = bm[4 + i];
+      float Rk[9], c[3]; mulMM(Rk, Rown, lir); mulMV(c, Rown, lip);
+      for (int i = 0; i < 3; i++) c[i] += pown[i];
+      const float cc = dot3(c, c);
+      Ib[0] = mass; Ib[1] = mass * c[0]; Ib[2] = mass * c[1]; Ib[3] = mass * c[2];
+      const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        float v = 0.f;
+        for (int t = 0; t < 3; t++) v += Rk[ia[e] * 3 + t] * di[t] * Rk[ib[e] * 3 + t];
+        Ib[4 + e] = isbody ? v + mass * ((ia[e] == ib[e] ? cc : 0.f) - c[ia[e]] * c[ib[e]]) : 0.f;
+      }
+      if (isbody) {
+        for (int i = 0; i < 10; i++) atomicAdd(&S.Ic[0][i], Ib[i]);
+        for (int t = 0; t < MAXD; t++) if (t <= cdepth) for (int i = 0; i < 10; i++) atomicAdd(&S.Ic[1 + cstart + t][i], Ib[i]);
+      }
+    }
+    __syncthreads();
+    // ================================================================ inertia rows (mj_crb) and bias forces (mj_rne with gravity as base acceleration)
+    if (hasdof) {
+      float I10[10], f[6];
+      for (int i = 0; i < 10; i++) I10[i] = S.Ic[bidx][i];
+      inertia6_mul(f, I10, Sown);
+      const int nb_ = isjoint ? 6 : l + 1;  // base columns
+      for (int j = 0; j < nb_; j++) { float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; const float v = dot6(f, sj); S.M[l][j] = v; S.M[j][l] = v; }
+      if (isjoint) for (int t = 0; t <= cdepth; t++) { const int j = 6 + cstart + t; float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; const float v = dot6(f, sj) + (j == l ? c_arm : 0.f); S.M[l][j] = v; S.M[j][l] = v; }
+    }
+    if (isbody) {
+      float vel[6] = {0, 0, 0, 0, 0, 0}, acc[6] = {0, 0, 0, -grav[0], -grav[1], -grav[2]};
+      for (int j = 0; j < 3; j++) vel[3 + j] += S.qd[j];  // translational axes are world-fixed unit vectors
+      float Sd[3][6], sr[3][6];
+      for (int j = 0; j < 3; j++) { for (int i = 0; i < 6; i++) sr[j][i] = S.Sax[3 + j][i]; crossm6(Sd[j], vel, sr[j]); }
+      for (int j = 0; j < 3; j++) { const float w = S.qd[3 + j]; for (int i = 0; i < 6; i++) { acc[i] += Sd[j][i] * w; vel[i] += sr[j][i] * w; } }
+      for (int t = 0; t < MAXD; t++) if (t <= cdepth) {
+        const int j = 6 + cstart + t; float sj[6], sd[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i];
+        crossm6(sd, vel, sj); const float w = S.qd[j];
+        for (int i = 0; i < 6; i++) { acc[i] += sd[i] * w; vel[i] += sj[i] * w; }
+      }
+      float Ia[6], Iv[6], vIv[6], frc[6];
+      inertia6_mul(Ia, Ib, acc); inertia6_mul(Iv, Ib, vel); crossf6(vIv, vel, Iv);
+      for (int i = 0; i < 6; i++) frc[i] = Ia[i] + vIv[i];
+      for (int j = 0; j < 6; j++) { float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; atomicAdd(&S.bias[j], dot6(sj, frc)); }
+      for (int t = 0; t < MAXD; t++) if (t <= cdepth) { const int j = 6 + cstart + t; float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; atomicAdd(&S.bias[j], dot6(sj, frc)); }
+    }
+    __syncthreads();
+    // ================================================================ smooth force, inertia row into registers, unconstrained acceleration
+    float Mrow[NVT], fs_own = 0.f, a0_own = 0.f, Md_own = 1.f, kv_eff = 0.f;
+    {
+      float fa = 0.f;
+      if (hasact) {
+        float cc = u; if (c_clim != 0.f) cc = jh_clampf(cc, c_clo, c_chi);
+        fa = c_kp * (cc - q) - c_kv * qd;
+        kv_eff = c_kv;
+        if (c_flim != 0.f) { if (fa <= c_flo || fa >= c_fhi) kv_eff = 0.f; fa = jh_clampf(fa, c_flo, c_fhi); }  // a saturated servo has no velocity derivative (implicitfast)
+      }
+      if (hasdof) fs_own = -c_damp * qd - S.bias[l] + fa;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) Mrow[j] = hasdof ? S.M[l][j] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) if (j == l) Md_own = Mrow[j];
+      if (hasdof) S.vec[0][l] = fs_own;
+      __syncthreads();  // every lane has read its row of M: the storage becomes the Cholesky workspace
+      float row[NR], x[NVT];
+#pragma unroll
+      for (int j = 0; j < NVT; j++) row[j] = l == NVT ? S.vec[0][j] : Mrow[j];
+      row[NVT] = 0.f;
+      row_cholesky_solve(row, S, l, x);
+#pragma unroll
+      for (int j = 0; j < NVT; j++) if (j == l) a0_own = x[j];
+    }
+    // ================================================================ collision: every robot geom against the plane
+    if (l < ng) {
+      const float* gf = gF + oGF + l * TG_F; const int owner = gI[oGI + l * TG_I], gtype = gI[oGI + l * TG_I + 1];
+      const int gb = owner < 0 ? 0 : 1 + owner;
+      float bR[9], gp[3], lp[3] = {gf[GF4_POS], gf[GF4_POS + 1], gf[GF4_POS + 2]};
+      for (int i = 0; i < 9; i++) bR[i] = S.xR[gb][i];
+      mulMV(gp, bR, lp); for (int i = 0; i < 3; i++) gp[i] += S.xpos[gb][i];
+      // plane point relative to the base origin
+      const float pr[3] = {plp[0] - qb[0], plp[1] - qb[1], plp[2] - qb[2]};
+      auto push = [&](const float* pos, float dist, const float* tng) __attribute__((always_inline)) {
+        const int i = atomicAdd(&S.ncon, 1);
+        if (i >= NCP) { if (stats) atomicAdd(stats, 1); return; }
+        float* e = S.raw[i];
+        e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = dist; e[4] = __int_as_float(l); e[5] = tng[0]; e[6] = tng[1]; e[7] = tng[2];
+      };
+      const float zero3[3] = {0.f, 0.f, 0.f};
+      if (gtype == 2 || gtype == 3) {  // sphere, or the two end spheres of a capsule (+ end first)
+        float lr[9], gR[9], axis[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < 9; i++) lr[i] = gf[GF4_R + i];
+        mulMM(gR, bR, lr);
+        const float rad = gf[GF4_SIZE], half = gtype == 3 ? gf[GF4_SIZE + 1] : 0.f;
+        if (gtype == 3) col3(axis, gR, 2);
+        for (int e = 0; e < (gtype == 3 ? 2 : 1); e++) {
+          const float sg = e == 0 ? 1.f : -1.f;
+          const float c[3] = {gp[0] + sg * half * axis[0], gp[1] + sg * half * axis[1], gp[2] + sg * half * axis[2]};
+          const float dif[3] = {c[0] - pr[0], c[1] - pr[1], c[2] - pr[2]};
+          const float dist = dot3(dif, pln) - rad;
+          if (dist <= 0.f) { const float pos[3] = {c[0] - pln[0] * (rad + 0.5f * dist), c[1] - pln[1] * (rad + 0.5f * dist), c[2] - pln[2] * (rad + 0.5f * dist)}; push(pos, dist, gtype == 3 ? axis : zero3); }
+        }
+      } else {  // box: corners in MuJoCo's order, at most 4 contacts
+        float lr[9], gR[9]; for (int i = 0; i < 9; i++) lr[i] = gf[GF4_R + i];
+        mulMM(gR, bR, lr);
+        const float hs[3] = {gf[GF4_SIZE], gf[GF4_SIZE + 1], gf[GF4_SIZE + 2]};
+        const float dif[3] = {gp[0] - pr[0], gp[1] - pr[1], gp[2] - pr[2]};
+        const float dist0 = dot3(dif, pln);
+        int cnt = 0;
+        for (int i = 0; i < 8; i++) {
+          const float vl[3] = {(i & 1) ? hs[0] : -hs[0], (i & 2) ? hs[1] : -hs[1], (i & 4) ? hs[2] : -hs[2]};
+          float vec3[3]; mulMV(vec3, gR, vl);
+          const float d = dist0 + dot3(pln, vec3);
+          if (d <= 0.f && cnt < 4) { const float pos[3] = {gp[0] + vec3[0] - pln[0] * 0.5f * d, gp[1] + vec3[1] - pln[1] * 0.5f * d, gp[2] + vec3[2] - pln[2] * 0.5f * d}; push(pos, d, zero3); cnt++; }
+        }
+      }
+    }
+    __syncthreads();
+    // ================================================================ constraint rows
+    const int ncon = S.ncon < NCP ? S.ncon : NCP;
+    Slot4 sl;
+    sl.valid = l < ncon; sl.D = 0.f; sl.mu = 0.f;
+    for (int w = 0; w < 3; w++) sl.aref[w] = sl.jar[w] = sl.jp[w] = 0.f;
+    if (sl.valid) {  // contact frame: plane normal (from the plane, geom 1, to the robot geom), second axis along a capsule's axis
+      float fr[9] = {pln[0], pln[1], pln[2], 0, 0, 0, 0, 0, 0};
+      make_frame(fr);
+      const float* e = S.raw[l];
+      float y[3] = {e[5], e[6], e[7]};
+      const float dp = dot3(fr, y); y[0] -= fr[0] * dp; y[1] -= fr[1] * dp; y[2] -= fr[2] * dp;
+      const float nn = sqrtf(dot3(y, y));
+      if (nn > 0.5e-3f) { for (int i = 0; i < 3; i++) fr[3 + i] = y[i] / nn; cross3(fr + 6, fr, fr + 3); }
+      for (int w = 0; w < 9; w++) S.fW[l][w] = fr[w];
+    }
+    __syncthreads();
+    for (int c = 0; c < ncon; c++) {  // Jacobian: lane r computes column r of every contact (robot side only: the plane is static)
+      if (hasdof) {
+        const float* e = S.raw[c];
+        const float pos[3] = {e[0], e[1], e[2]};
+        const int gid = __float_as_int(e[4]);
+        const int owner = gI[oGI + gid * TG_I];
+        bool anc = isbase;
+        if (isjoint && owner >= 0) { const int os = gI[TH_I + owner * TD_I + 1], od = gI[TH_I + owner * TD_I + 2]; anc = os == cstart && cdepth <= od; }
+        float col[3] = {0.f, 0.f, 0.f};
+        if (anc) {
+          float v[3]; cross3(v, Sown, pos); for (int i = 0; i < 3; i++) v[i] += Sown[3 + i];
+          const float* fr = S.fW[c];
+          col[0] = dot3(fr, v); col[1] = dot3(fr + 3, v); col[2] = dot3(fr + 6, v);
+        }
+        S.J[c][3 * l] = col[0]; S.J[c][3 * l + 1] = col[1]; S.J[c][3 * l + 2] = col[2];
+      }
+    }
+    __syncthreads();
+    if (sl.valid) {
+      const float* e = S.raw[l]; const float dist = e[3]; const int gid = __float_as_int(e[4]);
+      const float* gf = gF + oGF + gid * TG_F;
+      float si[5]; for (int w = 0; w < 5; w++) si[w] = gf[GF4_SOLIMP + w];
+      const float mu = gf[GF4_MU], imp = impedance(si, dist);
+      const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * gf[GF4_TRAN] * (1.f + mu * mu));
+      const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
+      sl.D = 1.f / Rpy; sl.mu = mu;
+      float vel[3] = {0.f, 0.f, 0.f};
+      const float* Jc = S.J[l];
+      for (int j = 0; j < NVT; j++) { const float w = S.qd[j]; vel[0] = fmaf(Jc[3 * j], w, vel[0]); vel[1] = fmaf(Jc[3 * j + 1], w, vel[1]); vel[2] = fmaf(Jc[3 * j + 2], w, vel[2]); }
+      sl.aref[0] = -gf[GF4_B] * vel[0] - gf[GF4_K] * imp * dist; sl.aref[1] = -gf[GF4_B] * vel[1]; sl.aref[2] = -gf[GF4_B] * vel[2];
+    }
+    DofRows4 dr;
+    dr.fl = c_fl; dr.fD = c_fD; dr.fR = c_fD > 0.f ? 1.f / c_fD : 0.f; dr.faref = -c_fB * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
+    if (c_limited != 0.f) {
+      const float dlo = q - c_lo, dhi = c_hi - q, dist = fminf(dlo, dhi);
+      if (dist < 0.f) {
+        const float sg = dlo < dhi ? 1.f : -1.f, imp = impedance(c_si, dist), R = fmaxf(1e-15f, (1.f - imp) / imp * c_invw);
+        dr.lims = sg; dr.lD = 1.f / R; dr.laref = -c_lB * (sg * qd) - c_lK * imp * dist;
+      }
+    }
+    // ================================================================ Newton solver (dense row-per-lane Hessian)
+    float a_own = a0_own;
+    const float iMd = 1.f / Md_own;
+    const float snorm = gsum32(hasdof ? fs_own * fs_own * iMd : 0.f);
+    int iters_this = 0;
+    {
+      // ---- warm start: the better of last step's acceleration and the unconstrained one
+      if (hasdof) { S.vec[0][l] = qws; S.vec[1][l] = a0_own; S.vec[2][l] = qws - a0_own; }
+      __syncthreads();
+      float jar_ws[3] = {0.f, 0.f, 0.f};
+      if (sl.valid) { const float* Jc = S.J[l]; float o[3] = {0, 0, 0}; for (int j = 0; j < NVT; j++) { const float w = S.vec[0][j]; o[0] = fmaf(Jc[3 * j], w, o[0]); o[1] = fmaf(Jc[3 * j + 1], w, o[1]); o[2] = fmaf(Jc[3 * j + 2], w, o[2]); } for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
+      dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
+      float mdw = 0.f;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) mdw = fmaf(Mrow[j], S.vec[2][j], mdw);
+      const float cost_ws = gsum32(lane_cost4(sl, dr) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
+      for (int w = 0; w < 3; w++) jar_ws[w] = sl.jar[w];
+      const float jf_ws = dr.jf, jl_ws = dr.jl;
+      if (sl.valid) { const float* Jc = S.J[l]; float o[3] = {0, 0, 0}; for (int j = 0; j < NVT; j++) { const float w = S.vec[1][j]; o[0] = fmaf(Jc[3 * j], w, o[0]); o[1] = fmaf(Jc[3 * j + 1], w, o[1]); o[2] = fmaf(Jc[3 * j + 2], w, o[2]); } for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
+      dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
+      const float cost_0 = gsum32(lane_cost4(sl, dr));
+      if (cost_ws < cost_0) { a_own = qws; for (int w = 0; w < 3; w++) sl.jar[w] = jar_ws[w]; dr.jf = jf_ws; dr.jl = jl_ws; }
+      __syncthreads();
+      bool act = gor32((int)(sl.valid || dr.fl > 0.f || dr.lims != 0.f)) != 0;
+      if (!act) a_own = a0_own;
+      for (int it = 0; it < cap && __any(act); it++) {
+        // ---- (1) gradient row
+        const float da_own = a_own - a0_own;
+        if (hasdof) S.vec[0][l] = da_own;
+        if (sl.valid) { float f[3], Wm[6]; pyramid_eval(sl.jar, sl.D, sl.mu, f, Wm); float* o = S.fW[l]; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[3 + w] = Wm[w]; }
+        __syncthreads();
+        float g_own = 0.f, hd = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVT; j++) g_own = fmaf(Mrow[j], S.vec[0][j], g_own);
+        if (dr.fl > 0.f) {
+          const float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+          if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += dr.fD * x; hd += dr.fD; }
+        }
+        if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
+        if (hasdof) for (int c = 0; c < ncon; c++) { const float* jc = S.J[c] + 3 * l; const float* fc = S.fW[c]; g_own -= jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]; }
+        // ---- (2) convergence; leave before any Hessian work once both rollouts of the wave are done
+        const float gn = gsum32(hasdof ? g_own * g_own * iMd : 0.f);
+        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        if (!__any(act)) break;
+        if (act) iters_this++;
+        // ---- (3) Hessian row (columns 0..r); lane NVT holds -g
+        if (hasdof) S.vec[1][l] = -g_own;
+        float row[NR];
+#pragma unroll
+        for (int j = 0; j < NVT; j++) row[j] = Mrow[j];
+        row[NVT] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVT; j++) if (j == l) row[j] += hd;
+        if (hasdof) for (int c = 0; c < ncon; c++) {
+          const float* fc = S.fW[c];
+          if (fc[3] == 0.f && fc[5] == 0.f && fc[8] == 0.f) continue;
+          const float* Jc = S.J[c];
+          const float j0 = Jc[3 * l], j1 = Jc[3 * l + 1], j2 = Jc[3 * l + 2];
+          const float G0 = fc[3] * j0 + fc[4] * j1 + fc[6] * j2, G1 = fc[4] * j0 + fc[5] * j1 + fc[7] * j2, G2 = fc[6] * j0 + fc[7] * j1 + fc[8] * j2;
+#pragma unroll
+          for (int j = 0; j < NVT; j++) row[j] += Jc[3 * j] * G0 + Jc[3 * j + 1] * G1 + Jc[3 * j + 2] * G2;
+        }
+        __syncthreads();
+        if (l == NVT) {
+#pragma unroll
+          for (int j = 0; j < NVT; j++) row[j] = S.vec[1][j];
+        }
+        // ---- (4) factorise and solve: every lane gets the whole direction
+        float p[NVT];
+        row_cholesky_solve(row, S, l, p);
+        float p_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
+        // ---- (5) exact line search
+        float Mp_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVT; j++) Mp_own = fmaf(Mrow[j], p[j], Mp_own);
+        const float pMp = gsum32(p_own * Mp_own), pMd = gsum32(Mp_own * da_own), gp = gsum32(g_own * p_own);
+        if (act && !(gp < 0.f)) act = false;
+        if (sl.valid) { const float* Jc = S.J[l]; float o[3] = {0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < NVT; j++) { o[0] = fmaf(Jc[3 * j], p[j], o[0]); o[1] = fmaf(Jc[3 * j + 1], p[j], o[1]); o[2] = fmaf(Jc[3 * j + 2], p[j], o[2]); }
+          sl.jp[0] = o[0]; sl.jp[1] = o[1]; sl.jp[2] = o[2]; }
+        dr.pf = p_own; dr.pl = dr.lims * p_own;
+        float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
+        for (int ls = 0; ls < 12 && __any(lsact); ls++) {
+          float d1, d2;
+          lane_dir4(sl, dr, alpha, &d1, &d2);
+          d1 = gsum32(d1) + pMd + alpha * pMp; d2 = gsum32(d2) + pMp;
+          if (lsact) {
+            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
+            else {
+              if (d1 < 0.f) lo = alpha; else hi = alpha;
+              float nx = alpha - d1 * __frcp_rn(d2);
+              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
+              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
+              alpha = nx;
+            }
+          }
+        }
+        // ---- (6) step
+        if (act) {
+          a_own += alpha * p_own;
+          for (int w = 0; w < 3; w++) sl.jar[w] += alpha * sl.jp[w];
+          dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
+          if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        }
+        __syncthreads();
+      }
+      if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
+    }
+    // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
+    {
+      __syncthreads();
+      const float da_own = a_own - a0_own;
+      if (hasdof) S.vec[0][l] = da_own;
+      __syncthreads();
+      float rhs_own = fs_own;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) rhs_own = fmaf(Mrow[j], S.vec[0][j], rhs_own);
+      if (hasdof) S.vec[1][l] = rhs_own;
+      __syncthreads();
+      float row[NR], x[NVT];
+#pragma unroll
+      for (int j = 0; j < NVT; j++) row[j] = l == NVT ? S.vec[1][j] : Mrow[j];
+      row[NVT] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) if (j == l) row[j] += h * (c_damp + kv_eff);
+      row_cholesky_solve(row, S, l, x);
+      float qacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) if (j == l) qacc = x[j];
+      if (isjoint) { qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); }
+      qws = a_own;
+      for (int i = 0; i < 6; i++) vb[i] = fmaf(h, x[i], vb[i]);  // free base: every lane integrates the replicated state
+      for (int i = 0; i < 3; i++) qb[i] = fmaf(h, vb[i], qb[i]);
+      const float wn = sqrtf(vb[3] * vb[3] + vb[4] * vb[4] + vb[5] * vb[5]), ang = wn * h;
+      if (ang > 0.f) {
+        float sn, cs; sincosf(0.5f * ang, &sn, &cs); const float kk = sn / wn;
+        float dq[4] = {cs, vb[3] * kk, vb[4] * kk, vb[5] * kk}, *qq = qb + 3;
+        const float r0 = qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2] - qq[3] * dq[3];
+        const float r1 = qq[0] * dq[1] + qq[1] * dq[0] + qq[2] * dq[3] - qq[3] * dq[2];
+        const float r2 = qq[0] * dq[2] - qq[1] * dq[3] + qq[2] * dq[0] + qq[3] * dq[1];
+        const float r3 = qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1] + qq[3] * dq[0];
+        qq[0] = r0; qq[1] = r1; qq[2] = r2; qq[3] = r3;
+      }
+      const float nn = rsqrtf(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+      qb[3] *= nn; qb[4] *= nn; qb[5] *= nn; qb[6] *= nn;
+    }
+    __syncthreads();
+  }
+  if (live) {
+    float* o = state_out + (size_t)n * NX;
+    if (isjoint) { o[7 + k] = q; o[NQ + 6 + k] = qd; }
+    if (l < 7) o[l] = qb[l];
+    if (l < 6) o[NQ + l] = vb[l];
+    if (hasdof && warm) warm[(size_t)n * NVT + l] = qws;
+    if (stats && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, substeps); }
+  }
+}
+
+}  // namespace
+
+struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv; };
+
+extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
+  JH_REQUIRE(blob && out && nbytes >= 16, "tree_create: null or short blob");
+  const unsigned* hd = (const unsigned*)blob;
+  JH_REQUIRE(hd[0] == 0x34564A54u, "tree_create: bad magic");
+  const size_t nf = hd[1], ni = hd[2];
+  JH_REQUIRE(nbytes == 16 + 4 * (nf + ni), "tree_create: blob size mismatch");
+  const float* f = (const float*)(hd + 4); const int* ii = (const int*)(f + nf);
+  JH_REQUIRE(ii[0] == NJ && ii[2] == NQ && ii[3] == NVT && ii[1] <= G - 1, "tree_create: the kernel is instantiated for a free base + 19 hinges (got %d joints, nq %d, nv %d, %d geoms)", ii[0], ii[2], ii[3], ii[1]);
+  jh_tree* t = new jh_tree();
+  t->nj = ii[0]; t->ng = ii[1]; t->nq = ii[2]; t->nv = ii[3];
+  JH_HIP(hipMalloc(&t->d_f, 4 * nf)); JH_HIP(hipMalloc(&t->d_i, 4 * ni)); JH_HIP(hipMalloc(&t->d_stats, 64 * sizeof(int)));
+  JH_HIP(hipMemcpy(t->d_f, f, 4 * nf, hipMemcpyHostToDevice)); JH_HIP(hipMemcpy(t->d_i, ii, 4 * ni, hipMemcpyHostToDevice));
+  JH_HIP(hipMemset(t->d_stats, 0, 64 * sizeof(int)));
+  *out = t;
+  return JH_OK;
+}
+
+extern "C" void jh_tree_destroy(jh_tree* t) {
+  if (!t) return;
+  (void)hipFree(t->d_f); (void)hipFree(t->d_i); (void)hipFree(t->d_stats);
+  delete t;
+}
+
+extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
+  JH_REQUIRE(t && out4, "tree_stats: null pointer");
+  JH_HIP(hipDeviceSynchronize());
+  JH_HIP(hipMemcpy(out4, t->d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  if (reset) JH_HIP(hipMemset(t->d_stats, 0, 64 * sizeof(int)));
+  return JH_OK;
+}
+
+extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream) {
+  JH_REQUIRE(t && state_in && ctrl && state_out, "tree_substeps: null pointer");
+  JH_REQUIRE(N > 0 && substeps > 0, "tree_substeps: need at least one rollout and one step");
+  hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, state_in, ctrl, warmstart, N, substeps, state_out, t->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

@@ -6,8 +6,13 @@ System::setObservation + System::policyInference, mujoco_extensions/system/syste
 
 `states` (N, nq+nv), `commands` (N, 25) in the layout `SpotBase.task_to_sim_ctrl` produces (judo/tasks/spot/spot_base.py:325-391),
 `last_policy_output` (N, 12).  Returns the 19 joint position targets the plant applies for the next `physics_substeps` steps and
-the new policy output.  numpy in -> numpy out; torch device tensors in -> torch device tensors out.  The physics between two
-policy steps needs the Spot model, which the engine kernels do not cover yet.
+the new policy output.  numpy in -> numpy out; torch device tensors in -> torch device tensors out.
+
+    backend = PolicyRolloutBackend(num_threads=N)         # judo/utils/policy_mj_rollout_backend.py: same rollout() signature
+    states, sensors, policy_outputs = backend.rollout(x0, commands, last_policy_output)
+
+alternates the policy step with `physics_substeps` engine steps of the Spot model on the ground plane (`SpotTreeEngine`,
+csrc/jh_engine_v4.hip), the whole of `threaded_rollout` (mujoco_extensions/system/system_class.cpp:277-367) without its wall-clock cutoff.
 """
 
 from __future__ import annotations
@@ -21,6 +26,8 @@ import torch
 
 from judo_amd import _lib
 from judo_amd.device import current_stream_ptr, f32, require_gpu
+from judo_amd.models import load_description
+from judo_amd.tree_model import pack_tree_blob
 
 POLICY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "spot_locomotion_policy.npz")
 
@@ -81,3 +88,100 @@ class SpotLocomotionPolicy:
                 self.handle = None
         except Exception:
             pass
+
+
+class SpotTreeEngine:
+    """The Spot model on the ground plane as a device engine: `substeps(states, ctrl, warmstart, n)` = n x mj_step with the control held."""
+
+    NQ, NV, NU = 26, 25, 19
+
+    def __init__(self, desc: dict | None = None, device: torch.device | None = None) -> None:
+        self.device = device or require_gpu()
+        self.desc = desc if desc is not None else load_description("spot")
+        blob = pack_tree_blob(self.desc)
+        self._blob = (C.c_char * len(blob)).from_buffer_copy(blob)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().jh_tree_create(C.cast(self._blob, C.c_void_p), len(blob), C.byref(handle)), "jh_tree_create")
+        self.handle = handle
+        self.timestep = float(self.desc["option"]["timestep"])
+
+    def substeps(self, states: torch.Tensor, ctrl: torch.Tensor, warmstart: torch.Tensor | None, n: int, out: torch.Tensor | None = None) -> torch.Tensor:
+        nx = self.NQ + self.NV
+        if states.ndim != 2 or states.shape[1] != nx or not states.is_contiguous() or states.dtype != torch.float32:
+            raise ValueError(f"states must be a contiguous float32 (N, {nx}) tensor")
+        N = int(states.shape[0])
+        if tuple(ctrl.shape) != (N, self.NU) or not ctrl.is_contiguous():
+            raise ValueError(f"ctrl must be a contiguous (N, {self.NU}) tensor")
+        if warmstart is not None and (tuple(warmstart.shape) != (N, self.NV) or not warmstart.is_contiguous()):
+            raise ValueError(f"warmstart must be a contiguous (N, {self.NV}) tensor")
+        if out is None:
+            out = torch.empty_like(states)
+        s = _lib.lib().jh_tree_substeps(self.handle, _lib.ptr(states), _lib.ptr(ctrl), _lib.ptr(warmstart) if warmstart is not None else None, N, int(n), _lib.ptr(out),
+                                        current_stream_ptr())
+        _lib.check(s, "jh_tree_substeps")
+        return out
+
+    def stats(self, reset: bool = True) -> dict:
+        buf = (C.c_int * 4)()
+        _lib.check(_lib.lib().jh_tree_stats(self.handle, buf, int(reset)), "jh_tree_stats")
+        return dict(contacts_dropped=buf[0], steps_at_cap=buf[1], newton_iterations=buf[2], steps=buf[3])
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().jh_tree_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class PolicyRolloutBackend:
+    """Drop-in for `PolicyMJRolloutBackend` (judo/utils/policy_mj_rollout_backend.py:20-125): N rollouts of the Spot plant under the locomotion
+    policy, one policy step per command row followed by `physics_substeps` engine steps; the state is recorded after the substeps.
+
+    `carry_warmstart`: the reference keeps one mjData per system, so the solver's warm start carries over from one control step (and one
+    `rollout` call) to the next; False restarts every control step from a zero warm start (what the oracle's `policy_rollout` does)."""
+
+    def __init__(self, num_threads: int, physics_substeps: int = 2, policy_path: str = POLICY_PATH, desc: dict | None = None, device: torch.device | None = None,
+                 carry_warmstart: bool = True) -> None:
+        self.device = device or require_gpu()
+        self.engine = SpotTreeEngine(desc, self.device)
+        self.policy = SpotLocomotionPolicy(policy_path, self.device)
+        self.layout = SpotStateLayout(nq=SpotTreeEngine.NQ, nv=SpotTreeEngine.NV)
+        self.physics_substeps = int(physics_substeps)
+        self.carry_warmstart = carry_warmstart
+        self.update(num_threads)
+
+    def update(self, num_threads: int) -> None:
+        self.num_threads = int(num_threads)
+        self._warm = torch.zeros((self.num_threads, SpotTreeEngine.NV), dtype=torch.float32, device=self.device)
+
+    def rollout(self, x0, controls, last_policy_output=None):
+        if last_policy_output is None:
+            raise ValueError("last_policy_output is required for PolicyRolloutBackend")
+        as_numpy = not isinstance(controls, torch.Tensor)
+        cmd = f32(controls, self.device) if as_numpy else controls.to(torch.float32)
+        if cmd.ndim != 3 or cmd.shape[0] != self.num_threads or cmd.shape[2] != SpotLocomotionPolicy.NCMD:
+            raise ValueError(f"controls must be ({self.num_threads}, T, 25), got {tuple(cmd.shape)}")
+        N, T = int(cmd.shape[0]), int(cmd.shape[1])
+        x = f32(x0, self.device) if not isinstance(x0, torch.Tensor) else x0.to(torch.float32)
+        nx = SpotTreeEngine.NQ + SpotTreeEngine.NV
+        if x.ndim == 1:
+            x = x.expand(N, nx)
+        if tuple(x.shape) != (N, nx):
+            raise ValueError(f"x0 must be ({nx},) or ({N}, {nx}), got {tuple(x.shape)}")
+        x = x.contiguous().clone()
+        out = f32(last_policy_output, self.device) if not isinstance(last_policy_output, torch.Tensor) else last_policy_output.to(torch.float32)
+        if tuple(out.shape) != (N, SpotLocomotionPolicy.ACT):
+            raise ValueError(f"last_policy_output must be ({N}, 12), got {tuple(out.shape)}")
+        states = torch.empty((T, N, nx), dtype=torch.float32, device=self.device)  # step-major while rolling: every step writes one contiguous slab
+        for t in range(T):
+            ctrl, out = self.policy.step(x, cmd[:, t].contiguous(), out, self.layout)
+            if not self.carry_warmstart:
+                self._warm.zero_()
+            x = self.engine.substeps(x, ctrl, self._warm, self.physics_substeps, out=states[t])
+        states = states.permute(1, 0, 2).contiguous()
+        sensors = torch.zeros((N, T, 0), dtype=torch.float32, device=self.device)
+        if as_numpy:
+            return states.cpu().numpy().astype(np.float64), sensors.cpu().numpy().astype(np.float64), out.cpu().numpy().astype(np.float64)
+        return states, sensors, out

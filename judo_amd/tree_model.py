@@ -1,0 +1,158 @@
+"""Model image of a floating-base robot on a ground plane for the cooperative tree kernel (`csrc/jh_engine_v4.hip`).
+
+Structure accepted (the Spot model, judo/models/xml/spot_primitive/robot.xml): one free base body; serial chains of hinge joints hanging
+off the base (4 legs x 3, one arm x 7), one body per joint, joint anchors at the body origins; position servos with ctrl and force
+ranges; friction loss and limits on every joint; sphere / capsule / box collision geoms against ONE static plane (robot self-collision
+pairs are not generated this round, as in the oracle); pyramidal cones.  Contact parameters are mixed on the host: the plane has the
+higher priority in the shipped model, so its friction / solref / solimp apply (mj_contactParam).
+
+Float image F / int image I (little-endian fp32 / int32), see the enums at the top of jh_engine_v4.hip.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from judo_amd.models import MINVAL, clamp_solimp, inverse_weights, layout, quat_to_mat, solref_to_kb
+
+TH_F, TH_I = 32, 16           # header sizes
+TD_F, TD_I = 56, 4            # per joint dof
+TG_F, TG_I = 28, 2            # per geom
+SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-3
+GTYPE = {"sphere": 2, "capsule": 3, "box": 6}
+MAX_JOINTS, MAX_GEOMS, MAX_DEPTH = 25, 31, 7
+
+
+def tree_structure(desc: dict) -> dict:
+    """Base body, joint bodies in dof order, per-joint (parent joint, chain start, depth)."""
+    lay = layout(desc)
+    bodies, joints = desc["bodies"], desc["joints"]
+    free = [j for j, jn in enumerate(joints) if jn["type"] == "free"]
+    if len(free) != 1 or lay.jnt_dofadr[free[0]] != 0:
+        raise NotImplementedError("tree kernel: exactly one free joint, first in the dof order")
+    base = joints[free[0]]["body"]
+    if bodies[base]["parent"] != 0 and any(len(lay.body_joints[b]) for b in [bodies[base]["parent"]]):
+        raise NotImplementedError("tree kernel: the free body must hang off the world")
+    hinges = [j for j, jn in enumerate(joints) if jn["type"] != "free"]
+    body_of = {}
+    info = []
+    for k, j in enumerate(hinges):
+        jn = joints[j]
+        if jn["type"] != "hinge" or np.abs(jn["pos"]).max() > 0 or lay.jnt_dofadr[j] != 6 + k or len(lay.body_joints[jn["body"]]) != 1:
+            raise NotImplementedError("tree kernel: one hinge per body, anchored at the body origin, dofs in joint order")
+        body_of[jn["body"]] = k
+    for k, j in enumerate(hinges):
+        b = joints[j]["body"]
+        p = bodies[b]["parent"]
+        if p == base:
+            info.append(dict(parent=-1, start=k, depth=0))
+        elif p in body_of:
+            pk = body_of[p]
+            info.append(dict(parent=pk, start=info[pk]["start"], depth=info[pk]["depth"] + 1))
+            if pk != k - 1:
+                raise NotImplementedError("tree kernel: chains must be contiguous in the dof order")
+        else:
+            raise NotImplementedError("tree kernel: every jointed body must hang off the base or off another jointed body")
+    if len(hinges) > MAX_JOINTS or max(i["depth"] for i in info) >= MAX_DEPTH:
+        raise NotImplementedError("tree kernel: at most 25 joints in chains of at most 7")
+    return dict(layout=lay, base=base, hinges=hinges, body_of=body_of, info=info)
+
+
+def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
+    st = tree_structure(desc)
+    lay, base, hinges, body_of, info = st["layout"], st["base"], st["hinges"], st["body_of"], st["info"]
+    bodies, joints, geoms, o = desc["bodies"], desc["joints"], desc["geoms"], desc["option"]
+    if o["cone"] != "pyramidal" or o["integrator"] != "implicitfast":
+        raise NotImplementedError("tree kernel: pyramidal cones, implicitfast integrator")
+    dofw, bodyw = inverse_weights(desc)
+    nj = len(hinges)
+    planes = [g for g in geoms if g["type"] == "plane"]
+    if len(planes) != 1 or len(lay.body_joints[planes[0]["body"]]) != 0:
+        raise NotImplementedError("tree kernel: exactly one static plane")
+    plane = planes[0]
+    pb = bodies[plane["body"]]
+    Rp = quat_to_mat(pb["quat"]) @ quat_to_mat(plane["quat"])
+    ppos = np.array(pb["pos"]) + quat_to_mat(pb["quat"]) @ np.array(plane["pos"])
+    robot_geoms = [g for g in geoms if g is not plane]
+    if len(robot_geoms) > MAX_GEOMS:
+        raise NotImplementedError("tree kernel: too many collision geoms")
+    act_of = {a["joint"]: a for a in desc["actuators"]}
+    if len(act_of) != len(desc["actuators"]) or any(a["gear"] != 1.0 for a in desc["actuators"]):
+        raise NotImplementedError("tree kernel: at most one unit-gear position servo per joint")
+
+    F = np.zeros(TH_F + nj * TD_F + len(robot_geoms) * TG_F, dtype=np.float32)
+    I = np.zeros(TH_I + nj * TD_I + len(robot_geoms) * TG_I, dtype=np.int32)
+    bb = bodies[base]
+    F[0:8] = [o["timestep"], o["impratio"], SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL, *o["gravity"]]
+    F[8:14] = [*ppos, *Rp[:, 2]]                       # plane point, plane normal
+    F[14] = bb["mass"]
+    F[15:18] = bb["ipos"]
+    F[18:27] = quat_to_mat(bb["iquat"]).reshape(-1)
+    F[27:30] = bb["inertia"]
+    I[0:4] = [nj, len(robot_geoms), lay.nq, lay.nv]
+    for k, j in enumerate(hinges):
+        jn, b = joints[j], bodies[joints[j]["body"]]
+        d = 6 + k
+        f = F[TH_F + k * TD_F: TH_F + (k + 1) * TD_F]
+        f[0:3] = b["pos"]
+        f[3:12] = quat_to_mat(b["quat"]).reshape(-1)
+        f[12:15] = jn["axis"]
+        f[15] = b["mass"]
+        f[16:19] = b["ipos"]
+        f[19:28] = quat_to_mat(b["iquat"]).reshape(-1)
+        f[28:31] = b["inertia"]
+        f[31], f[32] = jn["damping"], jn["armature"]
+        fl = jn["frictionloss"]
+        si = clamp_solimp(jn["solimpfriction"])
+        imp0 = si[0] if not (si[0] == si[1] or si[2] <= MINVAL) else 0.5 * (si[0] + si[1])
+        _, fB = solref_to_kb(jn["solreffriction"], jn["solimpfriction"], o["timestep"])
+        fR = max(MINVAL, (1 - imp0) / imp0 * dofw[d])
+        f[33:36] = [fl, fB, 1.0 / fR if fl > 0 else 0.0]
+        f[36] = dofw[d]
+        rng = jn["range"]
+        lK, lB = solref_to_kb(jn["solreflimit"], jn["solimplimit"], o["timestep"])
+        f[37:42] = [float(rng is not None), *(rng or (0, 0)), lK, lB]
+        f[42:47] = clamp_solimp(jn["solimplimit"])
+        a = act_of.get(j)
+        if a is not None:
+            cr, fr = a["ctrlrange"], a["forcerange"]
+            f[47:55] = [a["kp"], a["kv"], float(cr is not None), *(cr or (0, 0)), float(fr is not None), *(fr or (0, 0))]
+        if jn["actuatorfrcrange"] is not None:
+            raise NotImplementedError("tree kernel: joint-level actuatorfrcrange")
+        I[TH_I + k * TD_I: TH_I + (k + 1) * TD_I] = [info[k]["parent"], info[k]["start"], info[k]["depth"], 1 if a is not None else 0]
+    og_f, og_i = TH_F + nj * TD_F, TH_I + nj * TD_I
+    pri_p = plane.get("priority", 0)
+    for gi, g in enumerate(robot_geoms):
+        if g["type"] not in GTYPE or g["condim"] != 3 or g["margin"] != 0 or g["gap"] != 0:
+            raise NotImplementedError(f"tree kernel: geom {g['name']} ({g['type']})")
+        gb = g["body"]
+        owner = -1 if gb == base else body_of.get(gb)
+        if owner is None:
+            raise NotImplementedError("tree kernel: collision geoms must sit on the base or on a jointed body")
+        pri_g = g.get("priority", 0)
+        if pri_p > pri_g:
+            mu, solref, solimp = plane["friction"][0], plane["solref"], plane["solimp"]
+        elif pri_g > pri_p:
+            mu, solref, solimp = g["friction"][0], g["solref"], g["solimp"]
+        else:
+            mu = max(plane["friction"][0], g["friction"][0])
+            solref = [0.5 * (plane["solref"][i] + g["solref"][i]) for i in range(2)]
+            solimp = [0.5 * (plane["solimp"][i] + g["solimp"][i]) for i in range(5)]
+        cK, cB = solref_to_kb(solref, solimp, o["timestep"])
+        size = (list(g["size"]) + [0, 0, 0])[:3]
+        f = F[og_f + gi * TG_F: og_f + (gi + 1) * TG_F]
+        f[0:3] = size
+        f[3:6] = g["pos"]
+        f[6:15] = quat_to_mat(g["quat"]).reshape(-1)
+        f[15] = max(1e-5, mu)
+        f[16:18] = [cK, cB]
+        f[18:23] = clamp_solimp(solimp)
+        f[23] = bodyw[gb][0] + bodyw[plane["body"]][0]   # diagApprox: translational inverse weights of both bodies
+        I[og_i + gi * TG_I: og_i + (gi + 1) * TG_I] = [owner, GTYPE[g["type"]]]
+    return F, I
+
+
+def pack_tree_blob(desc: dict) -> bytes:
+    """Header (magic, counts) + float image + int image, the form jh_tree_create takes."""
+    F, I = pack_tree_model(desc)
+    return np.array([0x34564A54, F.size, I.size, 0], dtype=np.uint32).tobytes() + F.tobytes() + I.tobytes()

@@ -1,0 +1,140 @@
+"""Spot policy rollout on the GPU: the tree kernel (csrc/jh_engine_v4.hip, through jh_tree_substeps) against the
+oracle engine on the Spot model, and the whole `threaded_rollout` replacement (policy step + physics substeps) against `oracle.policy.policy_rollout`.
+
+Floating point: the kernel is fp32, the oracle fp64; both stop Newton at MuJoCo's tolerance (1e-4 on the scaled gradient), so velocities agree
+to ~1e-5 and positions to ~1e-6 per step (measured: 1e-7 .. 3e-5); the tolerances below are 10x that."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(pos=2e-6, quat=2e-6, q=1e-5, vlin=2e-5, vang=1e-4, qd=3e-4)
+SL = dict(pos=slice(0, 3), quat=slice(3, 7), q=slice(7, 26), vlin=slice(26, 29), vang=slice(29, 32), qd=slice(32, 51))
+
+
+def _check(got, ref, scale=1.0):
+    for name, sl in SL.items():
+        err = np.abs(got[..., sl] - ref[..., sl]).max()
+        assert err <= TOL[name] * scale, f"{name}: {err:.3e} > {TOL[name] * scale:.1e}"
+
+
+@pytest.fixture(scope="module")
+def spot(gpu):
+    from judo_amd.policy import SpotTreeEngine
+    from oracle import policy as P
+
+    return P, P.spot_model(), SpotTreeEngine()
+
+
+def _oracle_steps(om, X, U, k):
+    return np.stack([om.rollout(X[i], np.repeat(U[i][None], k, axis=0)[None], nthread=1)[0][0, -1] for i in range(X.shape[0])])
+
+
+def test_tree_model_image_matches_oracle_model(spot):
+    """Host-side packing: inertia about the reference pose and the inverse weights the constraint regularisers use."""
+    from judo_amd import models
+    from judo_amd.tree_model import pack_tree_model, tree_structure
+
+    P, om, eng = spot
+    st = tree_structure(eng.desc)
+    assert [(i["start"], i["depth"]) for i in st["info"][:3]] == [(0, 0), (0, 1), (0, 2)] and st["info"][-1]["depth"] == 6
+    F, I = pack_tree_model(eng.desc)
+    assert list(I[:4]) == [19, 27, 26, 25] and F.dtype == np.float32
+    dofw, _ = models.inverse_weights(eng.desc)
+    np.testing.assert_allclose(dofw, om.invweight0()[0], rtol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["air", "stand", "tilt"])
+def test_tree_substeps_match_oracle(spot, case):
+    import torch
+
+    P, om, eng = spot
+    rng = np.random.default_rng({"air": 0, "stand": 1, "tilt": 2}[case])
+    x0 = P.spot_reset_state()
+    N = 6
+    X = np.tile(x0, (N, 1))
+    U = np.tile(P.DEFAULT_JOINT_POS, (N, 1))
+    if case == "air":       # no contacts: articulated-body dynamics, servos, joint friction, limits
+        X[:, 2] = 1.0
+        X[:, 7:26] += rng.standard_normal((N, 19)) * 0.1
+        X[:, 26:] = rng.standard_normal((N, 25)) * 0.3
+        X[0, 7 + 2] = -2.9   # a knee beyond its limit
+    elif case == "stand":   # four foot contacts
+        X[:, 7:19] += rng.standard_normal((N, 12)) * 0.02
+    else:                   # dropped, tilted, moving, off-nominal targets (some servos saturate)
+        X[:, 2] = 0.45
+        q = rng.standard_normal((N, 4)) * 0.15
+        q[:, 0] = 1
+        X[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        X[:, 26:] = rng.standard_normal((N, 25)) * 0.5
+        U = U + rng.standard_normal((N, 19)) * 0.4
+    xs = torch.as_tensor(X, dtype=torch.float32, device="cuda")
+    us = torch.as_tensor(U, dtype=torch.float32, device="cuda")
+    eng.stats()
+    for k in (1, 2, 5):
+        warm = torch.zeros((N, 25), dtype=torch.float32, device="cuda")
+        got = eng.substeps(xs, us, warm, k).cpu().numpy()
+        assert np.isfinite(got).all()
+        _check(got, _oracle_steps(om, X, U, k), scale=1.0 + 0.5 * (k - 1))
+        assert torch.isfinite(warm).all() and (case == "air" or float(warm.abs().max()) > 0)
+    st = eng.stats()
+    assert st["contacts_dropped"] == 0 and st["steps_at_cap"] == 0 and st["steps"] == N * 8
+    # in place, and without a warm-start buffer
+    y = xs.clone()
+    eng.substeps(y, us, None, 1, out=y)
+    _check(y.cpu().numpy(), _oracle_steps(om, X, U, 1))
+
+
+def test_policy_rollout_backend_matches_oracle(spot):
+    """PolicyMJRolloutBackend.rollout's contract: (N, T, 25) commands -> (N, T, nq+nv) states, empty sensors, (N, 12) last policy outputs."""
+    from judo_amd.policy import PolicyRolloutBackend
+
+    P, om, _ = spot
+    Ws, bs = P.load_actor()
+    N, T = 4, 40
+    x0 = P.spot_reset_state()
+    cmds = np.tile(P.DEFAULT_POLICY_COMMAND, (N, T, 1))
+    cmds[1, :, 0] = 0.5
+    cmds[2, :, 1] = 0.3
+    cmds[3, :, 2] = 0.5
+    be = PolicyRolloutBackend(N, carry_warmstart=False)   # the oracle restarts the solver's warm start at every control step
+    states, sensors, outs = be.rollout(x0, cmds, np.zeros((N, 12)))
+    assert states.shape == (N, T, 51) and sensors.shape == (N, T, 0) and outs.shape == (N, 12) and states.dtype == np.float64
+    for i in range(N):
+        ref, o = P.policy_rollout(om, Ws, bs, x0, cmds[i])
+        _check(states[i], ref, scale=10.0)   # 80 physics steps of a closed loop: fp32 differences feed back through the policy
+        np.testing.assert_allclose(outs[i], o, atol=5e-4)
+    assert abs(states[1, -1, 0] - 0.27) < 0.08 and abs(states[0, -1, 0]) < 0.02   # it walks forward when told to, stands otherwise
+    # the reference keeps its mjData between control steps: carrying the warm start changes the result only at solver-tolerance level
+    be2 = PolicyRolloutBackend(N)
+    s2, _, o2 = be2.rollout(x0, cmds, np.zeros((N, 12)))
+    assert np.abs(s2[:, :10] - states[:, :10]).max() < 5e-3 and np.isfinite(s2).all()
+    with pytest.raises(ValueError):
+        be.rollout(x0, cmds, None)
+    with pytest.raises(ValueError):
+        be.rollout(x0, cmds[:, :, :24], np.zeros((N, 12)))
+
+
+def test_policy_rollout_is_reproducible_and_batch_independent(spot):
+    import torch
+    from judo_amd.policy import PolicyRolloutBackend
+
+    P, _, _ = spot
+    x0 = P.spot_reset_state()
+    rng = np.random.default_rng(5)
+    N, T = 257, 6
+    cmds = np.tile(P.DEFAULT_POLICY_COMMAND, (N, T, 1))
+    cmds[:, :, :3] = rng.uniform(-0.5, 0.5, (N, 1, 3))
+    X = np.tile(x0, (N, 1))
+    X[:, 7:19] += rng.standard_normal((N, 12)) * 0.05
+    be = PolicyRolloutBackend(N)
+    a, _, oa = be.rollout(X, cmds, np.zeros((N, 12)))
+    be.update(N)
+    b, _, ob = be.rollout(X, cmds, np.zeros((N, 12)))
+    assert np.array_equal(a, b) and np.array_equal(oa, ob)
+    # a rollout's physics does not depend on its neighbours in the wave (the policy GEMM tiles do not mix rows either)
+    perm = rng.permutation(N)
+    c, _, _ = be.rollout(X[perm], cmds[perm], np.zeros((N, 12)))
+    assert np.array_equal(c, a[perm])
+    assert torch.cuda.is_available()
