@@ -104,6 +104,12 @@ def _register_shipped_overrides() -> None:
     set_config_overrides("fr3_pick", CrossEntropyMethodConfig, dict(fr3, sigma_min=0.01, sigma_max=0.3, num_elites=3))
     set_config_overrides("fr3_pick", MPPIConfig, dict(fr3, sigma=0.01, temperature=0.002))
     set_config_overrides("fr3_pick", ControllerConfig, {"horizon": 1.0, "spline_order": "linear", "max_num_traces": 3})
+    spot = {"num_rollouts": 24, "num_nodes": 3, "use_noise_ramp": True, "noise_ramp": 3.5}   # judo/optimizers/overrides.py:188-199
+    for task in ("spot_base", "spot_box_push", "spot_navigate", "spot_tire_roll", "spot_tire_upright"):
+        set_config_overrides(task, PredictiveSamplingConfig, dict(spot))
+        set_config_overrides(task, CrossEntropyMethodConfig, dict(spot, num_elites=3))
+        set_config_overrides(task, MPPIConfig, dict(spot))
+        set_config_overrides(task, ControllerConfig, {"horizon": 2.0})                          # judo/controller/overrides.py:79-88
 
 
 _register_shipped_overrides()

@@ -39,14 +39,25 @@ class Controller:
         self.group = group
         self.available_optimizers = get_registered_optimizers()
         self.available_tasks = get_registered_tasks()
-        self.model = task.gpu_model(self.device)
-        self.rollout_backend = GpuRolloutBackend(self.model, self.optimizer_cfg.num_rollouts)
+        if task.uses_locomotion_policy:  # judo/controller/controller.py:72-80: the policy backend is selected by the task
+            from judo_amd.policy import PolicyRolloutBackend
+            from judo_amd.spot_tasks import DEFAULT_SPOT_ROLLOUT_CUTOFF_TIME
+
+            world, rank = world_info(group)
+            self.model = None
+            self.rollout_backend = PolicyRolloutBackend(shard_rollouts(self.optimizer_cfg.num_rollouts, world, rank).count, physics_substeps=task.physics_substeps,
+                                                        policy_path=task.locomotion_policy_path, desc=task.desc, device=self.device)
+            self.rollout_cutoff_time: float | None = DEFAULT_SPOT_ROLLOUT_CUTOFF_TIME  # policy_mj_rollout_backend.py:94; None = no deadline
+        else:
+            self.model = task.gpu_model(self.device)
+            self.rollout_backend = GpuRolloutBackend(self.model, self.optimizer_cfg.num_rollouts)
+        self._last_policy_output: torch.Tensor | None = None  # (shard count, 12) device tensor once a policy rollout has run
         self.system_metadata: dict[str, Any] = {}
         self.current_state = np.concatenate([task.data.qpos, task.data.qvel])
         self.rewards = np.zeros((self.optimizer_cfg.num_rollouts,))
         self.costs_device: torch.Tensor | None = None
         self.traces = None
-        self.trace_sensors = [s for s in task.desc["sensors"] if s["type"] == "framepos" and s["name"].startswith("trace")]
+        self.trace_sensors = [] if task.uses_locomotion_policy else [s for s in task.desc["sensors"] if s["type"] == "framepos" and s["name"].startswith("trace")]
         self._w_cache: dict[tuple, torch.Tensor] = {}
         self._lohi_dev: torch.Tensor | None = None
         self.keep_candidates = False
@@ -196,8 +207,10 @@ class Controller:
         # time shift (host; needs the previous plan's spline)
         new_times = self.time + self.spline_timesteps
         nominal_knots = self.spline(new_times)
-        if self.rollout_backend.num_threads != N:
-            self.rollout_backend.update(N)
+        want_threads = shard.count if task.uses_locomotion_policy else N
+        if self.rollout_backend.num_threads != want_threads:  # controller.py:225-229
+            self.rollout_backend.update(want_threads)
+            self._last_policy_output = None
         nrm = self._current_normalizer()
         nominal_n = nrm.normalize(nominal_knots)  # the optimiser's state lives in normalised units (controller.py:222)
         opt.pre_optimization(self.times, new_times)
@@ -291,7 +304,13 @@ class Controller:
         st = lib.jh_spline_controls(_lib.ptr(W), None, _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(lohi_d), shard.count,
                                     shard.offset, H, K, nu, _lib.ptr(controls), stream)
         _lib.check(st, "jh_spline_controls")
-        states, sensors = self.rollout_backend.rollout_device(x0_d, controls)
+        if task.uses_locomotion_policy:  # controller.py:265-273: commands -> policy + plant; the policy outputs carry over to the next plan step
+            if self._last_policy_output is None:
+                self._last_policy_output = torch.zeros((shard.count, 12), dtype=torch.float32, device=self.device)
+            states, sensors, self._last_policy_output = self.rollout_backend.rollout(x0_d, task.task_to_sim_ctrl(controls), self._last_policy_output,
+                                                                                    cutoff_time=self.rollout_cutoff_time)
+        else:
+            states, sensors = self.rollout_backend.rollout_device(x0_d, controls)
         if getattr(task, "reward_accepts_torch", True):
             args = (states, sensors, controls)
         else:  # numpy-only plugin reward: one host round trip of the trajectories
@@ -315,6 +334,9 @@ class Controller:
         shape (E * n_trace_sensors * (H-1), 2, 3).  Re-rolls only the E elite rollouts in materialise mode."""
         if self.costs_device is None or self.optimizer.last_noise is None:
             raise RuntimeError("update_traces() needs a completed update_action()")
+        if not self.trace_sensors:
+            self.traces = np.zeros((0, 2, 3))
+            return
         self.traces = elite_traces(self, self._last_sigma_raw, self._last_nominal_before)
 
 

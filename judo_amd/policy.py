@@ -27,6 +27,7 @@ import torch
 from judo_amd import _lib
 from judo_amd.device import current_stream_ptr, f32, require_gpu
 from judo_amd.models import load_description
+from judo_amd.rollout_backend import RolloutBackend
 from judo_amd.tree_model import pack_tree_blob
 
 POLICY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "spot_locomotion_policy.npz")
@@ -135,7 +136,7 @@ class SpotTreeEngine:
             pass
 
 
-class PolicyRolloutBackend:
+class PolicyRolloutBackend(RolloutBackend):
     """Drop-in for `PolicyMJRolloutBackend` (judo/utils/policy_mj_rollout_backend.py:20-125): N rollouts of the Spot plant under the locomotion
     policy, one policy step per command row followed by `physics_substeps` engine steps; the state is recorded after the substeps.
 
@@ -156,7 +157,13 @@ class PolicyRolloutBackend:
         self.num_threads = int(num_threads)
         self._warm = torch.zeros((self.num_threads, SpotTreeEngine.NV), dtype=torch.float32, device=self.device)
 
-    def rollout(self, x0, controls, last_policy_output=None):
+    def rollout(self, x0, controls, last_policy_output=None, cutoff_time: float | None = None):
+        """(x0 (nx,) or (N, nx), controls (N, T, 25), last_policy_output (N, 12)) -> (states (N, T, nx), sensors (N, T, 0), policy outputs (N, 12)).
+
+        `cutoff_time` (seconds; the reference passes DEFAULT_SPOT_ROLLOUT_CUTOFF_TIME = 0.125 and checks its wall clock before every command
+        row, system_class.cpp:290-327): once the batch has used that much DEVICE time, the remaining rows repeat the last computed state and the
+        policy is not stepped further.  The check reads the event of the control step two back, so the launch queue never drains; None (default)
+        disables it -- 65 536 rollouts x 100 control steps take ~0.4 s, the 24 rollouts the reference ships take ~10 ms."""
         if last_policy_output is None:
             raise ValueError("last_policy_output is required for PolicyRolloutBackend")
         as_numpy = not isinstance(controls, torch.Tensor)
@@ -175,11 +182,34 @@ class PolicyRolloutBackend:
         if tuple(out.shape) != (N, SpotLocomotionPolicy.ACT):
             raise ValueError(f"last_policy_output must be ({N}, 12), got {tuple(out.shape)}")
         states = torch.empty((T, N, nx), dtype=torch.float32, device=self.device)  # step-major while rolling: every step writes one contiguous slab
+        cmd_t = cmd.permute(1, 0, 2).contiguous()
+        start, marks, done = None, [], T
+        if cutoff_time is not None:
+            start = torch.cuda.Event(enable_timing=True)
+            start.record()
         for t in range(T):
-            ctrl, out = self.policy.step(x, cmd[:, t].contiguous(), out, self.layout)
+            if start is not None:
+                elapsed = 0.0
+                if t >= 2:
+                    marks[t - 2].synchronize()
+                    elapsed = start.elapsed_time(marks[t - 2]) * 1e-3
+                if not elapsed < cutoff_time:
+                    done = t
+                    break
+            ctrl, out = self.policy.step(x, cmd_t[t], out, self.layout)
             if not self.carry_warmstart:
                 self._warm.zero_()
             x = self.engine.substeps(x, ctrl, self._warm, self.physics_substeps, out=states[t])
+            if start is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+        if done < T:  # fill with the last computed state (zeros when nothing was computed: the reference's states start as zeros)
+            if done == 0:
+                states.zero_()
+            else:
+                states[done:] = states[done - 1]
+        self.steps_computed = done
         states = states.permute(1, 0, 2).contiguous()
         sensors = torch.zeros((N, T, 0), dtype=torch.float32, device=self.device)
         if as_numpy:

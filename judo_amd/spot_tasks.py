@@ -1,0 +1,255 @@
+"""Spot tasks on the policy rollout (judo/tasks/spot/spot_base.py, spot_navigate.py, spot_constants.py).
+
+A Spot task optimises a compact command vector (base velocity, optionally arm / front-leg / torso targets), `task_to_sim_ctrl` expands it
+to the 25-d command of the locomotion policy, and the rollout runs policy + plant (`judo_amd.policy.PolicyRolloutBackend`).  Everything
+here accepts numpy arrays (host, float64, what the reference passes) or torch tensors (device, what the controller's materialise path passes).
+
+Scope this round: the robot alone on the ground plane (`spot_base`, `spot_navigate`).  The object tasks (`spot_box_push`, `spot_tire_roll`,
+`spot_tire_upright`) add free bodies the tree kernel does not carry yet.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from judo_amd.tasks import Task, TaskConfig, register_task
+
+# ---- judo/tasks/spot/spot_constants.py -------------------------------------------------------------------------------
+DEFAULT_SPOT_ROLLOUT_CUTOFF_TIME = 0.125   # :18
+POLICY_OUTPUT_DIM = 12                     # :23
+GRIPPER_CLOSED_POS, GRIPPER_OPEN_POS = 0.0, -1.54   # :52-53
+LEGS_STANDING_POS = np.array([0.12, 0.72, -1.45, -0.12, 0.72, -1.45, 0.12, 0.72, -1.45, -0.12, 0.72, -1.45])   # :55-70
+LEGS_STANDING_POS_RL = np.array([0.12, 0.5, -1.0, -0.12, 0.5, -1.0, 0.12, 0.5, -1.0, -0.12, 0.5, -1.0])        # :73-88
+ARM_STOWED_POS = np.array([0, -3.11, 3.13, 1.56, 0, -1.56, GRIPPER_CLOSED_POS])     # :90
+ARM_UNSTOWED_POS = np.array([0, -0.9, 1.8, 0, -0.9, 0, GRIPPER_CLOSED_POS])         # :92
+STANDING_HEIGHT = 0.52                     # :95
+STANDING_HEIGHT_CMD = STANDING_HEIGHT      # :96
+LEG_SOFT_LOWER_JOINT_LIMITS = np.array([-0.6, -0.8, -2.7] * 4)    # :99
+LEG_SOFT_UPPER_JOINT_LIMITS = np.array([0.6, 1.65, -0.3] * 4)     # :100
+ARM_SOFT_LOWER_JOINT_LIMITS = ARM_UNSTOWED_POS - np.array([1.0, 1.0, 0.8, np.pi / 2, 0.7, np.pi / 4, 0])   # :101
+ARM_SOFT_UPPER_JOINT_LIMITS = ARM_UNSTOWED_POS + np.array([1.0, 0.8, 0.6, np.pi / 2, 0.9, np.pi / 4, 0])   # :102
+BASE_VEL_CMD_INDS, ARM_CMD_INDS, FRONT_LEG_CMD_INDS, TORSO_CMD_INDS = [0, 1, 2], list(range(3, 10)), list(range(10, 16)), [22, 23, 24]   # :106-109
+BASE_SOFT_LIMITS = 0.7 * np.ones(3)        # :112
+TORSO_LOWER, TORSO_UPPER = np.array([-0.0, -1.0, 0.3]), np.array([+0.0, +1.0, 1.0])   # :115-116
+
+
+@dataclass
+class SpotBaseConfig(TaskConfig):          # spot_base.py:56-66
+    fall_penalty: float = 2500.0
+    spot_fallen_threshold: float = 0.35
+    w_goal: float = 60.0
+    w_controls: float = 0.0
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class SpotBase(Task[SpotBaseConfig]):
+    """spot_base.py:72-470: the compact command vector and its mapping to the policy command; zero reward."""
+
+    name = "spot_base"
+    model_name = "spot"
+    config_t = SpotBaseConfig
+
+    def __init__(self, use_arm: bool = True, use_gripper: bool = False, use_legs: bool = False, use_torso: bool = False, config: SpotBaseConfig | None = None) -> None:
+        self.use_arm, self.use_gripper, self.use_legs, self.use_torso = use_arm, use_gripper, use_legs, use_torso
+        self.leg_selection_index: int | None = None
+        self.gripper_selection_index: int | None = None
+        self.set_command_values()
+        self.default_policy_command = np.array([0, 0, 0] + list(ARM_STOWED_POS) + [0] * 12 + [0, 0, STANDING_HEIGHT_CMD])   # :159-161
+        super().__init__()
+        if config is not None:
+            self.config = config
+        self.reset()
+
+    # ---- facts -----------------------------------------------------------------------------------------------------------
+    @property
+    def physics_substeps(self) -> int:     # :113-116
+        return 2
+
+    @property
+    def uses_locomotion_policy(self) -> bool:
+        return True
+
+    @property
+    def locomotion_policy_path(self) -> str:
+        from judo_amd.policy import POLICY_PATH
+
+        return POLICY_PATH
+
+    @property
+    def nu(self) -> int:                   # :166-169
+        return len(self.default_command)
+
+    @property
+    def nsensordata(self) -> int:          # the model's sensors are not evaluated on this path
+        return 0
+
+    def task_params(self, system_metadata=None) -> np.ndarray:
+        return np.zeros(0, dtype=np.float32)
+
+    def gpu_model(self, device=None):
+        raise NotImplementedError("Spot tasks roll out through PolicyRolloutBackend (policy + tree kernel), not through a GpuModel")
+
+    @property
+    def actuator_ctrlrange(self) -> np.ndarray:   # :171-224
+        grip_lo = GRIPPER_OPEN_POS if self.use_gripper else GRIPPER_CLOSED_POS
+        arm_lo = np.concatenate((ARM_SOFT_LOWER_JOINT_LIMITS[:-1], [grip_lo]))
+        arm_hi = np.concatenate((ARM_SOFT_UPPER_JOINT_LIMITS[:-1], [GRIPPER_CLOSED_POS]))
+        lo, hi = [-BASE_SOFT_LIMITS], [BASE_SOFT_LIMITS]
+        if self.use_arm:
+            lo.append(arm_lo); hi.append(arm_hi)
+            if self.use_gripper:
+                lo.append(-np.ones(1)); hi.append(np.ones(1))
+        if self.use_legs:
+            lo += [LEG_SOFT_LOWER_JOINT_LIMITS[0:6], -np.ones(1)]; hi += [LEG_SOFT_UPPER_JOINT_LIMITS[0:6], np.ones(1)]
+        if self.use_torso:
+            lo.append(TORSO_LOWER); hi.append(TORSO_UPPER)
+        return np.stack([np.concatenate(lo), np.concatenate(hi)], axis=-1)
+
+    def set_command_values(self) -> None:  # :226-263
+        self.leg_selection_index = self.gripper_selection_index = None
+        vals: list[float] = [0, 0, 0]
+        mask = list(BASE_VEL_CMD_INDS)
+        if self.use_arm:
+            vals += list(ARM_UNSTOWED_POS); mask += ARM_CMD_INDS
+            if self.use_gripper:
+                vals.append(0.0)
+                self.gripper_selection_index = len(vals) - 1
+        if self.use_legs:
+            vals += [*LEGS_STANDING_POS[0:6], 0]; mask += FRONT_LEG_CMD_INDS
+            self.leg_selection_index = len(vals) - 1
+        if self.use_torso:
+            vals += [0, 0, STANDING_HEIGHT]; mask += TORSO_CMD_INDS
+        self.default_command = np.array(vals, dtype=np.float64)
+        self.command_mask = np.array(mask)
+
+    # ---- command mapping ---------------------------------------------------------------------------------------------------
+    def apply_selection_mask(self, controls):
+        """:265-331.  Leg selection in [-1, -0.5) keeps the front-left leg command, (0.5, 1] the front-right, otherwise neither;
+        gripper selection < 0 closes the gripper.  The selection entries are removed from the result."""
+        if self.leg_selection_index is None and self.gripper_selection_index is None:
+            return controls
+        tor = _is_torch(controls)
+        added = controls.ndim == 1
+        c = (controls.clone() if tor else np.array(controls, copy=True))
+        if added:
+            c = c[None]
+        if self.use_arm and self.use_gripper and self.gripper_selection_index is not None:
+            closed = c[..., self.gripper_selection_index] < 0.0
+            c[..., 9] = (c[..., 9].masked_fill(closed, GRIPPER_CLOSED_POS) if tor else np.where(closed, GRIPPER_CLOSED_POS, c[..., 9]))
+        if self.use_legs and self.leg_selection_index is not None:
+            sel = c[..., self.leg_selection_index]
+            keep_fl, keep_fr = sel < -0.5, sel > 0.5
+            s0 = 3 + ((7 + (1 if self.use_gripper else 0)) if self.use_arm else 0)
+            kf = keep_fl[..., None].to(c.dtype) if tor else keep_fl[..., None].astype(c.dtype)
+            kr = keep_fr[..., None].to(c.dtype) if tor else keep_fr[..., None].astype(c.dtype)
+            c[..., s0 : s0 + 3] = c[..., s0 : s0 + 3] * kf
+            c[..., s0 + 3 : s0 + 6] = c[..., s0 + 3 : s0 + 6] * kr
+        keep = [i for i in range(c.shape[-1]) if i not in (self.leg_selection_index, self.gripper_selection_index)]
+        c = c[..., keep]
+        return c[0] if added else c
+
+    def task_to_sim_ctrl(self, controls):
+        """:325-391: (..., nu) compact controls -> (..., 25) policy commands [base vel 3 | arm 7 | leg override 12 | torso roll, pitch, height].
+        Shapes as the reference returns them: (N, T, nu) -> (N, T, 25); (N, nu) -> (N, 25); (nu,) -> (1, 25); and (N, 1, nu) -> (N, 25) (its
+        single-timestep squeeze, :386-387)."""
+        tor = _is_torch(controls)
+        c = controls if tor else np.asarray(controls)
+        shape_in = c.shape
+        c = self.apply_selection_mask(c[None] if c.ndim == 1 else c)
+        if tor:
+            import torch
+
+            out = torch.as_tensor(self.default_policy_command, dtype=c.dtype, device=c.device).expand(*c.shape[:-1], 25).clone()
+        else:
+            out = np.broadcast_to(self.default_policy_command, (*c.shape[:-1], 25)).copy()
+        arm_end = 3 + (7 if self.use_arm else 0)
+        legs_end = arm_end + (6 if self.use_legs else 0)
+        out[..., 0:3] = c[..., 0:3]
+        if self.use_arm:
+            out[..., 3:10] = c[..., 3:arm_end]
+        if self.use_legs:
+            out[..., 10:16] = c[..., arm_end:legs_end]
+        if self.use_torso:
+            out[..., 22:25] = c[..., legs_end : legs_end + 3]
+        if len(shape_in) == 3 and shape_in[1] == 1:
+            return out[:, 0, :]
+        return out
+
+    # ---- reward / reset ------------------------------------------------------------------------------------------------------
+    def reward(self, states, sensors, controls, system_metadata: dict[str, Any] | None = None):   # :393-414
+        if _is_torch(states):
+            import torch
+
+            return torch.zeros(states.shape[0], dtype=states.dtype, device=states.device)
+        return np.zeros(states.shape[0])
+
+    @property
+    def reset_arm_pos(self) -> np.ndarray:   # :416-419
+        return ARM_UNSTOWED_POS if self.use_arm else ARM_STOWED_POS
+
+    @property
+    def reset_pose(self) -> np.ndarray:      # :421-435
+        return np.array([0.0, 0.0, STANDING_HEIGHT, 1, 0, 0, 0, *LEGS_STANDING_POS_RL, *self.reset_arm_pos])
+
+    def reset(self) -> None:                 # :437-441
+        self.data.qpos = np.array(self.reset_pose, dtype=np.float64)
+        self.data.qvel = np.zeros(self.nv)
+
+    def get_action_components(self) -> list[str]:   # :443-461
+        names = ["spot/base.vx", "spot/base.vy", "spot/base.vtheta"]
+        if self.use_arm:
+            names += [f"spot/{j}" for j in ("arm_sh0", "arm_sh1", "arm_el0", "arm_el1", "arm_wr0", "arm_wr1", "arm_f1x")]
+        if self.use_legs:
+            names += [f"spot/{j}" for j in ("fr_hx", "fr_hy", "fr_kn", "fl_hx", "fl_hy", "fl_kn")] + ["spot/leg_selection"]
+        if self.use_torso:
+            names += ["spot/torso.roll", "spot/torso.pitch", "spot/torso.height"]
+        return names
+
+
+@dataclass
+class SpotNavigateConfig(SpotBaseConfig):   # spot_navigate.py:19-33
+    w_goal: float = 60.0
+    fall_penalty: float = 2500.0
+    w_controls: float = 0.0
+    goal_position: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, STANDING_HEIGHT]))
+
+
+class SpotNavigate(SpotBase):
+    """spot_navigate.py:36-82: walk the base to a goal position; base-velocity commands only."""
+
+    name = "spot_navigate"
+    config_t = SpotNavigateConfig
+
+    def __init__(self, config: SpotNavigateConfig | None = None) -> None:
+        super().__init__(use_arm=False, config=config)
+        self.body_pose_idx = 0
+
+    def reward(self, states, sensors, controls, system_metadata: dict[str, Any] | None = None):   # :50-77
+        cfg = self.config
+        i = self.body_pose_idx
+        if _is_torch(states):
+            import torch
+
+            pos = states[..., i : i + 3]
+            goal = torch.as_tensor(np.asarray(cfg.goal_position), dtype=states.dtype, device=states.device)
+            fallen = (states[..., i + 2] <= cfg.spot_fallen_threshold).any(dim=-1).to(states.dtype)
+            r = -cfg.fall_penalty * fallen - cfg.w_goal * torch.linalg.norm(pos - goal, dim=-1).mean(-1)
+            return r - cfg.w_controls * torch.linalg.norm(controls, dim=-1).mean(-1)
+        pos = states[..., i : i + 3]
+        fallen = (states[..., i + 2] <= cfg.spot_fallen_threshold).any(axis=-1)
+        r = -cfg.fall_penalty * fallen - cfg.w_goal * np.linalg.norm(pos - np.asarray(cfg.goal_position)[None, None], axis=-1).mean(-1)
+        return r - cfg.w_controls * np.linalg.norm(controls, axis=-1).mean(-1)
+
+    @property
+    def reset_pose(self) -> np.ndarray:     # :79-82
+        return np.array([0, 0, STANDING_HEIGHT, 1, 0, 0, 0, *LEGS_STANDING_POS, *self.reset_arm_pos])
+
+
+register_task(SpotBase.name, SpotBase, SpotBaseConfig)
+register_task(SpotNavigate.name, SpotNavigate, SpotNavigateConfig)

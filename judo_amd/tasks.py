@@ -44,7 +44,7 @@ class Task(ABC, Generic[ConfigT]):
     reward_accepts_torch: bool = True  # a plugin whose overridden `reward` is numpy-only sets this to False
 
     def __init__(self) -> None:
-        self.desc = load_description(self.name)
+        self.desc = load_description(getattr(self, "model_name", None) or self.name)  # several tasks can share one model (the Spot tasks)
         self._layout = layout(self.desc)
         self.config = self.config_t()
         self.data = TaskData(qpos0(self.desc), np.zeros(self._layout.nv))
@@ -411,3 +411,6 @@ def get_registered_tasks() -> dict[str, tuple[type, type]]:
 def register_task(name: str, task_type: type, task_config_type: type) -> None:
     """judo/tasks/__init__.py:45."""
     _registered_tasks[name] = (task_type, task_config_type)
+
+
+from judo_amd import spot_tasks as _spot_tasks  # noqa: E402,F401  (registers spot_base / spot_navigate)

@@ -311,3 +311,76 @@ def test_running_normaliser_loop_matches_reference_golden():
         assert nrm.count == st[0]
         np.testing.assert_allclose(np.concatenate([nrm.mean, nrm.std, nrm.M2]), st[1:], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(nrm.denormalize(nominal_n), g["running_nominal_out"], rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ Spot task layer
+def test_spot_task_layer_matches_reference_golden():
+    """SpotBase command mapping for all 12 feature combinations, SpotNavigate.reward, overrides and constants (tools/gen_golden_spot.py)."""
+    import torch
+    from judo_amd import spot_tasks as ST
+    from judo_amd.config import ControllerConfig, CrossEntropyMethodConfig, MPPIConfig, PredictiveSamplingConfig
+
+    d = np.load(os.path.join(GOLDEN, "spot_tasks.npz"))
+    for ci, combo in enumerate(d["combos"]):
+        t = ST.SpotBase(*[bool(x) for x in combo])
+        assert np.array_equal(t.default_command, d[f"c{ci}_default_command"]) and np.array_equal(t.command_mask, d[f"c{ci}_command_mask"])
+        assert np.array_equal(t.actuator_ctrlrange, d[f"c{ci}_ctrlrange"]) and t.nu == len(t.default_command)
+        ctl = d[f"c{ci}_controls"]
+        assert np.array_equal(t.task_to_sim_ctrl(ctl), d[f"c{ci}_sim3"])
+        assert np.array_equal(t.task_to_sim_ctrl(ctl[:, 0]), d[f"c{ci}_sim2"])
+        assert np.array_equal(t.task_to_sim_ctrl(ctl[0, 0]), d[f"c{ci}_sim1"])
+        assert np.array_equal(t.task_to_sim_ctrl(torch.as_tensor(ctl)).numpy(), d[f"c{ci}_sim3"])   # the device path runs the same code on tensors
+        assert np.array_equal(ctl, d[f"c{ci}_controls"])                                             # inputs are not modified in place
+        assert len(t.get_action_components()) == t.nu - (t.gripper_selection_index is not None)
+    nav = ST.SpotNavigate()
+    assert nav.nu == 3 and (nav.nq, nav.nv) == (26, 25) and nav.physics_substeps == 2 and abs(nav.dt - 0.02) < 1e-15 and nav.uses_locomotion_policy
+    assert np.array_equal(nav.data.qpos[7:19], ST.LEGS_STANDING_POS) and np.array_equal(nav.data.qpos[19:], ST.ARM_STOWED_POS)
+    nav.config.goal_position = d["nav_goal"]
+    np.testing.assert_allclose(nav.reward(d["nav_states"], None, d["nav_controls"]), d["nav_reward"], rtol=1e-13)
+    np.testing.assert_allclose(nav.reward(torch.as_tensor(d["nav_states"]), None, torch.as_tensor(d["nav_controls"])).numpy(), d["nav_reward"], rtol=1e-13)
+    nav.config.w_controls = 0.25
+    np.testing.assert_allclose(nav.reward(d["nav_states"], None, d["nav_controls"]), d["nav_reward_wc"], rtol=1e-13)
+    assert not ST.SpotBase().reward(d["nav_states"], None, None).any()
+    g = json.load(open(os.path.join(GOLDEN, "spot_configs.json")))
+    for task in ("spot_base", "spot_navigate"):
+        for nm, cls in (("mppi", MPPIConfig), ("cem", CrossEntropyMethodConfig), ("ps", PredictiveSamplingConfig)):
+            c = cls()
+            c.set_override(task)
+            assert {k: getattr(c, k) for k in g["optimizer"][task][nm]} == g["optimizer"][task][nm]
+        c = ControllerConfig()
+        c.set_override(task)
+        assert vars(c) == g["controller"][task]
+    for k, v in g["constants"].items():
+        np.testing.assert_allclose(np.asarray(getattr(ST, k), dtype=np.float64), np.asarray(v, dtype=np.float64), rtol=0, atol=0)
+    cfg = ST.SpotNavigateConfig()
+    assert {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in vars(cfg).items()} == g["task_defaults"]["spot_navigate"]
+
+
+def test_tree_model_image():
+    """Host-side packing for the floating-base tree kernel: structure checks, image layout, rejection of models outside its scope."""
+    from judo_amd import models
+    from judo_amd.tree_model import TD_F, TD_I, TG_F, TG_I, TH_F, TH_I, pack_tree_blob, pack_tree_model, tree_structure
+
+    desc = models.load_description("spot")
+    st = tree_structure(desc)
+    chains = {}
+    for k, i in enumerate(st["info"]):
+        chains.setdefault(i["start"], []).append((k, i["depth"], i["parent"]))
+    assert sorted(len(v) for v in chains.values()) == [3, 3, 3, 3, 7]           # four legs, one arm
+    for start, links in chains.items():
+        assert [d for _, d, _ in links] == list(range(len(links))) and links[0][2] == -1 and all(p == k - 1 for k, _, p in links[1:])
+    F, I = pack_tree_model(desc)
+    nj, ng = int(I[0]), int(I[1])
+    assert (nj, ng, int(I[2]), int(I[3])) == (19, 27, 26, 25)
+    assert F.size == TH_F + nj * TD_F + ng * TG_F and I.size == TH_I + nj * TD_I + ng * TG_I and F.dtype == np.float32 and I.dtype == np.int32
+    assert abs(F[0] - 0.01) < 1e-9 and np.allclose(F[11:14], [0, 0, 1]) and np.allclose(F[5:8], [0, 0, -9.81])
+    M, _ = models.mass_matrix(desc, models.qpos0(desc))
+    assert abs(sum(F[TH_F + k * TD_F + 15] for k in range(nj)) + F[14] - M[0, 0]) < 1e-4   # link masses add up to the translational inertia
+    owners = I[TH_I + nj * TD_I :: TG_I][:ng]
+    assert owners.min() == -1 and owners.max() < nj
+    blob = pack_tree_blob(desc)
+    hd = np.frombuffer(blob[:16], dtype=np.uint32)
+    assert hd[0] == 0x34564A54 and hd[1] == F.size and hd[2] == I.size and len(blob) == 16 + 4 * (F.size + I.size)
+    for other in ("leap_cube", "fr3_pick", "cartpole"):
+        with pytest.raises(NotImplementedError):
+            pack_tree_model(models.load_description(other))
