@@ -22,7 +22,10 @@ namespace {
 
 constexpr int G = 32, RPW = 2, WAVE = 64;
 constexpr int NJ = 19, NVT = 25, NQ = 26, NX = 51, NB = 20, MAXD = 7;
-constexpr int NCP = 24, JW = NVT * 3, RAW_F = 8, NR = NVT + 1;  // NR: matrix rows incl. the right-hand-side row
+constexpr int NCP = 24, RAW_F = 8, NR = NVT + 1;  // NR: row registers
+// Contact Jacobian row (contact frame x dofs), compact: a ground contact moves with the base and ONE chain.  [3 b + r] base dof b, [JC + 3 m + r] position m of
+// the contact's chain (zero beyond the owner link), rows padded to float4s.
+constexpr int JC = 20, JW = 44;
 constexpr int TH_F = 32, TH_I = 16, TD_F = 56, TD_I = 4, TG_F = 28, TG_I = 2;  // judo_amd/tree_model.py
 // header floats
 enum { TF_DT = 0, TF_IMPRATIO, TF_TOL, TF_MAXITER, TF_LSTOL, TF_GRAV, TF_PLANE_P = 8, TF_PLANE_N = 11, TF_BMASS = 14, TF_BIPOS = 15, TF_BIR = 18, TF_BINERTIA = 27 };
@@ -32,25 +35,46 @@ enum { JF_LPOS = 0, JF_LR = 3, JF_AXIS = 12, JF_MASS = 15, JF_IPOS = 16, JF_IR =
 // geom floats
 enum { GF4_SIZE = 0, GF4_POS = 3, GF4_R = 6, GF4_MU = 15, GF4_K, GF4_B, GF4_SOLIMP = 18, GF4_TRAN = 23 };
 
+// Chain layout the kernel is instantiated for: four legs of three hinges and one arm of seven, contiguous in the dof order (checked by
+// jh_tree_create).  With the chains eliminated before the base, the Cholesky factor of the inertia and of every Newton Hessian has no fill-in:
+// chain blocks (3x3, 7x7), base-chain coupling, base block -- contacts with the ground couple the base with ONE chain, friction loss and limits
+// are diagonal -- so the chains factorise side by side (7 levels) and only the 6 base pivots are sequential (mj_factorM's sparsity, cooperative).
+constexpr int NCH = 5;
+__host__ __device__ constexpr int CS(int c) { return c < 4 ? 3 * c : 12; }
+__host__ __device__ constexpr int CL(int c) { return c < 4 ? 3 : 7; }
+constexpr int SF_MAX = 2048, SI_MAX = 160, LBW = 28;
+
 struct __attribute__((aligned(16))) RS4 {  // per-rollout shared state; positions are relative to the base origin
+  float vec[3][G];                        // broadcast vectors (read as float4)
+  float Lb[7][LBW];                       // base rows (6 = the rhs) pushed through the chain factors: [0..18] chain columns
+  float LbT[NJ][8];                       // the same, transposed: per joint the six base-row entries and the rhs entry
+  float Hc[NJ][8];                        // rows of the chain blocks: [m] = entry at chain position m <= own
+  float Sb[7][8];                         // reduced base system: rows 0..5 lower triangle, row 6 the rhs
+  float Tl[NJ][12];                       // this step's joint transforms: body offset (3), body frame x joint rotation (9)
+  float Ib[NB][12];                       // body spatial inertias about the base origin: mass, m c (3), rotational part (xx, xy, xz, yy, yz, zz)
+  float Icr[NCH][12];                     // composite inertia of each chain
+  float frc[NB][8];                       // body bias wrenches
   float xpos[NB][3], xR[NB][9];           // body 0 = base, 1 + k = link of joint k
   float Sax[NVT][6];                      // spatial axes (angular, linear)
-  float Ic[NB][10];                       // composite spatial inertia: mass, m c (3), rotational part (xx, xy, xz, yy, yz, zz)
-  float q[NJ + 1], qd[G];
-  float bias[G];
-  float vec[3][G];
-  union { float M[NVT][NVT]; float Lrow[NR][NR]; };  // the inertia lives in LDS only until every lane has its row in registers
-  float raw[NCP][RAW_F];                  // pos3 (relative), dist, geom, tangent hint 3
-  float J[NCP][JW];
+  float qd[G];
+  float raw[NCP][RAW_F];                  // pos3 (relative), dist, geom | chain, tangent hint 3
   float fW[NCP][9];
+  union { float M[NVT][NVT]; float J[NCP][JW]; };  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 24*44)
   int ncon;
 };
 
-__device__ __forceinline__ float gsum32(float v) {  // sum over the 32 lanes of a rollout, bit-identical in every lane
+// Sum over the 32 lanes (two DPP rows) of a rollout, bit-identical in every lane.  The row exchange is gfx950's v_permlane16_swap: with both
+// operands = v it leaves (row0, row0, row2, row2) in one and (row1, row1, row3, row3) in the other -- a VALU op, no trip through the LDS crossbar.
+__device__ __forceinline__ float gsum32(float v) {
   v = gsum(v);
-  return v + __shfl_xor(v, 16, 64);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ int gor32(int v) { v = gor(v); return v | __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ int gor32(int v) {
+  v = gor(v);
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)(r[0] | r[1]);
+}
 
 __device__ __forceinline__ void rodrigues4(float* Rq, const float* al, float q) {
   float sn, cs; sincosf(q, &sn, &cs); const float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
@@ -113,62 +137,245 @@ __device__ __forceinline__ void lane_dir4(const Slot4& sl, const DofRows4& dr, f
   *d1 = g1; *d2 = g2;
 }
 
-// Left-looking row Cholesky through LDS + redundant backward solve.  Lane r < NVT holds row r of the symmetric matrix in row[0..r], lane NVT
-// the right-hand side in row[0..NVT-1]; on return every lane holds the whole solution x.  (row is clobbered.)
-__device__ __forceinline__ void row_cholesky_solve(float* row, RS4& S, int l, float* x) {
-#pragma unroll
-  for (int k = 0; k < NVT; k++) {
-    if (l == k) {
-      float d = row[k];
-#pragma unroll
-      for (int j = 0; j < k; j++) d -= row[j] * row[j];
-      const float rinv = __frsqrt_rn(fmaxf(d, 1e-30f));
-#pragma unroll
-      for (int j = 0; j < k; j++) S.Lrow[k][j] = row[j];
-      S.Lrow[k][k] = rinv;
-    }
-    __syncthreads();
-    if (l > k && l <= NVT) {
-      float s = row[k];
-#pragma unroll
-      for (int j = 0; j < k; j++) s -= row[j] * S.Lrow[k][j];
-      row[k] = s * S.Lrow[k][k];
-    }
+#ifdef JH_V4_PHASES
+#define PH_DECL long long ph_t = __builtin_readcyclecounter(), ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long* pa = ph_acc;
+#define PH(i) { const long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
+#define PH_FLUSH if (stats && lane == 0) for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)(stats + 8) + i, (unsigned long long)ph_acc[i]);
+#define PHS(i) { const long long ph_n = __builtin_readcyclecounter(); pa[i] += ph_n - ph_s; ph_s = ph_n; }
+#define PHS_DECL long long ph_s = __builtin_readcyclecounter();
+#define PA_ARG , pa
+#define PA_PARAM , long long* pa
+#else
+#define PHS(i)
+#define PHS_DECL
+#define PA_ARG
+#define PA_PARAM
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH
+#endif
+
+// who a lane is in the factorisation
+struct Role {
+  bool isjoint; int cdepth, cstart, clen, cid;  // chain lanes: position in the chain, first joint of the chain, chain length, chain index
+  int bl;                                       // base lanes 0..5, the right-hand-side lane 6, everybody else -1
+};
+
+// Row layout (26 registers): chain lane at position t: row[m] = A[i][chain position m], m <= t.  Base lane b: row[j] = A[b][joint j] (j < 19),
+// row[19 + m] = A[b][base m] (m <= b).  Lane 6 of the base group: the right-hand side in the same layout.
+__device__ __forceinline__ float chain_entry(const float* fullrow, int cid, int m) {  // fullrow[6 + CS(cid) + m] without a run-time register index
+  float v = m < CL(4) ? fullrow[6 + CS(4) + m] : 0.f;
+  if (m < 3) {  // (pinned: otherwise the selects fold back into one load from a computed address, i.e. the row moves to scratch memory)
+    float c0 = fullrow[6 + CS(0) + m], c1 = fullrow[6 + CS(1) + m], c2 = fullrow[6 + CS(2) + m], c3 = fullrow[6 + CS(3) + m];
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+    v = cid == 0 ? c0 : (cid == 1 ? c1 : (cid == 2 ? c2 : (cid == 3 ? c3 : v)));
   }
-  if (l == NVT) {
+  return v;
+}
+__device__ __forceinline__ void load_row(float* row, const float* fullrow, const Role& R, const float* rhs /*LDS, dof order*/, float diag_add) {
+  if (R.bl == 6) {
 #pragma unroll
-    for (int j = 0; j < NVT; j++) S.Lrow[NVT][j] = row[j];
+    for (int j = 0; j < NJ; j++) row[j] = rhs[6 + j];
+#pragma unroll
+    for (int m = 0; m < 6; m++) row[NJ + m] = rhs[m];
+    row[NVT] = 0.f;
+  } else if (R.bl >= 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) row[j] = fullrow[6 + j];
+#pragma unroll
+    for (int m = 0; m < 6; m++) row[NJ + m] = fullrow[m] + (m == R.bl ? diag_add : 0.f);
+    row[NVT] = 0.f;
+  } else {
+#pragma unroll
+    for (int m = 0; m < 7; m++) row[m] = chain_entry(fullrow, R.cid, m) + (m == R.cdepth ? diag_add : 0.f);
+#pragma unroll
+    for (int m = 7; m < NR; m++) row[m] = 0.f;
   }
-  __syncthreads();
-#pragma unroll
-  for (int k = NVT - 1; k >= 0; k--) {
-    float s = S.Lrow[NVT][k];
-#pragma unroll
-    for (int j = k + 1; j < NVT; j++) s -= S.Lrow[j][k] * x[j];
-    x[k] = s * S.Lrow[k][k];
-  }
-  __syncthreads();
 }
 
-__global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ state_in, const float* __restrict__ ctrl,
-                                                    float* __restrict__ warm, int N, int substeps, float* __restrict__ state_out, int* __restrict__ stats) {
+__host__ __device__ constexpr int tri4(int p, int m) { return p * (p + 1) / 2 + m; }
+
+// In-place Cholesky of an N x N block held as packed lower-triangular registers; the diagonal slots end up holding 1 / L_pp.
+template <int N>
+__device__ __forceinline__ void chol_packed(float* a) {
+#pragma unroll
+  for (int p = 0; p < N; p++) {
+#pragma unroll
+    for (int m = 0; m < p; m++) {
+      float s = a[tri4(p, m)];
+#pragma unroll
+      for (int q = 0; q < m; q++) s -= a[tri4(p, q)] * a[tri4(m, q)];
+      a[tri4(p, m)] = s * a[tri4(m, m)];
+    }
+    float d = a[tri4(p, p)];
+#pragma unroll
+    for (int q = 0; q < p; q++) d -= a[tri4(p, q)] * a[tri4(p, q)];
+    a[tri4(p, p)] = __frsqrt_rn(fmaxf(d, 1e-30f));
+  }
+}
+// v <- v L^-T restricted to one block: forward substitution of a row segment through the block's factor
+template <int N>
+__device__ __forceinline__ void fwd_packed(float* v, const float* L) {
+#pragma unroll
+  for (int m = 0; m < N; m++) {
+    float s = v[m];
+#pragma unroll
+    for (int q = 0; q < m; q++) s -= v[q] * L[tri4(m, q)];
+    v[m] = s * L[tri4(m, m)];
+  }
+}
+
+// Solve A x = rhs for the tree-structured matrix with three LDS exchanges instead of one per pivot: a lane on its own SIMD pays every LDS
+// round trip and barrier in full, so the small dense blocks are factorised redundantly in registers by every lane that needs them.
+//   1. chain lanes publish their rows of the chain blocks; every joint lane factorises its own chain's block (legs padded to 7 x 7 with the
+//      identity), the base lanes and the rhs lane all five, and push their 19 chain-column entries through those factors;
+//   2. base lanes publish those entries, take the Schur complement against the earlier base rows and publish the reduced 6 x 6 system + rhs;
+//   3. every lane factorises the reduced system and solves it (base solution in every lane); every joint lane back-substitutes its own chain.
+// Returns the lane's own entry of x; xb = the six base entries.
+__device__ __forceinline__ float tree_cholesky_solve(float* row, RS4& S, const Role& R, int k, float* xb PA_PARAM) {
+  PHS_DECL
+  if (R.isjoint) {
+#pragma unroll
+    for (int m = 0; m < 7; m++) if (m <= R.cdepth) S.Hc[k][m] = row[m];
+  }
+  __syncthreads();
+  const int fcs = R.isjoint ? R.cstart : CS(4), flen = R.isjoint ? R.clen : 7;
+  float L[28];
+#pragma unroll
+  for (int pp = 0; pp < 7; pp++) {
+    const float* hr = S.Hc[fcs + pp];
+#pragma unroll
+    for (int m = 0; m <= pp; m++) L[tri4(pp, m)] = pp < flen ? hr[m] : (m == pp ? 1.f : 0.f);
+  }
+  chol_packed<7>(L);
+  PHS(10)
+  if (R.bl >= 0) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float Lg[6];
+#pragma unroll
+      for (int pp = 0; pp < 3; pp++) {
+#pragma unroll
+        for (int m = 0; m <= pp; m++) Lg[tri4(pp, m)] = S.Hc[CS(c) + pp][m];
+      }
+      chol_packed<3>(Lg);
+      fwd_packed<3>(row + CS(c), Lg);
+    }
+    fwd_packed<7>(row + CS(4), L);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { S.Lb[R.bl][j] = row[j]; S.LbT[j][R.bl] = row[j]; }
+  }
+  __syncthreads();
+  if (R.bl >= 0) {
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+      if (b <= R.bl) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) d = fmaf(row[j], S.Lb[b][j], d);
+        row[NJ + b] -= d;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 6; m++) S.Sb[R.bl][m] = row[NJ + m];
+  }
+  __syncthreads();
+  PHS(11)
+  {
+    float B[21], yb[6];
+#pragma unroll
+    for (int pp = 0; pp < 6; pp++) {
+#pragma unroll
+      for (int m = 0; m <= pp; m++) B[tri4(pp, m)] = S.Sb[pp][m];
+      yb[pp] = S.Sb[6][pp];
+    }
+    chol_packed<6>(B);
+    fwd_packed<6>(yb, B);
+#pragma unroll
+    for (int m = 5; m >= 0; m--) {
+      float sx = yb[m];
+#pragma unroll
+      for (int q = m + 1; q < 6; q++) sx -= B[tri4(q, m)] * xb[q];
+      xb[m] = sx * B[tri4(m, m)];
+    }
+  }
+  PHS(12)
+  float x_own = 0.f;
+#pragma unroll
+  for (int b = 0; b < 6; b++) x_own = R.bl == b ? xb[b] : x_own;
+  if (R.isjoint) {
+    float xc[7];
+#pragma unroll
+    for (int m = 0; m < 7; m++) {  // rhs of the chain's triangular system: y minus the base part
+      const float* t = S.LbT[R.cstart + m];
+      float z = t[6];
+#pragma unroll
+      for (int b = 0; b < 6; b++) z -= t[b] * xb[b];
+      xc[m] = m < R.clen ? z : 0.f;
+    }
+#pragma unroll
+    for (int m = 6; m >= 0; m--) {
+      float sx = xc[m];
+#pragma unroll
+      for (int q = m + 1; q < 7; q++) sx -= L[tri4(q, m)] * xc[q];
+      xc[m] = sx * L[tri4(m, m)];
+    }
+#pragma unroll
+    for (int tt = 0; tt < 7; tt++) x_own = R.cdepth == tt ? xc[tt] : x_own;
+  }
+  __syncthreads();
+  PHS(13)
+  return x_own;
+}
+
+// contact-frame 3-vector J_c v for a dof vector v in LDS (dof order); cs = first joint of the contact's chain
+__device__ __forceinline__ void jac_mul(float* o, const float* Jc, const float* v, int cs) {
+  o[0] = o[1] = o[2] = 0.f;
+#pragma unroll
+  for (int b = 0; b < 6; b++) { const float w = v[b]; o[0] = fmaf(Jc[3 * b], w, o[0]); o[1] = fmaf(Jc[3 * b + 1], w, o[1]); o[2] = fmaf(Jc[3 * b + 2], w, o[2]); }
+  const float* vc = v + 6 + cs;
+#pragma unroll
+  for (int m = 0; m < 7; m++) { const float w = vc[m]; o[0] = fmaf(Jc[JC + 3 * m], w, o[0]); o[1] = fmaf(Jc[JC + 3 * m + 1], w, o[1]); o[2] = fmaf(Jc[JC + 3 * m + 2], w, o[2]); }
+}
+
+// dot of a register row (dof order) with a broadcast LDS vector
+__device__ __forceinline__ float dot_row(const float* Mrow, const float* v) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NVT; j++) s = fmaf(Mrow[j], v[j], s);
+  return s;
+}
+
+
+__global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI, const float* __restrict__ state_in,
+                                                    const float* __restrict__ ctrl, float* __restrict__ warm, int N, int substeps, float* __restrict__ state_out,
+                                                    int* __restrict__ stats) {
   __shared__ RS4 sRS[RPW];
+  __shared__ __attribute__((aligned(16))) float sF[SF_MAX];  // the model image, shared by the rollouts of the wave
+  __shared__ int sI[SI_MAX];
   const int lane = threadIdx.x, l = lane & 31, r = lane >> 5;
   RS4& S = sRS[r];
+  for (int i = lane; i < nF; i += WAVE) sF[i] = gF[i];
+  for (int i = lane; i < nI; i += WAVE) sI[i] = gI[i];
+  __syncthreads();
   const int n = blockIdx.x * RPW + r;
   const bool live = n < N;
   const int nc = live ? n : N - 1;
-  const int nj = gI[0], ng = gI[1];
+  const int nj = NJ, ng = sI[1];
   const bool isbase = l < 6, isjoint = l >= 6 && l < 6 + nj, hasdof = isbase || isjoint, isbody = l == 0 || isjoint;
   const int k = isjoint ? l - 6 : 0;                   // own joint
   const int bidx = isjoint ? 1 + k : 0;                // own body
-  const float* jf = gF + TH_F + k * TD_F;
-  const int* ji = gI + TH_I + k * TD_I;
-  const int cstart = isjoint ? ji[1] : 0, cdepth = isjoint ? ji[2] : -1;  // chain dofs cstart .. cstart + cdepth are the joint ancestors incl. self
+  const float* jf = sF + TH_F + k * TD_F;
+  const int* ji = sI + TH_I + k * TD_I;
+  Role R;
+  R.isjoint = isjoint; R.cstart = isjoint ? ji[1] : 0; R.cdepth = isjoint ? ji[2] : -1;
+  R.cid = R.cstart < 12 ? R.cstart / 3 : 4; R.clen = R.cid < 4 ? 3 : 7;
+  R.bl = l < 6 ? l : (l == NVT ? 6 : -1);
+  const int cstart = R.cstart, cdepth = R.cdepth;
   const int oGF = TH_F + nj * TD_F, oGI = TH_I + nj * TD_I;
-  const float h = gF[TF_DT], impratio = gF[TF_IMPRATIO], tol = gF[TF_TOL], lstol = gF[TF_LSTOL]; const int cap = (int)gF[TF_MAXITER];
-  const float grav[3] = {gF[TF_GRAV], gF[TF_GRAV + 1], gF[TF_GRAV + 2]};
-  const float pln[3] = {gF[TF_PLANE_N], gF[TF_PLANE_N + 1], gF[TF_PLANE_N + 2]}, plp[3] = {gF[TF_PLANE_P], gF[TF_PLANE_P + 1], gF[TF_PLANE_P + 2]};
+  const float h = sF[TF_DT], impratio = sF[TF_IMPRATIO], tol = sF[TF_TOL], lstol = sF[TF_LSTOL]; const int cap = (int)sF[TF_MAXITER];
+  const float grav[3] = {sF[TF_GRAV], sF[TF_GRAV + 1], sF[TF_GRAV + 2]};
+  const float pln[3] = {sF[TF_PLANE_N], sF[TF_PLANE_N + 1], sF[TF_PLANE_N + 2]}, plp[3] = {sF[TF_PLANE_P], sF[TF_PLANE_P + 1], sF[TF_PLANE_P + 2]};
   const float en = isjoint ? 1.f : 0.f;
   const float c_damp = jf[JF_DAMP] * en, c_arm = jf[JF_ARM] * en, c_fl = jf[JF_FL] * en, c_fB = jf[JF_FB], c_fD = jf[JF_FD], c_invw = jf[JF_INVW];
   const float c_limited = jf[JF_LIMITED] * en, c_lo = jf[JF_LO], c_hi = jf[JF_HI], c_lK = jf[JF_LK], c_lB = jf[JF_LB];
@@ -187,19 +394,25 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
   }
   const float u = hasact ? ctrl[(size_t)nc * NJ + k] : 0.f;
   int n_iters = 0, n_maxed = 0;
+  PH_DECL
 
   for (int step = 0; step < substeps; step++) {
-    // ================================================================ publish joint state, clear accumulators
-    if (isjoint) S.q[k] = q;
+    // ================================================================ joint transforms (one sincos per joint), velocities
+    float Rq[9];
     {
+      rodrigues4(Rq, jf + JF_AXIS, q);
+      if (isjoint) {
+        float Tl[9]; mulMM(Tl, jf + JF_LR, Rq);
+        float* o = S.Tl[k];
+        o[0] = jf[JF_LPOS]; o[1] = jf[JF_LPOS + 1]; o[2] = jf[JF_LPOS + 2];
+        for (int i = 0; i < 9; i++) o[3 + i] = Tl[i];
+      }
       float myqd = qd;
 #pragma unroll
       for (int i = 0; i < 6; i++) if (i == l) myqd = vb[i];
       if (hasdof) S.qd[l] = myqd;
+      if (l == 0) S.ncon = 0;
     }
-    if (l < NB) for (int i = 0; i < 10; i++) S.Ic[l][i] = 0.f;
-    if (l < NVT) { for (int j = 0; j < NVT; j++) S.M[l][j] = 0.f; S.bias[l] = 0.f; }
-    if (l == 0) S.ncon = 0;
     __syncthreads();
     // ================================================================ kinematics (positions relative to the base origin)
     float Rb[9], Rown[9], pown[3] = {0.f, 0.f, 0.f}, Sown[6] = {0, 0, 0, 0, 0, 0};
@@ -207,27 +420,25 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       const float nn = rsqrtf(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
       qb[3] *= nn; qb[4] *= nn; qb[5] *= nn; qb[6] *= nn;
       quat2mat(Rb, qb + 3);
-      float P[3] = {0.f, 0.f, 0.f}, R[9];
-      for (int i = 0; i < 9; i++) { R[i] = Rb[i]; Rown[i] = Rb[i]; }
-      float axw[3] = {0.f, 0.f, 0.f};
+      float P[3] = {0.f, 0.f, 0.f}, Rm[9];
+      for (int i = 0; i < 9; i++) { Rm[i] = Rb[i]; Rown[i] = Rb[i]; }
 #pragma unroll
-      for (int t = 0; t < MAXD; t++) {
-        if (t <= cdepth) {  // chain link t of the own chain (lane-dependent records: vector loads from the L1-resident image)
-          const float* f = gF + TH_F + (cstart + t) * TD_F;
-          float lp[3] = {f[JF_LPOS], f[JF_LPOS + 1], f[JF_LPOS + 2]}, lr[9], la[3] = {f[JF_AXIS], f[JF_AXIS + 1], f[JF_AXIS + 2]};
-          for (int i = 0; i < 9; i++) lr[i] = f[JF_LR + i];
-          float P2[3], R0[9], Rq[9];
-          mulMV(P2, R, lp); for (int i = 0; i < 3; i++) P2[i] += P[i];
-          mulMM(R0, R, lr);
-          mulMV(axw, R0, la);
-          rodrigues4(Rq, la, S.q[cstart + t]);
-          mulMM(R, R0, Rq);
-          for (int i = 0; i < 3; i++) P[i] = P2[i];
+      for (int t = 0; t < MAXD - 1; t++) {
+        if (t < cdepth) {  // ancestors in the own chain
+          const float* T = S.Tl[cstart + t];
+          float lp[3] = {T[0], T[1], T[2]}, Tl[9], P2[3], R2[9];
+          for (int i = 0; i < 9; i++) Tl[i] = T[3 + i];
+          mulMV(P2, Rm, lp); mulMM(R2, Rm, Tl);
+          for (int i = 0; i < 3; i++) P[i] += P2[i];
+          for (int i = 0; i < 9; i++) Rm[i] = R2[i];
         }
       }
       if (isjoint) {
-        for (int i = 0; i < 3; i++) pown[i] = P[i];
-        for (int i = 0; i < 9; i++) Rown[i] = R[i];
+        float lp[3] = {jf[JF_LPOS], jf[JF_LPOS + 1], jf[JF_LPOS + 2]}, la[3] = {jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]}, P2[3], R0[9], axw[3];
+        mulMV(P2, Rm, lp); for (int i = 0; i < 3; i++) pown[i] = P[i] + P2[i];
+        mulMM(R0, Rm, jf + JF_LR);
+        mulMV(axw, R0, la);
+        mulMM(Rown, R0, Rq);
         float lin[3]; cross3(lin, pown, axw);  // velocity of the reference point under unit joint rate: anchor x axis
         for (int i = 0; i < 3; i++) { Sown[i] = axw[i]; Sown[3 + i] = lin[i]; }
       } else if (l < 3) Sown[3 + l] = 1.f;
@@ -235,10 +446,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (hasdof) for (int i = 0; i < 6; i++) S.Sax[l][i] = Sown[i];
       if (isbody) { for (int i = 0; i < 3; i++) S.xpos[bidx][i] = pown[i]; for (int i = 0; i < 9; i++) S.xR[bidx][i] = Rown[i]; }
     }
-    // ================================================================ body spatial inertia, composite inertias along the ancestor chains
-    float Ib[10];
+    PH(0)
+    // ================================================================ body spatial inertia; composite inertias = suffix sums along the chains
+    float Ib[10], Ic[10];
     {
-      const float* bm = isjoint ? jf + JF_MASS : gF + TF_BMASS;  // mass, ipos(3), iR(9), inertia(3) in both records
+      const float* bm = isjoint ? jf + JF_MASS : sF + TF_BMASS;  // mass, ipos(3), iR(9), inertia(3) in both records
       const float mass = isbody ? bm[0] : 0.f;
       float lip[3] = {bm[1], bm[2], bm[3]}, lir[9], di[3] = {bm[13], bm[14], bm[15]};
       for (int i = 0; i < 9; i++) lir[i] = bm[4 + i];
@@ -253,41 +465,97 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         for (int t = 0; t < 3; t++) v += Rk[ia[e] * 3 + t] * di[t] * Rk[ib[e] * 3 + t];
         Ib[4 + e] = isbody ? v + mass * ((ia[e] == ib[e] ? cc : 0.f) - c[ia[e]] * c[ib[e]]) : 0.f;
       }
-      if (isbody) {
-        for (int i = 0; i < 10; i++) atomicAdd(&S.Ic[0][i], Ib[i]);
-        for (int t = 0; t < MAXD; t++) if (t <= cdepth) for (int i = 0; i < 10; i++) atomicAdd(&S.Ic[1 + cstart + t][i], Ib[i]);
+      if (isbody) for (int i = 0; i < 10; i++) S.Ib[bidx][i] = Ib[i];
+    }
+    __syncthreads();
+    {
+      for (int i = 0; i < 10; i++) Ic[i] = 0.f;
+      if (isjoint) {
+#pragma unroll
+        for (int t = MAXD - 1; t >= 0; t--)
+          if (t >= cdepth && t < R.clen) { const float* o = S.Ib[1 + cstart + t]; for (int i = 0; i < 10; i++) Ic[i] += o[i]; }
+        if (cdepth == 0) for (int i = 0; i < 10; i++) S.Icr[R.cid][i] = Ic[i];
       }
     }
     __syncthreads();
+    if (isbase) {
+      for (int i = 0; i < 10; i++) Ic[i] = S.Ib[0][i];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) for (int i = 0; i < 10; i++) Ic[i] += S.Icr[c][i];
+    }
     // ================================================================ inertia rows (mj_crb) and bias forces (mj_rne with gravity as base acceleration)
+    float Mrow[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; j++) Mrow[j] = 0.f;
     if (hasdof) {
-      float I10[10], f[6];
-      for (int i = 0; i < 10; i++) I10[i] = S.Ic[bidx][i];
-      inertia6_mul(f, I10, Sown);
-      const int nb_ = isjoint ? 6 : l + 1;  // base columns
-      for (int j = 0; j < nb_; j++) { float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; const float v = dot6(f, sj); S.M[l][j] = v; S.M[j][l] = v; }
-      if (isjoint) for (int t = 0; t <= cdepth; t++) { const int j = 6 + cstart + t; float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; const float v = dot6(f, sj) + (j == l ? c_arm : 0.f); S.M[l][j] = v; S.M[j][l] = v; }
-    }
-    if (isbody) {
-      float vel[6] = {0, 0, 0, 0, 0, 0}, acc[6] = {0, 0, 0, -grav[0], -grav[1], -grav[2]};
-      for (int j = 0; j < 3; j++) vel[3 + j] += S.qd[j];  // translational axes are world-fixed unit vectors
-      float Sd[3][6], sr[3][6];
-      for (int j = 0; j < 3; j++) { for (int i = 0; i < 6; i++) sr[j][i] = S.Sax[3 + j][i]; crossm6(Sd[j], vel, sr[j]); }
-      for (int j = 0; j < 3; j++) { const float w = S.qd[3 + j]; for (int i = 0; i < 6; i++) { acc[i] += Sd[j][i] * w; vel[i] += sr[j][i] * w; } }
-      for (int t = 0; t < MAXD; t++) if (t <= cdepth) {
-        const int j = 6 + cstart + t; float sj[6], sd[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i];
-        crossm6(sd, vel, sj); const float w = S.qd[j];
-        for (int i = 0; i < 6; i++) { acc[i] += sd[i] * w; vel[i] += sj[i] * w; }
+      float f[6];
+      inertia6_mul(f, Ic, Sown);
+#pragma unroll
+      for (int j = 0; j < 6; j++) { float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; Mrow[j] = dot6(f, sj); }   // base columns (base rows: all six by symmetry)
+      if (isjoint) {
+#pragma unroll
+        for (int t = 0; t < MAXD; t++) {
+          float v = 0.f;
+          if (t <= cdepth) { float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[6 + cstart + t][i]; v = dot6(f, sj) + (t == cdepth ? c_arm : 0.f); }
+          // scatter to column 6 + cstart + t without a run-time register index
+#pragma unroll
+          for (int c = 0; c < NCH; c++) if (t < CL(c)) Mrow[6 + CS(c) + t] = (R.cid == c && t <= cdepth) ? v : Mrow[6 + CS(c) + t];
+        }
       }
-      float Ia[6], Iv[6], vIv[6], frc[6];
-      inertia6_mul(Ia, Ib, acc); inertia6_mul(Iv, Ib, vel); crossf6(vIv, vel, Iv);
-      for (int i = 0; i < 6; i++) frc[i] = Ia[i] + vIv[i];
-      for (int j = 0; j < 6; j++) { float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; atomicAdd(&S.bias[j], dot6(sj, frc)); }
-      for (int t = 0; t < MAXD; t++) if (t <= cdepth) { const int j = 6 + cstart + t; float sj[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i]; atomicAdd(&S.bias[j], dot6(sj, frc)); }
+    }
+    if (hasdof) {  // publish the lower triangle; the descendants' columns and the base rows' joint columns come back mirrored
+#pragma unroll
+      for (int j = 0; j < NVT; j++) S.M[l][j] = Mrow[j];
     }
     __syncthreads();
-    // ================================================================ smooth force, inertia row into registers, unconstrained acceleration
-    float Mrow[NVT], fs_own = 0.f, a0_own = 0.f, Md_own = 1.f, kv_eff = 0.f;
+    if (hasdof) {
+      if (isbase) {
+#pragma unroll
+        for (int j = 6; j < NVT; j++) Mrow[j] = S.M[j][l];
+      } else {
+#pragma unroll
+        for (int t = 0; t < MAXD; t++) {
+          float v = 0.f;
+          if (t > cdepth && t < R.clen) v = S.M[6 + cstart + t][l];
+#pragma unroll
+          for (int c = 0; c < NCH; c++) if (t < CL(c)) Mrow[6 + CS(c) + t] = (R.cid == c && t > cdepth) ? v : Mrow[6 + CS(c) + t];
+        }
+      }
+    }
+    float bias_own = 0.f;
+    {
+      float frc[6] = {0, 0, 0, 0, 0, 0};
+      if (isbody) {
+        float vel[6] = {0, 0, 0, 0, 0, 0}, acc[6] = {0, 0, 0, -grav[0], -grav[1], -grav[2]};
+        for (int j = 0; j < 3; j++) vel[3 + j] += S.qd[j];  // translational axes are world-fixed unit vectors
+        float Sd[3][6], sr[3][6];
+        for (int j = 0; j < 3; j++) { for (int i = 0; i < 6; i++) sr[j][i] = S.Sax[3 + j][i]; crossm6(Sd[j], vel, sr[j]); }
+        for (int j = 0; j < 3; j++) { const float w = S.qd[3 + j]; for (int i = 0; i < 6; i++) { acc[i] += Sd[j][i] * w; vel[i] += sr[j][i] * w; } }
+#pragma unroll
+        for (int t = 0; t < MAXD; t++) if (t <= cdepth) {
+          const int j = 6 + cstart + t; float sj[6], sd[6]; for (int i = 0; i < 6; i++) sj[i] = S.Sax[j][i];
+          crossm6(sd, vel, sj); const float w = S.qd[j];
+          for (int i = 0; i < 6; i++) { acc[i] += sd[i] * w; vel[i] += sj[i] * w; }
+        }
+        float Ia[6], Iv[6], vIv[6];
+        inertia6_mul(Ia, Ib, acc); inertia6_mul(Iv, Ib, vel); crossf6(vIv, vel, Iv);
+        for (int i = 0; i < 6; i++) { frc[i] = Ia[i] + vIv[i]; S.frc[bidx][i] = frc[i]; }
+      }
+      __syncthreads();
+      if (hasdof) {  // wrench of the subtree the dof carries: the chain tail for a joint, every body for the base
+        float Fs[6] = {0, 0, 0, 0, 0, 0};
+        if (isjoint) {
+#pragma unroll
+          for (int t = MAXD - 1; t >= 0; t--) if (t >= cdepth && t < R.clen) { const float* o = S.frc[1 + cstart + t]; for (int i = 0; i < 6; i++) Fs[i] += o[i]; }
+        } else {
+          for (int b = 0; b < NB; b++) { const float* o = S.frc[b]; for (int i = 0; i < 6; i++) Fs[i] += o[i]; }
+        }
+        bias_own = dot6(Sown, Fs);
+      }
+    }
+    PH(1)
+    // ================================================================ smooth force, unconstrained acceleration
+    float fs_own = 0.f, a0_own = 0.f, Md_own = 1.f, kv_eff = 0.f;
     {
       float fa = 0.f;
       if (hasact) {
@@ -296,41 +564,37 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         kv_eff = c_kv;
         if (c_flim != 0.f) { if (fa <= c_flo || fa >= c_fhi) kv_eff = 0.f; fa = jh_clampf(fa, c_flo, c_fhi); }  // a saturated servo has no velocity derivative (implicitfast)
       }
-      if (hasdof) fs_own = -c_damp * qd - S.bias[l] + fa;
-#pragma unroll
-      for (int j = 0; j < NVT; j++) Mrow[j] = hasdof ? S.M[l][j] : 0.f;
+      if (hasdof) fs_own = -c_damp * qd - bias_own + fa;
 #pragma unroll
       for (int j = 0; j < NVT; j++) if (j == l) Md_own = Mrow[j];
       if (hasdof) S.vec[0][l] = fs_own;
-      __syncthreads();  // every lane has read its row of M: the storage becomes the Cholesky workspace
-      float row[NR], x[NVT];
-#pragma unroll
-      for (int j = 0; j < NVT; j++) row[j] = l == NVT ? S.vec[0][j] : Mrow[j];
-      row[NVT] = 0.f;
-      row_cholesky_solve(row, S, l, x);
-#pragma unroll
-      for (int j = 0; j < NVT; j++) if (j == l) a0_own = x[j];
+      __syncthreads();
+      float row[NR], xb[6];
+      load_row(row, Mrow, R, S.vec[0], 0.f);
+      a0_own = tree_cholesky_solve(row, S, R, k, xb PA_ARG);
     }
+    PH(2)
     // ================================================================ collision: every robot geom against the plane
     if (l < ng) {
-      const float* gf = gF + oGF + l * TG_F; const int owner = gI[oGI + l * TG_I], gtype = gI[oGI + l * TG_I + 1];
+      const float* gf = sF + oGF + l * TG_F; const int owner = sI[oGI + l * TG_I], gtype = sI[oGI + l * TG_I + 1];
       const int gb = owner < 0 ? 0 : 1 + owner;
+      const int och = owner < 0 ? 0 : 1 + (sI[TH_I + owner * TD_I + 1] < 12 ? sI[TH_I + owner * TD_I + 1] / 3 : 4);  // 0: base geom, 1 + chain otherwise
       float bR[9], gp[3], lp[3] = {gf[GF4_POS], gf[GF4_POS + 1], gf[GF4_POS + 2]};
       for (int i = 0; i < 9; i++) bR[i] = S.xR[gb][i];
       mulMV(gp, bR, lp); for (int i = 0; i < 3; i++) gp[i] += S.xpos[gb][i];
-      // plane point relative to the base origin
-      const float pr[3] = {plp[0] - qb[0], plp[1] - qb[1], plp[2] - qb[2]};
+      const float pr[3] = {plp[0] - qb[0], plp[1] - qb[1], plp[2] - qb[2]};  // plane point relative to the base origin
       auto push = [&](const float* pos, float dist, const float* tng) __attribute__((always_inline)) {
         const int i = atomicAdd(&S.ncon, 1);
         if (i >= NCP) { if (stats) atomicAdd(stats, 1); return; }
         float* e = S.raw[i];
-        e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = dist; e[4] = __int_as_float(l); e[5] = tng[0]; e[6] = tng[1]; e[7] = tng[2];
+        e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = dist; e[4] = __int_as_float(l | (och << 8)); e[5] = tng[0]; e[6] = tng[1]; e[7] = tng[2];
       };
       const float zero3[3] = {0.f, 0.f, 0.f};
+      float lr[9], gR[9];
+      for (int i = 0; i < 9; i++) lr[i] = gf[GF4_R + i];
+      mulMM(gR, bR, lr);
       if (gtype == 2 || gtype == 3) {  // sphere, or the two end spheres of a capsule (+ end first)
-        float lr[9], gR[9], axis[3] = {0.f, 0.f, 0.f};
-        for (int i = 0; i < 9; i++) lr[i] = gf[GF4_R + i];
-        mulMM(gR, bR, lr);
+        float axis[3] = {0.f, 0.f, 0.f};
         const float rad = gf[GF4_SIZE], half = gtype == 3 ? gf[GF4_SIZE + 1] : 0.f;
         if (gtype == 3) col3(axis, gR, 2);
         for (int e = 0; e < (gtype == 3 ? 2 : 1); e++) {
@@ -341,8 +605,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           if (dist <= 0.f) { const float pos[3] = {c[0] - pln[0] * (rad + 0.5f * dist), c[1] - pln[1] * (rad + 0.5f * dist), c[2] - pln[2] * (rad + 0.5f * dist)}; push(pos, dist, gtype == 3 ? axis : zero3); }
         }
       } else {  // box: corners in MuJoCo's order, at most 4 contacts
-        float lr[9], gR[9]; for (int i = 0; i < 9; i++) lr[i] = gf[GF4_R + i];
-        mulMM(gR, bR, lr);
         const float hs[3] = {gf[GF4_SIZE], gf[GF4_SIZE + 1], gf[GF4_SIZE + 2]};
         const float dif[3] = {gp[0] - pr[0], gp[1] - pr[1], gp[2] - pr[2]};
         const float dist0 = dot3(dif, pln);
@@ -360,6 +622,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
     Slot4 sl;
     sl.valid = l < ncon; sl.D = 0.f; sl.mu = 0.f;
+    int my_cs = 0;  // first joint of the own contact's chain
+    if (sl.valid) { const int och = __float_as_int(S.raw[l][4]) >> 8; my_cs = och == 0 ? 0 : (och <= 4 ? 3 * (och - 1) : CS(4)); }
     for (int w = 0; w < 3; w++) sl.aref[w] = sl.jar[w] = sl.jp[w] = 0.f;
     if (sl.valid) {  // contact frame: plane normal (from the plane, geom 1, to the robot geom), second axis along a capsule's axis
       float fr[9] = {pln[0], pln[1], pln[2], 0, 0, 0, 0, 0, 0};
@@ -372,35 +636,35 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       for (int w = 0; w < 9; w++) S.fW[l][w] = fr[w];
     }
     __syncthreads();
-    for (int c = 0; c < ncon; c++) {  // Jacobian: lane r computes column r of every contact (robot side only: the plane is static)
-      if (hasdof) {
-        const float* e = S.raw[c];
+    for (int c = 0; c < ncon; c++) {  // Jacobian: every dof lane its own column (robot side only: the plane is static); the spare lanes clear the padding
+      const float* e = S.raw[c];
+      const int och = __float_as_int(e[4]) >> 8, odepth = och == 0 ? -1 : sI[TH_I + sI[oGI + (__float_as_int(e[4]) & 255) * TG_I] * TD_I + 2];
+      if (isbase || (isjoint && och == 1 + R.cid)) {
         const float pos[3] = {e[0], e[1], e[2]};
-        const int gid = __float_as_int(e[4]);
-        const int owner = gI[oGI + gid * TG_I];
-        bool anc = isbase;
-        if (isjoint && owner >= 0) { const int os = gI[TH_I + owner * TD_I + 1], od = gI[TH_I + owner * TD_I + 2]; anc = os == cstart && cdepth <= od; }
         float col[3] = {0.f, 0.f, 0.f};
-        if (anc) {
+        if (isbase || cdepth <= odepth) {
           float v[3]; cross3(v, Sown, pos); for (int i = 0; i < 3; i++) v[i] += Sown[3 + i];
           const float* fr = S.fW[c];
           col[0] = dot3(fr, v); col[1] = dot3(fr + 3, v); col[2] = dot3(fr + 6, v);
         }
-        S.J[c][3 * l] = col[0]; S.J[c][3 * l + 1] = col[1]; S.J[c][3 * l + 2] = col[2];
+        float* o = S.J[c] + (isbase ? 3 * l : JC + 3 * cdepth);
+        o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
+      } else if (l >= NVT) {  // positions the contact's chain does not have (legs: 3..6; base geoms: all)
+        const int m = l - NVT, len = och == 0 ? 0 : (och < 5 ? 3 : 7);
+        if (m >= len) { float* o = S.J[c] + JC + 3 * m; o[0] = o[1] = o[2] = 0.f; }
       }
     }
     __syncthreads();
     if (sl.valid) {
-      const float* e = S.raw[l]; const float dist = e[3]; const int gid = __float_as_int(e[4]);
-      const float* gf = gF + oGF + gid * TG_F;
+      const float* e = S.raw[l]; const float dist = e[3]; const int gid = __float_as_int(e[4]) & 255;
+      const float* gf = sF + oGF + gid * TG_F;
       float si[5]; for (int w = 0; w < 5; w++) si[w] = gf[GF4_SOLIMP + w];
       const float mu = gf[GF4_MU], imp = impedance(si, dist);
       const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * gf[GF4_TRAN] * (1.f + mu * mu));
       const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
       sl.D = 1.f / Rpy; sl.mu = mu;
-      float vel[3] = {0.f, 0.f, 0.f};
-      const float* Jc = S.J[l];
-      for (int j = 0; j < NVT; j++) { const float w = S.qd[j]; vel[0] = fmaf(Jc[3 * j], w, vel[0]); vel[1] = fmaf(Jc[3 * j + 1], w, vel[1]); vel[2] = fmaf(Jc[3 * j + 2], w, vel[2]); }
+      float vel[3];
+      jac_mul(vel, S.J[l], S.qd, my_cs);
       sl.aref[0] = -gf[GF4_B] * vel[0] - gf[GF4_K] * imp * dist; sl.aref[1] = -gf[GF4_B] * vel[1]; sl.aref[2] = -gf[GF4_B] * vel[2];
     }
     DofRows4 dr;
@@ -408,12 +672,14 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
     if (c_limited != 0.f) {
       const float dlo = q - c_lo, dhi = c_hi - q, dist = fminf(dlo, dhi);
       if (dist < 0.f) {
-        const float sg = dlo < dhi ? 1.f : -1.f, imp = impedance(c_si, dist), R = fmaxf(1e-15f, (1.f - imp) / imp * c_invw);
-        dr.lims = sg; dr.lD = 1.f / R; dr.laref = -c_lB * (sg * qd) - c_lK * imp * dist;
+        const float sg = dlo < dhi ? 1.f : -1.f, imp = impedance(c_si, dist), Rr = fmaxf(1e-15f, (1.f - imp) / imp * c_invw);
+        dr.lims = sg; dr.lD = 1.f / Rr; dr.laref = -c_lB * (sg * qd) - c_lK * imp * dist;
       }
     }
-    // ================================================================ Newton solver (dense row-per-lane Hessian)
+    PH(3)
+    // ================================================================ Newton solver (tree-structured Hessian, one row per lane)
     float a_own = a0_own;
+    const int own_col = isbase ? 3 * l : JC + 3 * (cdepth < 0 ? 0 : cdepth);  // own column in a compact Jacobian row
     const float iMd = 1.f / Md_own;
     const float snorm = gsum32(hasdof ? fs_own * fs_own * iMd : 0.f);
     int iters_this = 0;
@@ -422,15 +688,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (hasdof) { S.vec[0][l] = qws; S.vec[1][l] = a0_own; S.vec[2][l] = qws - a0_own; }
       __syncthreads();
       float jar_ws[3] = {0.f, 0.f, 0.f};
-      if (sl.valid) { const float* Jc = S.J[l]; float o[3] = {0, 0, 0}; for (int j = 0; j < NVT; j++) { const float w = S.vec[0][j]; o[0] = fmaf(Jc[3 * j], w, o[0]); o[1] = fmaf(Jc[3 * j + 1], w, o[1]); o[2] = fmaf(Jc[3 * j + 2], w, o[2]); } for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
+      if (sl.valid) { float o[3]; jac_mul(o, S.J[l], S.vec[0], my_cs); for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
       dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
-      float mdw = 0.f;
-#pragma unroll
-      for (int j = 0; j < NVT; j++) mdw = fmaf(Mrow[j], S.vec[2][j], mdw);
+      const float mdw = dot_row(Mrow, S.vec[2]);
       const float cost_ws = gsum32(lane_cost4(sl, dr) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
       for (int w = 0; w < 3; w++) jar_ws[w] = sl.jar[w];
       const float jf_ws = dr.jf, jl_ws = dr.jl;
-      if (sl.valid) { const float* Jc = S.J[l]; float o[3] = {0, 0, 0}; for (int j = 0; j < NVT; j++) { const float w = S.vec[1][j]; o[0] = fmaf(Jc[3 * j], w, o[0]); o[1] = fmaf(Jc[3 * j + 1], w, o[1]); o[2] = fmaf(Jc[3 * j + 2], w, o[2]); } for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
+      if (sl.valid) { float o[3]; jac_mul(o, S.J[l], S.vec[1], my_cs); for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
       dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
       const float cost_0 = gsum32(lane_cost4(sl, dr));
       if (cost_ws < cost_0) { a_own = qws; for (int w = 0; w < 3; w++) sl.jar[w] = jar_ws[w]; dr.jf = jf_ws; dr.jl = jl_ws; }
@@ -438,63 +702,66 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       bool act = gor32((int)(sl.valid || dr.fl > 0.f || dr.lims != 0.f)) != 0;
       if (!act) a_own = a0_own;
       for (int it = 0; it < cap && __any(act); it++) {
+        PH(4)
         // ---- (1) gradient row
         const float da_own = a_own - a0_own;
         if (hasdof) S.vec[0][l] = da_own;
         if (sl.valid) { float f[3], Wm[6]; pyramid_eval(sl.jar, sl.D, sl.mu, f, Wm); float* o = S.fW[l]; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[3 + w] = Wm[w]; }
         __syncthreads();
-        float g_own = 0.f, hd = 0.f;
-#pragma unroll
-        for (int j = 0; j < NVT; j++) g_own = fmaf(Mrow[j], S.vec[0][j], g_own);
+        float g_own = dot_row(Mrow, S.vec[0]), hd = 0.f;
         if (dr.fl > 0.f) {
           const float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
           if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += dr.fD * x; hd += dr.fD; }
         }
         if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
-        if (hasdof) for (int c = 0; c < ncon; c++) { const float* jc = S.J[c] + 3 * l; const float* fc = S.fW[c]; g_own -= jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]; }
+        if (hasdof) for (int c = 0; c < ncon; c++) {
+          const int och = __float_as_int(S.raw[c][4]) >> 8;
+          if (isbase || och == 1 + R.cid) { const float* jc = S.J[c] + own_col; const float* fc = S.fW[c]; g_own -= jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]; }
+        }
         // ---- (2) convergence; leave before any Hessian work once both rollouts of the wave are done
         const float gn = gsum32(hasdof ? g_own * g_own * iMd : 0.f);
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
-        // ---- (3) Hessian row (columns 0..r); lane NVT holds -g
+        PH(5)
+        // ---- (3) Hessian row in the factorisation layout; the rhs lane takes -g
         if (hasdof) S.vec[1][l] = -g_own;
+        __syncthreads();
         float row[NR];
-#pragma unroll
-        for (int j = 0; j < NVT; j++) row[j] = Mrow[j];
-        row[NVT] = 0.f;
-#pragma unroll
-        for (int j = 0; j < NVT; j++) if (j == l) row[j] += hd;
+        load_row(row, Mrow, R, S.vec[1], hd);
         if (hasdof) for (int c = 0; c < ncon; c++) {
           const float* fc = S.fW[c];
           if (fc[3] == 0.f && fc[5] == 0.f && fc[8] == 0.f) continue;
+          const int och = __float_as_int(S.raw[c][4]) >> 8;  // 0: the geom sits on the base, else 1 + chain
+          if (!(isbase || och == 1 + R.cid)) continue;
           const float* Jc = S.J[c];
-          const float j0 = Jc[3 * l], j1 = Jc[3 * l + 1], j2 = Jc[3 * l + 2];
+          const float j0 = Jc[own_col], j1 = Jc[own_col + 1], j2 = Jc[own_col + 2];
           const float G0 = fc[3] * j0 + fc[4] * j1 + fc[6] * j2, G1 = fc[4] * j0 + fc[5] * j1 + fc[7] * j2, G2 = fc[6] * j0 + fc[7] * j1 + fc[8] * j2;
+          if (isbase) {
 #pragma unroll
-          for (int j = 0; j < NVT; j++) row[j] += Jc[3 * j] * G0 + Jc[3 * j + 1] * G1 + Jc[3 * j + 2] * G2;
+            for (int ch = 0; ch < NCH; ch++) if (och == 1 + ch) {
+#pragma unroll
+              for (int m = 0; m < CL(ch); m++) row[CS(ch) + m] += Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2;
+            }
+#pragma unroll
+            for (int m = 0; m < 6; m++) row[NJ + m] += Jc[3 * m] * G0 + Jc[3 * m + 1] * G1 + Jc[3 * m + 2] * G2;
+          } else {
+#pragma unroll
+            for (int m = 0; m < MAXD; m++) if (m <= cdepth) row[m] += Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2;
+          }
         }
+        PH(6)
+        // ---- (4) factorise and solve; the direction goes back through LDS
+        float xb[6];
+        const float p_own = tree_cholesky_solve(row, S, R, k, xb PA_ARG);
+        if (hasdof) S.vec[2][l] = p_own;
         __syncthreads();
-        if (l == NVT) {
-#pragma unroll
-          for (int j = 0; j < NVT; j++) row[j] = S.vec[1][j];
-        }
-        // ---- (4) factorise and solve: every lane gets the whole direction
-        float p[NVT];
-        row_cholesky_solve(row, S, l, p);
-        float p_own = 0.f;
-#pragma unroll
-        for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
+        PH(7)
         // ---- (5) exact line search
-        float Mp_own = 0.f;
-#pragma unroll
-        for (int j = 0; j < NVT; j++) Mp_own = fmaf(Mrow[j], p[j], Mp_own);
-        const float pMp = gsum32(p_own * Mp_own), pMd = gsum32(Mp_own * da_own), gp = gsum32(g_own * p_own);
+        const float Mp_own = dot_row(Mrow, S.vec[2]);
+        const float pMp = gsum32(hasdof ? p_own * Mp_own : 0.f), pMd = gsum32(hasdof ? Mp_own * da_own : 0.f), gp = gsum32(hasdof ? g_own * p_own : 0.f);
         if (act && !(gp < 0.f)) act = false;
-        if (sl.valid) { const float* Jc = S.J[l]; float o[3] = {0, 0, 0};
-#pragma unroll
-          for (int j = 0; j < NVT; j++) { o[0] = fmaf(Jc[3 * j], p[j], o[0]); o[1] = fmaf(Jc[3 * j + 1], p[j], o[1]); o[2] = fmaf(Jc[3 * j + 2], p[j], o[2]); }
-          sl.jp[0] = o[0]; sl.jp[1] = o[1]; sl.jp[2] = o[2]; }
+        if (sl.valid) jac_mul(sl.jp, S.J[l], S.vec[2], my_cs);
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
         for (int ls = 0; ls < 12 && __any(lsact); ls++) {
@@ -512,6 +779,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
             }
           }
         }
+        PH(8)
         // ---- (6) step
         if (act) {
           a_own += alpha * p_own;
@@ -523,27 +791,19 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       }
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
+    PH(4)
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
       __syncthreads();
       const float da_own = a_own - a0_own;
       if (hasdof) S.vec[0][l] = da_own;
       __syncthreads();
-      float rhs_own = fs_own;
-#pragma unroll
-      for (int j = 0; j < NVT; j++) rhs_own = fmaf(Mrow[j], S.vec[0][j], rhs_own);
+      const float rhs_own = fs_own + dot_row(Mrow, S.vec[0]);
       if (hasdof) S.vec[1][l] = rhs_own;
       __syncthreads();
-      float row[NR], x[NVT];
-#pragma unroll
-      for (int j = 0; j < NVT; j++) row[j] = l == NVT ? S.vec[1][j] : Mrow[j];
-      row[NVT] = 0.f;
-#pragma unroll
-      for (int j = 0; j < NVT; j++) if (j == l) row[j] += h * (c_damp + kv_eff);
-      row_cholesky_solve(row, S, l, x);
-      float qacc = 0.f;
-#pragma unroll
-      for (int j = 0; j < NVT; j++) if (j == l) qacc = x[j];
+      float row[NR], x[6];
+      load_row(row, Mrow, R, S.vec[1], h * (c_damp + kv_eff));
+      const float qacc = tree_cholesky_solve(row, S, R, k, x PA_ARG);
       if (isjoint) { qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); }
       qws = a_own;
       for (int i = 0; i < 6; i++) vb[i] = fmaf(h, x[i], vb[i]);  // free base: every lane integrates the replicated state
@@ -562,7 +822,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       qb[3] *= nn; qb[4] *= nn; qb[5] *= nn; qb[6] *= nn;
     }
     __syncthreads();
+    PH(9)
   }
+  PH_FLUSH
   if (live) {
     float* o = state_out + (size_t)n * NX;
     if (isjoint) { o[7 + k] = q; o[NQ + 6 + k] = qd; }
@@ -575,7 +837,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
 
 }  // namespace
 
-struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv; };
+struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni; };
 
 extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(blob && out && nbytes >= 16, "tree_create: null or short blob");
@@ -585,7 +847,14 @@ extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(nbytes == 16 + 4 * (nf + ni), "tree_create: blob size mismatch");
   const float* f = (const float*)(hd + 4); const int* ii = (const int*)(f + nf);
   JH_REQUIRE(ii[0] == NJ && ii[2] == NQ && ii[3] == NVT && ii[1] <= G - 1, "tree_create: the kernel is instantiated for a free base + 19 hinges (got %d joints, nq %d, nv %d, %d geoms)", ii[0], ii[2], ii[3], ii[1]);
+  JH_REQUIRE(nf <= (size_t)SF_MAX && ni <= (size_t)SI_MAX, "tree_create: model image too large for the kernel's LDS copy");
+  for (int c = 0; c < NCH; c++)
+    for (int m = 0; m < CL(c); m++) {
+      const int* jr = ii + TH_I + (CS(c) + m) * TD_I;
+      JH_REQUIRE(jr[1] == CS(c) && jr[2] == m, "tree_create: the kernel is instantiated for four 3-joint chains followed by one 7-joint chain (joint %d: chain start %d, depth %d)", CS(c) + m, jr[1], jr[2]);
+    }
   jh_tree* t = new jh_tree();
+  t->nf = (int)nf; t->ni = (int)ni;
   t->nj = ii[0]; t->ng = ii[1]; t->nq = ii[2]; t->nv = ii[3];
   JH_HIP(hipMalloc(&t->d_f, 4 * nf)); JH_HIP(hipMalloc(&t->d_i, 4 * ni)); JH_HIP(hipMalloc(&t->d_stats, 64 * sizeof(int)));
   JH_HIP(hipMemcpy(t->d_f, f, 4 * nf, hipMemcpyHostToDevice)); JH_HIP(hipMemcpy(t->d_i, ii, 4 * ni, hipMemcpyHostToDevice));
@@ -604,6 +873,17 @@ extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
   JH_REQUIRE(t && out4, "tree_stats: null pointer");
   JH_HIP(hipDeviceSynchronize());
   JH_HIP(hipMemcpy(out4, t->d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
+#ifdef JH_V4_PHASES
+  {
+    unsigned long long ph[16]; double tot = 0;
+    JH_HIP(hipMemcpy(ph, t->d_stats + 8, sizeof(ph), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 10; i++) tot += (double)ph[i];
+    const char* nm[10] = {"kinematics", "inertia+bias", "a0 solve", "collision+rows", "warm/step", "gradient", "hessian", "factor", "linesearch", "integrate"};
+    for (int i = 0; i < 10; i++) fprintf(stderr, "  phase %-15s %6.2f%%  %.0f cycles/step/wave\n", nm[i], 100.0 * ph[i] / (tot > 0 ? tot : 1), out4[3] ? 2.0 * ph[i] / out4[3] : 0.0);
+    const char* sn[4] = {"chain blocks", "base rows+schur", "reduced system", "chain backsub"};
+    for (int i = 0; i < 4; i++) fprintf(stderr, "    solve: %-15s %.0f cycles/step/wave\n", sn[i], out4[3] ? 2.0 * ph[10 + i] / out4[3] : 0.0);
+  }
+#endif
   if (reset) JH_HIP(hipMemset(t->d_stats, 0, 64 * sizeof(int)));
   return JH_OK;
 }
@@ -611,7 +891,7 @@ extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
 extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream) {
   JH_REQUIRE(t && state_in && ctrl && state_out, "tree_substeps: null pointer");
   JH_REQUIRE(N > 0 && substeps > 0, "tree_substeps: need at least one rollout and one step");
-  hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, state_in, ctrl, warmstart, N, substeps, state_out, t->d_stats);
+  hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, ctrl, warmstart, N, substeps, state_out, t->d_stats);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
