@@ -52,13 +52,12 @@ struct __attribute__((aligned(16))) RS4 {  // per-rollout shared state; position
   float Sb[7][8];                         // reduced base system: rows 0..5 lower triangle, row 6 the rhs
   float Tl[NJ][12];                       // this step's joint transforms: body offset (3), body frame x joint rotation (9)
   float Ib[NB][12];                       // body spatial inertias about the base origin: mass, m c (3), rotational part (xx, xy, xz, yy, yz, zz)
-  float Icr[NCH][12];                     // composite inertia of each chain
   float frc[NB][8];                       // body bias wrenches
   float xpos[NB][3], xR[NB][9];           // body 0 = base, 1 + k = link of joint k
   float Sax[NVT][6];                      // spatial axes (angular, linear)
   float qd[G];
   float raw[NCP][RAW_F];                  // pos3 (relative), dist, geom | chain, tangent hint 3
-  float fW[NCP][9];
+  float fW[NCP][12];                      // contact frame (9) while the rows are built; then force [0..2] and the 3x3 weight [4..9] of the current Newton iterate
   union { float M[NVT][NVT]; float J[NCP][JW]; };  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 24*44)
   int ncon;
 };
@@ -161,36 +160,31 @@ struct Role {
   int bl;                                       // base lanes 0..5, the right-hand-side lane 6, everybody else -1
 };
 
-// Row layout (26 registers): chain lane at position t: row[m] = A[i][chain position m], m <= t.  Base lane b: row[j] = A[b][joint j] (j < 19),
-// row[19 + m] = A[b][base m] (m <= b).  Lane 6 of the base group: the right-hand side in the same layout.
-__device__ __forceinline__ float chain_entry(const float* fullrow, int cid, int m) {  // fullrow[6 + CS(cid) + m] without a run-time register index
-  float v = m < CL(4) ? fullrow[6 + CS(4) + m] : 0.f;
+// Row layout (26 registers), the same for every lane: row[j] = A[i][joint j] (j < 19), row[19 + m] = A[i][base m].  A joint lane only ever uses
+// the entries of its own chain up to itself, a base lane b its 19 joint columns and base columns m <= b; lane 6 of the base group (the rhs lane)
+// carries the right-hand side in the same layout.  One layout = one instruction stream for the accumulation of J' W J.
+__device__ __forceinline__ float chain_entry(const float* row, int cid, int m) {  // row[CS(cid) + m] without a run-time register index
+  float v = m < CL(4) ? row[CS(4) + m] : 0.f;
   if (m < 3) {  // (pinned: otherwise the selects fold back into one load from a computed address, i.e. the row moves to scratch memory)
-    float c0 = fullrow[6 + CS(0) + m], c1 = fullrow[6 + CS(1) + m], c2 = fullrow[6 + CS(2) + m], c3 = fullrow[6 + CS(3) + m];
+    float c0 = row[CS(0) + m], c1 = row[CS(1) + m], c2 = row[CS(2) + m], c3 = row[CS(3) + m];
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     v = cid == 0 ? c0 : (cid == 1 ? c1 : (cid == 2 ? c2 : (cid == 3 ? c3 : v)));
   }
   return v;
 }
-__device__ __forceinline__ void load_row(float* row, const float* fullrow, const Role& R, const float* rhs /*LDS, dof order*/, float diag_add) {
+__device__ __forceinline__ void load_row(float* row, const float* fullrow, const Role& R, int k, const float* rhs /*LDS, dof order*/, float diag_add) {
   if (R.bl == 6) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) row[j] = rhs[6 + j];
 #pragma unroll
     for (int m = 0; m < 6; m++) row[NJ + m] = rhs[m];
-    row[NVT] = 0.f;
-  } else if (R.bl >= 0) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) row[j] = fullrow[6 + j];
-#pragma unroll
-    for (int m = 0; m < 6; m++) row[NJ + m] = fullrow[m] + (m == R.bl ? diag_add : 0.f);
-    row[NVT] = 0.f;
   } else {
 #pragma unroll
-    for (int m = 0; m < 7; m++) row[m] = chain_entry(fullrow, R.cid, m) + (m == R.cdepth ? diag_add : 0.f);
+    for (int j = 0; j < NJ; j++) row[j] = fullrow[6 + j] + ((R.isjoint && j == k) ? diag_add : 0.f);
 #pragma unroll
-    for (int m = 7; m < NR; m++) row[m] = 0.f;
+    for (int m = 0; m < 6; m++) row[NJ + m] = fullrow[m] + (m == R.bl ? diag_add : 0.f);
   }
+  row[NVT] = 0.f;
 }
 
 __host__ __device__ constexpr int tri4(int p, int m) { return p * (p + 1) / 2 + m; }
@@ -236,7 +230,7 @@ __device__ __forceinline__ float tree_cholesky_solve(float* row, RS4& S, const R
   PHS_DECL
   if (R.isjoint) {
 #pragma unroll
-    for (int m = 0; m < 7; m++) if (m <= R.cdepth) S.Hc[k][m] = row[m];
+    for (int m = 0; m < 7; m++) { const float v = chain_entry(row, R.cid, m); if (m <= R.cdepth) S.Hc[k][m] = v; }
   }
   __syncthreads();
   const int fcs = R.isjoint ? R.cstart : CS(4), flen = R.isjoint ? R.clen : 7;
@@ -264,20 +258,21 @@ __device__ __forceinline__ float tree_cholesky_solve(float* row, RS4& S, const R
     fwd_packed<7>(row + CS(4), L);
 #pragma unroll
     for (int j = 0; j < NJ; j++) { S.Lb[R.bl][j] = row[j]; S.LbT[j][R.bl] = row[j]; }
+#pragma unroll
+    for (int m = 0; m < 6; m++) S.Lb[R.bl][NJ + m] = row[NJ + m];
   }
   __syncthreads();
-  if (R.bl >= 0) {
+  {  // Schur complement: the 21 + 6 pairs (b' >= b) of base rows / rhs row, one 19-term dot product per lane
+    const int pl = threadIdx.x & 31;
+    const int bp = pl >= 21 ? 6 : (pl >= 15 ? 5 : (pl >= 10 ? 4 : (pl >= 6 ? 3 : (pl >= 3 ? 2 : (pl >= 1 ? 1 : 0)))));
+    const int bq = pl >= 21 ? pl - 21 : pl - bp * (bp + 1) / 2;
+    if (pl < 27) {
+      const float* ra = S.Lb[bp]; const float* rb = S.Lb[bq];
+      float d = 0.f;
 #pragma unroll
-    for (int b = 0; b < 6; b++) {
-      if (b <= R.bl) {
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) d = fmaf(row[j], S.Lb[b][j], d);
-        row[NJ + b] -= d;
-      }
+      for (int j = 0; j < NJ; j++) d = fmaf(ra[j], rb[j], d);
+      S.Sb[bp][bq] = ra[NJ + bq] - d;
     }
-#pragma unroll
-    for (int m = 0; m < 6; m++) S.Sb[R.bl][m] = row[NJ + m];
   }
   __syncthreads();
   PHS(11)
@@ -469,19 +464,14 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
     }
     __syncthreads();
     {
-      for (int i = 0; i < 10; i++) Ic[i] = 0.f;
+      float tot[10];  // whole robot: a reduction over the body lanes (two DPP rows), no LDS
+#pragma unroll
+      for (int i = 0; i < 10; i++) { tot[i] = gsum32(Ib[i]); Ic[i] = isbase ? tot[i] : 0.f; }
       if (isjoint) {
 #pragma unroll
         for (int t = MAXD - 1; t >= 0; t--)
           if (t >= cdepth && t < R.clen) { const float* o = S.Ib[1 + cstart + t]; for (int i = 0; i < 10; i++) Ic[i] += o[i]; }
-        if (cdepth == 0) for (int i = 0; i < 10; i++) S.Icr[R.cid][i] = Ic[i];
       }
-    }
-    __syncthreads();
-    if (isbase) {
-      for (int i = 0; i < 10; i++) Ic[i] = S.Ib[0][i];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) for (int i = 0; i < 10; i++) Ic[i] += S.Icr[c][i];
     }
     // ================================================================ inertia rows (mj_crb) and bias forces (mj_rne with gravity as base acceleration)
     float Mrow[NVT];
@@ -542,15 +532,15 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         for (int i = 0; i < 6; i++) { frc[i] = Ia[i] + vIv[i]; S.frc[bidx][i] = frc[i]; }
       }
       __syncthreads();
-      if (hasdof) {  // wrench of the subtree the dof carries: the chain tail for a joint, every body for the base
-        float Fs[6] = {0, 0, 0, 0, 0, 0};
+      {  // wrench of the subtree the dof carries: the chain tail for a joint, every body for the base
+        float Fs[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { const float tot = gsum32(frc[i]); Fs[i] = isbase ? tot : 0.f; }
         if (isjoint) {
 #pragma unroll
           for (int t = MAXD - 1; t >= 0; t--) if (t >= cdepth && t < R.clen) { const float* o = S.frc[1 + cstart + t]; for (int i = 0; i < 6; i++) Fs[i] += o[i]; }
-        } else {
-          for (int b = 0; b < NB; b++) { const float* o = S.frc[b]; for (int i = 0; i < 6; i++) Fs[i] += o[i]; }
         }
-        bias_own = dot6(Sown, Fs);
+        if (hasdof) bias_own = dot6(Sown, Fs);
       }
     }
     PH(1)
@@ -570,7 +560,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (hasdof) S.vec[0][l] = fs_own;
       __syncthreads();
       float row[NR], xb[6];
-      load_row(row, Mrow, R, S.vec[0], 0.f);
+      load_row(row, Mrow, R, k, S.vec[0], 0.f);
       a0_own = tree_cholesky_solve(row, S, R, k, xb PA_ARG);
     }
     PH(2)
@@ -679,6 +669,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
     PH(3)
     // ================================================================ Newton solver (tree-structured Hessian, one row per lane)
     float a_own = a0_own;
+    unsigned involved = 0;  // bit c: contact c moves with this lane's dof (base lanes: every contact; joint lanes: contacts on their chain)
+    if (hasdof) for (int c = 0; c < ncon; c++) involved |= (isbase || (__float_as_int(S.raw[c][4]) >> 8) == 1 + R.cid) ? (1u << c) : 0u;
     const int own_col = isbase ? 3 * l : JC + 3 * (cdepth < 0 ? 0 : cdepth);  // own column in a compact Jacobian row
     const float iMd = 1.f / Md_own;
     const float snorm = gsum32(hasdof ? fs_own * fs_own * iMd : 0.f);
@@ -706,7 +698,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         // ---- (1) gradient row
         const float da_own = a_own - a0_own;
         if (hasdof) S.vec[0][l] = da_own;
-        if (sl.valid) { float f[3], Wm[6]; pyramid_eval(sl.jar, sl.D, sl.mu, f, Wm); float* o = S.fW[l]; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[3 + w] = Wm[w]; }
+        if (sl.valid) { float f[3], Wm[6]; pyramid_eval(sl.jar, sl.D, sl.mu, f, Wm); float* o = S.fW[l]; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[4 + w] = Wm[w]; }
         __syncthreads();
         float g_own = dot_row(Mrow, S.vec[0]), hd = 0.f;
         if (dr.fl > 0.f) {
@@ -714,9 +706,10 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += dr.fD * x; hd += dr.fD; }
         }
         if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
-        if (hasdof) for (int c = 0; c < ncon; c++) {
-          const int och = __float_as_int(S.raw[c][4]) >> 8;
-          if (isbase || och == 1 + R.cid) { const float* jc = S.J[c] + own_col; const float* fc = S.fW[c]; g_own -= jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]; }
+        for (int c = 0; c < ncon; c++) {  // branch-free: a lane the contact does not move reads some other column and multiplies it by zero
+          const float* jc = S.J[c] + own_col; const float* fc = S.fW[c];
+          const float on = (involved >> c) & 1u ? 1.f : 0.f;
+          g_own -= on * (jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]);
         }
         // ---- (2) convergence; leave before any Hessian work once both rollouts of the wave are done
         const float gn = gsum32(hasdof ? g_own * g_own * iMd : 0.f);
@@ -728,27 +721,26 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         if (hasdof) S.vec[1][l] = -g_own;
         __syncthreads();
         float row[NR];
-        load_row(row, Mrow, R, S.vec[1], hd);
-        if (hasdof) for (int c = 0; c < ncon; c++) {
-          const float* fc = S.fW[c];
-          if (fc[3] == 0.f && fc[5] == 0.f && fc[8] == 0.f) continue;
-          const int och = __float_as_int(S.raw[c][4]) >> 8;  // 0: the geom sits on the base, else 1 + chain
-          if (!(isbase || och == 1 + R.cid)) continue;
-          const float* Jc = S.J[c];
-          const float j0 = Jc[own_col], j1 = Jc[own_col + 1], j2 = Jc[own_col + 2];
-          const float G0 = fc[3] * j0 + fc[4] * j1 + fc[6] * j2, G1 = fc[4] * j0 + fc[5] * j1 + fc[7] * j2, G2 = fc[6] * j0 + fc[7] * j1 + fc[8] * j2;
-          if (isbase) {
+        load_row(row, Mrow, R, k, S.vec[1], hd);
+        for (int c = 0; c < ncon; c++) {  // branch-free accumulation of J' W J: the row of the compact Jacobian is the same for every lane
+          const float* fc = S.fW[c]; const float* Jc = S.J[c];
+          const float on = (involved >> c) & 1u ? 1.f : 0.f;
+          const float j0 = on * Jc[own_col], j1 = on * Jc[own_col + 1], j2 = on * Jc[own_col + 2];
+          const float G0 = fc[4] * j0 + fc[5] * j1 + fc[7] * j2, G1 = fc[5] * j0 + fc[6] * j1 + fc[8] * j2, G2 = fc[7] * j0 + fc[8] * j1 + fc[9] * j2;
+          float dch[7], dba[6];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ch++) if (och == 1 + ch) {
+          for (int m = 0; m < 7; m++) dch[m] = Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2;
 #pragma unroll
-              for (int m = 0; m < CL(ch); m++) row[CS(ch) + m] += Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2;
-            }
+          for (int m = 0; m < 6; m++) dba[m] = Jc[3 * m] * G0 + Jc[3 * m + 1] * G1 + Jc[3 * m + 2] * G2;
+          const int och = __float_as_int(S.raw[c][4]) >> 8;  // 0: the geom sits on the base (its chain part is zero), else 1 + chain
 #pragma unroll
-            for (int m = 0; m < 6; m++) row[NJ + m] += Jc[3 * m] * G0 + Jc[3 * m + 1] * G1 + Jc[3 * m + 2] * G2;
-          } else {
+          for (int ch = 0; ch < NCH; ch++) {
+            const float sel = och == 1 + ch ? 1.f : 0.f;
 #pragma unroll
-            for (int m = 0; m < MAXD; m++) if (m <= cdepth) row[m] += Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2;
+            for (int m = 0; m < CL(ch); m++) row[CS(ch) + m] = fmaf(sel, dch[m], row[CS(ch) + m]);
           }
+#pragma unroll
+          for (int m = 0; m < 6; m++) row[NJ + m] += dba[m];
         }
         PH(6)
         // ---- (4) factorise and solve; the direction goes back through LDS
@@ -802,7 +794,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (hasdof) S.vec[1][l] = rhs_own;
       __syncthreads();
       float row[NR], x[6];
-      load_row(row, Mrow, R, S.vec[1], h * (c_damp + kv_eff));
+      load_row(row, Mrow, R, k, S.vec[1], h * (c_damp + kv_eff));
       const float qacc = tree_cholesky_solve(row, S, R, k, x PA_ARG);
       if (isjoint) { qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); }
       qws = a_own;
