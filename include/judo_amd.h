@@ -157,6 +157,17 @@ void jh_tree_destroy(jh_tree* t);
 int jh_tree_stats(jh_tree* t, int* out4, int reset);
 int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream);
 
+/* ---- the whole of threaded_rollout (mujoco_extensions/system/system_class.cpp:277-367; pybind entry mujoco_extensions/policy_rollout/pybind/policy_rollout.cpp:65)
+ * in the reference's array layouts: x0 is one (51) state (x0_batched = 0) or (N x 51); commands (N x T x 25); states (N x T x 51), row [n][i] = the state after
+ * command row i's policy step and `substeps` engine steps; policy_out (N x 12) in/out (last_policy_output -> policy_outputs).  warmstart (N x 25, may be NULL)
+ * carries mjData.qacc_warmstart from call to call as the reference's per-thread mjData does; reset_warmstart != 0 zeroes it before every control step instead.
+ * cutoff_seconds >= 0: the rollout stops issuing command rows once that much DEVICE time has passed since the call started (checked against the control
+ * step two back) and the remaining rows repeat the last computed state, as System::rollout does with its wall clock; < 0: no deadline.  *steps_done = rows
+ * computed.  scratch holds jh_policy_rollout_scratch_floats(N) floats.  With a deadline the call synchronises with the stream two control steps behind. */
+size_t jh_policy_rollout_scratch_floats(int N);
+int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0, int x0_batched, const float* commands, float* policy_out, float* warmstart, int reset_warmstart,
+                      int N, int T, int substeps, double cutoff_seconds, float* states, float* scratch, int* steps_done, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@
 // Contacts: sphere / capsule / box against the plane (mjc_PlaneSphere / PlaneCapsule / PlaneBox), pyramidal cones, parameters mixed on the host.
 #include "jh_coop.h"
 
+#include <vector>
+
 using namespace jh_eng;
 using namespace jh_coop;
 
@@ -342,8 +344,8 @@ __device__ __forceinline__ float dot_row(const float* Mrow, const float* v) {
 }
 
 
-__global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI, const float* __restrict__ state_in,
-                                                    const float* __restrict__ ctrl, float* __restrict__ warm, int N, int substeps, float* __restrict__ state_out,
+__global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI, const float* state_in, int ld_in,
+                                                    const float* __restrict__ ctrl, float* __restrict__ warm, int N, int substeps, float* state_out, int ld_out,
                                                     int* __restrict__ stats) {
   __shared__ RS4 sRS[RPW];
   __shared__ __attribute__((aligned(16))) float sF[SF_MAX];  // the model image, shared by the rollouts of the wave
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
   // ---- state: replicated base + own joint
   float qb[7], vb[6], q = 0.f, qd = 0.f, qws = 0.f;
   {
-    const float* xi = state_in + (size_t)nc * NX;
+    const float* xi = state_in + (size_t)nc * ld_in;  // ld_in = 0: one state for every rollout
     for (int i = 0; i < 7; i++) qb[i] = xi[i];
     for (int i = 0; i < 6; i++) vb[i] = xi[NQ + i];
     if (isjoint) { q = xi[7 + k]; qd = xi[NQ + 6 + k]; }
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
   }
   PH_FLUSH
   if (live) {
-    float* o = state_out + (size_t)n * NX;
+    float* o = state_out + (size_t)n * ld_out;
     if (isjoint) { o[7 + k] = q; o[NQ + 6 + k] = qd; }
     if (l < 7) o[l] = qb[l];
     if (l < 6) o[NQ + l] = vb[l];
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
 
 }  // namespace
 
-struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni; };
+struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni; std::vector<hipEvent_t> events; };
 
 extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(blob && out && nbytes >= 16, "tree_create: null or short blob");
@@ -858,6 +860,7 @@ extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
 extern "C" void jh_tree_destroy(jh_tree* t) {
   if (!t) return;
   (void)hipFree(t->d_f); (void)hipFree(t->d_i); (void)hipFree(t->d_stats);
+  for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
   delete t;
 }
 
@@ -883,7 +886,58 @@ extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
 extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream) {
   JH_REQUIRE(t && state_in && ctrl && state_out, "tree_substeps: null pointer");
   JH_REQUIRE(N > 0 && substeps > 0, "tree_substeps: need at least one rollout and one step");
-  hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, ctrl, warmstart, N, substeps, state_out, t->d_stats);
+  hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
+                     t->d_stats);
   JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+namespace {
+__global__ void k_fill_after_cutoff(float* states, int N, int T, int done) {  // rows done..T-1 of every rollout repeat row done-1 (zeros when nothing was computed)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)(T - done) * NX;
+  if (i >= (size_t)N * per) return;
+  const size_t n = i / per, r = i % per, tt = done + r / NX, c = r % NX;
+  states[(n * T + tt) * NX + c] = done > 0 ? states[(n * T + done - 1) * NX + c] : 0.f;
+}
+}  // namespace
+
+extern "C" size_t jh_policy_rollout_scratch_floats(int N) { return jh_policy_scratch_floats(N) + (size_t)(N > 0 ? N : 0) * NJ; }
+
+extern "C" int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0, int x0_batched, const float* commands, float* policy_out, float* warmstart, int reset_warmstart,
+                                 int N, int T, int substeps, double cutoff_seconds, float* states, float* scratch, int* steps_done, void* stream) {
+  JH_REQUIRE(p && t && x0 && commands && policy_out && states && scratch, "policy_rollout: null pointer");
+  JH_REQUIRE(N > 0 && T > 0 && substeps > 0, "policy_rollout: need at least one rollout, one command row and one substep");
+  JH_REQUIRE(!reset_warmstart || warmstart, "policy_rollout: reset_warmstart needs a warmstart buffer");
+  hipStream_t st = (hipStream_t)stream;
+  float* control = scratch + jh_policy_scratch_floats(N);
+  const bool deadline = cutoff_seconds >= 0.0;
+  if (deadline) {
+    while ((int)t->events.size() < T + 1) { hipEvent_t e; JH_HIP(hipEventCreate(&e)); t->events.push_back(e); }
+    JH_HIP(hipEventRecord(t->events[0], st));
+  }
+  int done = T;
+  for (int i = 0; i < T; i++) {
+    if (deadline) {  // System::rollout checks its clock before every command row; here: device time, read two control steps back so the queue never drains
+      float ms = 0.f;
+      if (i >= 2) { JH_HIP(hipEventSynchronize(t->events[i - 1])); JH_HIP(hipEventElapsedTime(&ms, t->events[0], t->events[i - 1])); }
+      if (!((double)ms * 1e-3 < cutoff_seconds)) { done = i; break; }
+    }
+    const float* xin = i == 0 ? x0 : states + (size_t)(i - 1) * NX;
+    const int ld = i == 0 ? (x0_batched ? NX : 0) : T * NX;
+    const int rc = jh_policy_step_strided(p, xin, ld, NQ, 0, 0, 7, 6, commands + (size_t)i * 25, T * 25, policy_out, control, scratch, N, st);
+    if (rc != JH_OK) return rc;
+    if (reset_warmstart) JH_HIP(hipMemsetAsync(warmstart, 0, (size_t)N * NVT * sizeof(float), st));
+    hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
+                       t->d_stats);
+    if (deadline) JH_HIP(hipEventRecord(t->events[i + 1], st));
+  }
+  JH_HIP(hipGetLastError());
+  if (done < T) {
+    const size_t tot = (size_t)N * (T - done) * NX;
+    hipLaunchKernelGGL(k_fill_after_cutoff, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, states, N, T, done);
+    JH_HIP(hipGetLastError());
+  }
+  if (steps_done) *steps_done = done;
   return JH_OK;
 }

@@ -107,3 +107,8 @@ __device__ __forceinline__ float jh_impedance(float s0, float s1, float s2, floa
 }
 
 __device__ __forceinline__ float jh_clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+
+// jh_policy.hip: one policy step with explicit row strides (used by the policy rollout loop in jh_engine_v4.hip)
+struct jh_policy;
+int jh_policy_step_strided(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel, const float* command, int ldc,
+                           float* policy_out, float* control, float* scratch, int N, hipStream_t st);

@@ -28,12 +28,12 @@ __device__ __forceinline__ void rot_vec_quat(float* r, const float* v, const flo
 
 // one thread per rollout; the row is assembled in registers and written as 84 consecutive floats
 __global__ __launch_bounds__(256) void k_policy_obs(PolicyTables T, const float* __restrict__ states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos,
-                                                    int leg_qvel, const float* __restrict__ command, const float* __restrict__ prev_out, int N,
+                                                    int leg_qvel, const float* __restrict__ command, int ldc, const float* __restrict__ prev_out, int N,
                                                     float* __restrict__ obs) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   const float* qpos = states + (size_t)n * ld; const float* qvel = qpos + nq;
-  const float* cmd = command + (size_t)n * NCMD;
+  const float* cmd = command + (size_t)n * ldc;
   float* o = obs + (size_t)n * OBS;
   const float inv[4] = {qpos[base_qpos + 3], -qpos[base_qpos + 4], -qpos[base_qpos + 5], -qpos[base_qpos + 6]};
   const float lv[3] = {qvel[base_qvel], qvel[base_qvel + 1], qvel[base_qvel + 2]}, g0[3] = {0.f, 0.f, -1.f};
@@ -150,16 +150,12 @@ extern "C" void jh_policy_destroy(jh_policy* p) {
 
 extern "C" size_t jh_policy_scratch_floats(int N) { return (size_t)(N > 0 ? N : 0) * (OBS + H0 + H1 + H2 + ACT); }
 
-extern "C" int jh_policy_step(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel,
-                              const float* command, float* policy_out, float* control, float* scratch, int N, void* stream) {
-  JH_REQUIRE(p && states && command && policy_out && control && scratch, "policy_step: null pointer");
-  JH_REQUIRE(N > 0, "policy_step: need at least one rollout");
-  JH_REQUIRE(nq > 0 && ld >= nq + leg_qvel + NJ && base_qpos >= 0 && base_qpos + 7 <= nq && leg_qpos >= 0 && leg_qpos + NJ <= nq && base_qvel >= 0 && leg_qvel >= 0,
-             "policy_step: state layout (ld=%d nq=%d base %d/%d joints %d/%d) does not hold a free base and 19 joints", ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel);
-  hipStream_t st = (hipStream_t)stream;
+// One policy step with row strides for the states (ld; 0 = one state broadcast to every rollout) and the commands (ldc): the form the rollout loop uses.
+int jh_policy_step_strided(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel, const float* command, int ldc,
+                           float* policy_out, float* control, float* scratch, int N, hipStream_t st) {
   float* obs = scratch; float* h0 = obs + (size_t)N * OBS; float* h1 = h0 + (size_t)N * H0; float* h2 = h1 + (size_t)N * H1; float* act = h2 + (size_t)N * H2;
   const int nb = (N + 255) / 256;
-  hipLaunchKernelGGL(k_policy_obs, dim3(nb), dim3(256), 0, st, p->tab, states, ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, command, policy_out, N, obs);
+  hipLaunchKernelGGL(k_policy_obs, dim3(nb), dim3(256), 0, st, p->tab, states, ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, command, ldc, policy_out, N, obs);
   const int mb = (N + 127) / 128;
   hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H0 / 128), dim3(256), 0, st, obs, p->d_w[0], p->d_b[0], N, OBS, H0, h0);
   hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H1 / 128), dim3(256), 0, st, h0, p->d_w[1], p->d_b[1], N, H0, H1, h1);
@@ -168,4 +164,13 @@ extern "C" int jh_policy_step(const jh_policy* p, const float* states, int ld, i
   hipLaunchKernelGGL(k_policy_control, dim3(nb), dim3(256), 0, st, p->tab, obs, act, N, policy_out, control);
   JH_HIP(hipGetLastError());
   return JH_OK;
+}
+
+extern "C" int jh_policy_step(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel,
+                              const float* command, float* policy_out, float* control, float* scratch, int N, void* stream) {
+  JH_REQUIRE(p && states && command && policy_out && control && scratch, "policy_step: null pointer");
+  JH_REQUIRE(N > 0, "policy_step: need at least one rollout");
+  JH_REQUIRE(nq > 0 && ld >= nq + leg_qvel + NJ && base_qpos >= 0 && base_qpos + 7 <= nq && leg_qpos >= 0 && leg_qpos + NJ <= nq && base_qvel >= 0 && leg_qvel >= 0,
+             "policy_step: state layout (ld=%d nq=%d base %d/%d joints %d/%d) does not hold a free base and 19 joints", ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel);
+  return jh_policy_step_strided(p, states, ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, command, NCMD, policy_out, control, scratch, N, (hipStream_t)stream);
 }

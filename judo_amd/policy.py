@@ -156,6 +156,7 @@ class PolicyRolloutBackend(RolloutBackend):
     def update(self, num_threads: int) -> None:
         self.num_threads = int(num_threads)
         self._warm = torch.zeros((self.num_threads, SpotTreeEngine.NV), dtype=torch.float32, device=self.device)
+        self._scratch = None
 
     def rollout(self, x0, controls, last_policy_output=None, cutoff_time: float | None = None):
         """(x0 (nx,) or (N, nx), controls (N, T, 25), last_policy_output (N, 12)) -> (states (N, T, nx), sensors (N, T, 0), policy outputs (N, 12)).
@@ -163,7 +164,7 @@ class PolicyRolloutBackend(RolloutBackend):
         `cutoff_time` (seconds; the reference passes DEFAULT_SPOT_ROLLOUT_CUTOFF_TIME = 0.125 and checks its wall clock before every command
         row, system_class.cpp:290-327): once the batch has used that much DEVICE time, the remaining rows repeat the last computed state and the
         policy is not stepped further.  The check reads the event of the control step two back, so the launch queue never drains; None (default)
-        disables it -- 65 536 rollouts x 100 control steps take ~0.4 s, the 24 rollouts the reference ships take ~10 ms."""
+        disables it.  The loop over the command rows runs inside the library (`jh_policy_rollout`: 7 launches per row, no Python in between)."""
         if last_policy_output is None:
             raise ValueError("last_policy_output is required for PolicyRolloutBackend")
         as_numpy = not isinstance(controls, torch.Tensor)
@@ -173,44 +174,25 @@ class PolicyRolloutBackend(RolloutBackend):
         N, T = int(cmd.shape[0]), int(cmd.shape[1])
         x = f32(x0, self.device) if not isinstance(x0, torch.Tensor) else x0.to(torch.float32)
         nx = SpotTreeEngine.NQ + SpotTreeEngine.NV
-        if x.ndim == 1:
-            x = x.expand(N, nx)
-        if tuple(x.shape) != (N, nx):
+        if tuple(x.shape) not in ((nx,), (N, nx)):
             raise ValueError(f"x0 must be ({nx},) or ({N}, {nx}), got {tuple(x.shape)}")
-        x = x.contiguous().clone()
+        x = x.contiguous()
         out = f32(last_policy_output, self.device) if not isinstance(last_policy_output, torch.Tensor) else last_policy_output.to(torch.float32)
         if tuple(out.shape) != (N, SpotLocomotionPolicy.ACT):
             raise ValueError(f"last_policy_output must be ({N}, 12), got {tuple(out.shape)}")
-        states = torch.empty((T, N, nx), dtype=torch.float32, device=self.device)  # step-major while rolling: every step writes one contiguous slab
-        cmd_t = cmd.permute(1, 0, 2).contiguous()
-        start, marks, done = None, [], T
-        if cutoff_time is not None:
-            start = torch.cuda.Event(enable_timing=True)
-            start.record()
-        for t in range(T):
-            if start is not None:
-                elapsed = 0.0
-                if t >= 2:
-                    marks[t - 2].synchronize()
-                    elapsed = start.elapsed_time(marks[t - 2]) * 1e-3
-                if not elapsed < cutoff_time:
-                    done = t
-                    break
-            ctrl, out = self.policy.step(x, cmd_t[t], out, self.layout)
-            if not self.carry_warmstart:
-                self._warm.zero_()
-            x = self.engine.substeps(x, ctrl, self._warm, self.physics_substeps, out=states[t])
-            if start is not None:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
-                marks.append(ev)
-        if done < T:  # fill with the last computed state (zeros when nothing was computed: the reference's states start as zeros)
-            if done == 0:
-                states.zero_()
-            else:
-                states[done:] = states[done - 1]
-        self.steps_computed = done
-        states = states.permute(1, 0, 2).contiguous()
+        out = out.clone().contiguous()
+        cmd = cmd.contiguous()
+        states = torch.empty((N, T, nx), dtype=torch.float32, device=self.device)
+        L = _lib.lib()
+        need = int(L.jh_policy_rollout_scratch_floats(N))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        done = C.c_int(0)
+        s = L.jh_policy_rollout(self.policy.handle, self.engine.handle, _lib.ptr(x), int(x.ndim == 2), _lib.ptr(cmd), _lib.ptr(out), _lib.ptr(self._warm), int(not self.carry_warmstart),
+                                N, T, self.physics_substeps, -1.0 if cutoff_time is None else float(cutoff_time), _lib.ptr(states), _lib.ptr(self._scratch), C.byref(done),
+                                current_stream_ptr())
+        _lib.check(s, "jh_policy_rollout")
+        self.steps_computed = int(done.value)
         sensors = torch.zeros((N, T, 0), dtype=torch.float32, device=self.device)
         if as_numpy:
             return states.cpu().numpy().astype(np.float64), sensors.cpu().numpy().astype(np.float64), out.cpu().numpy().astype(np.float64)
