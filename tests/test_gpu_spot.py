@@ -1,8 +1,8 @@
 """Spot policy rollout on the GPU: the tree kernel (csrc/jh_engine_v4.hip, through jh_tree_substeps) against the
 oracle engine on the Spot model, and the whole `threaded_rollout` replacement (policy step + physics substeps) against `oracle.policy.policy_rollout`.
 
-Floating point: the kernel is fp32, the oracle fp64; both stop Newton at MuJoCo's tolerance (1e-4 on the scaled gradient), so velocities agree
-to ~1e-5 and positions to ~1e-6 per step (measured: 1e-7 .. 3e-5); the tolerances below are 10x that."""
+Floating point: the kernel is fp32 and stops Newton at 1e-4 on the scaled gradient (the fp32 floor), the oracle is fp64 with
+tolerance 1e-10; velocities agree to ~1e-5 and positions to ~1e-6 per step (measured: 1e-7 .. 3e-5); the tolerances below are 10x that."""
 
 import numpy as np
 import pytest
