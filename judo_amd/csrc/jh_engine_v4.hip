@@ -5,7 +5,7 @@
 //   lane l < 6    free-base dof l (world-frame translation, body-frame rotation: MuJoCo's free-joint convention)
 //   lane 6..24    joint dof l-6 (4 legs x 3 + arm x 7): joint state, servo, friction-loss / limit rows, its link's inertia and geoms
 //   lane 25       carries the right-hand side as an extra matrix row through the factorisations
-//   every lane    one contact slot (capacity 24 per rollout)
+//   every lane    one contact slot (capacity 32 per rollout)
 //
 // Dynamics in spatial-vector form about the base origin (an inertial point at this instant; keeps fp32 magnitudes small however far the
 // robot has walked): each dof lane publishes its spatial axis, each body lane its spatial inertia (10 numbers), composite inertias and bias
@@ -24,7 +24,7 @@ namespace {
 
 constexpr int G = 32, RPW = 2, WAVE = 64;
 constexpr int NJ = 19, NVT = 25, NQ = 26, NX = 51, NB = 20, MAXD = 7;
-constexpr int NCP = 24, RAW_F = 8, NR = NVT + 1;  // NR: row registers
+constexpr int NCP = 32, RAW_F = 8, NR = NVT + 1;  // NR: row registers
 // Contact Jacobian row (contact frame x dofs), compact: a ground contact moves with the base and ONE chain.  [3 b + r] base dof b, [JC + 3 m + r] position m of
 // the contact's chain (zero beyond the owner link), rows padded to float4s.
 constexpr int JC = 20, JW = 44;
@@ -60,7 +60,7 @@ struct __attribute__((aligned(16))) RS4 {  // per-rollout shared state; position
   float qd[G];
   float raw[NCP][RAW_F];                  // pos3 (relative), dist, geom | chain, tangent hint 3
   float fW[NCP][12];                      // contact frame (9) while the rows are built; then force [0..2] and the 3x3 weight [4..9] of the current Newton iterate
-  union { float M[NVT][NVT]; float J[NCP][JW]; };  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 24*44)
+  union { float M[NVT][NVT]; float J[NCP][JW]; };  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 32*44)
   int ncon;
 };
 

@@ -209,3 +209,36 @@ def test_policy_rollout_deadline(spot):
     k = be.steps_computed
     assert 2 <= k < T
     assert np.array_equal(part[:, :k], full[:, :k]) and np.array_equal(part[:, k:], np.repeat(part[:, k - 1 : k], T - k, axis=1))
+
+
+def test_tree_kernel_survives_falls(spot):
+    """Robots thrown at the ground in arbitrary attitudes: body, leg and arm geoms all end up in contact (up to the 32-contact capacity).  Nothing may go
+    non-finite, nothing may tunnel through the plane, and the common cases must not drop contacts."""
+    import torch
+
+    P, om, eng = spot
+    rng = np.random.default_rng(9)
+    N = 512
+    X = np.tile(P.spot_reset_state(), (N, 1))
+    X[:, 2] = rng.uniform(0.3, 0.8, N)
+    q = rng.standard_normal((N, 4))
+    X[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    X[:, 7:26] += rng.standard_normal((N, 19)) * 0.3
+    X[:, 26:32] = rng.standard_normal((N, 6)) * 1.0
+    X[:, 32:] = rng.standard_normal((N, 19)) * 2.0
+    xs = torch.as_tensor(X, dtype=torch.float32, device="cuda")
+    us = torch.as_tensor(np.tile(P.DEFAULT_JOINT_POS, (N, 1)), dtype=torch.float32, device="cuda")
+    warm = torch.zeros((N, 25), dtype=torch.float32, device="cuda")
+    eng.stats()
+    for _ in range(10):
+        xs = eng.substeps(xs, us, warm, 10)
+    got = xs.cpu().numpy()
+    st = eng.stats()
+    assert np.isfinite(got).all()
+    assert got[:, 2].min() > 0.02 and got[:, 2].max() < 3.0          # nothing tunnels through the plane, nothing is shot into the sky
+    assert np.abs(got[:, 26:]).max() < 50.0
+    assert st["steps"] == N * 100 and st["contacts_dropped"] < 0.01 * st["steps"], st
+    # one of them against the oracle for a few steps (a tumbling robot is chaotic: short horizon, loose tolerance)
+    ref = om.rollout(X[0], np.repeat(P.DEFAULT_JOINT_POS[None], 5, axis=0)[None], nthread=1)[0][0, -1]
+    got5 = eng.substeps(torch.as_tensor(X[:1], dtype=torch.float32, device="cuda"), us[:1], torch.zeros((1, 25), device="cuda"), 5).cpu().numpy()[0]
+    assert np.abs(got5[:7] - ref[:7]).max() < 1e-3
