@@ -36,6 +36,8 @@ WORKLOADS = {
     "cylinder_push": ("mppi", 16384, 64),
     "fr3_pick": ("cem", 32768, 40),
     "leap_cube": ("mppi", 65536, 64),
+    # not a BASELINE config: the Spot policy rollout at the headline batch, the shipped 2 s horizon = 100 control steps x 2 physics substeps
+    "spot_navigate": ("mppi", 65536, 100),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -86,6 +88,26 @@ def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
     ctrl.optimizer.config.num_rollouts = saved
     return {"value": total_rollouts / total_t, "unit": "rollouts/s", "cores": cores, "kind": "port",
             "sample": f"{total_rollouts} rollouts x H={H} of the same plan step (fp64 oracle engine, {cores} pthreads = usable CPUs of {os.cpu_count()} hardware threads), {total_t:.1f} s"}
+
+
+def cpu_baseline_policy(ctrl, seconds_target: float = 15.0) -> dict:
+    """The oracle's policy rollout (numpy actor + fp64 engine, one thread: `oracle.policy.policy_rollout` is a per-rollout Python loop) on a bounded sample."""
+    from oracle import policy as P
+
+    om = P.spot_model()
+    Ws, bs = P.load_actor()
+    H = ctrl.num_timesteps
+    rng = np.random.default_rng(0)
+    x0 = np.asarray(ctrl.current_state, dtype=np.float64)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_target / 2:
+        cmds = np.tile(P.DEFAULT_POLICY_COMMAND, (H, 1))
+        cmds[:, :3] = rng.uniform(-0.5, 0.5, 3)
+        P.policy_rollout(om, Ws, bs, x0, cmds, physics_substeps=ctrl.task.physics_substeps)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rollouts/s", "cores": 1, "kind": "port",
+            "sample": f"{n} rollouts x {H} control steps x {ctrl.task.physics_substeps} substeps (numpy actor + fp64 oracle engine, 1 thread), {dt:.1f} s"}
 
 
 def materialize_line(args, torch, world: int, rank: int) -> None:
@@ -184,6 +206,10 @@ def main() -> None:
     ctrl.current_state = ctrl.task.default_state()
     ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if args.task == "leap_cube" else {}
     ctrl.optimizer.seed(1234 + rank)
+    is_policy = ctrl.task.uses_locomotion_policy
+    if is_policy:
+        ctrl.rollout_cutoff_time = None  # throughput run: no 125 ms deadline
+        ctrl.task.config.goal_position = np.array([2.0, 1.0, 0.52])
     K, nu = ctrl.optimizer.num_nodes, ctrl.nu
     assert ctrl.num_timesteps == H
 
@@ -217,8 +243,13 @@ def main() -> None:
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])) if ctrl.kernel_events else float("nan")
     n_local = ctrl.last_shard.count
-    alg_bytes = (4 * K * nu + 4) * n_local
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    substeps = ctrl.task.physics_substeps
+    if is_policy:  # per control step the tree kernel reads state + control + warm start and writes state + warm start; H launches inside the timed region
+        alg_bytes = (2 * 51 + 19 + 2 * 25) * 4 * n_local
+        achieved = alg_bytes * H / (kern_ms * 1e-3) / 1e9
+    else:
+        alg_bytes = (4 * K * nu + 4) * n_local
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
     # measurement of this exact launch (profiles/, separate --pmc passes) is reported when the workload matches.
@@ -248,14 +279,15 @@ def main() -> None:
                        "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters},
             "plan_step_ms": {"mean": float(ms.mean()), "std": float(ms.std()), "median": float(np.median(ms)), "iqr": float(np.percentile(ms, 75) - np.percentile(ms, 25)),
                              "min": float(ms.min()), "max": float(ms.max())},
-            "physics_steps_per_s": N * H * args.steps / elapsed,
+            "physics_steps_per_s": N * H * substeps * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fused rollout+cost", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": ("policy rollout: per control step k_tree_v4 (2 substeps) + the policy step kernels; kernel_ms covers all H control steps and the reward"
+                                    if is_policy else "fused rollout+cost"), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_source": traffic_src,
                          "note": "latency/VALU-issue-bound by construction (H serial physics steps, ~1e5 flop per step against a few hundred algorithmic bytes per rollout); see DESIGN.md section 6"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.task, ctrl)
+            line["cpu_baseline"] = cpu_baseline_policy(ctrl) if is_policy else cpu_baseline(args.task, ctrl)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
