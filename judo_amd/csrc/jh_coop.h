@@ -44,6 +44,52 @@ __device__ __forceinline__ float gmin(float v) {  // min over the 16 lanes of a 
   return v;
 }
 
+// ---- small dense blocks in registers (packed lower-triangular, compile-time indices only).  A wave that runs alone on its SIMD pays every LDS round
+// trip and barrier in full, so blocks of up to ~9 x 9 are cheaper to factorise redundantly in every lane than to pass pivot rows through LDS.
+__host__ __device__ constexpr int tri4(int p, int m) { return p * (p + 1) / 2 + m; }
+
+// In-place Cholesky of an N x N block held as packed lower-triangular registers; the diagonal slots end up holding 1 / L_pp.
+template <int N>
+__device__ __forceinline__ void chol_packed(float* a) {
+#pragma unroll
+  for (int p = 0; p < N; p++) {
+#pragma unroll
+    for (int m = 0; m < p; m++) {
+      float s = a[tri4(p, m)];
+#pragma unroll
+      for (int q = 0; q < m; q++) s -= a[tri4(p, q)] * a[tri4(m, q)];
+      a[tri4(p, m)] = s * a[tri4(m, m)];
+    }
+    float d = a[tri4(p, p)];
+#pragma unroll
+    for (int q = 0; q < p; q++) d -= a[tri4(p, q)] * a[tri4(p, q)];
+    a[tri4(p, p)] = __frsqrt_rn(fmaxf(d, 1e-30f));
+  }
+}
+// v <- v L^-T restricted to one block: forward substitution of a row segment through the block's factor
+template <int N>
+__device__ __forceinline__ void fwd_packed(float* v, const float* L) {
+#pragma unroll
+  for (int m = 0; m < N; m++) {
+    float s = v[m];
+#pragma unroll
+    for (int q = 0; q < m; q++) s -= v[q] * L[tri4(m, q)];
+    v[m] = s * L[tri4(m, m)];
+  }
+}
+
+// x <- L^-T x for a factor from chol_packed (back substitution)
+template <int N>
+__device__ __forceinline__ void bwd_packed(float* v, const float* L) {
+#pragma unroll
+  for (int m = N - 1; m >= 0; m--) {
+    float s = v[m];
+#pragma unroll
+    for (int q = m + 1; q < N; q++) s -= L[tri4(q, m)] * v[q];
+    v[m] = s * L[tri4(m, m)];
+  }
+}
+
 // box-box contacts, normal from box 1 to box 2 (same algorithm as jh_engine.hip / the oracle); every contact goes to sk.push(pos, normal, dist)
 // element / row i (0..2, a run-time value) of a register array, and the triple rotated to start at i: compare-and-select instead of
 // an indexed read, so that the arrays stay in registers (an indexed read, or picking between two arrays through a pointer, puts them

@@ -189,38 +189,6 @@ __device__ __forceinline__ void load_row(float* row, const float* fullrow, const
   row[NVT] = 0.f;
 }
 
-__host__ __device__ constexpr int tri4(int p, int m) { return p * (p + 1) / 2 + m; }
-
-// In-place Cholesky of an N x N block held as packed lower-triangular registers; the diagonal slots end up holding 1 / L_pp.
-template <int N>
-__device__ __forceinline__ void chol_packed(float* a) {
-#pragma unroll
-  for (int p = 0; p < N; p++) {
-#pragma unroll
-    for (int m = 0; m < p; m++) {
-      float s = a[tri4(p, m)];
-#pragma unroll
-      for (int q = 0; q < m; q++) s -= a[tri4(p, q)] * a[tri4(m, q)];
-      a[tri4(p, m)] = s * a[tri4(m, m)];
-    }
-    float d = a[tri4(p, p)];
-#pragma unroll
-    for (int q = 0; q < p; q++) d -= a[tri4(p, q)] * a[tri4(p, q)];
-    a[tri4(p, p)] = __frsqrt_rn(fmaxf(d, 1e-30f));
-  }
-}
-// v <- v L^-T restricted to one block: forward substitution of a row segment through the block's factor
-template <int N>
-__device__ __forceinline__ void fwd_packed(float* v, const float* L) {
-#pragma unroll
-  for (int m = 0; m < N; m++) {
-    float s = v[m];
-#pragma unroll
-    for (int q = 0; q < m; q++) s -= v[q] * L[tri4(m, q)];
-    v[m] = s * L[tri4(m, m)];
-  }
-}
-
 // Solve A x = rhs for the tree-structured matrix with three LDS exchanges instead of one per pivot: a lane on its own SIMD pays every LDS
 // round trip and barrier in full, so the small dense blocks are factorised redundantly in registers by every lane that needs them.
 //   1. chain lanes publish their rows of the chain blocks; every joint lane factorises its own chain's block (legs padded to 7 x 7 with the
