@@ -11,6 +11,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _knots(task):
+    return 3 if task.startswith("spot") else 4   # the shipped num_nodes overrides
+
+
 def _plan(task, opt, N, noise, group=None):
     import torch
     from judo_amd.controller import make_controller
@@ -21,6 +25,9 @@ def _plan(task, opt, N, noise, group=None):
     ctrl.reset()
     ctrl.current_state = ctrl.task.default_state()
     ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}  # (the task draws a random goal per instance)
+    if ctrl.task.uses_locomotion_policy:  # the Spot policy rollout: policy step (MFMA GEMMs) + tree kernel per control step, sharded like everything else
+        ctrl.rollout_cutoff_time = None
+        ctrl.task.config.goal_position = np.array([1.0, 0.5, 0.52])
     ctrl.optimizer.injected_noise = noise
     ctrl.update_action()
     torch.cuda.synchronize()
@@ -37,7 +44,7 @@ def _worker(rank, world, port, cases, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
-        noise = np.random.default_rng(seed).standard_normal((N - 1, 4, nu)).astype(np.float32)
+        noise = np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
         nom, sig, shard, costs = _plan(task, opt, N, noise, group=dist.group.WORLD)
         assert (shard.world, shard.rank) == (world, rank) and shard.count in (N // world, N // world + 1)
         np.savez(os.path.join(out_dir, f"case{i}_rank{rank}.npz"), nom=nom, sig=sig, costs=costs)
@@ -49,11 +56,11 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
     import torch.multiprocessing as mp
 
     cases = [("cartpole", "mppi", 257, 1, 1), ("cylinder_push", "cem", 128, 2, 2), ("leap_cube", "mppi", 130, 16, 3), ("fr3_pick", "cem", 96, 8, 4),
-             ("cartpole", "ps", 64, 1, 5)]
+             ("cartpole", "ps", 64, 1, 5), ("spot_navigate", "mppi", 49, 3, 6)]
     world, port = 2, 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, cases, str(tmp_path)), nprocs=world, join=True)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
-        noise = np.random.default_rng(seed).standard_normal((N - 1, 4, nu)).astype(np.float32)
+        noise = np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
         nom1, sig1, _, costs1 = _plan(task, opt, N, noise)
         r0, r1 = np.load(tmp_path / f"case{i}_rank0.npz"), np.load(tmp_path / f"case{i}_rank1.npz")
         np.testing.assert_array_equal(r0["nom"], r1["nom"])  # identical on every rank without a broadcast
