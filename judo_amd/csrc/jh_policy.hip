@@ -4,8 +4,8 @@
 //                     (v_mfma_f32_32x32x2_f32; same arithmetic as an fmaf chain, at the f32 vector rate but one VGPR per operand)
 //   k_policy_control  System::policyInference's mapping of the 12 actions to the 19 joint targets, arm pass-through, leg override
 // This is the one dense contraction on the path: a batch of N rollouts is an (N x 84) x (84 x 512) ... GEMM chain,
-// 0.42 MFLOP per rollout and control step.  The physics substeps between two policy steps need the Spot model, which the engine kernels
-// do not cover yet; this file is the policy step only.
+// 0.42 MFLOP per rollout and control step.  The physics substeps between two policy steps are jh_engine_v4.hip (k_tree_v4); jh_policy_rollout there
+// alternates the two for a whole rollout.
 #include "jh_internal.h"
 
 namespace {
