@@ -149,24 +149,27 @@ int jh_policy_step(const jh_policy* p, const float* states, int ld, int nq, int 
  * N rollouts of a floating-base robot on a ground plane by `substeps` engine steps with the control held.  The model image is what
  * judo_amd/tree_model.py packs (free base + 19 hinges in 5 chains, plane contacts, pyramidal cones, implicitfast).  state_in / state_out are
  * (N x 51) rows [qpos(26), qvel(25)] and may alias; ctrl is (N x 19) joint position targets; warmstart (N x 25, may be NULL) is the solver's
- * starting acceleration, read and overwritten with this call's last constraint-consistent acceleration (mjData.qacc_warmstart).
+ * starting acceleration, read and overwritten with this call's last constraint-consistent acceleration (mjData.qacc_warmstart).  sensors_out (N x nsensordata,
+ * may be NULL): mjData.sensordata as mj_step leaves it after the last step, i.e. the site positions / frame axes of that step's forward pass.
  * jh_tree_stats: [contacts dropped over capacity, steps at the iteration cap, Newton iterations, steps]. */
 typedef struct jh_tree jh_tree;
 int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out);
 void jh_tree_destroy(jh_tree* t);
 int jh_tree_stats(jh_tree* t, int* out4, int reset);
-int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream);
+int jh_tree_dims(const jh_tree* t, int* out4 /* nq, nv, joints (= controls), nsensordata */);
+int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, float* sensors_out,
+                     void* stream);
 
 /* ---- the whole of threaded_rollout (mujoco_extensions/system/system_class.cpp:277-367; pybind entry mujoco_extensions/policy_rollout/pybind/policy_rollout.cpp:65)
  * in the reference's array layouts: x0 is one (51) state (x0_batched = 0) or (N x 51); commands (N x T x 25); states (N x T x 51), row [n][i] = the state after
- * command row i's policy step and `substeps` engine steps; policy_out (N x 12) in/out (last_policy_output -> policy_outputs).  warmstart (N x 25, may be NULL)
+ * command row i's policy step and `substeps` engine steps, sensors (N x T x nsensordata, may be NULL) the sensordata of the same row; policy_out (N x 12) in/out (last_policy_output -> policy_outputs).  warmstart (N x 25, may be NULL)
  * carries mjData.qacc_warmstart from call to call as the reference's per-thread mjData does; reset_warmstart != 0 zeroes it before every control step instead.
  * cutoff_seconds >= 0: the rollout stops issuing command rows once that much DEVICE time has passed since the call started (checked against the control
  * step two back) and the remaining rows repeat the last computed state, as System::rollout does with its wall clock; < 0: no deadline.  *steps_done = rows
  * computed.  scratch holds jh_policy_rollout_scratch_floats(N) floats.  With a deadline the call synchronises with the stream two control steps behind. */
 size_t jh_policy_rollout_scratch_floats(int N);
 int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0, int x0_batched, const float* commands, float* policy_out, float* warmstart, int reset_warmstart,
-                      int N, int T, int substeps, double cutoff_seconds, float* states, float* scratch, int* steps_done, void* stream);
+                      int N, int T, int substeps, double cutoff_seconds, float* states, float* sensors, float* scratch, int* steps_done, void* stream);
 
 #ifdef __cplusplus
 }

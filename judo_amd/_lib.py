@@ -37,9 +37,10 @@ _SIGNATURES = {
     "jh_tree_create": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "jh_tree_destroy": (None, [C.c_void_p]),
     "jh_tree_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
-    "jh_tree_substeps": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_void_p]),
+    "jh_tree_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "jh_tree_substeps": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_policy_rollout_scratch_floats": (C.c_size_t, [C.c_int]),
-    "jh_policy_rollout": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, f32p, C.POINTER(C.c_int), C.c_void_p]),
+    "jh_policy_rollout": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, f32p, f32p, C.POINTER(C.c_int), C.c_void_p]),
     "jh_update_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "jh_mppi_partial": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p, f32p, C.c_void_p]),
     "jh_mppi_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_float, f32p, C.c_void_p]),

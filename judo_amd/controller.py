@@ -57,7 +57,7 @@ class Controller:
         self.rewards = np.zeros((self.optimizer_cfg.num_rollouts,))
         self.costs_device: torch.Tensor | None = None
         self.traces = None
-        self.trace_sensors = [] if task.uses_locomotion_policy else [s for s in task.desc["sensors"] if s["type"] == "framepos" and s["name"].startswith("trace")]
+        self.trace_sensors = [s for s in task.desc["sensors"] if s["type"] == "framepos" and s["name"].startswith("trace")]
         self._w_cache: dict[tuple, torch.Tensor] = {}
         self._lohi_dev: torch.Tensor | None = None
         self.keep_candidates = False
@@ -336,6 +336,14 @@ class Controller:
             raise RuntimeError("update_traces() needs a completed update_action()")
         if not self.trace_sensors:
             self.traces = np.zeros((0, 2, 3))
+            return
+        if self.task.uses_locomotion_policy:  # the materialise path kept every rollout's sensors: pick the elites' rows, no re-rollout
+            sensors = self.last_rollout[1]
+            E = min(self.max_num_traces, int(self.costs_device.numel()))
+            order = torch.argsort(self.costs_device, stable=True)[:E]
+            sel = sensors[order].cpu().numpy().astype(np.float64)
+            segs = [np.stack([sel[e, :-1, s["adr"] : s["adr"] + 3], sel[e, 1:, s["adr"] : s["adr"] + 3]], axis=1) for e in range(E) for s in self.trace_sensors]
+            self.traces = np.concatenate(segs, axis=0)
             return
         self.traces = elite_traces(self, self._last_sigma_raw, self._last_nominal_before)
 

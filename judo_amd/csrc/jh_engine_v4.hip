@@ -28,7 +28,7 @@ constexpr int NCP = 32, RAW_F = 8, NR = NVT + 1;  // NR: row registers
 // Contact Jacobian row (contact frame x dofs), compact: a ground contact moves with the base and ONE chain.  [3 b + r] base dof b, [JC + 3 m + r] position m of
 // the contact's chain (zero beyond the owner link), rows padded to float4s.
 constexpr int JC = 20, JW = 44;
-constexpr int TH_F = 32, TH_I = 16, TD_F = 56, TD_I = 4, TG_F = 28, TG_I = 2;  // judo_amd/tree_model.py
+constexpr int TH_F = 32, TH_I = 16, TD_F = 56, TD_I = 4, TG_F = 28, TG_I = 2, TS_F = 16, TS_I = 4;  // judo_amd/tree_model.py
 // header floats
 enum { TF_DT = 0, TF_IMPRATIO, TF_TOL, TF_MAXITER, TF_LSTOL, TF_GRAV, TF_PLANE_P = 8, TF_PLANE_N = 11, TF_BMASS = 14, TF_BIPOS = 15, TF_BIR = 18, TF_BINERTIA = 27 };
 // joint floats
@@ -314,14 +314,14 @@ __device__ __forceinline__ float dot_row(const float* Mrow, const float* v) {
 
 __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI, const float* state_in, int ld_in,
                                                     const float* __restrict__ ctrl, float* __restrict__ warm, int N, int substeps, float* state_out, int ld_out,
-                                                    int* __restrict__ stats) {
+                                                    float* __restrict__ sensors_out, int ld_sens, int* __restrict__ stats) {
   __shared__ RS4 sRS[RPW];
   __shared__ __attribute__((aligned(16))) float sF[SF_MAX];  // the model image, shared by the rollouts of the wave
   __shared__ int sI[SI_MAX];
   const int lane = threadIdx.x, l = lane & 31, r = lane >> 5;
   RS4& S = sRS[r];
-  for (int i = lane; i < nF; i += WAVE) sF[i] = gF[i];
-  for (int i = lane; i < nI; i += WAVE) sI[i] = gI[i];
+  for (int i = lane; i < nF && i < SF_MAX; i += WAVE) sF[i] = gF[i];  // (the sensor records at the end of the image are read from global memory, once per launch)
+  for (int i = lane; i < nI && i < SI_MAX; i += WAVE) sI[i] = gI[i];
   __syncthreads();
   const int n = blockIdx.x * RPW + r;
   const bool live = n < N;
@@ -433,6 +433,26 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (isbody) for (int i = 0; i < 10; i++) S.Ib[bidx][i] = Ib[i];
     }
     __syncthreads();
+    // ================================================================ sensors of the step that produces the returned state (mjData.sensordata after mj_step holds
+    // the values of that step's forward pass, i.e. of the state before its integration): site positions / frame axes, one sensor per lane
+    if (sensors_out && step == substeps - 1 && live && l < sI[4]) {
+      const int oSF = oGF + ng * TG_F, oSI = oGI + ng * TG_I;
+      const float* sf = gF + oSF + l * TS_F; const int* si = gI + oSI + l * TS_I;
+      const int kind = si[0], owner = si[1], adr = si[2], hasref = si[3];
+      float o[3] = {sf[0], sf[1], sf[2]};
+      if (owner > -2) {
+        const int b = owner < 0 ? 0 : 1 + owner;
+        float Rs[9]; for (int i = 0; i < 9; i++) Rs[i] = S.xR[b][i];
+        if (kind == 0) { float w[3]; mulMV(w, Rs, o); for (int i = 0; i < 3; i++) o[i] = w[i] + S.xpos[b][i] + qb[i]; }
+        else col3(o, Rs, kind - 1);
+      }
+      if (hasref) {  // position in the frame of a world-fixed reference site: R_ref' (p - p_ref)
+        const float dv[3] = {o[0] - sf[3], o[1] - sf[4], o[2] - sf[5]};
+        for (int i = 0; i < 3; i++) o[i] = sf[6 + i] * dv[0] + sf[9 + i] * dv[1] + sf[12 + i] * dv[2];
+      }
+      float* out = sensors_out + (size_t)n * ld_sens + adr;
+      out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
+    }
     {
       float tot[10];  // whole robot: a reduction over the body lanes (two DPP rows), no LDS
 #pragma unroll
@@ -799,7 +819,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
 
 }  // namespace
 
-struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni; std::vector<hipEvent_t> events; };
+struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni, ns; std::vector<hipEvent_t> events; };
 
 extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(blob && out && nbytes >= 16, "tree_create: null or short blob");
@@ -809,14 +829,17 @@ extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(nbytes == 16 + 4 * (nf + ni), "tree_create: blob size mismatch");
   const float* f = (const float*)(hd + 4); const int* ii = (const int*)(f + nf);
   JH_REQUIRE(ii[0] == NJ && ii[2] == NQ && ii[3] == NVT && ii[1] <= G - 1, "tree_create: the kernel is instantiated for a free base + 19 hinges (got %d joints, nq %d, nv %d, %d geoms)", ii[0], ii[2], ii[3], ii[1]);
-  JH_REQUIRE(nf <= (size_t)SF_MAX && ni <= (size_t)SI_MAX, "tree_create: model image too large for the kernel's LDS copy");
+  JH_REQUIRE((size_t)(TH_F + ii[0] * TD_F + ii[1] * TG_F) <= (size_t)SF_MAX && (size_t)(TH_I + ii[0] * TD_I + ii[1] * TG_I) <= (size_t)SI_MAX,
+             "tree_create: model image too large for the kernel's LDS copy");
+  JH_REQUIRE(ii[4] >= 0 && ii[4] <= G && nf == (size_t)(TH_F + ii[0] * TD_F + ii[1] * TG_F + ii[4] * TS_F) && ni == (size_t)(TH_I + ii[0] * TD_I + ii[1] * TG_I + ii[4] * TS_I),
+             "tree_create: image sizes do not match the counts in its header (or more than 32 sensors)");
   for (int c = 0; c < NCH; c++)
     for (int m = 0; m < CL(c); m++) {
       const int* jr = ii + TH_I + (CS(c) + m) * TD_I;
       JH_REQUIRE(jr[1] == CS(c) && jr[2] == m, "tree_create: the kernel is instantiated for four 3-joint chains followed by one 7-joint chain (joint %d: chain start %d, depth %d)", CS(c) + m, jr[1], jr[2]);
     }
   jh_tree* t = new jh_tree();
-  t->nf = (int)nf; t->ni = (int)ni;
+  t->nf = (int)nf; t->ni = (int)ni; t->ns = ii[5];
   t->nj = ii[0]; t->ng = ii[1]; t->nq = ii[2]; t->nv = ii[3];
   JH_HIP(hipMalloc(&t->d_f, 4 * nf)); JH_HIP(hipMalloc(&t->d_i, 4 * ni)); JH_HIP(hipMalloc(&t->d_stats, 64 * sizeof(int)));
   JH_HIP(hipMemcpy(t->d_f, f, 4 * nf, hipMemcpyHostToDevice)); JH_HIP(hipMemcpy(t->d_i, ii, 4 * ni, hipMemcpyHostToDevice));
@@ -851,29 +874,36 @@ extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
   return JH_OK;
 }
 
-extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, void* stream) {
+extern "C" int jh_tree_dims(const jh_tree* t, int* out4) {
+  JH_REQUIRE(t && out4, "tree_dims: null pointer");
+  out4[0] = t->nq; out4[1] = t->nv; out4[2] = t->nj; out4[3] = t->ns;
+  return JH_OK;
+}
+
+extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, float* sensors_out,
+                                void* stream) {
   JH_REQUIRE(t && state_in && ctrl && state_out, "tree_substeps: null pointer");
   JH_REQUIRE(N > 0 && substeps > 0, "tree_substeps: need at least one rollout and one step");
   hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
-                     t->d_stats);
+                     sensors_out, t->ns, t->d_stats);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
 
 namespace {
-__global__ void k_fill_after_cutoff(float* states, int N, int T, int done) {  // rows done..T-1 of every rollout repeat row done-1 (zeros when nothing was computed)
+__global__ void k_fill_after_cutoff(float* rows, int W, int N, int T, int done) {  // rows done..T-1 of every rollout repeat row done-1 (zeros when nothing was computed)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t per = (size_t)(T - done) * NX;
+  const size_t per = (size_t)(T - done) * W;
   if (i >= (size_t)N * per) return;
-  const size_t n = i / per, r = i % per, tt = done + r / NX, c = r % NX;
-  states[(n * T + tt) * NX + c] = done > 0 ? states[(n * T + done - 1) * NX + c] : 0.f;
+  const size_t n = i / per, r = i % per, tt = done + r / W, c = r % W;
+  rows[(n * T + tt) * W + c] = done > 0 ? rows[(n * T + done - 1) * W + c] : 0.f;
 }
 }  // namespace
 
 extern "C" size_t jh_policy_rollout_scratch_floats(int N) { return jh_policy_scratch_floats(N) + (size_t)(N > 0 ? N : 0) * NJ; }
 
 extern "C" int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0, int x0_batched, const float* commands, float* policy_out, float* warmstart, int reset_warmstart,
-                                 int N, int T, int substeps, double cutoff_seconds, float* states, float* scratch, int* steps_done, void* stream) {
+                                 int N, int T, int substeps, double cutoff_seconds, float* states, float* sensors, float* scratch, int* steps_done, void* stream) {
   JH_REQUIRE(p && t && x0 && commands && policy_out && states && scratch, "policy_rollout: null pointer");
   JH_REQUIRE(N > 0 && T > 0 && substeps > 0, "policy_rollout: need at least one rollout, one command row and one substep");
   JH_REQUIRE(!reset_warmstart || warmstart, "policy_rollout: reset_warmstart needs a warmstart buffer");
@@ -897,13 +927,17 @@ extern "C" int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0
     if (rc != JH_OK) return rc;
     if (reset_warmstart) JH_HIP(hipMemsetAsync(warmstart, 0, (size_t)N * NVT * sizeof(float), st));
     hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
-                       t->d_stats);
+                       sensors ? sensors + (size_t)i * t->ns : nullptr, T * t->ns, t->d_stats);
     if (deadline) JH_HIP(hipEventRecord(t->events[i + 1], st));
   }
   JH_HIP(hipGetLastError());
   if (done < T) {
     const size_t tot = (size_t)N * (T - done) * NX;
-    hipLaunchKernelGGL(k_fill_after_cutoff, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, states, N, T, done);
+    hipLaunchKernelGGL(k_fill_after_cutoff, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, states, NX, N, T, done);
+    if (sensors && t->ns > 0) {
+      const size_t tots = (size_t)N * (T - done) * t->ns;
+      hipLaunchKernelGGL(k_fill_after_cutoff, dim3((unsigned)((tots + 255) / 256)), dim3(256), 0, st, sensors, t->ns, N, T, done);
+    }
     JH_HIP(hipGetLastError());
   }
   if (steps_done) *steps_done = done;

@@ -106,8 +106,12 @@ class SpotTreeEngine:
             _lib.check(_lib.lib().jh_tree_create(C.cast(self._blob, C.c_void_p), len(blob), C.byref(handle)), "jh_tree_create")
         self.handle = handle
         self.timestep = float(self.desc["option"]["timestep"])
+        dims = (C.c_int * 4)()
+        _lib.check(_lib.lib().jh_tree_dims(self.handle, dims), "jh_tree_dims")
+        self.nsensordata = int(dims[3])
 
-    def substeps(self, states: torch.Tensor, ctrl: torch.Tensor, warmstart: torch.Tensor | None, n: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    def substeps(self, states: torch.Tensor, ctrl: torch.Tensor, warmstart: torch.Tensor | None, n: int, out: torch.Tensor | None = None,
+                 sensors: torch.Tensor | None = None) -> torch.Tensor:
         nx = self.NQ + self.NV
         if states.ndim != 2 or states.shape[1] != nx or not states.is_contiguous() or states.dtype != torch.float32:
             raise ValueError(f"states must be a contiguous float32 (N, {nx}) tensor")
@@ -118,8 +122,10 @@ class SpotTreeEngine:
             raise ValueError(f"warmstart must be a contiguous (N, {self.NV}) tensor")
         if out is None:
             out = torch.empty_like(states)
+        if sensors is not None and (tuple(sensors.shape) != (N, self.nsensordata) or not sensors.is_contiguous() or sensors.dtype != torch.float32):
+            raise ValueError(f"sensors must be a contiguous float32 ({N}, {self.nsensordata}) tensor")
         s = _lib.lib().jh_tree_substeps(self.handle, _lib.ptr(states), _lib.ptr(ctrl), _lib.ptr(warmstart) if warmstart is not None else None, N, int(n), _lib.ptr(out),
-                                        current_stream_ptr())
+                                        _lib.ptr(sensors) if sensors is not None else None, current_stream_ptr())
         _lib.check(s, "jh_tree_substeps")
         return out
 
@@ -159,7 +165,7 @@ class PolicyRolloutBackend(RolloutBackend):
         self._scratch = None
 
     def rollout(self, x0, controls, last_policy_output=None, cutoff_time: float | None = None):
-        """(x0 (nx,) or (N, nx), controls (N, T, 25), last_policy_output (N, 12)) -> (states (N, T, nx), sensors (N, T, 0), policy outputs (N, 12)).
+        """(x0 (nx,) or (N, nx), controls (N, T, 25), last_policy_output (N, 12)) -> (states (N, T, nx), sensors (N, T, ns), policy outputs (N, 12)).
 
         `cutoff_time` (seconds; the reference passes DEFAULT_SPOT_ROLLOUT_CUTOFF_TIME = 0.125 and checks its wall clock before every command
         row, system_class.cpp:290-327): once the batch has used that much DEVICE time, the remaining rows repeat the last computed state and the
@@ -183,17 +189,17 @@ class PolicyRolloutBackend(RolloutBackend):
         out = out.clone().contiguous()
         cmd = cmd.contiguous()
         states = torch.empty((N, T, nx), dtype=torch.float32, device=self.device)
+        sensors = torch.empty((N, T, self.engine.nsensordata), dtype=torch.float32, device=self.device)
         L = _lib.lib()
         need = int(L.jh_policy_rollout_scratch_floats(N))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
         done = C.c_int(0)
         s = L.jh_policy_rollout(self.policy.handle, self.engine.handle, _lib.ptr(x), int(x.ndim == 2), _lib.ptr(cmd), _lib.ptr(out), _lib.ptr(self._warm), int(not self.carry_warmstart),
-                                N, T, self.physics_substeps, -1.0 if cutoff_time is None else float(cutoff_time), _lib.ptr(states), _lib.ptr(self._scratch), C.byref(done),
+                                N, T, self.physics_substeps, -1.0 if cutoff_time is None else float(cutoff_time), _lib.ptr(states), _lib.ptr(sensors) if sensors.numel() else None, _lib.ptr(self._scratch), C.byref(done),
                                 current_stream_ptr())
         _lib.check(s, "jh_policy_rollout")
         self.steps_computed = int(done.value)
-        sensors = torch.zeros((N, T, 0), dtype=torch.float32, device=self.device)
         if as_numpy:
             return states.cpu().numpy().astype(np.float64), sensors.cpu().numpy().astype(np.float64), out.cpu().numpy().astype(np.float64)
         return states, sensors, out

@@ -85,10 +85,6 @@ class SpotBase(Task[SpotBaseConfig]):
     def nu(self) -> int:                   # :166-169
         return len(self.default_command)
 
-    @property
-    def nsensordata(self) -> int:          # the model's sensors are not evaluated on this path
-        return 0
-
     def task_params(self, system_metadata=None) -> np.ndarray:
         return np.zeros(0, dtype=np.float32)
 

@@ -18,6 +18,7 @@ from judo_amd.models import MINVAL, clamp_solimp, inverse_weights, layout, quat_
 TH_F, TH_I = 32, 16           # header sizes
 TD_F, TD_I = 56, 4            # per joint dof
 TG_F, TG_I = 28, 2            # per geom
+TS_F, TS_I = 16, 4            # per sensor
 SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-3
 GTYPE = {"sphere": 2, "capsule": 3, "box": 6}
 MAX_JOINTS, MAX_GEOMS, MAX_DEPTH = 25, 31, 7
@@ -80,8 +81,9 @@ def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
     if len(act_of) != len(desc["actuators"]) or any(a["gear"] != 1.0 for a in desc["actuators"]):
         raise NotImplementedError("tree kernel: at most one unit-gear position servo per joint")
 
-    F = np.zeros(TH_F + nj * TD_F + len(robot_geoms) * TG_F, dtype=np.float32)
-    I = np.zeros(TH_I + nj * TD_I + len(robot_geoms) * TG_I, dtype=np.int32)
+    sensors = desc.get("sensors", [])
+    F = np.zeros(TH_F + nj * TD_F + len(robot_geoms) * TG_F + len(sensors) * TS_F, dtype=np.float32)
+    I = np.zeros(TH_I + nj * TD_I + len(robot_geoms) * TG_I + len(sensors) * TS_I, dtype=np.int32)
     bb = bodies[base]
     F[0:8] = [o["timestep"], o["impratio"], SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL, *o["gravity"]]
     F[8:14] = [*ppos, *Rp[:, 2]]                       # plane point, plane normal
@@ -149,6 +151,45 @@ def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
         f[18:23] = clamp_solimp(solimp)
         f[23] = bodyw[gb][0] + bodyw[plane["body"]][0]   # diagApprox: translational inverse weights of both bodies
         I[og_i + gi * TG_I: og_i + (gi + 1) * TG_I] = [owner, GTYPE[g["type"]]]
+    # sensors: site positions (optionally in the frame of a world-fixed reference site) and site frame axes, as the Spot models declare them
+    os_f, os_i = og_f + len(robot_geoms) * TG_F, og_i + len(robot_geoms) * TG_I
+    nsd = 0
+
+    def site_owner(si: int):
+        st = desc["sites"][si]
+        if list(st["quat"]) != [1.0, 0.0, 0.0, 0.0]:
+            raise NotImplementedError("tree kernel: sites with their own rotation")
+        b = st["body"]
+        if b == base:
+            return -1, np.array(st["pos"], dtype=np.float64), np.eye(3)
+        if b in body_of:
+            return body_of[b], np.array(st["pos"], dtype=np.float64), np.eye(3)
+        if len(lay.body_joints[b]) == 0 and (bodies[b]["parent"] == 0 or b == 0):   # world-fixed: fold the body pose into the site
+            Rw = quat_to_mat(bodies[b]["quat"]) if b != 0 else np.eye(3)
+            pw = (np.array(bodies[b]["pos"]) if b != 0 else np.zeros(3)) + Rw @ np.array(st["pos"])
+            return -2, pw, Rw
+        raise NotImplementedError("tree kernel: sensor site on an unsupported body")
+
+    for k, sn in enumerate(sensors):
+        kind = {"framepos": 0, "framexaxis": 1, "frameyaxis": 2, "framezaxis": 3}.get(sn["type"])
+        if kind is None or sn.get("objtype") != "site" or sn["dim"] != 3 or sn["adr"] != nsd:
+            raise NotImplementedError(f"tree kernel: sensor {sn['name']} ({sn['type']})")
+        owner, lp, Rw = site_owner(sn["obj"])
+        f = F[os_f + k * TS_F: os_f + (k + 1) * TS_F]
+        f[0:3] = lp
+        has_ref = 0
+        if sn.get("reftype") is not None:
+            if kind != 0 or sn["reftype"] != "site":
+                raise NotImplementedError("tree kernel: reference frames for position sensors on sites only")
+            ro, rp, rR = site_owner(sn["ref"])
+            if ro != -2:
+                raise NotImplementedError("tree kernel: the reference site must be world-fixed")
+            f[3:6], f[6:15], has_ref = rp, rR.reshape(-1), 1
+        if owner == -2 and kind != 0:      # axis of a world-fixed site: a constant
+            f[0:3] = Rw[:, kind - 1]
+        I[os_i + k * TS_I: os_i + (k + 1) * TS_I] = [kind, owner, sn["adr"], has_ref]
+        nsd += 3
+    I[4:6] = [len(sensors), nsd]
     return F, I
 
 

@@ -899,7 +899,17 @@ static void sensors(const jo_model* m, jo_data* d) {
   for (int s = 0; s < m->nsensor; s++) {
     double* o = d->sensordata + m->sensor_adr[s]; int obj = m->sensor_obj[s];
     switch (m->sensor_type[s]) {
-      case JO_SENS_FRAMEPOS_SITE: copy3(o, d->site_xpos[obj]); break;
+      case JO_SENS_FRAMEPOS_SITE: /* obj2 >= 0: expressed in the frame of that reference site (mj_sensorPos, reftype site): R_ref' (p - p_ref) */
+        copy3(o, d->site_xpos[obj]);
+        if (m->sensor_obj2[s] >= 0) {
+          int rs = m->sensor_obj2[s]; const double* R = d->xmat[m->site_body[rs]];
+          double dv[3] = {o[0] - d->site_xpos[rs][0], o[1] - d->site_xpos[rs][1], o[2] - d->site_xpos[rs][2]};
+          for (int k = 0; k < 3; k++) o[k] = R[k] * dv[0] + R[3 + k] * dv[1] + R[6 + k] * dv[2];
+        }
+        break;
+      case JO_SENS_FRAMEXAXIS_SITE: col(o, d->xmat[m->site_body[obj]], 0); break;
+      case JO_SENS_FRAMEYAXIS_SITE: col(o, d->xmat[m->site_body[obj]], 1); break;
+      case JO_SENS_FRAMEZAXIS_SITE: col(o, d->xmat[m->site_body[obj]], 2); break;
       case JO_SENS_FRAMEPOS_BODY: copy3(o, d->xpos[obj]); break;
       case JO_SENS_JOINTPOS: o[0] = d->qpos[m->jnt_qposadr[obj]]; break;
       case JO_SENS_FRAMEZAXIS_BODY: col(o, d->xmat[obj], 2); break;

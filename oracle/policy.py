@@ -80,7 +80,7 @@ def spot_model():
     sensors (relative frame positions, frame axes) are not evaluated."""
     from oracle import oracle as O
 
-    desc = dict(O.load_description("spot"), sensors=[])
+    desc = O.load_description("spot")
     plane = next(i for i, g in enumerate(desc["geoms"]) if g["type"] == "plane")
     pairs = [(min(plane, i), max(plane, i)) for i, g in enumerate(desc["geoms"]) if i != plane]
     return O.Model("spot", desc=desc, pairs=pairs)
@@ -91,17 +91,19 @@ def spot_reset_state(arm=ARM_STOWED_POS):
     return np.concatenate([[0, 0, STANDING_HEIGHT, 1, 0, 0, 0], LEGS_STANDING_POS_RL, arm, np.zeros(25)])
 
 
-def policy_rollout(om, Ws, bs, state, commands, physics_substeps=2, last_policy_output=None):
+def policy_rollout(om, Ws, bs, state, commands, physics_substeps=2, last_policy_output=None, with_sensors=False):
     """System::rollout (system_class.cpp:277-331) without the wall-clock cutoff: per command row one policy step, then
     `physics_substeps` engine steps with that control held; the state is recorded at the end of the substeps."""
     nq = om.nq
     x = np.asarray(state, dtype=np.float64).copy()
     out = np.zeros(12) if last_policy_output is None else np.asarray(last_policy_output, dtype=np.float64)
     states = np.zeros((len(commands), om.nx))
+    sensors = np.zeros((len(commands), om.ns))
     for i, cmd in enumerate(np.asarray(commands, dtype=np.float64)):
         _, ctrl, o = policy_step(Ws, bs, x[None, :nq], x[None, nq:], cmd[None], out[None])
         out = o[0]
-        st, _ = om.rollout(x, np.repeat(ctrl, physics_substeps, axis=0)[None], nthread=1)
+        st, se = om.rollout(x, np.repeat(ctrl, physics_substeps, axis=0)[None], nthread=1)
         x = st[0, -1]
         states[i] = x
-    return states, out
+        sensors[i] = se[0, -1]   # mjData.sensordata after the last mj_step of the row: from that step's forward pass (system_class.cpp:312-314)
+    return (states, sensors, out) if with_sensors else (states, out)

@@ -27,8 +27,10 @@ def spot(gpu):
     return P, P.spot_model(), SpotTreeEngine()
 
 
-def _oracle_steps(om, X, U, k):
-    return np.stack([om.rollout(X[i], np.repeat(U[i][None], k, axis=0)[None], nthread=1)[0][0, -1] for i in range(X.shape[0])])
+def _oracle_steps(om, X, U, k, with_sensors=False):
+    res = [om.rollout(X[i], np.repeat(U[i][None], k, axis=0)[None], nthread=1) for i in range(X.shape[0])]
+    st = np.stack([r[0][0, -1] for r in res])
+    return (st, np.stack([r[1][0, -1] for r in res])) if with_sensors else st
 
 
 def test_tree_model_image_matches_oracle_model(spot):
@@ -40,7 +42,7 @@ def test_tree_model_image_matches_oracle_model(spot):
     st = tree_structure(eng.desc)
     assert [(i["start"], i["depth"]) for i in st["info"][:3]] == [(0, 0), (0, 1), (0, 2)] and st["info"][-1]["depth"] == 6
     F, I = pack_tree_model(eng.desc)
-    assert list(I[:4]) == [19, 27, 26, 25] and F.dtype == np.float32
+    assert list(I[:6]) == [19, 27, 26, 25, 16, 48] and F.dtype == np.float32 and eng.nsensordata == 48
     dofw, _ = models.inverse_weights(eng.desc)
     np.testing.assert_allclose(dofw, om.invweight0()[0], rtol=1e-9)
 
@@ -84,6 +86,13 @@ def test_tree_substeps_match_oracle(spot, case):
     y = xs.clone()
     eng.substeps(y, us, None, 1, out=y)
     _check(y.cpu().numpy(), _oracle_steps(om, X, U, 1))
+    # sensordata as mj_step leaves it: site positions / frame axes of the last step's forward pass (the state before its integration)
+    sens = torch.full((N, 48), float("nan"), dtype=torch.float32, device="cuda")
+    eng.substeps(xs, us, torch.zeros((N, 25), dtype=torch.float32, device="cuda"), 3, sensors=sens)
+    _, sref = _oracle_steps(om, X, U, 3, with_sensors=True)
+    np.testing.assert_allclose(sens.cpu().numpy(), sref, rtol=0, atol=3e-6)
+    with pytest.raises(ValueError):
+        eng.substeps(xs, us, None, 1, sensors=sens[:, :47].contiguous())
 
 
 def test_policy_rollout_backend_matches_oracle(spot):
@@ -100,10 +109,11 @@ def test_policy_rollout_backend_matches_oracle(spot):
     cmds[3, :, 2] = 0.5
     be = PolicyRolloutBackend(N, carry_warmstart=False)   # the oracle restarts the solver's warm start at every control step
     states, sensors, outs = be.rollout(x0, cmds, np.zeros((N, 12)))
-    assert states.shape == (N, T, 51) and sensors.shape == (N, T, 0) and outs.shape == (N, 12) and states.dtype == np.float64
+    assert states.shape == (N, T, 51) and sensors.shape == (N, T, 48) and outs.shape == (N, 12) and states.dtype == np.float64
     for i in range(N):
-        ref, o = P.policy_rollout(om, Ws, bs, x0, cmds[i])
+        ref, sref, o = P.policy_rollout(om, Ws, bs, x0, cmds[i], with_sensors=True)
         _check(states[i], ref, scale=10.0)   # 80 physics steps of a closed loop: fp32 differences feed back through the policy
+        np.testing.assert_allclose(sensors[i], sref, rtol=0, atol=3e-5)
         np.testing.assert_allclose(outs[i], o, atol=5e-4)
     assert abs(states[1, -1, 0] - 0.27) < 0.08 and abs(states[0, -1, 0]) < 0.02   # it walks forward when told to, stands otherwise
     # the reference keeps its mjData between control steps: carrying the warm start changes the result only at solver-tolerance level
@@ -158,7 +168,7 @@ def test_spot_navigate_controller_plans_through_the_policy_rollout(spot):
     x0 = c.current_state.copy()
     c.update_action()
     states, sensors, controls = c.last_rollout
-    assert states.shape == (24, 100, 51) and sensors.shape == (24, 100, 0) and controls.shape == (24, 100, 3)
+    assert states.shape == (24, 100, 51) and sensors.shape == (24, 100, 48) and controls.shape == (24, 100, 3)
     assert c.rollout_backend.steps_computed == 100   # 24 rollouts x 100 control steps fit the 125 ms deadline with room to spare
     rewards = c.rewards_local
     ctl = controls.cpu().numpy().astype(np.float64)
@@ -186,8 +196,10 @@ def test_spot_navigate_controller_plans_through_the_policy_rollout(spot):
             x, t = st[0, -1], t + c.task.dt
     d0, d1 = np.linalg.norm(x0[:2] - [1.0, 0.3]), np.linalg.norm(x[:2] - [1.0, 0.3])
     assert x[2] > 0.4 and d1 < 0.6 * d0, (d0, d1, x[:3])
-    c.update_traces()
-    assert c.traces.shape == (0, 2, 3)
+    c.update_traces()   # the gripper trace (`trace_fngr_site`) of the 5 best rollouts: (E * 1 * (H - 1), 2, 3) segments, consecutive points
+    assert c.traces.shape == (5 * 99, 2, 3) and np.array_equal(c.traces[0, 1], c.traces[1, 0]) and np.isfinite(c.traces).all()
+    best = int(np.argmax(c.rewards_local))
+    np.testing.assert_allclose(c.traces[0, 0], c.last_rollout[1][best, 0, 12:15].cpu().numpy(), atol=1e-7)
 
 
 def test_policy_rollout_deadline(spot):
@@ -202,13 +214,14 @@ def test_policy_rollout_deadline(spot):
     full, _, out_full = be.rollout(x0, cmds, np.zeros((N, 12)), cutoff_time=None)
     assert be.steps_computed == T
     be.update(N)
-    z, _, out0 = be.rollout(x0, cmds, np.ones((N, 12)), cutoff_time=0.0)
-    assert be.steps_computed == 0 and not z.any() and np.array_equal(out0, np.ones((N, 12)))
+    z, zs, out0 = be.rollout(x0, cmds, np.ones((N, 12)), cutoff_time=0.0)
+    assert be.steps_computed == 0 and not z.any() and not zs.any() and np.array_equal(out0, np.ones((N, 12)))
     be.update(N)
-    part, _, _ = be.rollout(x0, cmds, np.zeros((N, 12)), cutoff_time=2e-3)   # a few control steps of 4096 rollouts
+    part, parts, _ = be.rollout(x0, cmds, np.zeros((N, 12)), cutoff_time=2e-3)   # a few control steps of 4096 rollouts
     k = be.steps_computed
     assert 2 <= k < T
     assert np.array_equal(part[:, :k], full[:, :k]) and np.array_equal(part[:, k:], np.repeat(part[:, k - 1 : k], T - k, axis=1))
+    assert np.array_equal(parts[:, k:], np.repeat(parts[:, k - 1 : k], T - k, axis=1)) and np.isfinite(parts).all()
 
 
 def test_tree_kernel_survives_falls(spot):

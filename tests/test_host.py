@@ -359,7 +359,7 @@ def test_spot_task_layer_matches_reference_golden():
 def test_tree_model_image():
     """Host-side packing for the floating-base tree kernel: structure checks, image layout, rejection of models outside its scope."""
     from judo_amd import models
-    from judo_amd.tree_model import TD_F, TD_I, TG_F, TG_I, TH_F, TH_I, pack_tree_blob, pack_tree_model, tree_structure
+    from judo_amd.tree_model import TD_F, TD_I, TG_F, TG_I, TH_F, TH_I, TS_F, TS_I, pack_tree_blob, pack_tree_model, tree_structure
 
     desc = models.load_description("spot")
     st = tree_structure(desc)
@@ -372,11 +372,15 @@ def test_tree_model_image():
     F, I = pack_tree_model(desc)
     nj, ng = int(I[0]), int(I[1])
     assert (nj, ng, int(I[2]), int(I[3])) == (19, 27, 26, 25)
-    assert F.size == TH_F + nj * TD_F + ng * TG_F and I.size == TH_I + nj * TD_I + ng * TG_I and F.dtype == np.float32 and I.dtype == np.int32
+    nsen, nsd = int(I[4]), int(I[5])
+    assert (nsen, nsd) == (16, 48)
+    assert F.size == TH_F + nj * TD_F + ng * TG_F + nsen * TS_F and I.size == TH_I + nj * TD_I + ng * TG_I + nsen * TS_I and F.dtype == np.float32 and I.dtype == np.int32
+    srec = I[TH_I + nj * TD_I + ng * TG_I :].reshape(nsen, TS_I)
+    assert list(srec[:, 2]) == list(range(0, 48, 3)) and set(srec[:, 0]) == {0, 1, 2, 3} and srec[0, 3] == 1 and (srec[2:4, 1] == -2).all()   # object axes sit on a world-fixed site
     assert abs(F[0] - 0.01) < 1e-9 and np.allclose(F[11:14], [0, 0, 1]) and np.allclose(F[5:8], [0, 0, -9.81])
     M, _ = models.mass_matrix(desc, models.qpos0(desc))
     assert abs(sum(F[TH_F + k * TD_F + 15] for k in range(nj)) + F[14] - M[0, 0]) < 1e-4   # link masses add up to the translational inertia
-    owners = I[TH_I + nj * TD_I :: TG_I][:ng]
+    owners = I[TH_I + nj * TD_I : TH_I + nj * TD_I + ng * TG_I : TG_I]
     assert owners.min() == -1 and owners.max() < nj
     blob = pack_tree_blob(desc)
     hd = np.frombuffer(blob[:16], dtype=np.uint32)
