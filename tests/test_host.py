@@ -388,3 +388,32 @@ def test_tree_model_image():
     for other in ("leap_cube", "fr3_pick", "cartpole"):
         with pytest.raises(NotImplementedError):
             pack_tree_model(models.load_description(other))
+
+
+def test_tree_create_rejects_images_outside_the_kernel_instantiation():
+    """jh_tree_create validates the image before it touches the device: these calls fail with a message on a box without a GPU too."""
+    from judo_amd import _lib, models
+    from judo_amd.tree_model import TD_I, TH_I, pack_tree_blob
+
+    L = _lib.lib()
+    L.jh_last_error.restype = ctypes.c_char_p
+    blob = bytearray(pack_tree_blob(models.load_description("spot")))
+
+    def create(b):
+        buf = (ctypes.c_char * len(b)).from_buffer_copy(bytes(b))
+        h = ctypes.c_void_p()
+        rc = L.jh_tree_create(ctypes.cast(buf, ctypes.c_void_p), len(b), ctypes.byref(h))
+        return rc, (L.jh_last_error() or b"").decode()
+
+    bad = bytearray(blob); bad[0] ^= 0xFF
+    rc, msg = create(bad)
+    assert rc < 0 and "magic" in msg
+    rc, msg = create(blob[:-4])
+    assert rc < 0 and "size" in msg
+    hd = np.frombuffer(bytes(blob[:16]), dtype=np.uint32)
+    nf = int(hd[1])
+    ints = np.frombuffer(bytes(blob[16 + 4 * nf :]), dtype=np.int32).copy()
+    ints[TH_I + 3 * TD_I + 1 : TH_I + 3 * TD_I + 3] = [0, 3]       # the fourth joint claims to extend the first leg: not the {3,3,3,3,7} layout
+    wrong = bytes(blob[: 16 + 4 * nf]) + ints.tobytes()
+    rc, msg = create(wrong)
+    assert rc < 0 and "chain" in msg
