@@ -8,6 +8,10 @@
 // alternates the two for a whole rollout.
 #include "jh_internal.h"
 
+#ifndef JH_POLICY_SMALL_MAX
+#define JH_POLICY_SMALL_MAX 1024
+#endif
+
 namespace {
 
 constexpr int OBS = 84, H0 = 512, H1 = 256, H2 = 128, ACT = 12, NJ = 19, NCMD = 25;
@@ -26,12 +30,12 @@ __device__ __forceinline__ void rot_vec_quat(float* r, const float* v, const flo
   r[2] = 2 * (x * z - w * y) * v[0] + 2 * (y * z + w * x) * v[1] + (1 - 2 * (x * x + y * y)) * v[2];
 }
 
-// one thread per rollout; the row is assembled in registers and written as 84 consecutive floats
-__global__ __launch_bounds__(256) void k_policy_obs(PolicyTables T, const float* __restrict__ states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos,
-                                                    int leg_qvel, const float* __restrict__ command, int ldc, const float* __restrict__ prev_out, int N,
-                                                    float* __restrict__ obs) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+struct ObsLayout { int ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, ldc; };
+
+// one thread per rollout; the row is written as 84 consecutive floats
+__device__ __forceinline__ void obs_row(const PolicyTables& T, const float* __restrict__ states, const ObsLayout& Y, const float* __restrict__ command,
+                                        const float* __restrict__ prev_out, int n, float* __restrict__ obs) {
+  const int ld = Y.ld, nq = Y.nq, base_qpos = Y.base_qpos, base_qvel = Y.base_qvel, leg_qpos = Y.leg_qpos, leg_qvel = Y.leg_qvel, ldc = Y.ldc;
   const float* qpos = states + (size_t)n * ld; const float* qvel = qpos + nq;
   const float* cmd = command + (size_t)n * ldc;
   float* o = obs + (size_t)n * OBS;
@@ -44,32 +48,52 @@ __global__ __launch_bounds__(256) void k_policy_obs(PolicyTables T, const float*
   for (int i = 0; i < 12; i++) { o[19 + i] = cmd[10 + i]; o[72 + i] = prev_out[(size_t)n * ACT + i]; }
   for (int i = 0; i < NJ; i++) { o[34 + T.m2o[i]] = qpos[leg_qpos + i] - T.default_pos[i]; o[53 + T.m2o[i]] = qvel[leg_qvel + i]; }
 }
+__global__ __launch_bounds__(256) void k_policy_obs(PolicyTables T, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
+                                                    const float* __restrict__ prev_out, int N, float* __restrict__ obs) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) obs_row(T, states, Y, command, prev_out, n, obs);
+}
 
 // C (M x Nout) = act(A (M x K) * W^T + b), W is (Nout x K) row-major (the ONNX Gemm layout with transB = 1).
 // Workgroup = 4 waves, tile 128 x 128, K in chunks of 32 staged in LDS; each wave owns a 64 x 64 quadrant as 2 x 2 MFMA accumulators
 // (four independent accumulation chains keep the matrix pipe busy from a single wave per SIMD).
 // Operand map of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
 // result register v of lane l is C[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31].
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
+
 template <bool ELU>
 __global__ __launch_bounds__(256) void k_gemm_bias_act(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
                                                        int Nout, float* __restrict__ C) {
-  constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
   __shared__ float sA[BM * LDT], sW[BN * LDT];
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, wm = wave & 1, wn = wave >> 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   f32x16 acc[2][2];
   for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int v = 0; v < 16; v++) acc[i][j][v] = 0.f;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  // Software pipeline: the global loads of chunk k+1 are in flight while the MFMAs of chunk k run (each thread stages 4 + 4 float4 in registers).
+  // At the few dozen rollouts the reference ships a layer is one or two workgroups walking K serially: the exposed load latency per chunk was the
+  // whole cost of the policy step there.
+  constexpr int PER = BM * (BK / 4) / 256;  // float4 slots per thread and matrix
+  f32x4 ra[PER], rw[PER];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4, k = k0 + c;  // K is a multiple of 4 on every layer: 16-byte loads, 8 per row and chunk
+      ra[q] = f32x4{0.f, 0.f, 0.f, 0.f}; rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m0 + r < M && k < K) ra[q] = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
+      if (n0 + r < Nout && k < K) rw[q] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += BK) {
-    for (int e = tid; e < BM * (BK / 4); e += 256) {  // K is a multiple of 4 on every layer: 16-byte loads, 8 per row and chunk
-      const int r = e >> 3, c = (e & 7) * 4, k = k0 + c;
-      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < M && k < K) va = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
-      if (n0 + r < Nout && k < K) vw = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4;
       float* pa_ = sA + r * LDT + c; float* pw_ = sW + r * LDT + c;
-      pa_[0] = va.x; pa_[1] = va.y; pa_[2] = va.z; pa_[3] = va.w; pw_[0] = vw.x; pw_[1] = vw.y; pw_[2] = vw.z; pw_[3] = vw.w;
+      pa_[0] = ra[q].x; pa_[1] = ra[q].y; pa_[2] = ra[q].z; pa_[3] = ra[q].w; pw_[0] = rw[q].x; pw_[1] = rw[q].y; pw_[2] = rw[q].z; pw_[3] = rw[q].w;
     }
     __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
     const float* pa = sA + (64 * wm + (l & 31)) * LDT + (l >> 5);
     const float* pw = sW + (64 * wn + (l & 31)) * LDT + (l >> 5);
 #pragma unroll
@@ -101,10 +125,8 @@ __global__ __launch_bounds__(256) void k_gemm_bias_act(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void k_policy_control(PolicyTables T, const float* __restrict__ obs, const float* __restrict__ actions, int N,
-                                                        float* __restrict__ policy_out, float* __restrict__ control) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+__device__ __forceinline__ void control_row(const PolicyTables& T, const float* __restrict__ obs, const float* __restrict__ actions, int n,
+                                            float* __restrict__ policy_out, float* __restrict__ control) {
   const float* o = obs + (size_t)n * OBS; const float* a = actions + (size_t)n * ACT;
   float c[NJ];
   for (int i = 0; i < ACT; i++) { const float ai = a[i]; policy_out[(size_t)n * ACT + i] = ai; c[T.o2m_legs[i]] = 0.2f * ai; }
@@ -116,6 +138,78 @@ __global__ __launch_bounds__(256) void k_policy_control(PolicyTables T, const fl
     if (!done && x * x + y * y + z * z > 0.f) { c[3 * leg] = x; c[3 * leg + 1] = y; c[3 * leg + 2] = z; done = true; }
   }
   for (int i = 0; i < NJ; i++) control[(size_t)n * NJ + i] = c[i];
+}
+__global__ __launch_bounds__(256) void k_policy_control(PolicyTables T, const float* __restrict__ obs, const float* __restrict__ actions, int N,
+                                                        float* __restrict__ policy_out, float* __restrict__ control) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) control_row(T, obs, actions, n, policy_out, control);
+}
+
+// ---- the latency regime (the reference ships 24 rollouts): the whole policy step in ONE launch.  A workgroup takes 32 rollouts through the observation, the four
+// layers and the control mapping; a layer's column tiles (32 x 128: one 32 x 32 MFMA accumulator per wave) are walked one after the other with the next K-chunk's
+// loads in flight, the activations go through the global scratch (L2).  Six launches of mostly empty 128-row tiles cost ~100 us at 24 rollouts, this ~35.
+struct ActorWeights { const float* w[4]; const float* b[4]; };
+constexpr int SM = 32;
+
+template <bool ELU>
+__device__ __forceinline__ void small_layer(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias, int M, int K, int Nout,
+                                            float* __restrict__ C, int m0, float* sA, float* sW) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+  for (int n0 = 0; n0 < Nout; n0 += BN) {
+    f32x16 acc;
+    for (int v = 0; v < 16; v++) acc[v] = 0.f;
+    f32x4 ra, rw[4];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+      {  // A: 32 rows x 8 float4 = one per thread
+        const int r = tid >> 3, c = (tid & 7) * 4, k = k0 + c;
+        ra = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M && k < K) ra = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {  // W: 128 rows x 8 float4 = four per thread
+        const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4, k = k0 + c;
+        rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n0 + r < Nout && k < K) rw[q] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
+      }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+      { const int r = tid >> 3, c = (tid & 7) * 4; float* pa_ = sA + r * LDT + c; pa_[0] = ra.x; pa_[1] = ra.y; pa_[2] = ra.z; pa_[3] = ra.w; }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4; float* pw_ = sW + r * LDT + c; pw_[0] = rw[q].x; pw_[1] = rw[q].y; pw_[2] = rw[q].z; pw_[3] = rw[q].w; }
+      __syncthreads();
+      if (k0 + BK < K) fetch(k0 + BK);
+      const float* pa = sA + (l & 31) * LDT + (l >> 5);
+      const float* pw = sW + (32 * wave + (l & 31)) * LDT + (l >> 5);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pw[kk], acc, 0, 0, 0);
+      __syncthreads();
+    }
+    const int col = n0 + 32 * wave + (l & 31);
+    if (col < Nout) {
+      const float b = bias[col];
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int row = m0 + (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+        if (row < M) { float x = acc[v] + b; if (ELU) x = x > 0.f ? x : expm1f(x); C[(size_t)row * Nout + col] = x; }
+      }
+    }
+  }
+  __syncthreads();  // the layer's activations are visible to the whole workgroup before the next layer reads them
+}
+
+__global__ __launch_bounds__(256) void k_policy_small(PolicyTables T, ActorWeights Wt, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
+                                                      float* policy_out, int N, float* obs, float* h0, float* h1, float* h2, float* act, float* __restrict__ control) {
+  __shared__ float sA[SM * LDT], sW[BN * LDT];
+  const int m0 = blockIdx.x * SM;
+  if ((int)threadIdx.x < SM && m0 + (int)threadIdx.x < N) obs_row(T, states, Y, command, policy_out, m0 + threadIdx.x, obs);
+  __syncthreads();
+  small_layer<true>(obs, Wt.w[0], Wt.b[0], N, OBS, H0, h0, m0, sA, sW);
+  small_layer<true>(h0, Wt.w[1], Wt.b[1], N, H0, H1, h1, m0, sA, sW);
+  small_layer<true>(h1, Wt.w[2], Wt.b[2], N, H1, H2, h2, m0, sA, sW);
+  small_layer<false>(h2, Wt.w[3], Wt.b[3], N, H2, ACT, act, m0, sA, sW);
+  if ((int)threadIdx.x < SM && m0 + (int)threadIdx.x < N) control_row(T, obs, act, m0 + threadIdx.x, policy_out, control);
 }
 
 }  // namespace
@@ -154,14 +248,19 @@ extern "C" size_t jh_policy_scratch_floats(int N) { return (size_t)(N > 0 ? N : 
 int jh_policy_step_strided(const jh_policy* p, const float* states, int ld, int nq, int base_qpos, int base_qvel, int leg_qpos, int leg_qvel, const float* command, int ldc,
                            float* policy_out, float* control, float* scratch, int N, hipStream_t st) {
   float* obs = scratch; float* h0 = obs + (size_t)N * OBS; float* h1 = h0 + (size_t)N * H0; float* h2 = h1 + (size_t)N * H1; float* act = h2 + (size_t)N * H2;
-  const int nb = (N + 255) / 256;
-  hipLaunchKernelGGL(k_policy_obs, dim3(nb), dim3(256), 0, st, p->tab, states, ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, command, ldc, policy_out, N, obs);
-  const int mb = (N + 127) / 128;
-  hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H0 / 128), dim3(256), 0, st, obs, p->d_w[0], p->d_b[0], N, OBS, H0, h0);
-  hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H1 / 128), dim3(256), 0, st, h0, p->d_w[1], p->d_b[1], N, H0, H1, h1);
-  hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H2 / 128), dim3(256), 0, st, h1, p->d_w[2], p->d_b[2], N, H1, H2, h2);
-  hipLaunchKernelGGL(k_gemm_bias_act<false>, dim3(mb, 1), dim3(256), 0, st, h2, p->d_w[3], p->d_b[3], N, H2, ACT, act);
-  hipLaunchKernelGGL(k_policy_control, dim3(nb), dim3(256), 0, st, p->tab, obs, act, N, policy_out, control);
+  const ObsLayout Y = {ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, ldc};
+  if (N <= JH_POLICY_SMALL_MAX) {  // latency regime: one launch
+    ActorWeights Wt; for (int i = 0; i < 4; i++) { Wt.w[i] = p->d_w[i]; Wt.b[i] = p->d_b[i]; }
+    hipLaunchKernelGGL(k_policy_small, dim3((N + SM - 1) / SM), dim3(256), 0, st, p->tab, Wt, states, Y, command, policy_out, N, obs, h0, h1, h2, act, control);
+  } else {          // throughput regime: every layer fills the chip with its own grid of 128 x 128 tiles
+    const int nb = (N + 255) / 256, mb = (N + 127) / 128;
+    hipLaunchKernelGGL(k_policy_obs, dim3(nb), dim3(256), 0, st, p->tab, states, Y, command, policy_out, N, obs);
+    hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H0 / 128), dim3(256), 0, st, obs, p->d_w[0], p->d_b[0], N, OBS, H0, h0);
+    hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H1 / 128), dim3(256), 0, st, h0, p->d_w[1], p->d_b[1], N, H0, H1, h1);
+    hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H2 / 128), dim3(256), 0, st, h1, p->d_w[2], p->d_b[2], N, H1, H2, h2);
+    hipLaunchKernelGGL(k_gemm_bias_act<false>, dim3(mb, 1), dim3(256), 0, st, h2, p->d_w[3], p->d_b[3], N, H2, ACT, act);
+    hipLaunchKernelGGL(k_policy_control, dim3(nb), dim3(256), 0, st, p->tab, obs, act, N, policy_out, control);
+  }
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
