@@ -1,16 +1,13 @@
 // jh_policy.hip -- the policy half of the Spot policy rollout (mujoco_extensions/system/system_class.cpp:125-238), batched over rollouts:
-//   k_policy_obs      System::setObservation: 84-d observation per rollout from its state, its 25-d command and its previous policy output
-//   k_gemm_bias_act   the actor 84 -> 512 -> 256 -> 128 -> 12 (Gemm + Elu, spot_locomotion.onnx): exact-f32 MFMA tiles
-//                     (v_mfma_f32_32x32x2_f32; same arithmetic as an fmaf chain, at the f32 vector rate but one VGPR per operand)
-//   k_policy_control  System::policyInference's mapping of the 12 actions to the 19 joint targets, arm pass-through, leg override
+//   obs_row       System::setObservation: 84-d observation per rollout from its state, its 25-d command and its previous policy output
+//   small_layer   the actor 84 -> 512 -> 256 -> 128 -> 12 (Gemm + Elu, spot_locomotion.onnx): exact-f32 MFMA tiles
+//                 (v_mfma_f32_32x32x2_f32; same arithmetic as an fmaf chain, at the f32 vector rate but one VGPR per operand)
+//   control_row   System::policyInference's mapping of the 12 actions to the 19 joint targets, arm pass-through, leg override
+//   k_policy_step all of it in one launch
 // This is the one dense contraction on the path: a batch of N rollouts is an (N x 84) x (84 x 512) ... GEMM chain,
 // 0.42 MFLOP per rollout and control step.  The physics substeps between two policy steps are jh_engine_v4.hip (k_tree_v4); jh_policy_rollout there
 // alternates the two for a whole rollout.
 #include "jh_internal.h"
-
-#ifndef JH_POLICY_SMALL_MAX
-#define JH_POLICY_SMALL_MAX 1024
-#endif
 
 namespace {
 
@@ -48,82 +45,7 @@ __device__ __forceinline__ void obs_row(const PolicyTables& T, const float* __re
   for (int i = 0; i < 12; i++) { o[19 + i] = cmd[10 + i]; o[72 + i] = prev_out[(size_t)n * ACT + i]; }
   for (int i = 0; i < NJ; i++) { o[34 + T.m2o[i]] = qpos[leg_qpos + i] - T.default_pos[i]; o[53 + T.m2o[i]] = qvel[leg_qvel + i]; }
 }
-__global__ __launch_bounds__(256) void k_policy_obs(PolicyTables T, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
-                                                    const float* __restrict__ prev_out, int N, float* __restrict__ obs) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n < N) obs_row(T, states, Y, command, prev_out, n, obs);
-}
-
-// C (M x Nout) = act(A (M x K) * W^T + b), W is (Nout x K) row-major (the ONNX Gemm layout with transB = 1).
-// Workgroup = 4 waves, tile 128 x 128, K in chunks of 32 staged in LDS; each wave owns a 64 x 64 quadrant as 2 x 2 MFMA accumulators
-// (four independent accumulation chains keep the matrix pipe busy from a single wave per SIMD).
-// Operand map of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
-// result register v of lane l is C[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31].
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
-
-template <bool ELU>
-__global__ __launch_bounds__(256) void k_gemm_bias_act(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias, int M, int K,
-                                                       int Nout, float* __restrict__ C) {
-  __shared__ float sA[BM * LDT], sW[BN * LDT];
-  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  f32x16 acc[2][2];
-  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int v = 0; v < 16; v++) acc[i][j][v] = 0.f;
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  // Software pipeline: the global loads of chunk k+1 are in flight while the MFMAs of chunk k run (each thread stages 4 + 4 float4 in registers).
-  // At the few dozen rollouts the reference ships a layer is one or two workgroups walking K serially: the exposed load latency per chunk was the
-  // whole cost of the policy step there.
-  constexpr int PER = BM * (BK / 4) / 256;  // float4 slots per thread and matrix
-  f32x4 ra[PER], rw[PER];
-  auto fetch = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < PER; q++) {
-      const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4, k = k0 + c;  // K is a multiple of 4 on every layer: 16-byte loads, 8 per row and chunk
-      ra[q] = f32x4{0.f, 0.f, 0.f, 0.f}; rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < M && k < K) ra[q] = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
-      if (n0 + r < Nout && k < K) rw[q] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
-    }
-  };
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-#pragma unroll
-    for (int q = 0; q < PER; q++) {
-      const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4;
-      float* pa_ = sA + r * LDT + c; float* pw_ = sW + r * LDT + c;
-      pa_[0] = ra[q].x; pa_[1] = ra[q].y; pa_[2] = ra[q].z; pa_[3] = ra[q].w; pw_[0] = rw[q].x; pw_[1] = rw[q].y; pw_[2] = rw[q].z; pw_[3] = rw[q].w;
-    }
-    __syncthreads();
-    if (k0 + BK < K) fetch(k0 + BK);
-    const float* pa = sA + (64 * wm + (l & 31)) * LDT + (l >> 5);
-    const float* pw = sW + (64 * wn + (l & 31)) * LDT + (l >> 5);
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = pa[kk], a1 = pa[32 * LDT + kk], b0 = pw[kk], b1 = pw[32 * LDT + kk];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int col = n0 + 64 * wn + 32 * j + (l & 31);
-    if (col >= Nout) continue;
-    const float b = bias[col];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int v = 0; v < 16; v++) {
-        const int row = m0 + 64 * wm + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
-        if (row < M) {
-          float x = acc[i][j][v] + b;
-          if (ELU) x = x > 0.f ? x : expm1f(x);
-          C[(size_t)row * Nout + col] = x;
-        }
-      }
-  }
-}
+constexpr int BN = 128, BK = 32, LDT = BK + 1;
 
 __device__ __forceinline__ void control_row(const PolicyTables& T, const float* __restrict__ obs, const float* __restrict__ actions, int n,
                                             float* __restrict__ policy_out, float* __restrict__ control) {
@@ -139,15 +61,13 @@ __device__ __forceinline__ void control_row(const PolicyTables& T, const float* 
   }
   for (int i = 0; i < NJ; i++) control[(size_t)n * NJ + i] = c[i];
 }
-__global__ __launch_bounds__(256) void k_policy_control(PolicyTables T, const float* __restrict__ obs, const float* __restrict__ actions, int N,
-                                                        float* __restrict__ policy_out, float* __restrict__ control) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n < N) control_row(T, obs, actions, n, policy_out, control);
-}
-
-// ---- the latency regime (the reference ships 24 rollouts): the whole policy step in ONE launch.  A workgroup takes 32 rollouts through the observation, the four
-// layers and the control mapping; a layer's column tiles (32 x 128: one 32 x 32 MFMA accumulator per wave) are walked one after the other with the next K-chunk's
-// loads in flight, the activations go through the global scratch (L2).  Six launches of mostly empty 128-row tiles cost ~100 us at 24 rollouts, this ~35.
+// ---- the whole policy step in ONE launch.  A workgroup (4 waves) takes 32 rollouts through the observation, the four layers and the control mapping.
+// C (32 x Nout) = act(A (32 x K) W^T + b), W (Nout x K) row-major (the ONNX Gemm layout with transB = 1): a layer's column tiles (32 x 128, one 32 x 32 MFMA
+// accumulator per wave) are walked one after the other, K in chunks of 32 staged in LDS with the next chunk's global loads in flight; the activations go through
+// the global scratch (L2-resident).  Operand map of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; result
+// register v of lane l is C[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31].
+// History: one launch per layer with 128 x 128 tiles (2 x 2 accumulators per wave) took 510 us at 65 536 rollouts and ~100 us at the 24 the reference ships (six
+// launches of mostly empty tiles); this kernel takes 380 us and 45 us.
 struct ActorWeights { const float* w[4]; const float* b[4]; };
 constexpr int SM = 32;
 
@@ -199,7 +119,7 @@ __device__ __forceinline__ void small_layer(const float* __restrict__ A, const f
   __syncthreads();  // the layer's activations are visible to the whole workgroup before the next layer reads them
 }
 
-__global__ __launch_bounds__(256) void k_policy_small(PolicyTables T, ActorWeights Wt, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
+__global__ __launch_bounds__(256) void k_policy_step(PolicyTables T, ActorWeights Wt, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
                                                       float* policy_out, int N, float* obs, float* h0, float* h1, float* h2, float* act, float* __restrict__ control) {
   __shared__ float sA[SM * LDT], sW[BN * LDT];
   const int m0 = blockIdx.x * SM;
@@ -249,18 +169,8 @@ int jh_policy_step_strided(const jh_policy* p, const float* states, int ld, int 
                            float* policy_out, float* control, float* scratch, int N, hipStream_t st) {
   float* obs = scratch; float* h0 = obs + (size_t)N * OBS; float* h1 = h0 + (size_t)N * H0; float* h2 = h1 + (size_t)N * H1; float* act = h2 + (size_t)N * H2;
   const ObsLayout Y = {ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, ldc};
-  if (N <= JH_POLICY_SMALL_MAX) {  // latency regime: one launch
-    ActorWeights Wt; for (int i = 0; i < 4; i++) { Wt.w[i] = p->d_w[i]; Wt.b[i] = p->d_b[i]; }
-    hipLaunchKernelGGL(k_policy_small, dim3((N + SM - 1) / SM), dim3(256), 0, st, p->tab, Wt, states, Y, command, policy_out, N, obs, h0, h1, h2, act, control);
-  } else {          // throughput regime: every layer fills the chip with its own grid of 128 x 128 tiles
-    const int nb = (N + 255) / 256, mb = (N + 127) / 128;
-    hipLaunchKernelGGL(k_policy_obs, dim3(nb), dim3(256), 0, st, p->tab, states, Y, command, policy_out, N, obs);
-    hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H0 / 128), dim3(256), 0, st, obs, p->d_w[0], p->d_b[0], N, OBS, H0, h0);
-    hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H1 / 128), dim3(256), 0, st, h0, p->d_w[1], p->d_b[1], N, H0, H1, h1);
-    hipLaunchKernelGGL(k_gemm_bias_act<true>, dim3(mb, H2 / 128), dim3(256), 0, st, h1, p->d_w[2], p->d_b[2], N, H1, H2, h2);
-    hipLaunchKernelGGL(k_gemm_bias_act<false>, dim3(mb, 1), dim3(256), 0, st, h2, p->d_w[3], p->d_b[3], N, H2, ACT, act);
-    hipLaunchKernelGGL(k_policy_control, dim3(nb), dim3(256), 0, st, p->tab, obs, act, N, policy_out, control);
-  }
+  ActorWeights Wt; for (int i = 0; i < 4; i++) { Wt.w[i] = p->d_w[i]; Wt.b[i] = p->d_b[i]; }
+  hipLaunchKernelGGL(k_policy_step, dim3((N + SM - 1) / SM), dim3(256), 0, st, p->tab, Wt, states, Y, command, policy_out, N, obs, h0, h1, h2, act, control);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
