@@ -240,7 +240,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
       v = jh_clampf(v, lohi[l], lohi[NU + l]);
       kn[k] = v;
+#ifndef JH_V2_ITERDUMP
       if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
+#endif
     }
   }
   int n_overflow = 0, n_iters = 0, n_maxed = 0;
@@ -769,6 +771,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
 #endif
       }
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
+#ifdef JH_V2_ITERDUMP  // diagnostics: Newton iterations of every rollout and step, in the buffer of the candidate knots ((K nu) x N floats >= H x N)
+      if (l == 0 && live && knots_out && hh < 64) knots_out[(size_t)hh * ldn + n] = (float)iters_this;
+#endif
 #ifdef JH_ENGINE_PROFILE
       if (l == 0 && live && stats) atomicAdd(stats + 24 + (iters_this < 23 ? iters_this : 23), 1);
 #endif
