@@ -31,9 +31,6 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V2_NSLOT
 #define JH_V2_NSLOT 2
 #endif
-#ifndef JH_V2_LSSAFE
-#define JH_V2_LSSAFE 3  // line search: free Newton steps for the first evaluations, then every evaluation has to halve the bracket or is followed by a bisection
-#endif
 constexpr int NSLOT = JH_V2_NSLOT;
 constexpr int NCP = 16 * NSLOT;  // contact pool per rollout = NSLOT slots per lane
 constexpr int MAXHIT = 32;  // broad-phase survivors per rollout
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
       if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
       v = jh_clampf(v, lohi[l], lohi[NU + l]);
       kn[k] = v;
-#if !defined(JH_V2_ITERDUMP) && !defined(JH_V2_LSTRACE)
+#ifndef JH_V2_ITERDUMP
       if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
 #endif
     }
@@ -723,19 +720,11 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         for (int k = 0; k < NSLOT; k++) if (sl[k].valid) slot_Jx(sl[k], xc6, S.p, sl[k].jp);
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo, hi, alpha, dlo, dhi; int side; bool lsact;
-#ifdef JH_V2_LSTRACE
-        float tr_a[12], tr_d1[12], tr_d2[12];
-        for (int q = 0; q < 12; q++) tr_a[q] = tr_d1[q] = tr_d2[q] = 0.f;
-#endif
 #if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
         int ls_evals = 0;
 #endif
         V2_REPEAT(3) {
         lo = 0.f; hi = -1.f; alpha = 1.f; dlo = gp; dhi = 0.f; side = 0; lsact = act;
-#ifndef JH_V2_LSSINGLE
-        float clo = -gp, chi = 0.f;  // curvature at the bracket ends (at 0: p'Hp = -g'p)
-        float wprev = 3.0e38f;       // width of the bracket after the previous evaluation
-#endif
         V2_OPAQUE(alpha);
         for (int ls = 0; ls < JH_V2_LSMAX && __any(lsact); ls++) {
           float d1, d2;
@@ -744,37 +733,10 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
 #endif
           lane_rows_dir(sl, dr, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
-#ifdef JH_V2_LSTRACE
-          if (lsact && ls < 12) { tr_a[ls] = alpha; tr_d1[ls] = d1; tr_d2[ls] = d2; }
-#endif
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
               // bracket [lo, hi] with the slopes at both ends; Newton step from the current point, else Illinois secant, else bisection
-#ifndef JH_V2_LSSINGLE
-              const bool left = d1 < 0.f;
-              if (left) { lo = alpha; dlo = d1; clo = d2; } else { hi = alpha; dhi = d1; chi = d2; }
-              float nx = alpha - d1 * __frcp_rn(d2);
-              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
-              else if (nx <= lo || nx >= hi) {
-                // the Newton step from the new point leaves the bracket: take the one from the opposite end (its slope and curvature are known), then bisect
-                const float ox = left ? hi : lo, od = left ? dhi : dlo, oc = left ? chi : clo;
-                nx = ox - od * __frcp_rn(oc);
-                if (!(nx > lo && nx < hi)) nx = 0.5f * (lo + hi);
-              }
-#ifdef JH_V2_LSSAFE
-              if (hi > 0.f && ls >= JH_V2_LSSAFE) {  // safeguard (rtsafe), after the first JH_V2_LSSAFE free Newton evaluations: an evaluation that did not at least halve the bracket is followed by a bisection -- Newton creeping up
-                const float w = hi - lo;  // on the root from one side (curvature jumps at the cone-zone boundaries) otherwise ran into the evaluation cap
-                if (w > 0.5f * wprev) nx = 0.5f * (lo + hi);
-                wprev = w;
-              }
-#endif
-              alpha = nx;
-            }
-          }
-        }
-        }  // V2_REPEAT(3)
-#else
               if (d1 < 0.f) { lo = alpha; dlo = d1; if (side < 0) dhi *= 0.5f; side = -1; } else { hi = alpha; dhi = d1; if (side > 0) dlo *= 0.5f; side = 1; }
               float nx = alpha - d1 * __frcp_rn(d2);
               if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
@@ -792,35 +754,8 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
           }
         }
         }  // V2_REPEAT(3)
-#endif
-#if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST) && !defined(JH_V2_LSCAPDIAG)
+#if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSHIST)
         if (l == 0 && live && stats && act) atomicAdd(stats + 48 + (ls_evals < 15 ? ls_evals : 15), 1);
-#endif
-#ifdef JH_V2_LSTRACE  // the evaluation sequences of the first line searches that run into the cap, into the candidate-knot buffer (40 floats each)
-        if (l == 0 && live && stats && act && lsact && knots_out) {
-          const int slot = atomicAdd(stats + 60, 1);
-          if (slot < 200) {
-            float* o = knots_out + (size_t)slot * 40;
-            o[0] = gp; o[1] = pMp; o[2] = pMd; o[3] = (float)it;
-            for (int q = 0; q < 12; q++) { o[4 + 3 * q] = tr_a[q]; o[5 + 3 * q] = tr_d1[q]; o[6 + 3 * q] = tr_d2[q]; }
-          }
-        }
-#endif
-#if defined(JH_ENGINE_PROFILE) && defined(JH_V2_LSCAPDIAG)  // why do line searches run into the evaluation cap?  (slots 48..: categories)
-        if (l == 0 && live && stats && act) {
-          atomicAdd(stats + 48, 1);
-          if (lsact) {
-            float d1e, d2e; (void)d2e;
-            atomicAdd(stats + 49, 1);
-            if (hi < 0.f) atomicAdd(stats + 50, 1);                                   // never bracketed
-            else if (hi - lo <= 1e-3f * hi) atomicAdd(stats + 51, 1);                 // bracket tight, slope test still failing
-            else if (hi - lo <= 1e-1f * hi) atomicAdd(stats + 52, 1);
-            else atomicAdd(stats + 53, 1);                                           // bracket still wide
-            if (fabsf(gp) <= 1e-6f * fmaxf(snorm, 1e-12f)) atomicAdd(stats + 54, 1);  // tiny expected decrease (last iterations)
-            if (alpha < 1e-3f) atomicAdd(stats + 55, 1);
-            if (alpha > 10.f) atomicAdd(stats + 56, 1);
-          }
-        }
 #endif
         // ---- (6) step
         if (act) {

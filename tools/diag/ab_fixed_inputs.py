@@ -1,0 +1,27 @@
+"""Fair A/B of two library builds on the headline workload: the plan inputs (nominal knots, knot times) of 40 consecutive plan steps are recorded once
+(`record`), then every build replays exactly those inputs with the same noise (`replay`), so the plans cannot drift apart between the variants."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from judo_amd.controller import make_controller
+mode, path = sys.argv[1], sys.argv[2]
+S = 40
+c = make_controller("leap_cube", "mppi"); c.optimizer.config.num_rollouts = 65536; c.controller_cfg.horizon = 0.64
+c.reset(); c.current_state = c.task.default_state(); c.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])}
+if mode == "record":
+    c.optimizer.seed(1234); rec = []; t = 0.0
+    for i in range(S):
+        rec.append((c.nominal_knots.copy(), c.times.copy(), t)); c.time = t; c.update_action(); t += 0.05
+    np.savez(path, knots=np.stack([r[0] for r in rec]), times=np.stack([r[1] for r in rec]), t=np.array([r[2] for r in rec]))
+else:
+    d = np.load(path)
+    c.record_kernel_events = True
+    for rep in range(2):
+        c.kernel_events.clear()
+        for i in range(S):
+            c.optimizer.seed(1000 + i)
+            c.nominal_knots = d["knots"][i].copy(); c.times = d["times"][i].copy(); c.update_spline(c.times, c.nominal_knots); c.time = float(d["t"][i])
+            c.update_action()
+        torch.cuda.synchronize()
+        k = np.array([a.elapsed_time(b) for a, b in c.kernel_events])
+        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {c.model.stats()['newton_iters'] / (65536 * 64 * S):.3f}")
