@@ -23,7 +23,10 @@ namespace {
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V2_LSMAX
-#define JH_V2_LSMAX 12
+#define JH_V2_LSMAX 16  // line-search evaluation cap (MuJoCo: ls_iterations 50); measured on fixed plan inputs: 8 -> 96.5 ms, 10 -> 87.6, 12 -> 82.9, 16 -> 82.5, 24 -> 82.8
+#endif
+#if !defined(JH_V2_KEEPW) && !defined(JH_V2_RECOMPUTEW)
+#define JH_V2_KEEPW 1     // keep the cone weights of the gradient pass for the Hessian pass (12 registers) instead of evaluating the cones twice: -1.5 % on fixed plan inputs
 #endif
 #ifndef JH_V2_LSBRACKET
 #define JH_V2_LSBRACKET 0.f

@@ -16,7 +16,7 @@ if mode == "record":
 else:
     d = np.load(path)
     c.record_kernel_events = True
-    for rep in range(2):
+    for rep in range(int(os.environ.get("REPS", "1"))):
         c.kernel_events.clear()
         for i in range(S):
             c.optimizer.seed(1000 + i)
