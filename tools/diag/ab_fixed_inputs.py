@@ -5,14 +5,17 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from judo_amd.controller import make_controller
 mode, path = sys.argv[1], sys.argv[2]
+task = sys.argv[3] if len(sys.argv) > 3 else "leap_cube"
 S = 40
-c = make_controller("leap_cube", "mppi"); c.optimizer.config.num_rollouts = 65536; c.controller_cfg.horizon = 0.64
-c.reset(); c.current_state = c.task.default_state(); c.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])}
+OPT, NR, HS = {"leap_cube": ("mppi", 65536, 64), "fr3_pick": ("cem", 32768, 40)}[task]
+c = make_controller(task, OPT); c.optimizer.config.num_rollouts = NR; c.controller_cfg.horizon = HS * c.task.dt
+c.reset(); c.current_state = c.task.default_state(); c.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
 if mode == "record":
     c.optimizer.seed(1234); rec = []; t = 0.0
     for i in range(S):
-        rec.append((c.nominal_knots.copy(), c.times.copy(), t)); c.time = t; c.update_action(); t += 0.05
-    np.savez(path, knots=np.stack([r[0] for r in rec]), times=np.stack([r[1] for r in rec]), t=np.array([r[2] for r in rec]))
+        sig = np.array(getattr(c.optimizer, "sigma", 0.0)).copy()
+        rec.append((c.nominal_knots.copy(), c.times.copy(), t, sig)); c.time = t; c.update_action(); t += 0.05
+    np.savez(path, knots=np.stack([r[0] for r in rec]), times=np.stack([r[1] for r in rec]), t=np.array([r[2] for r in rec]), sigma=np.stack([r[3] for r in rec]))
 else:
     d = np.load(path)
     c.record_kernel_events = True
@@ -21,7 +24,8 @@ else:
         for i in range(S):
             c.optimizer.seed(1000 + i)
             c.nominal_knots = d["knots"][i].copy(); c.times = d["times"][i].copy(); c.update_spline(c.times, c.nominal_knots); c.time = float(d["t"][i])
+            if OPT == "cem": c.optimizer.sigma = d["sigma"][i].copy()
             c.update_action()
         torch.cuda.synchronize()
         k = np.array([a.elapsed_time(b) for a, b in c.kernel_events])
-        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {c.model.stats()['newton_iters'] / (65536 * 64 * S):.3f}")
+        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {c.model.stats()['newton_iters'] / (NR * HS * S):.3f}")
