@@ -258,6 +258,12 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
   __syncthreads();
   const int ndt = sNDT;
 
+#ifdef JH_V3_PHASES
+  long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH3(i) { const long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
+#else
+#define PH3(i)
+#endif
   for (int hh = 0; hh < H; hh++) {
     // ================================================================ controls
     float u = 0.f;
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       if (l == 0) { for (int k = 0; k < 3; k++) S.xpos[0][k] = qc[k]; for (int k = 0; k < 9; k++) S.xR[0][k] = Rc[k]; }
     }
     __syncthreads();
+    PH3(0)
     // ================================================================ sensors of this forward pass
     {
       if (l < m.NGS) {
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       __syncthreads();
       if (MATERIALIZE && sensors && live && l < NS) sensors[((size_t)nc * H + hh) * NS + l] = S.y[l];
     }
+    PH3(1)
     // ================================================================ arm dynamics: 9x9 inertia and bias from per-link contributions
     float Mrow[NA], a0_own, fs_own, Md_own, fsc[6], a0c[6];
     {
@@ -451,6 +459,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       if (!hasdof) { fs_own = 0.f; a0_own = 0.f; Md_own = 1.f; }
     }
     __syncthreads();
+    PH3(2)
     // ================================================================ collision: 63 candidate pairs over the lanes, balanced narrow phase
     {
       int nh = 0;
@@ -487,6 +496,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       }
     }
     __syncthreads();
+    PH3(3)
     // ================================================================ constraint rows
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
     const int nff = S.nff < NFF ? S.nff : NFF;
@@ -601,6 +611,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       const float imp = impedance(e_si, pos), R = fmaxf(1e-15f, (1.f - imp) / imp * e_invw);
       eD = 1.f / R; earef = -e_B * vel - e_K * imp * pos;
     }
+    PH3(4)
     // ================================================================ Newton solver
     float a_own;
     const float iMd = 1.f / Md_own;
@@ -812,6 +823,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       if (act) n_x[3]++;
 #endif
     }
+    PH3(5)
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
       __syncthreads();
@@ -879,6 +891,10 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
   if (!MATERIALIZE && live && l == 0) costs[n] = acc;
 #ifdef JH_V3_EXITSTATS
   if (stats && live && l == 0) for (int k = 0; k < 4; k++) atomicAdd(stats + 24 + k, n_x[k]);
+#ifdef JH_V3_PHASES
+  PH3(6)
+  if (stats && lane == 0) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)ph_acc[k]);
+#endif
 #endif
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
 }
