@@ -8,11 +8,12 @@
 //   every lane    one contact slot (capacity 32 per rollout)
 //
 // Dynamics in spatial-vector form about the base origin (an inertial point at this instant; keeps fp32 magnitudes small however far the
-// robot has walked): each dof lane publishes its spatial axis, each body lane its spatial inertia (10 numbers), composite inertias and bias
-// projections are accumulated along the (short) ancestor chains with LDS float atomics, M rows are `S_j . (Ic_i S_i)` over the ancestors
-// (mj_crb / mj_rne restated; oracle/jo_engine.c crb(), rne_bias()).  The three dense solves of a step -- M^-1 f, the Newton systems,
-// (M + h D)^-1 -- all run through one left-looking row Cholesky in which lane k publishes row k through LDS (same scheme as jh_engine_v3.hip).
-// Contacts: sphere / capsule / box against the plane (mjc_PlaneSphere / PlaneCapsule / PlaneBox), pyramidal cones, parameters mixed on the host.
+// robot has walked): each dof lane publishes its spatial axis, each body lane its spatial inertia (10 numbers) and bias wrench; composite inertias and
+// subtree wrenches are suffix sums along the chains plus one wave reduction for the base (fixed order, no atomics); M rows are `S_j . (Ic_i S_i)` over
+// the ancestors (mj_crb / mj_rne restated; oracle/jo_engine.c crb(), rne_bias()).  The solves of a step -- M^-1 f, the Newton systems, (M + h D)^-1 --
+// all run through tree_cholesky_solve: chains eliminated before the base (no fill-in), the small diagonal blocks factorised redundantly in registers,
+// three LDS exchanges per solve.  Contacts: sphere / capsule / box against the plane (mjc_PlaneSphere / PlaneCapsule / PlaneBox), pyramidal cones,
+// parameters mixed on the host; the contact Jacobian is compact (base + the contact's chain).  Sensors (site positions / frame axes) in the last step.
 #include "jh_coop.h"
 
 #include <vector>
