@@ -4,7 +4,7 @@
 A "step" is one full plan step (`Controller.update_action`): sample -> clip -> spline -> rollout -> cost -> update,
 including the all-gather when several GPUs take part and the device->host copy of the new nominal knots.
 Default workload = BASELINE.json's metric configuration: leap_cube MPPI, 65 536 rollouts x H = 64 (K = 4, cubic,
-sigma = 0.2 ramp 4, lambda = 0.0025), synthetic standard-normal noise drawn on the device (seed 1234 + rank), inputs
+sigma = 0.2 ramp 4, lambda = 0.0025), synthetic standard-normal noise drawn on the device (seed 1234; every rank keeps its shard of the same draw), inputs
 resident in HBM; the plan time advances 0.05 s per step (control_freq 20 Hz).  With N GPUs the 65 536 rollouts are
 sharded (strong scaling: total work fixed) -- one process per GPU, one RCCL all-gather of a 66-float record per step.
 
@@ -205,7 +205,7 @@ def main() -> None:
     ctrl.reset()
     ctrl.current_state = ctrl.task.default_state()
     ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if args.task == "leap_cube" else {}
-    ctrl.optimizer.seed(1234 + rank)
+    ctrl.optimizer.seed(1234)  # the same seed on every rank: each rank slices its shard out of the same noise, the plan does not depend on --gpus
     is_policy = ctrl.task.uses_locomotion_policy
     if is_policy:
         ctrl.rollout_cutoff_time = None  # throughput run: no 125 ms deadline

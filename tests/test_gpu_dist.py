@@ -28,7 +28,10 @@ def _plan(task, opt, N, noise, group=None):
     if ctrl.task.uses_locomotion_policy:  # the Spot policy rollout: policy step (MFMA GEMMs) + tree kernel per control step, sharded like everything else
         ctrl.rollout_cutoff_time = None
         ctrl.task.config.goal_position = np.array([1.0, 0.5, 0.52])
-    ctrl.optimizer.injected_noise = noise
+    if noise is None:
+        ctrl.optimizer.seed(77)   # device noise: every rank draws all rollouts' noise from the same seed and keeps its shard's columns
+    else:
+        ctrl.optimizer.injected_noise = noise
     ctrl.update_action()
     torch.cuda.synchronize()
     sig = np.asarray(ctrl.optimizer.sigma, dtype=np.float64) if opt == "cem" else np.zeros(1)
@@ -44,7 +47,7 @@ def _worker(rank, world, port, cases, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
-        noise = np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
+        noise = None if seed < 0 else np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
         nom, sig, shard, costs = _plan(task, opt, N, noise, group=dist.group.WORLD)
         assert (shard.world, shard.rank) == (world, rank) and shard.count in (N // world, N // world + 1)
         np.savez(os.path.join(out_dir, f"case{i}_rank{rank}.npz"), nom=nom, sig=sig, costs=costs)
@@ -56,11 +59,12 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
     import torch.multiprocessing as mp
 
     cases = [("cartpole", "mppi", 257, 1, 1), ("cylinder_push", "cem", 128, 2, 2), ("leap_cube", "mppi", 130, 16, 3), ("fr3_pick", "cem", 96, 8, 4),
-             ("cartpole", "ps", 64, 1, 5), ("spot_navigate", "mppi", 49, 3, 6)]
+             ("cartpole", "ps", 64, 1, 5), ("spot_navigate", "mppi", 49, 3, 6),
+             ("leap_cube", "mppi", 131, 16, -1), ("fr3_pick", "cem", 97, 8, -1)]   # seed < 0: noise drawn on the device, same seed on every rank
     world, port = 2, 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, cases, str(tmp_path)), nprocs=world, join=True)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
-        noise = np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
+        noise = None if seed < 0 else np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
         nom1, sig1, _, costs1 = _plan(task, opt, N, noise)
         r0, r1 = np.load(tmp_path / f"case{i}_rank0.npz"), np.load(tmp_path / f"case{i}_rank1.npz")
         np.testing.assert_array_equal(r0["nom"], r1["nom"])  # identical on every rank without a broadcast
