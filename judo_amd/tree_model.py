@@ -19,7 +19,7 @@ TH_F, TH_I = 32, 16           # header sizes
 TD_F, TD_I = 56, 4            # per joint dof
 TG_F, TG_I = 28, 2            # per geom
 TS_F, TS_I = 16, 4            # per sensor
-SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-3
+SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-4, 20, 1e-2
 GTYPE = {"sphere": 2, "capsule": 3, "box": 6}
 MAX_JOINTS, MAX_GEOMS, MAX_DEPTH = 25, 31, 7
 

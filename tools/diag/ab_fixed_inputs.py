@@ -4,6 +4,9 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from judo_amd.controller import make_controller
+from judo_amd import engine_model as EM
+if os.environ.get("LSTOL"): EM.SOLVER_LS_TOL = float(os.environ["LSTOL"])
+if os.environ.get("TOL"): EM.SOLVER_TOL = float(os.environ["TOL"])
 mode, path = sys.argv[1], sys.argv[2]
 task = sys.argv[3] if len(sys.argv) > 3 else "leap_cube"
 S = 40
@@ -28,4 +31,4 @@ else:
             c.update_action()
         torch.cuda.synchronize()
         k = np.array([a.elapsed_time(b) for a, b in c.kernel_events])
-        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {c.model.stats()['newton_iters'] / (NR * HS * S):.3f}")
+        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')} lstol={EM.SOLVER_LS_TOL:g} tol={EM.SOLVER_TOL:g}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {c.model.stats()['newton_iters'] / (NR * HS * S):.3f}")
