@@ -14,4 +14,4 @@ for task in leap_cube fr3_pick; do
   done
   python $root/tools/rocpd_summary.py $(find $out -name "${task}_results.db" | sort) > $out/${task}_summary.txt 2>&1
 done
-ls $out; tail -3 $out/*_bench_under_rocprof.json | cut -c1-200
+ls $out; for f in $out/*_bench_under_rocprof.json; do tail -n 1 $f | cut -c1-200; done
