@@ -162,6 +162,24 @@ def materialize_line(args, torch, world: int, rank: int) -> None:
         torch.distributed.destroy_process_group()
 
 
+def launch_ranks(n: int, n_devices: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks, one per GPU, over RCCL
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`).  Returns the exit status."""
+    import socket
+    import subprocess
+
+    if n_devices < n:
+        print(f"bench.py: --gpus {n} but only {n_devices} GPU(s) are visible; refusing to run a smaller job under that label", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,19 +194,26 @@ def main() -> None:
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and world != args.gpus:  # never run a smaller (or larger) job under the --gpus label
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (plain `python bench.py --gpus N` spawns them itself)")
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, torch.cuda.device_count()))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     if args.mode == "materialize":
         return materialize_line(args, torch, world, rank)

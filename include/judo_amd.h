@@ -44,8 +44,8 @@ enum jh_task_kind { JH_TASK_CARTPOLE = 0, JH_TASK_CYLINDER_PUSH = 1, JH_TASK_LEA
 enum jh_spline_kind { JH_SPLINE_ZERO = 0, JH_SPLINE_LINEAR = 1, JH_SPLINE_CUBIC = 3 };
 
 #define JH_MAX_TASK_PARAMS 32
-#define JH_MAX_KNOT_DIM 128 /* K * nu */
-#define JH_MAX_ELITES 8
+#define JH_MAX_KNOT_DIM 512 /* K * nu */
+#define JH_MAX_ELITES 32
 
 const char* jh_last_error(void);
 int jh_version(void);
@@ -65,6 +65,22 @@ int jh_model_stats(jh_model* m, int* out /* HOST, 4 ints */, int reset);
 /* Articulated-body engine kernel generation for this model: 2 (default) = cooperative kernel, 16 lanes per rollout;
  * 1 = one lane per rollout (kept as an independent second implementation for the parity tests). */
 int jh_model_set_kernel(jh_model* m, int generation);
+
+/* Limits of this model's kernels: out[0] = largest knot count K the fused kernel (jh_rollout_cost) accepts -- the cooperative
+ * leap_cube / fr3_pick kernels keep a lane's knots in 8 registers, a larger K goes through jh_spline_controls + jh_rollout_materialize +
+ * jh_task_reward, which have no such limit; out[1] = JH_MAX_KNOT_DIM; out[2] = JH_MAX_ELITES; out[3] = contact capacity per rollout
+ * (0 = the model has at most one contact).  HOST pointer. */
+int jh_model_limits(const jh_model* m, int* out /* HOST, 4 ints */);
+
+/* Plan-step I/O in one call each (the two transfers of a plan step: < 2 KB down, the new nominal knots up): an asynchronous copy of `nbytes` from
+ * pinned HOST memory to the device on `stream`; and an asynchronous copy from the device to pinned HOST memory followed by a wait for `stream`
+ * (the only synchronisation of an optimiser iteration, judo/controller/controller.py:283 needs the new nominal on the host). */
+int jh_upload_async(void* dst_device, const void* src_host, size_t nbytes, void* stream);
+int jh_download_wait(void* dst_host, const void* src_device, size_t nbytes, void* stream);
+/* The same in two halves: `begin` enqueues the copy and marks its end on `stream`; work enqueued afterwards (the trace records of update_traces)
+ * runs behind it; `end` waits for the mark only.  One transfer in flight per host thread. */
+int jh_download_begin(void* dst_host, const void* src_device, size_t nbytes, void* stream);
+int jh_download_end(void);
 
 /* Fused plan-step kernel.  Replaces, for N rollouts in one launch:
  *   Optimizer.sample_control_knots         judo/optimizers/{mppi.py:38-59,ps.py:29-50,cem.py:55-74}

@@ -24,6 +24,11 @@ _SIGNATURES = {
     "jh_model_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "jh_model_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "jh_model_set_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "jh_model_limits": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "jh_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "jh_download_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "jh_download_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "jh_download_end": (C.c_int, []),
     "jh_rollout_cost": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_rollout_materialize": (C.c_int, [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_task_reward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
@@ -49,6 +54,11 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+# compile-time limits of the library (include/judo_amd.h; tests/test_host.py checks that the two agree)
+MAX_KNOT_DIM = 512  # JH_MAX_KNOT_DIM: K * nu
+MAX_ELITES = 32  # JH_MAX_ELITES: CEM elites / trace elites
+MAX_TASK_PARAMS = 32  # JH_MAX_TASK_PARAMS
 
 
 class JudoAmdError(RuntimeError):
@@ -85,5 +95,7 @@ def check(status: int, what: str) -> None:
 
 
 def ptr(t) -> int | None:
-    """data_ptr of a torch tensor (None passes a NULL pointer)."""
-    return None if t is None else t.data_ptr()
+    """data_ptr of a torch tensor (None passes a NULL pointer; an int is a raw device address and passes through)."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()

@@ -5,7 +5,18 @@ normaliser bookkeeping, per-knot sigma, the H x K spline matrix W (cached).  Dev
 ONE fused kernel launch for sample -> clip -> spline -> rollout -> cost (`jh_rollout_cost`), one shard-local reduction,
 one all-gather when several GPUs take part, one merge.  Candidates, controls, states and sensors are never
 materialised on this path; the elite traces the GUI wants (`update_traces`, :323-363) are recovered by re-rolling
-only the E <= max_num_traces best rollouts in materialise mode.
+only the E <= max_num_traces best rollouts in materialise mode, when somebody reads `Controller.traces`.
+
+Three ways through one optimiser iteration, chosen per plan step:
+  fused        a `FusedOptimizer` (GpuMPPI / GpuCEM / GpuPS) on a task whose cost is the one compiled into the rollout kernel;
+  materialise  a `FusedOptimizer` on a task that brings its own `Task.reward` (plugin), a policy task (Spot), or a knot count
+               the fused kernel does not hold in registers: candidate controls -> `RolloutBackend.rollout` -> `Task.reward`,
+               all on device arrays, then the same update kernels;
+  candidates   any other `Optimizer` (a plugin with the reference's two numpy methods): its candidates are uploaded, rolled
+               out and scored on the device, the rewards go back to its `update_nominal_knots`.
+
+All per-step device and pinned-host buffers live in a `_PlanBuffers` cache keyed by the problem size: a plan step allocates
+nothing, does one asynchronous H2D copy of a < 2 KB block, one asynchronous D2H copy of the new nominal and one stream wait.
 """
 
 from __future__ import annotations
@@ -21,10 +32,38 @@ from judo_amd.config import ControllerConfig, OptimizerConfig
 from judo_amd.device import current_stream_ptr, require_gpu
 from judo_amd.distributed import Shard, all_gather_records, shard_rollouts, world_info
 from judo_amd.normalization import Normalizer, make_normalizer, normalizer_registry
-from judo_amd.optimizers import Optimizer, get_registered_optimizers
+from judo_amd.optimizers import FusedOptimizer, Optimizer, get_registered_optimizers
 from judo_amd.rollout_backend import GpuRolloutBackend
 from judo_amd.spline import SPLINE_KINDS, evaluate, spline_weights
 from judo_amd.tasks import Task, get_registered_tasks
+
+POLICY_OUTPUT_DIM = 12  # judo/tasks/spot/spot_constants.py
+
+
+class _PlanBuffers:
+    """Everything a plan step touches on the device, allocated once per (shard size, K, nu, nx, task params, record size)."""
+
+    def __init__(self, dev: torch.device, n_local: int, K: int, nu: int, nx: int, ntp: int, rec_floats: int, trace_k: int) -> None:
+        L = _lib.lib()
+        self.sizes = [nx, K * nu, K * nu, ntp, 2 * nu]
+        nblk = sum(self.sizes)
+        self.host = torch.empty(nblk, dtype=torch.float32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.host_ptr, self.nblk_bytes = self.host.data_ptr(), 4 * nblk
+        self.blk = torch.empty(nblk, dtype=torch.float32, device=dev)
+        self.x0, self.nominal, self.sigma, self.tp, self.lohi = torch.split(self.blk, self.sizes)
+        self.costs = torch.empty(n_local, dtype=torch.float32, device=dev)
+        self.scratch = torch.empty(int(L.jh_update_scratch_floats(n_local, K, nu)), dtype=torch.float32, device=dev)
+        self.rec = torch.empty(max(rec_floats, 1), dtype=torch.float32, device=dev)
+        self.out = torch.empty(2 * K * nu, dtype=torch.float32, device=dev)
+        self.out_host = torch.empty(2 * K * nu, dtype=torch.float32).pin_memory()
+        self.out_np = self.out_host.numpy()
+        self.out_host_ptr = self.out_host.data_ptr()
+        self.trace_recs = [torch.full((max(trace_k, 1) * (2 + K * nu),), float("inf"), dtype=torch.float32, device=dev) for _ in range(2)]  # alternated per plan step
+        self.trace_flip = 0
+        self.knots_out: torch.Tensor | None = None
+        self.knots_nku: torch.Tensor | None = None
+        self.mom: torch.Tensor | None = None
 
 
 class Controller:
@@ -54,18 +93,27 @@ class Controller:
         self._last_policy_output: torch.Tensor | None = None  # (shard count, 12) device tensor once a policy rollout has run
         self.system_metadata: dict[str, Any] = {}
         self.current_state = np.concatenate([task.data.qpos, task.data.qvel])
-        self.rewards = np.zeros((self.optimizer_cfg.num_rollouts,))
+        self._rewards: np.ndarray | None = np.zeros((self.optimizer_cfg.num_rollouts,))
         self.costs_device: torch.Tensor | None = None
-        self.traces = None
-        self.trace_sensors = [s for s in task.desc["sensors"] if s["type"] == "framepos" and s["name"].startswith("trace")]
+        self._last_fused: dict | None = None
+        self.trace_sensors = [s for s in task.desc["sensors"] if s["type"] == "framepos" and "trace" in s["name"]]  # visualizers/utils.py:169-178
+        self._traces: np.ndarray | None = None
+        self._trace_stage: dict | None = None
         self._w_cache: dict[tuple, torch.Tensor] = {}
-        self._lohi_dev: torch.Tensor | None = None
+        self._shift_cache: tuple = (None, None)
+        self._grid_cache: tuple = (None, None)
+        self._lohi_cache: tuple = (None, None)
+        self._bufs: _PlanBuffers | None = None
+        self._bufs_key: tuple | None = None
+        self._noise_buf: torch.Tensor | None = None
         self.keep_candidates = False
         self.force_materialize = False  # True: always take the materialise path (rollout arrays + Task.reward), e.g. to inspect trajectories
         self.last_rollout = None  # (states, sensors, controls) device tensors of the last materialised iteration
         self.record_kernel_events = False  # bench.py: HIP events around the rollout kernel on the launch stream
         self.kernel_events: list[tuple[torch.cuda.Event, torch.cuda.Event]] = []
         self.candidate_knots_device: torch.Tensor | None = None
+        self._candidate_knots: np.ndarray | None = None
+        self.solver_warnings = True  # warn when the articulated-body kernels dropped contacts or ran into the Newton cap (checked in `solver_stats`)
         self.reset()
 
     # ---- config passthrough (mirrors controller.py:109-208) --------------------------------------------------
@@ -76,6 +124,7 @@ class Controller:
     @controller_cfg.setter
     def controller_cfg(self, cfg: ControllerConfig) -> None:
         self._controller_cfg = cfg
+        self.action_normalizer = self._init_action_normalizer()  # controller.py:205-208
 
     @property
     def optimizer_cfg(self) -> OptimizerConfig:
@@ -111,7 +160,12 @@ class Controller:
 
     @property
     def spline_timesteps(self) -> np.ndarray:
-        return np.linspace(0, self.horizon, self.optimizer_cfg.num_nodes, endpoint=True)
+        key = (self.horizon, self.optimizer_cfg.num_nodes)
+        if self._grid_cache[0] != key:
+            g = np.linspace(0, key[0], key[1], endpoint=True)
+            g.setflags(write=False)
+            self._grid_cache = (key, g)
+        return self._grid_cache[1]
 
     @property
     def time(self) -> float:
@@ -131,6 +185,18 @@ class Controller:
     def update_spline(self, times: np.ndarray, controls: np.ndarray) -> None:
         self._spline_times, self._spline_knots, self._spline_kind = np.array(times, dtype=np.float64), np.array(controls, dtype=np.float64), self.spline_order
 
+    def _shifted_nominal(self, new_times: np.ndarray) -> np.ndarray:
+        """`nominal = prev_spline(new_times)` (controller.py:220-221).  The weights depend only on the spline kind and on the two knot grids relative to
+        each other, which repeat from plan step to plan step at a fixed control period: cached on those (to 1e-9 s)."""
+        t = self._spline_times
+        key = (self._spline_kind, len(t), len(new_times), round(float(t[-1] - t[0]), 9), round(float(new_times[0] - t[0]), 9), round(float(new_times[-1] - new_times[0]), 9))
+        if self._shift_cache[0] != key:
+            uniform = np.allclose(np.diff(t), (t[-1] - t[0]) / (len(t) - 1), rtol=0, atol=1e-12)
+            if not uniform:
+                return evaluate(self._spline_kind, t, self._spline_knots, new_times)
+            self._shift_cache = (key, spline_weights(self._spline_kind, t - t[0], new_times - t[0]))
+        return self._shift_cache[1] @ self._spline_knots
+
     def action(self, time: float) -> np.ndarray:
         return self.spline(time)
 
@@ -140,13 +206,19 @@ class Controller:
             self.optimizer_cfg.num_nodes = 4
 
     def reset(self) -> None:
+        """judo/controller/controller.py:306-321."""
         self.task.reset()
         self._fix_num_nodes()
         self.nominal_knots = np.tile(self.task.optimizer_warm_start(), (self.optimizer_cfg.num_nodes, 1))
+        self._candidate_knots, self._last_fused = None, None  # `candidate_knots` reads as tile(nominal) until a plan step has run (controller.py:313)
         self.times = self.task.data.time + self.spline_timesteps
         self.update_spline(self.times, self.nominal_knots)
         self.current_state = np.concatenate([self.task.data.qpos, self.task.data.qvel])
-        self.action_normalizer = self._init_action_normalizer()  # judo/controller/controller.py:208
+        self._current_normalizer()  # (re-)initialised when missing or when the configured type changed
+        if self.task.uses_locomotion_policy:  # :318-321: the policy starts the new episode from zero outputs; so does the plant solver's warm start
+            self._last_policy_output = None  # re-created as zeros by the next rollout
+            self.rollout_backend.update(self.rollout_backend.num_threads)
+        self._traces, self._trace_stage = None, None
 
     def update_states(self, qpos, qvel: np.ndarray | None = None, time: float | None = None, sim_metadata: dict | None = None) -> None:
         """Either the reference's call `update_states(MujocoState)` (judo/controller/controller.py:188-194) or the unpacked fields."""
@@ -191,7 +263,38 @@ class Controller:
             self.action_normalizer = self._init_action_normalizer()
         return self.action_normalizer
 
+    def _buffers(self, n_local: int, K: int, nu: int, nx: int, ntp: int, rec_floats: int, trace_k: int) -> _PlanBuffers:
+        key = (n_local, K, nu, nx, ntp, rec_floats, trace_k)
+        if self._bufs_key != key:
+            self._bufs, self._bufs_key = _PlanBuffers(self.device, *key), key
+        return self._bufs
+
+    def _draw_noise(self, n_local: int, n_offset: int) -> torch.Tensor:
+        """The optimizer's noise for this shard, drawn into a persistent (K, nu, N) buffer when it comes from the device generator."""
+        opt = self.optimizer
+        if opt.injected_noise is None:
+            K, nu = opt.num_nodes, self.nu
+            total = max(int(opt.num_rollouts), n_offset + n_local)
+            if self._noise_buf is None or tuple(self._noise_buf.shape) != (K, nu, total):
+                self._noise_buf = torch.empty((K, nu, total), dtype=torch.float32, device=self.device)
+            return opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buf)
+        return opt.draw_noise(n_local, n_offset, self.device)
+
     # ---- the plan step -------------------------------------------------------------------------------------------
+    @property
+    def uses_fused_optimizer(self) -> bool:
+        return isinstance(self.optimizer, FusedOptimizer)
+
+    @property
+    def uses_fused_cost(self) -> bool:
+        """True when the task's cost is the one fused into the rollout kernel.  A task that overrides `Task.reward` (a plugin
+        registered through `register_task` with its own reward on one of the shipped models) is served by the materialise path:
+        candidate controls -> full state/sensor trajectories -> the task's own `reward`, all on device arrays.  So is a knot count
+        above what the fused kernel of this model holds in registers (a live `num_nodes` edit must not kill the control loop)."""
+        if self.force_materialize or type(self.task).reward is not Task.reward or self.model is None or not self.uses_fused_optimizer:
+            return False
+        return self.optimizer.num_nodes <= self.model.max_fused_knots
+
     def update_action(self) -> None:
         lib = _lib.lib()
         opt, task, dev = self.optimizer, self.task, self.device
@@ -201,12 +304,14 @@ class Controller:
             raise ValueError("need at least one rollout")
         self._fix_num_nodes()
         N, K, nu, H = opt.num_rollouts, opt.num_nodes, self.nu, self.num_timesteps
+        if K * nu > _lib.MAX_KNOT_DIM:
+            raise ValueError(f"num_nodes * nu = {K * nu} exceeds the update kernels' limit of {_lib.MAX_KNOT_DIM} (include/judo_amd.h JH_MAX_KNOT_DIM)")
         world, rank = world_info(self.group)
         shard: Shard = shard_rollouts(N, world, rank)
 
         # time shift (host; needs the previous plan's spline)
         new_times = self.time + self.spline_timesteps
-        nominal_knots = self.spline(new_times)
+        nominal_knots = self._shifted_nominal(new_times)
         want_threads = shard.count if task.uses_locomotion_policy else N
         if self.rollout_backend.num_threads != want_threads:  # controller.py:225-229
             self.rollout_backend.update(want_threads)
@@ -216,107 +321,187 @@ class Controller:
         opt.pre_optimization(self.times, new_times)
 
         W = self._weights(K, H)
-        ctrl_lo, ctrl_hi = task.actuator_ctrlrange[:, 0], task.actuator_ctrlrange[:, 1]
-        mom = torch.empty(2 * nu, dtype=torch.float32, device=dev) if nrm.needs_moments else None
-        nx, ntp = task.nq + task.nv, len(task.task_params(self.system_metadata))
-        host = np.empty(nx + 2 * K * nu + ntp + 2 * nu, dtype=np.float32)
-        costs = torch.empty(shard.count, dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.jh_update_scratch_floats(shard.count, K, nu)), dtype=torch.float32, device=dev)
-        rec = torch.empty(opt.record_floats(), dtype=torch.float32, device=dev)
-        out = torch.empty(2 * K * nu, dtype=torch.float32, device=dev)
-        knots_out = torch.empty((K, nu, shard.count), dtype=torch.float32, device=dev) if self.keep_candidates else None
-        stream = current_stream_ptr()
+        x0 = np.array(self.current_state, dtype=np.float64)
+        fused_opt = self.uses_fused_optimizer
+        E = self._num_trace_elites(N)
+        tp0 = task.task_params(self.system_metadata)
+        b = self._buffers(shard.count, K, nu, task.nq + task.nv, len(tp0), opt.record_floats() if fused_opt else 0, E)
+        stream = self._stream = current_stream_ptr()
+        state: dict[str, Any] = {}
+        staged = False
 
         i = 0
         while i < self.max_opt_iters and not opt.stop_cond():
-            sigma_n = np.asarray(opt.knot_sigma(), dtype=np.float64)  # normalised units; may advance CEM state
-            # every shipped normaliser is affine per actuator: raw = center + scale * normalised (judo_amd/normalization.py)
-            scale, center = nrm.noise_scale(), nrm.denormalize(np.zeros(nu))
-            nominal_knots = nrm.denormalize(nominal_n)
-            with np.errstate(invalid="ignore"):
-                lohi_np = np.concatenate([nrm.denormalize(nrm.normalize(ctrl_lo)), nrm.denormalize(nrm.normalize(ctrl_hi))])
-            lohi_np = np.nan_to_num(np.where(np.isnan(lohi_np), np.concatenate([ctrl_lo, ctrl_hi]), lohi_np).astype(np.float32), posinf=3.0e38, neginf=-3.0e38)
             task.pre_rollout(self.current_state)
-            # one small H2D transfer: x0 | nominal | sigma | task params | ctrl bounds
-            o = 0
-            host[o : o + nx] = self.current_state; o += nx
-            host[o : o + K * nu] = nominal_knots.reshape(-1); o += K * nu
-            host[o : o + K * nu] = (sigma_n * scale[None, :]).reshape(-1); o += K * nu
-            host[o : o + ntp] = task.task_params(self.system_metadata); o += ntp
-            host[o : o + 2 * nu] = lohi_np
-            blk = torch.from_numpy(host).to(dev)
-            x0_d, nom_d, sig_d, tp_d, lohi_d = torch.split(blk, [nx, K * nu, K * nu, ntp, 2 * nu])
-            noise = opt.draw_noise(shard.count, shard.offset, dev)
-            self._last_sigma_raw, self._last_nominal_before = sigma_n * scale[None, :], nominal_knots.copy()
-            if self.record_kernel_events:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            if self.uses_fused_cost:
-                st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(x0_d), _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(W),
-                                         _lib.ptr(lohi_d), _lib.ptr(tp_d), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(costs),
-                                         _lib.ptr(knots_out), stream)
-                _lib.check(st, "jh_rollout_cost")
+            if fused_opt:
+                # the trace records of the (presumably) last iteration are enqueued before its result is waited for: their host cost hides behind the kernels
+                state["stage"] = (lambda: self._stage_traces(lib, b, state, shard, world, E, x0, new_times, K, nu, stream)) if i == self.max_opt_iters - 1 else None
+                nominal_n = self._fused_iteration(lib, b, nrm, nominal_n, W, shard, world, H, K, nu, N, stream, state)
+                staged = state["stage"] is not None
             else:
-                costs = self._materialised_costs(x0_d, nom_d, noise, sig_d, lohi_d, W, shard, H, K, stream)
-            if self.record_kernel_events:
-                ev1.record()
-                self.kernel_events.append((ev0, ev1))
-            opt.device_partial(costs, None, nom_d, noise, sig_d, lohi_d, shard.count, shard.offset, scratch, rec)
-            recs = all_gather_records(rec, self.group)
-            opt.device_merge(recs, world, out[: K * nu], out[K * nu :], clip_sigma=False)
-            res = out.cpu().numpy().astype(np.float64)  # the only sync of the iteration
-            nominal_n = (res[: K * nu].reshape(K, nu) - center[None, :]) / scale[None, :]  # the update acted on the normalised candidates
-            if hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray):  # CEM: refit in normalised units
-                opt.sigma = np.clip(res[K * nu :].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
-            if nrm.needs_moments:  # running statistics over this iteration's raw candidates, all ranks (controller.py:290-291)
-                ctr = torch.from_numpy(np.asarray(nrm.mean, dtype=np.float32)).to(dev)
-                st = lib.jh_knot_moments(None, _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(lohi_d), _lib.ptr(ctr),
-                                         shard.count, shard.offset, K, nu, _lib.ptr(mom), stream)
-                _lib.check(st, "jh_knot_moments")
-                m = all_gather_records(mom, self.group).cpu().numpy().astype(np.float64).reshape(world, 2, nu).sum(0)
-                # the kernel centred on the fp32 image of the mean: shift the moments to the fp64 mean
-                dm = np.asarray(nrm.mean, dtype=np.float32).astype(np.float64) - nrm.mean
-                cnt = N * K
-                s1 = m[0] + cnt * dm
-                s2 = m[1] + 2 * dm * m[0] + cnt * dm * dm
-                nrm.update_from_moments(cnt, s1, s2)
+                nominal_n = self._candidates_iteration(lib, b, nrm, nominal_n, W, shard, H, K, nu, N, stream, state)
             i += 1
 
-        self.costs_device = costs
-        self.candidate_knots_device = knots_out
+        if i > 0:
+            self.costs_device = state["costs"]
+            self.candidate_knots_device = state.get("knots_out")
+            if not staged:
+                self._stage_traces(lib, b, state, shard, world, E, x0, new_times, K, nu, stream)
         self.last_shard = shard
         self.nominal_knots = nrm.denormalize(nominal_n)  # with the statistics as updated in the loop (controller.py:296)
         self.times = new_times
         self.update_spline(self.times, self.nominal_knots)
 
-    @property
-    def uses_fused_cost(self) -> bool:
-        """True when the task's cost is the one fused into the rollout kernel.  A task that overrides `Task.reward` (a plugin
-        registered through `register_task` with its own reward on one of the shipped models) is served by the materialise path:
-        candidate controls -> full state/sensor trajectories -> the task's own `reward`, all on device arrays."""
-        return not self.force_materialize and type(self.task).reward is Task.reward
+    def _pack_block(self, b: _PlanBuffers, nominal_raw: np.ndarray, sigma_raw: np.ndarray | None, lohi: np.ndarray) -> None:
+        """x0 | nominal | sigma | task params | ctrl bounds -> pinned host block -> device, one asynchronous copy."""
+        h, o = b.host_np, 0
+        n = b.sizes[0]; h[o : o + n] = self.current_state; o += n
+        n = b.sizes[1]; h[o : o + n] = nominal_raw.reshape(-1); o += n
+        n = b.sizes[2]; h[o : o + n] = 0.0 if sigma_raw is None else sigma_raw.reshape(-1); o += n
+        n = b.sizes[3]; h[o : o + n] = self.task.task_params(self.system_metadata); o += n
+        h[o:] = lohi
+        _lib.check(_lib.lib().jh_upload_async(b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, self._stream), "jh_upload_async")
 
-    def _materialised_costs(self, x0_d, nom_d, noise, sig_d, lohi_d, W, shard: Shard, H: int, K: int, stream) -> torch.Tensor:
+    def _raw_bounds(self, nrm: Normalizer) -> np.ndarray:
+        r = self.task.actuator_ctrlrange
+        ctrl_lo, ctrl_hi = r[:, 0], r[:, 1]
+        if type(nrm).__name__ == "IdentityNormalizer":
+            if self._lohi_cache[0] is r:
+                return self._lohi_cache[1]
+            lohi = np.concatenate([ctrl_lo, ctrl_hi])
+            out = np.nan_to_num(lohi.astype(np.float32), posinf=3.0e38, neginf=-3.0e38)
+            self._lohi_cache = (r, out)
+            return out
+        else:
+            with np.errstate(invalid="ignore"):
+                lohi = np.concatenate([nrm.denormalize(nrm.normalize(ctrl_lo)), nrm.denormalize(nrm.normalize(ctrl_hi))])
+            lohi = np.where(np.isnan(lohi), np.concatenate([ctrl_lo, ctrl_hi]), lohi)
+        return np.nan_to_num(lohi.astype(np.float32), posinf=3.0e38, neginf=-3.0e38)
+
+    def _fetch(self, b: _PlanBuffers, n: int, behind=None) -> np.ndarray:
+        """Device result -> pinned host memory, one wait: the only synchronisation of an iteration.  `behind` enqueues work that may run after the
+        copy (the trace records): it is launched while the copy is in flight and is not waited for."""
+        L = _lib.lib()
+        _lib.check(L.jh_download_begin(b.out_host_ptr, b.out.data_ptr(), 4 * n, self._stream), "jh_download_begin")
+        if behind is not None:
+            behind()
+        _lib.check(L.jh_download_end(), "jh_download_end")
+        return b.out_np[:n].astype(np.float64)
+
+    def _fused_iteration(self, lib, b: _PlanBuffers, nrm: Normalizer, nominal_n: np.ndarray, W, shard: Shard, world: int, H: int, K: int, nu: int, N: int,
+                         stream, state: dict) -> np.ndarray:
+        opt, task = self.optimizer, self.task
+        sigma_n = np.asarray(opt.knot_sigma(), dtype=np.float64)  # normalised units; may advance CEM state
+        # every shipped normaliser is affine per actuator: raw = center + scale * normalised (judo_amd/normalization.py)
+        scale, center = nrm.noise_scale(), nrm.denormalize(np.zeros(nu))
+        nominal_raw = nrm.denormalize(nominal_n)
+        sigma_raw = sigma_n * scale[None, :]
+        self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm))
+        noise = self._draw_noise(shard.count, shard.offset)  # (K, nu, shard.count), possibly a view into the full draw
+        ldn, noise_p = int(noise.stride(1)), noise.data_ptr()
+        self._last_sigma_raw, self._last_nominal_before = sigma_raw, nominal_raw.copy()
+        if self.keep_candidates and b.knots_out is None:
+            b.knots_out = torch.empty((K, nu, shard.count), dtype=torch.float32, device=self.device)
+        knots_out = b.knots_out if self.keep_candidates else None
+        if self.record_kernel_events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        if self.uses_fused_cost:
+            st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(b.x0), _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(W),
+                                     _lib.ptr(b.lohi), _lib.ptr(b.tp), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs),
+                                     _lib.ptr(knots_out), stream)
+            _lib.check(st, "jh_rollout_cost")
+            costs = b.costs
+        else:
+            costs = self._materialised_costs(b.x0, b.nominal, noise_p, ldn, b.sigma, b.lohi, None, W, shard, H, K, stream)
+            if knots_out is not None:  # the materialise path never wrote the candidates: sample them into the (K, nu, N) layout the fused kernel uses
+                tmp = torch.empty((shard.count, K, nu), dtype=torch.float32, device=self.device)
+                st = lib.jh_sample_knots(_lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(b.lohi), shard.count, shard.offset, K, nu, _lib.ptr(tmp), stream)
+                _lib.check(st, "jh_sample_knots")
+                knots_out.copy_(tmp.permute(1, 2, 0))
+        if self.record_kernel_events:
+            ev1.record()
+            self.kernel_events.append((ev0, ev1))
+        opt.device_partial(costs, None, b.nominal, noise_p, b.sigma, b.lohi, shard.count, shard.offset, b.scratch, b.rec, ldn=ldn, stream=stream)
+        recs = all_gather_records(b.rec, self.group)
+        opt.device_merge(recs, world, b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, clip_sigma=False, stream=stream)
+        state.update(costs=costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
+        is_cem = hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray)
+        res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))
+        nominal_n = (res[: K * nu].reshape(K, nu) - center[None, :]) / scale[None, :]  # the update acted on the normalised candidates
+        if is_cem:  # CEM: refit in normalised units
+            opt.sigma = np.clip(res[K * nu :].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
+        if nrm.needs_moments:  # running statistics over this iteration's raw candidates, all ranks (controller.py:290-291)
+            if b.mom is None:
+                b.mom = torch.empty(2 * nu, dtype=torch.float32, device=self.device)
+            ctr = torch.from_numpy(np.asarray(nrm.mean, dtype=np.float32)).to(self.device)
+            st = lib.jh_knot_moments(None, _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(b.lohi), _lib.ptr(ctr),
+                                     shard.count, shard.offset, K, nu, _lib.ptr(b.mom), stream)
+            _lib.check(st, "jh_knot_moments")
+            m = all_gather_records(b.mom, self.group).cpu().numpy().astype(np.float64).reshape(world, 2, nu).sum(0)
+            # the kernel centred on the fp32 image of the mean: shift the moments to the fp64 mean
+            dm = np.asarray(nrm.mean, dtype=np.float32).astype(np.float64) - nrm.mean
+            cnt = N * K
+            s1 = m[0] + cnt * dm
+            s2 = m[1] + 2 * dm * m[0] + cnt * dm * dm
+            nrm.update_from_moments(cnt, s1, s2)
+        state.update(costs=costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
+        self._rewards, self._candidate_knots = None, None
+        self._last_fused = dict(b=b, noise=noise, noise_p=noise_p, ldn=ldn, shard=shard, K=K, nu=nu)
+        return nominal_n
+
+    def _candidates_iteration(self, lib, b: _PlanBuffers, nrm: Normalizer, nominal_n: np.ndarray, W, shard: Shard, H: int, K: int, nu: int, N: int,
+                              stream, state: dict) -> np.ndarray:
+        """judo/controller/controller.py:246-291 for an optimizer that only has the reference's numpy methods: its candidates are clipped on the
+        host as the reference does, the shard's rows go to the device, rollout and reward run there, the rewards come back for its update.
+        With several ranks every rank must sample the same candidates (seed numpy alike) -- the reference has no multi-process form of this."""
+        opt, task = self.optimizer, self.task
+        cand_n = np.asarray(opt.sample_control_knots(nominal_n), dtype=np.float64)
+        if cand_n.shape != (N, K, nu):
+            raise ValueError(f"sample_control_knots must return ({N}, {K}, {nu}), got {cand_n.shape}")
+        r = task.actuator_ctrlrange
+        cand_n = np.clip(cand_n, nrm.normalize(r[:, 0]), nrm.normalize(r[:, 1]))
+        self._candidate_knots, self._last_fused = nrm.denormalize(cand_n), None
+        self._pack_block(b, nrm.denormalize(nominal_n), None, self._raw_bounds(nrm))
+        if b.knots_nku is None:
+            b.knots_nku = torch.empty((shard.count, K, nu), dtype=torch.float32, device=self.device)
+        b.knots_nku.copy_(torch.from_numpy(np.ascontiguousarray(self._candidate_knots[shard.offset : shard.offset + shard.count], dtype=np.float32)))
+        costs = self._materialised_costs(b.x0, None, None, 0, None, b.lohi, b.knots_nku, W, shard, H, K, stream)
+        rewards = -costs.cpu().numpy().astype(np.float64)
+        if shard.world > 1:
+            from judo_amd.distributed import all_gather_costs
+
+            rewards = -all_gather_costs(costs, shard, self.group).cpu().numpy().astype(np.float64)
+        self._rewards = rewards
+        nominal_n = np.asarray(opt.update_nominal_knots(cand_n, rewards), dtype=np.float64)
+        nrm.update(self._candidate_knots)
+        state.update(costs=costs, knots_out=None, noise_p=None, ldn=0, knots_nku=b.knots_nku)
+        return nominal_n
+
+    def _materialised_costs(self, x0_d, nom_d, noise_p, ldn: int, sig_d, lohi_d, knots_nku, W, shard: Shard, H: int, K: int, stream) -> torch.Tensor:
         """judo/controller/controller.py:239-262 on the device: candidate splines at the rollout times, RolloutBackend.rollout,
         Task.reward, Task.post_rollout.  Returns costs = -rewards (fp32, device)."""
         lib, task, nu = _lib.lib(), self.task, self.nu
         controls = torch.empty((shard.count, H, nu), dtype=torch.float32, device=self.device)
-        st = lib.jh_spline_controls(_lib.ptr(W), None, _lib.ptr(nom_d), _lib.ptr(noise), shard.count, _lib.ptr(sig_d), _lib.ptr(lohi_d), shard.count,
-                                    shard.offset, H, K, nu, _lib.ptr(controls), stream)
+        st = lib.jh_spline_controls(_lib.ptr(W), _lib.ptr(knots_nku), _lib.ptr(nom_d), noise_p, ldn, _lib.ptr(sig_d), _lib.ptr(lohi_d) if knots_nku is None else None,
+                                    shard.count, shard.offset, H, K, nu, _lib.ptr(controls), stream)
         _lib.check(st, "jh_spline_controls")
         if task.uses_locomotion_policy:  # controller.py:265-273: commands -> policy + plant; the policy outputs carry over to the next plan step
             if self._last_policy_output is None:
-                self._last_policy_output = torch.zeros((shard.count, 12), dtype=torch.float32, device=self.device)
+                self._last_policy_output = torch.zeros((shard.count, POLICY_OUTPUT_DIM), dtype=torch.float32, device=self.device)
             states, sensors, self._last_policy_output = self.rollout_backend.rollout(x0_d, task.task_to_sim_ctrl(controls), self._last_policy_output,
                                                                                     cutoff_time=self.rollout_cutoff_time)
-        else:
-            states, sensors = self.rollout_backend.rollout_device(x0_d, controls)
+        elif hasattr(self.rollout_backend, "rollout_device"):
+            states, sensors = self.rollout_backend.rollout_device(x0_d, task.task_to_sim_ctrl(controls))
+        else:  # a RolloutBackend plugin with the reference's numpy signature only (assigned to `controller.rollout_backend`)
+            s_np, y_np, _ = self.rollout_backend.rollout(np.asarray(self.current_state), task.task_to_sim_ctrl(controls).cpu().numpy().astype(np.float64), None)
+            states, sensors = torch.as_tensor(s_np, dtype=torch.float32, device=self.device), torch.as_tensor(y_np, dtype=torch.float32, device=self.device)
         if getattr(task, "reward_accepts_torch", True):
             args = (states, sensors, controls)
         else:  # numpy-only plugin reward: one host round trip of the trajectories
             args = tuple(a.cpu().numpy().astype(np.float64) for a in (states, sensors, controls))
-        rewards = task.reward(*args, self.system_metadata)
         task.post_rollout(*args, self.system_metadata)
+        rewards = task.reward(*args, self.system_metadata)
         rewards = torch.as_tensor(rewards, device=self.device).to(torch.float32).reshape(-1)
         if rewards.shape[0] != shard.count:
             raise ValueError(f"Task.reward must return ({shard.count},) rewards, got {tuple(rewards.shape)}")
@@ -328,50 +513,127 @@ class Controller:
         """Rewards of this rank's shard of the last iteration (host copy on demand)."""
         return -self.costs_device.cpu().numpy().astype(np.float64)
 
+    @property
+    def rewards(self) -> np.ndarray:
+        """`Controller.rewards` of the reference (controller.py:279): the last iteration's rewards; on the fused path they stay on the
+        device until somebody reads them here (this rank's shard when the rollouts are sharded)."""
+        if self._rewards is None:
+            self._rewards = self.rewards_local
+        return self._rewards
+
+    @rewards.setter
+    def rewards(self, value) -> None:
+        self._rewards = value
+
+    @property
+    def candidate_knots(self) -> np.ndarray:
+        """`Controller.candidate_knots` of the reference (controller.py:258, :313): the (N, K, nu) clipped candidates of the last iteration.  The
+        fused path never stores them; they are re-derived from the noise of the last plan step (`jh_sample_knots`) when read (this rank's shard)."""
+        if self._candidate_knots is None:
+            f = self._last_fused
+            if f is None:
+                return np.tile(self.nominal_knots, (self.optimizer_cfg.num_rollouts, 1, 1))
+            b, sh = f["b"], f["shard"]
+            out = torch.empty((sh.count, f["K"], f["nu"]), dtype=torch.float32, device=self.device)
+            st = _lib.lib().jh_sample_knots(_lib.ptr(b.nominal), f["noise_p"], f["ldn"], _lib.ptr(b.sigma), _lib.ptr(b.lohi), sh.count, sh.offset, f["K"], f["nu"],
+                                            _lib.ptr(out), current_stream_ptr())
+            _lib.check(st, "jh_sample_knots")
+            self._candidate_knots = out.cpu().numpy().astype(np.float64)
+        return self._candidate_knots
+
+    def solver_stats(self, reset: bool = True) -> dict:
+        """Counters of the articulated-body kernels since the last call (synchronises): contacts dropped above the per-rollout capacity,
+        constraint solves stopped by the Newton iteration cap, iterations, steps.  Warns when rollouts were degraded by either limit."""
+        if self.model is None:
+            st = self.rollout_backend.engine.stats(reset)
+            st = {"contact_overflow": st["contacts_dropped"], "newton_cap_hits": st["steps_at_cap"], "newton_iters": st["newton_iterations"], "steps": st["steps"]}
+        else:
+            st = self.model.stats(reset)
+        if self.solver_warnings and st["steps"] > 0 and (st["contact_overflow"] > 1e-4 * st["steps"] or st["newton_cap_hits"] > 1e-2 * st["steps"]):
+            warnings.warn(f"{self.task.name}: {st['contact_overflow']} contacts dropped above the kernel's per-rollout capacity and {st['newton_cap_hits']} "
+                          f"constraint solves stopped at the iteration cap in {st['steps']} physics steps -- those rollouts are approximate", stacklevel=2)
+        return st
+
     # ---- traces --------------------------------------------------------------------------------------------------
+    def _num_trace_elites(self, N: int) -> int:
+        E = min(int(self.max_num_traces), N)  # controller.py:333-334
+        if E > _lib.MAX_ELITES:
+            warnings.warn(f"max_num_traces = {E} clamped to {_lib.MAX_ELITES} (include/judo_amd.h JH_MAX_ELITES)", stacklevel=3)
+            E = _lib.MAX_ELITES
+        return max(E, 0) if self.trace_sensors else 0
+
+    def _stage_traces(self, lib, b: _PlanBuffers, state: dict, shard: Shard, world: int, E: int, x0: np.ndarray, new_times: np.ndarray, K: int, nu: int, stream) -> None:
+        """What `update_traces` (controller.py:323-363) needs from this plan step, kept on the device: the E best rollouts of this shard as
+        records [cost, global index, payload], all-gathered over the ranks.  payload = their clipped candidate knots (re-rolled in materialise
+        mode when the traces are read) or, when the iteration materialised the sensors anyway, their trace-sensor rows.  No synchronisation here."""
+        self._traces, self._trace_stage = None, None
+        if E <= 0:
+            self._traces = np.zeros((0, 2, 3))
+            return
+        costs = state["costs"]
+        kl = min(E, shard.count)
+        H = self.num_timesteps
+        if self.last_rollout is not None and (not self.uses_fused_optimizer or not self.uses_fused_cost):
+            # ties: the reference takes argsort(rewards)[-E:][::-1], i.e. among equal rewards the higher index first
+            order = (shard.count - 1 - torch.argsort(costs.flip(0), stable=True))[:kl]
+            cols = [s["adr"] + k for s in self.trace_sensors for k in range(3)]
+            rows = self.last_rollout[1][order][:, :, cols].reshape(kl, -1)
+            rec = torch.full((E, 2 + rows.shape[1]), float("inf"), dtype=torch.float32, device=self.device)
+            rec[:kl, 0] = costs[order]
+            rec[:kl, 1] = (order + shard.offset).to(torch.float32)
+            rec[:kl, 2:] = rows
+            rec[kl:, 1] = -1.0
+            kind, stride = "sensors", 2 + rows.shape[1]
+            recs = all_gather_records(rec.reshape(-1), self.group)
+        else:
+            stride = 2 + K * nu
+            b.trace_flip ^= 1
+            trace_rec = b.trace_recs[b.trace_flip]  # the previous plan step's stage may still be read from the other buffer
+            if kl < E:
+                trace_rec.fill_(float("inf"))
+            st = lib.jh_topk_partial(_lib.ptr(costs), _lib.ptr(state["knots_nku"]), _lib.ptr(b.nominal), state["noise_p"], state["ldn"], _lib.ptr(b.sigma), _lib.ptr(b.lohi),
+                                     shard.count, shard.offset, K, nu, kl, 1, _lib.ptr(b.scratch), _lib.ptr(trace_rec), stream)
+            _lib.check(st, "jh_topk_partial")
+            kind = "knots"
+            recs = all_gather_records(trace_rec, self.group)
+        self._trace_stage = dict(kind=kind, recs=recs, stride=stride, E=E, x0=x0, times=np.array(new_times), order=self.spline_order, H=H, K=K, nu=nu,
+                                 index_is_bits=(kind == "knots"))
+
+    @property
+    def traces(self) -> np.ndarray | None:
+        """Line segments of the best rollouts' `trace*` framepos sensors, best rollout first: (E * n_trace_sensors * (H-1), 2, 3)
+        (controller.py:323-363).  The reference fills this inside `update_action`; here the elite rollouts are re-rolled when it is first read."""
+        if self._traces is None and self._trace_stage is not None:
+            self._traces = self._finish_traces(self._trace_stage)
+        return self._traces
+
+    @traces.setter
+    def traces(self, value) -> None:
+        self._traces = value
+
     def update_traces(self) -> None:
-        """Line segments of the best rollouts' `trace*` framepos sensors, best rollout first (controller.py:323-363):
-        shape (E * n_trace_sensors * (H-1), 2, 3).  Re-rolls only the E elite rollouts in materialise mode."""
-        if self.costs_device is None or self.optimizer.last_noise is None:
+        if self._trace_stage is None and self._traces is None:
             raise RuntimeError("update_traces() needs a completed update_action()")
-        if not self.trace_sensors:
-            self.traces = np.zeros((0, 2, 3))
-            return
-        if self.task.uses_locomotion_policy:  # the materialise path kept every rollout's sensors: pick the elites' rows, no re-rollout
-            sensors = self.last_rollout[1]
-            E = min(self.max_num_traces, int(self.costs_device.numel()))
-            order = torch.argsort(self.costs_device, stable=True)[:E]
-            sel = sensors[order].cpu().numpy().astype(np.float64)
-            segs = [np.stack([sel[e, :-1, s["adr"] : s["adr"] + 3], sel[e, 1:, s["adr"] : s["adr"] + 3]], axis=1) for e in range(E) for s in self.trace_sensors]
-            self.traces = np.concatenate(segs, axis=0)
-            return
-        self.traces = elite_traces(self, self._last_sigma_raw, self._last_nominal_before)
+        if self._trace_stage is not None:
+            self._traces = self._finish_traces(self._trace_stage)
 
-
-def elite_traces(controller: Controller, sigma_raw: np.ndarray, nominal_before: np.ndarray) -> np.ndarray:
-    """Trace segments for the E best rollouts of the last plan step.
-
-    nominal_before / sigma_raw are the nominal knots and raw-unit sigma that the step sampled around."""
-    opt, task = controller.optimizer, controller.task
-    shard = controller.last_shard
-    K, nu, H = opt.num_nodes, controller.nu, controller.num_timesteps
-    costs = controller.costs_device
-    E = min(controller.max_num_traces, int(costs.numel()))
-    order = torch.argsort(costs, stable=True)[:E]
-    eps = opt.last_noise[:, :, order].permute(2, 0, 1).cpu().numpy().astype(np.float64)  # (E, K, nu)
-    gidx = order.cpu().numpy() + shard.offset
-    knots = nominal_before[None] + sigma_raw[None] * eps
-    knots[gidx == 0] = nominal_before
-    r = task.actuator_ctrlrange
-    knots = np.clip(knots, r[:, 0], r[:, 1])
-    U = evaluate(controller.spline_order, controller.times, knots, controller.times[0] + controller.rollout_times)
-    _, sensors, _ = controller.rollout_backend.rollout(controller.current_state, U)
-    segs = []
-    for e in range(E):
-        for s in controller.trace_sensors:
-            p = sensors[e, :, s["adr"] : s["adr"] + 3]
-            segs.append(np.stack([p[:-1], p[1:]], axis=1))
-    return np.concatenate(segs, axis=0) if segs else np.zeros((0, 2, 3))
+    def _finish_traces(self, st: dict) -> np.ndarray:
+        S, H, E = len(self.trace_sensors), st["H"], st["E"]
+        recs = st["recs"].cpu().numpy().reshape(-1, st["stride"])
+        idx = recs[:, 1].view(np.int32).astype(np.int64) if st["index_is_bits"] else recs[:, 1].astype(np.int64)
+        cost = recs[:, 0].astype(np.float64)
+        ok = np.nonzero((idx >= 0) & np.isfinite(cost))[0]
+        # best first; among equal costs the higher global index first (argsort(rewards)[-E:][::-1] with a stable sort)
+        ok = ok[np.lexsort((-idx[ok], cost[ok]))][:E]
+        if st["kind"] == "sensors":
+            pts = recs[ok, 2:].astype(np.float64).reshape(len(ok), H, S, 3)
+        else:
+            knots = recs[ok, 2:].astype(np.float64).reshape(len(ok), st["K"], st["nu"])
+            U = evaluate(st["order"], st["times"], knots, st["times"][0] + self.task.dt * np.arange(H))
+            _, sensors, _ = GpuRolloutBackend(self.model, len(ok)).rollout(st["x0"], U)
+            pts = np.stack([sensors[:, :, s["adr"] : s["adr"] + 3] for s in self.trace_sensors], axis=2)
+        segs = np.stack([pts[:, :-1], pts[:, 1:]], axis=-2)  # (E, H-1, S, 2, 3)
+        return np.ascontiguousarray(segs.transpose(0, 2, 1, 3, 4)).reshape(-1, 2, 3)  # elite-major, then sensor, then time
 
 
 def make_controller(init_task: str, init_optimizer: str, device: torch.device | None = None, group: Any = None) -> Controller:

@@ -85,6 +85,45 @@ extern "C" int jh_model_set_kernel(jh_model* m, int generation) {
   return JH_OK;
 }
 
+extern "C" int jh_model_limits(const jh_model* m, int* out) {
+  JH_REQUIRE(m && out, "model_limits: null pointer");
+  const bool coop = m->kernel_gen == 2 && (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK);
+  out[0] = coop ? 8 : JH_MAX_KNOT_DIM / (m->nu > 0 ? m->nu : 1);
+  out[1] = JH_MAX_KNOT_DIM;
+  out[2] = JH_MAX_ELITES;
+  out[3] = (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK) ? 32 : 0;
+  return JH_OK;
+}
+
+extern "C" int jh_upload_async(void* dst, const void* src, size_t nbytes, void* stream) {
+  JH_REQUIRE(dst && src, "upload_async: null pointer");
+  JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return JH_OK;
+}
+
+extern "C" int jh_download_wait(void* dst, const void* src, size_t nbytes, void* stream) {
+  JH_REQUIRE(dst && src, "download_wait: null pointer");
+  JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  JH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return JH_OK;
+}
+
+static thread_local hipEvent_t g_dl_event = nullptr;
+
+extern "C" int jh_download_begin(void* dst, const void* src, size_t nbytes, void* stream) {
+  JH_REQUIRE(dst && src, "download_begin: null pointer");
+  if (!g_dl_event) JH_HIP(hipEventCreateWithFlags(&g_dl_event, hipEventDisableTiming));
+  JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  JH_HIP(hipEventRecord(g_dl_event, (hipStream_t)stream));
+  return JH_OK;
+}
+
+extern "C" int jh_download_end(void) {
+  JH_REQUIRE(g_dl_event != nullptr, "download_end without download_begin");
+  JH_HIP(hipEventSynchronize(g_dl_event));
+  return JH_OK;
+}
+
 extern "C" int jh_model_profile(jh_model* m, long long* out /* 8 phase cycle totals; zero unless built with JH_ENGINE_PROFILE */) {
   JH_REQUIRE(m && out, "model_profile: null pointer");
   JH_HIP(hipMemcpy(out, m->d_stats + 4, 8 * sizeof(long long), hipMemcpyDeviceToHost));

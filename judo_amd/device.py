@@ -53,6 +53,13 @@ class GpuModel:
         """Select the articulated-engine kernel generation (2 = cooperative, default; 1 = one lane per rollout)."""
         _lib.check(_lib.lib().jh_model_set_kernel(self.handle, int(generation)), "jh_model_set_kernel")
 
+    @property
+    def max_fused_knots(self) -> int:
+        """Largest knot count the fused rollout kernel of this model accepts (`jh_model_limits`)."""
+        out = (C.c_int * 4)()
+        _lib.check(_lib.lib().jh_model_limits(self.handle, out), "jh_model_limits")
+        return int(out[0])
+
     def stats(self, reset: bool = True) -> dict:
         """Diagnostic counters of the articulated-body kernels (synchronises)."""
         out = (C.c_int * 4)()

@@ -33,6 +33,11 @@ def ramp_linspace(lo: float, hi: float, K: int) -> np.ndarray:
     return np.linspace(lo, hi, K, endpoint=True)
 
 
+def _noise_ld(noise, n_local: int) -> int:
+    """Row stride of a (K, nu, n) noise tensor (a view into a wider draw keeps the wide stride)."""
+    return int(noise.stride(1)) if isinstance(noise, torch.Tensor) and noise.ndim == 3 else n_local
+
+
 class Optimizer(ABC, Generic[OptimizerConfigT]):
     """Base class (mirror of judo/optimizers/base.py:27-96)."""
 
@@ -74,14 +79,20 @@ class Optimizer(ABC, Generic[OptimizerConfigT]):
         self._seed = int(seed)
         self._generator = None
 
-    def draw_noise(self, n_local: int, n_offset: int, device: torch.device) -> torch.Tensor:
-        """Standard-normal fp32 noise in the kernels' (K, nu, N) layout (rollout index fastest).
+    def draw_noise(self, n_local: int, n_offset: int, device: torch.device, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Standard-normal fp32 noise in the kernels' (K, nu, N) layout (rollout index fastest): a (K, nu, n_local) tensor whose last
+        dimension is contiguous and whose row stride `stride(1)` is the `ldn` the kernels take (a view into the full draw when sharded).
 
-        With `injected_noise` (reference layout (N-1, K, nu), sample n uses row n-1) the shard's slice is uploaded
-        instead, so that a run can be replayed against the CPU oracle bit-for-bit on the input side."""
+        With `injected_noise` (reference layout (N-1, K, nu), sample n uses row n-1; or a list of such arrays, consumed one per call: one per
+        optimiser iteration) the shard's slice is uploaded instead, so that a run can be replayed against the CPU oracle bit-for-bit on the input side."""
         K, nu = self.num_nodes, self.nu
         if self.injected_noise is not None:
-            inj = np.asarray(self.injected_noise, dtype=np.float32)
+            inj = self.injected_noise
+            if isinstance(inj, (list, tuple)):
+                if not inj:
+                    raise ValueError("injected noise list is exhausted: one array per optimiser iteration is needed")
+                inj, self.injected_noise = inj[0], list(inj[1:])
+            inj = np.asarray(inj, dtype=np.float32)
             if inj.shape[1:] != (K, nu) or inj.shape[0] < n_offset + n_local - 1:
                 raise ValueError(f"injected noise has shape {inj.shape}, need (>= {n_offset + n_local - 1}, {K}, {nu})")
             full = np.zeros((n_local, K, nu), dtype=np.float32)
@@ -96,18 +107,35 @@ class Optimizer(ABC, Generic[OptimizerConfigT]):
             # plan -- do not depend on the number of GPUs (a sharded run reproduces the single-GPU run up to the summation order of the merge).  4.2 M normals at
             # the headline size: ~20 us, 17 MB.
             total = max(int(self.num_rollouts), n_offset + n_local)
-            noise = torch.randn((K, nu, total), generator=self._generator, device=device, dtype=torch.float32)
+            if out is not None and tuple(out.shape) == (K, nu, total) and out.is_contiguous():
+                noise = torch.randn((K, nu, total), generator=self._generator, out=out)
+            else:
+                noise = torch.randn((K, nu, total), generator=self._generator, device=device, dtype=torch.float32)
             if total != n_local:
-                noise = noise[:, :, n_offset : n_offset + n_local].contiguous()
+                noise = noise[:, :, n_offset : n_offset + n_local]  # a view: the kernels take the row stride
         self.last_noise = noise
         return noise
+
+    # -- drop-in API (the reference's two abstract methods, judo/optimizers/base.py:58-84) -----------------------------------
+    @abstractmethod
+    def sample_control_knots(self, nominal_knots: np.ndarray) -> np.ndarray:
+        """(K, nu) nominal knots -> (N, K, nu) candidates; row 0 is the nominal itself."""
+
+    @abstractmethod
+    def update_nominal_knots(self, sampled_knots: np.ndarray, rewards: np.ndarray) -> np.ndarray:
+        """(N, K, nu) candidates and their (N,) rewards -> new (K, nu) nominal knots."""
+
+
+class FusedOptimizer(Optimizer[OptimizerConfigT]):
+    """An optimizer the controller can run without ever materialising the candidates: it supplies the per-knot sigma, a shard-local
+    device reduction and a merge of the per-GPU records.  A plugin that only implements the reference's two methods (any
+    `Optimizer` subclass, e.g. the mock of the reference's tests/test_controller/test_controller.py:16-33) is served by the controller's candidate-array path."""
 
     # -- per-knot sigma (K, nu) -------------------------------------------------------------------------------
     @abstractmethod
     def knot_sigma(self) -> np.ndarray:
         """Per-(knot, actuator) standard deviation used by the next sampling call (may advance optimizer state)."""
 
-    # -- drop-in API ---------------------------------------------------------------------------------------------
     def sample_control_knots(self, nominal_knots: np.ndarray) -> np.ndarray:
         dev = require_gpu()
         N, K, nu = self.num_rollouts, self.num_nodes, self.nu
@@ -118,17 +146,13 @@ class Optimizer(ABC, Generic[OptimizerConfigT]):
         noise = self.draw_noise(N, 0, dev)
         out = torch.empty((N, K, nu), dtype=torch.float32, device=dev)
         nom = f32(nominal_knots, dev)
-        st = _lib.lib().jh_sample_knots(_lib.ptr(nom), _lib.ptr(noise), N, _lib.ptr(sigma), None, N, 0, K, nu, _lib.ptr(out), current_stream_ptr())
+        st = _lib.lib().jh_sample_knots(_lib.ptr(nom), _lib.ptr(noise), _noise_ld(noise, N), _lib.ptr(sigma), None, N, 0, K, nu, _lib.ptr(out), current_stream_ptr())
         _lib.check(st, "jh_sample_knots")
         return out.cpu().numpy().astype(np.float64)
 
-    @abstractmethod
-    def update_nominal_knots(self, sampled_knots: np.ndarray, rewards: np.ndarray) -> np.ndarray:
-        ...
-
     # -- fused path ----------------------------------------------------------------------------------------------
     @abstractmethod
-    def device_partial(self, costs, knots_nku, nominal, noise, sigma, lohi, n_local, n_offset, scratch, rec) -> None:
+    def device_partial(self, costs, knots_nku, nominal, noise, sigma, lohi, n_local, n_offset, scratch, rec, K=None, ldn=None, stream=None) -> None:
         """Shard-local reduction into `rec` (see include/judo_amd.h)."""
 
     @abstractmethod
@@ -136,7 +160,7 @@ class Optimizer(ABC, Generic[OptimizerConfigT]):
         ...
 
     @abstractmethod
-    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True) -> None:
+    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True, stream=None) -> None:
         ...
 
     def _check_update_args(self, sampled_knots, rewards):
@@ -166,7 +190,7 @@ class Optimizer(ABC, Generic[OptimizerConfigT]):
         return 2 + K * self.nu
 
 
-class GpuMPPI(Optimizer[MPPIConfig]):
+class GpuMPPI(FusedOptimizer[MPPIConfig]):
     """MPPI (judo/optimizers/mppi.py:21-82)."""
 
     def __init__(self, config: MPPIConfig, nu: int) -> None:
@@ -194,20 +218,20 @@ class GpuMPPI(Optimizer[MPPIConfig]):
     def record_floats(self) -> int:
         return self.record_floats_for(self.num_nodes)
 
-    def device_partial(self, costs, knots_nku, nominal, noise, sigma, lohi, n_local, n_offset, scratch, rec, K=None) -> None:
+    def device_partial(self, costs, knots_nku, nominal, noise, sigma, lohi, n_local, n_offset, scratch, rec, K=None, ldn=None, stream=None) -> None:
         K = K or self.num_nodes
-        ldn = int(noise.shape[-1]) if noise is not None else n_local
+        ldn = _noise_ld(noise, n_local) if ldn is None else int(ldn)
         st = _lib.lib().jh_mppi_partial(_lib.ptr(costs), _lib.ptr(knots_nku), _lib.ptr(nominal), _lib.ptr(noise), ldn, _lib.ptr(sigma), _lib.ptr(lohi),
-                                        n_local, n_offset, K, self.nu, float(self.temperature), _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr())
+                                        n_local, n_offset, K, self.nu, float(self.temperature), _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_mppi_partial")
 
-    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True) -> None:
+    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True, stream=None) -> None:
         K = K or self.num_nodes
-        st = _lib.lib().jh_mppi_merge(_lib.ptr(recs), G, K, self.nu, float(self.temperature), _lib.ptr(nominal_out), current_stream_ptr())
+        st = _lib.lib().jh_mppi_merge(_lib.ptr(recs), G, K, self.nu, float(self.temperature), _lib.ptr(nominal_out), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_mppi_merge")
 
 
-class _EliteOptimizer(Optimizer[OptimizerConfigT]):
+class _EliteOptimizer(FusedOptimizer[OptimizerConfigT]):
     """Shared top-k machinery of CEM (k = num_elites, ties high-index-first) and PS (k = 1, first argmax)."""
 
     tie_high = 1
@@ -224,20 +248,20 @@ class _EliteOptimizer(Optimizer[OptimizerConfigT]):
     def record_floats(self) -> int:
         return self.record_floats_for(self.num_nodes)
 
-    def device_partial(self, costs, knots_nku, nominal, noise, sigma, lohi, n_local, n_offset, scratch, rec, K=None) -> None:
+    def device_partial(self, costs, knots_nku, nominal, noise, sigma, lohi, n_local, n_offset, scratch, rec, K=None, ldn=None, stream=None) -> None:
         K = K or self.num_nodes
-        ldn = int(noise.shape[-1]) if noise is not None else n_local
+        ldn = _noise_ld(noise, n_local) if ldn is None else int(ldn)
         st = _lib.lib().jh_topk_partial(_lib.ptr(costs), _lib.ptr(knots_nku), _lib.ptr(nominal), _lib.ptr(noise), ldn, _lib.ptr(sigma), _lib.ptr(lohi),
-                                        n_local, n_offset, K, self.nu, self.num_keep(), self.tie_high, _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr())
+                                        n_local, n_offset, K, self.nu, self.num_keep(), self.tie_high, _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_topk_partial")
 
-    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True) -> None:
+    def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True, stream=None) -> None:
         """clip_sigma=False returns the raw population std: the controller clips it after mapping it back to the action normaliser's
         units (cem.py:91 clips the std of the NORMALISED elites)."""
         K = K or self.num_nodes
         smin, smax = self.sigma_bounds() if clip_sigma else (0.0, float("inf"))
         st = _lib.lib().jh_elite_merge(_lib.ptr(recs), G, self.num_keep(), K, self.nu, self.tie_high, smin, min(smax, 3.0e38), _lib.ptr(nominal_out),
-                                       _lib.ptr(sigma_out), current_stream_ptr())
+                                       _lib.ptr(sigma_out), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_elite_merge")
 
 

@@ -86,7 +86,10 @@ class Task(ABC, Generic[ConfigT]):
 
     @property
     def actuator_ctrlrange(self) -> np.ndarray:
-        return actuator_ctrlrange(self.desc)
+        if getattr(self, "_ctrlrange", None) is None:
+            self._ctrlrange = actuator_ctrlrange(self.desc)
+            self._ctrlrange.setflags(write=False)
+        return self._ctrlrange
 
     @property
     def uses_locomotion_policy(self) -> bool:

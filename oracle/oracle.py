@@ -374,3 +374,70 @@ def reward_fr3(states, sensors, phase: int, p=FR3_DEFAULT_P, arm_home=FR3_ARM_HO
     sa = (C.c_int * 5)(*sadr)
     lib().jo_reward_fr3(_d(states), _d(sensors), N, H, nq, nv, sensors.shape[-1], int(phase), _d(pp), sa, _d(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ action normalisers + the plan-step harness
+class OracleNormalizer:
+    """The three action normalisers (judo/utils/normalization.py:75-213) restated in numpy: "none" (:75-92), "min_max" over the finite
+    ctrlranges (:94-137), "running" with the batch form of Welford's update and the asymmetric normalize / denormalize pair (:138-213)."""
+
+    def __init__(self, kind: str, dim: int, lo=None, hi=None) -> None:
+        self.kind, self.dim = kind, dim
+        if kind == "min_max":
+            self.lo, self.hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+            self.dims = np.where((self.lo != -np.inf) & (self.hi != np.inf))[0]
+        elif kind == "running":
+            self.count, self.mean, self.std, self.M2 = 0, np.zeros(dim), np.ones(dim), np.zeros(dim)
+            self.min_std, self.max_std, self.eps = 1e-5, 1e3, 1e-6
+        elif kind != "none":
+            raise ValueError(kind)
+
+    def normalize(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self.kind == "none":
+            return x
+        if self.kind == "min_max":
+            out, d = x.copy(), self.dims
+            out[..., d] = 2 * (x[..., d] - self.lo[d]) / (self.hi[d] - self.lo[d]) - 1
+            return out
+        return (x - self.mean) / (self.std + self.eps)
+
+    def denormalize(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self.kind == "none":
+            return x
+        if self.kind == "min_max":
+            out, d = x.copy(), self.dims
+            out[..., d] = (x[..., d] + 1) * (self.hi[d] - self.lo[d]) / 2 + self.lo[d]
+            return out
+        return x * self.std + self.mean
+
+    def update(self, x) -> None:
+        if self.kind != "running":
+            return
+        x = np.asarray(x, dtype=np.float64)
+        axes = tuple(range(x.ndim - 1))
+        self.count += int(np.prod(x.shape[:-1]))
+        delta = x - self.mean
+        self.mean = self.mean + delta.sum(axis=axes) / self.count
+        self.M2 = np.maximum(self.M2 + (delta * (x - self.mean)).sum(axis=axes), 0)
+        self.std = np.clip(np.sqrt(self.M2 / self.count), self.min_std, self.max_std)
+
+
+def spline_resample(kind: str, old_times, old_knots, new_times) -> np.ndarray:
+    """`nominal = prev_spline(new_times)` (judo/controller/controller.py:220-221): the previous plan's interpolant (hold-ends) at the shifted knot times."""
+    return spline_eval(spline_weights(kind, old_times, new_times), np.asarray(old_knots, dtype=np.float64)[None])[0]
+
+
+def trace_segments(sensors, rewards, adrs, max_num_traces: int) -> np.ndarray:
+    """`Controller.update_traces` (judo/controller/controller.py:323-363): the min(max_num_traces, N) best rollouts, best first (equal rewards: the
+    higher index first, what argsort(...)[-E:][::-1] gives for a stable sort), per elite every trace sensor's (H-1) segments [p_h, p_{h+1}]."""
+    sensors, rewards = np.asarray(sensors, dtype=np.float64), np.asarray(rewards, dtype=np.float64)
+    E = min(int(max_num_traces), len(rewards))
+    elite = np.argsort(rewards, kind="stable")[len(rewards) - E :][::-1] if E > 0 else np.zeros(0, dtype=int)
+    out = []
+    for e in elite:
+        for a in adrs:
+            p = sensors[e, :, a : a + 3]
+            out.append(np.stack([p[:-1], p[1:]], axis=1))
+    return np.concatenate(out, axis=0) if out else np.zeros((0, 2, 3))

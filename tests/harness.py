@@ -57,3 +57,47 @@ def oracle_plan_step(om: "O.Model", ctrl, nominal_shifted: np.ndarray, noise: np
     else:
         out["nominal"], out["sigma"], out["elite_idx"] = O.cem_update(knots, rewards, cfg.num_elites, cfg.sigma_min, cfg.sigma_max)
     return out
+
+
+def oracle_update_action(opt_name: str, cfg, ccfg, nu: int, dt: float, ctrlrange: np.ndarray, rollout_fn, reward_fn, state: dict, x0: np.ndarray, time: float,
+                         noises: list[np.ndarray], trace_adrs=()) -> dict:
+    """The whole of `Controller.update_action` (judo/controller/controller.py:210-299) from oracle primitives, for any rollout / reward pair.
+
+    `state` carries what the controller object carries between plan steps: times, nominal_knots (raw), normalizer (O.OracleNormalizer), cem sigma.
+    `noises[i]` is the (N-1, K, nu) standard-normal draw of iteration i.  Returns the plan step's outputs and updates `state` in place."""
+    K = cfg.num_nodes
+    H = int(np.ceil(ccfg.horizon / dt))
+    order = ccfg.spline_order
+    new_times = time + np.linspace(0, ccfg.horizon, K, endpoint=True)
+    nrm = state["normalizer"]
+    nominal_n = nrm.normalize(O.spline_resample(order, state["times"], state["nominal_knots"], new_times))
+    if opt_name == "cem" and len(state["sigma"]) != K:
+        state["sigma"] = O.cem_pre_optimization(state["sigma"], state["times"], new_times)
+    W = O.spline_weights(order, new_times, time + dt * np.arange(H))
+    out = {}
+    for i in range(ccfg.max_opt_iters):
+        if opt_name == "cem":
+            state["sigma"] = O.cem_sigma_ramp(state["sigma"], cfg.use_noise_ramp, cfg.noise_ramp, cfg.sigma_min, cfg.sigma_max)  # cumulative (cem.py:69-72)
+            sigma = state["sigma"]
+        else:
+            sigma = O.mppi_sigma(cfg.sigma, cfg.use_noise_ramp, cfg.noise_ramp, K, nu)
+        cand_n = O.sample_knots(nominal_n, np.asarray(noises[i], dtype=np.float64), sigma)
+        cand_n = O.clip_knots(cand_n, nrm.normalize(ctrlrange[:, 0]), nrm.normalize(ctrlrange[:, 1]))
+        cand = nrm.denormalize(cand_n)
+        U = O.spline_eval(W, cand)
+        states, sensors = rollout_fn(x0, U)
+        rewards = reward_fn(states, sensors, U)
+        if opt_name == "mppi":
+            nominal_n = O.mppi_update(cand_n, rewards, cfg.temperature)
+        elif opt_name == "ps":
+            nominal_n = O.ps_update(cand_n, rewards)
+        else:
+            nominal_n, state["sigma"], _ = O.cem_update(cand_n, rewards, cfg.num_elites, cfg.sigma_min, cfg.sigma_max)
+        nrm.update(cand)
+        out.update(candidates=cand, controls=U, states=states, sensors=sensors, rewards=rewards)
+    state["nominal_knots"] = nrm.denormalize(nominal_n)
+    state["times"] = new_times
+    out["nominal"] = state["nominal_knots"].copy()
+    if trace_adrs:
+        out["traces"] = O.trace_segments(out["sensors"], out["rewards"], trace_adrs, ccfg.max_num_traces)
+    return out

@@ -1,0 +1,299 @@
+"""GPU: `judo_amd.Controller.update_action` as a drop-in for the reference's (judo/controller/controller.py:210-363).
+
+* against golden vectors of the reference's own update_action / update_traces run with a plugin task + plugin rollout backend
+  (tools/gen_golden_controller.py, tests/plugin_fixture.py): time shift, normalisers, clip, spline, several optimiser
+  iterations, the three update rules and the trace packing, with the device kernels doing sample/spline/update;
+* the reference's own controller tests mirrored (tests/test_controller/test_controller.py:41-117): max_opt_iters with a mock
+  optimizer that only has the two numpy methods, update_action with every registered optimizer;
+* the fused path over several iterations against the oracle harness; limits (knot count above the fused kernel's registers);
+* BASELINE configs 3 and 4 at full size through size-independent properties.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import plugin_fixture as PF  # noqa: E402
+from tests.conftest import GOLDEN  # noqa: E402
+from tests.test_controller_golden import PLAN_CASES  # noqa: E402
+
+
+def _plugin_controller(opt_name, okw, ckw):
+    import torch  # noqa: F401
+
+    from judo_amd.config import ControllerConfig
+    from judo_amd.controller import Controller
+    from judo_amd.optimizers import get_registered_optimizers
+    from judo_amd.tasks import Cartpole
+
+    class PluginTask(Cartpole):
+        """A third-party task on the cartpole model with its own numpy reward (served by the materialise path)."""
+
+        reward_accepts_torch = False
+
+        def reward(self, states, sensors, controls, system_metadata=None):
+            return PF.reward_numpy(states, sensors, controls)
+
+        def reset(self) -> None:
+            self.data.qpos = np.array([0.1, -0.3])
+            self.data.qvel = np.zeros(2)
+
+    cls, cfg_cls = get_registered_optimizers()[opt_name]
+    task = PluginTask()
+    ctrl = Controller(ControllerConfig(**ckw), task, cls(cfg_cls(**okw), task.nu))
+    ctrl.rollout_backend = PF.NumpyBackend(okw["num_rollouts"])  # assigned after construction, as the reference's tests do
+    return ctrl
+
+
+@pytest.mark.parametrize("case", sorted(PLAN_CASES))
+def test_controller_matches_reference_update_action(gpu, case):
+    g = np.load(os.path.join(GOLDEN, "controller.npz"))
+    opt_name, okw, ckw = PLAN_CASES[case]
+    ctrl = _plugin_controller(opt_name, okw, ckw)
+    assert not ctrl.uses_fused_cost and ctrl.uses_fused_optimizer
+    for step in range(3):
+        pre = f"plan_{case}_step{step}_"
+        ctrl.optimizer.injected_noise = [g[pre + f"noise{j}"] for j in range(int(g[pre + "ndraws"]))]
+        ctrl.current_state = g[pre + "x0"].copy()
+        ctrl.time = 0.05 * step
+        ctrl.update_action()
+        assert ctrl.optimizer.injected_noise == []  # one draw per optimiser iteration, as the reference made
+        # fp32 spline / update kernels against the reference's fp64 numpy (the rollout and the reward are the plugin's fp64 on both sides)
+        np.testing.assert_allclose(ctrl.nominal_knots, g[pre + "nominal"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(ctrl.times, g[pre + "times"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ctrl.rewards, g[pre + "rewards"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ctrl.action(ctrl.time + 0.013), g[pre + "action"], rtol=0, atol=2e-5)
+        assert ctrl.traces.shape == g[pre + "traces"].shape
+        np.testing.assert_allclose(ctrl.traces, g[pre + "traces"], rtol=0, atol=2e-5)
+        if opt_name == "cem":
+            np.testing.assert_allclose(ctrl.optimizer.sigma, g[pre + "sigma"], rtol=1e-4, atol=2e-6)
+    assert ctrl.rollout_backend.calls == 3 * ckw["max_opt_iters"]
+
+
+def test_max_opt_iters_with_a_numpy_only_optimizer(gpu):
+    """Mirror of the reference's tests/test_controller/test_controller.py:41-77: a mock optimizer with only sample_control_knots /
+    update_nominal_knots; the knots entering iteration 2 of a 2-iteration run equal the result of a 1-iteration run under one seed."""
+    from judo_amd.config import ControllerConfig, OptimizerConfig
+    from judo_amd.controller import make_controller
+    from judo_amd.optimizers import Optimizer
+
+    class MockOptimizerTrackNominalKnots(Optimizer):
+        def __init__(self, cfg, nu):
+            super().__init__(cfg, nu)
+            self.received_knots_history = []
+
+        def sample_control_knots(self, nominal_knots):
+            self.received_knots_history.append(nominal_knots.copy())
+            return nominal_knots + np.random.randn(self.num_rollouts, self.config.num_nodes, self.nu)
+
+        def update_nominal_knots(self, sampled_knots, rewards):
+            return sampled_knots[0]
+
+    def setup(max_opt_iters):
+        ctrl = make_controller("cylinder_push", "cem")
+        opt = MockOptimizerTrackNominalKnots(OptimizerConfig(), ctrl.task.nu)
+        ctrl.controller_cfg = ControllerConfig(max_opt_iters=max_opt_iters)
+        ctrl.optimizer = opt
+        return opt, ctrl
+
+    res = []
+    for iters in (1, 2):
+        np.random.seed(42)
+        opt, ctrl = setup(iters)
+        assert not ctrl.uses_fused_optimizer
+        ctrl.current_state = np.random.rand(ctrl.task.nq + ctrl.task.nv)
+        ctrl.time = 0.0
+        ctrl.update_action()
+        res.append((opt, ctrl))
+    (opt1, c1), (opt2, c2) = res
+    assert np.array_equal(opt1.received_knots_history[0], opt2.received_knots_history[0])
+    assert not np.array_equal(opt2.received_knots_history[-1], opt2.received_knots_history[0])
+    assert np.array_equal(opt2.received_knots_history[-1], c1.nominal_knots)
+    assert c1.candidate_knots.shape == (16, 4, 2) and c1.rewards.shape == (16,) and np.isfinite(c1.rewards).all()
+
+
+def test_update_action_with_every_registered_optimizer(gpu):
+    """Mirror of tests/test_controller/test_controller.py:80-117."""
+    from judo_amd.controller import make_controller
+    from judo_amd.optimizers import get_registered_optimizers
+
+    for name, (cls, cfg_cls) in get_registered_optimizers().items():
+        ctrl = make_controller("cylinder_push", "cem")
+        ctrl.optimizer = cls(cfg_cls(), ctrl.task.nu)
+        ctrl.current_state = np.random.rand(ctrl.task.nq + ctrl.task.nv)
+        ctrl.time = 0.0
+        before = ctrl.candidate_knots
+        assert before.shape == (ctrl.optimizer.num_rollouts, ctrl.optimizer.num_nodes, ctrl.optimizer.nu)
+        ctrl.update_action()
+        assert ctrl.nominal_knots.shape == (ctrl.optimizer.num_nodes, ctrl.optimizer.nu), name
+        assert ctrl.candidate_knots.shape == (ctrl.optimizer.num_rollouts, ctrl.optimizer.num_nodes, ctrl.optimizer.nu), name
+        np.testing.assert_allclose(ctrl.candidate_knots[0], np.clip(before[0], *ctrl.task.actuator_ctrlrange.T), atol=1e-6)  # sample 0 = the (shifted) nominal
+        assert ctrl.rewards.shape == (ctrl.optimizer.num_rollouts,)
+
+
+@pytest.mark.parametrize("task_name,opt_name,N,iters,normalizer", [
+    ("cartpole", "mppi", 256, 2, "none"), ("cartpole", "cem", 128, 3, "none"), ("cylinder_push", "ps", 64, 2, "min_max"), ("cylinder_push", "mppi", 200, 2, "running"),
+])
+def test_fused_path_several_iterations_match_oracle_harness(gpu, task_name, opt_name, N, iters, normalizer):
+    """max_opt_iters > 1 on the fused path (one kernel launch per iteration, the nominal of iteration i feeding iteration i+1) for two plan steps,
+    against the oracle's update_action (itself pinned to the reference's, tests/test_controller_golden.py) with the fp64 engine as the rollout."""
+    from judo_amd.controller import make_controller
+    from oracle import oracle as O
+    from tests.harness import oracle_reward, oracle_update_action
+
+    rng = np.random.default_rng(21)
+    ctrl = make_controller(task_name, opt_name)
+    cfg = ctrl.optimizer.config
+    cfg.num_rollouts = N
+    ctrl.controller_cfg.horizon = 32 * ctrl.task.dt
+    ctrl.controller_cfg.max_opt_iters = iters
+    ctrl.controller_cfg.action_normalizer = normalizer
+    ctrl.controller_cfg.max_num_traces = 3
+    ctrl.reset()
+    x0 = ctrl.task.default_state()
+    K, nu = cfg.num_nodes, ctrl.nu
+    om = O.Model(task_name)
+    r = ctrl.task.actuator_ctrlrange
+    state = dict(times=ctrl.times.copy(), nominal_knots=ctrl.nominal_knots.copy(), normalizer=O.OracleNormalizer(normalizer, nu, r[:, 0], r[:, 1]))
+    if opt_name == "cem":
+        state["sigma"] = ctrl.optimizer.sigma.copy()
+    adrs = [s["adr"] for s in ctrl.trace_sensors]
+    for step in range(2):
+        noises = [rng.standard_normal((N - 1, K, nu)).astype(np.float32) for _ in range(iters)]
+        ctrl.optimizer.injected_noise = list(noises)
+        ctrl.current_state, ctrl.time = x0.copy(), 0.05 * step
+        ctrl.update_action()
+        ref = oracle_update_action(opt_name, cfg, ctrl.controller_cfg, nu, ctrl.task.dt, r, om.rollout,
+                                   lambda s, y, u: oracle_reward(ctrl.task, s, y, u, ctrl.system_metadata), state, x0, 0.05 * step, noises, trace_adrs=adrs)
+        # fp32 rollouts against fp64: the stated tolerance on the returned nominal knots
+        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=5e-3 if opt_name != "ps" else 1e-5)
+        np.testing.assert_allclose(ctrl.rewards, ref["rewards"], rtol=3e-4, atol=3e-3)
+        np.testing.assert_allclose(ctrl.candidate_knots, ref["candidates"], rtol=0, atol=5e-3)
+        if opt_name == "cem":
+            np.testing.assert_allclose(ctrl.optimizer.sigma, state["sigma"], rtol=0, atol=5e-3)
+        # traces: the elites chosen by the GPU's own rewards, their sensor rows from the oracle rollouts
+        exp = O.trace_segments(ref["sensors"], ctrl.rewards, adrs, 3)
+        assert ctrl.traces.shape == exp.shape == (3 * len(adrs) * (ctrl.num_timesteps - 1), 2, 3)
+        np.testing.assert_allclose(ctrl.traces, exp, rtol=0, atol=5e-3)
+
+
+def test_knot_count_above_the_fused_kernels_registers_takes_the_materialise_path(gpu):
+    """A live `num_nodes` edit to 10 on leap_cube (the cooperative kernel holds 8 knots per actuator in registers) must not kill the control
+    loop: the plan step goes through spline -> rollout arrays -> reward kernels instead and still matches the oracle."""
+    import torch
+
+    from judo_amd.controller import make_controller
+    from oracle import oracle as O
+    from tests.harness import oracle_plan_step
+
+    rng = np.random.default_rng(8)
+    ctrl = make_controller("leap_cube", "mppi")
+    ctrl.optimizer.config.num_rollouts = 48
+    ctrl.controller_cfg.horizon = 0.2
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])}
+    ctrl.update_action()
+    assert ctrl.uses_fused_cost
+    ctrl.optimizer.config.num_nodes = 10
+    assert not ctrl.uses_fused_cost and ctrl.model.max_fused_knots == 8
+    noise = rng.standard_normal((47, 10, 16)).astype(np.float32)
+    ctrl.optimizer.injected_noise = noise
+    ctrl.keep_candidates = True
+    ctrl.time = 0.05
+    from judo_amd.spline import evaluate
+
+    shifted = evaluate(ctrl.spline_order, ctrl.times, ctrl.nominal_knots, ctrl.time + ctrl.spline_timesteps)
+    ctrl.update_action()
+    torch.cuda.synchronize()
+    ref = oracle_plan_step(O.Model("leap_cube"), ctrl, shifted, noise, "mppi")
+    cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
+    np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
+    d = np.abs(ctrl.rewards - ref["rewards"])
+    assert np.median(d) < 1e-5 and np.percentile(d, 95) < 2e-3
+    assert ctrl.nominal_knots.shape == (10, 16) and np.isfinite(ctrl.nominal_knots).all()
+    ctrl.optimizer.config.num_nodes = 40  # 640 knot values: above JH_MAX_KNOT_DIM, refused before anything is launched
+    with pytest.raises(ValueError):
+        ctrl.update_action()
+
+
+def test_reset_restarts_the_policy_state(gpu):
+    """judo/controller/controller.py:318-321: reset() zeroes the last policy output of a locomotion-policy task; the plant solver's warm start goes with it."""
+    import torch
+
+    from judo_amd.controller import make_controller
+
+    ctrl = make_controller("spot_navigate", "mppi")
+    ctrl.optimizer.config.num_rollouts = 8
+    ctrl.controller_cfg.horizon = 0.2
+    ctrl.rollout_cutoff_time = None
+    ctrl.reset()
+    ctrl.optimizer.seed(3)
+    ctrl.update_action()
+    first = ctrl.nominal_knots.copy()
+    assert ctrl._last_policy_output is not None and float(ctrl._last_policy_output.abs().max()) > 0
+    assert float(ctrl.rollout_backend._warm.abs().max()) > 0
+    ctrl.reset()
+    assert ctrl._last_policy_output is None and float(ctrl.rollout_backend._warm.abs().max()) == 0.0
+    ctrl.optimizer.seed(3)
+    ctrl.time = 0.0
+    ctrl.update_action()
+    np.testing.assert_array_equal(ctrl.nominal_knots, first)  # a reset controller replays the first plan step exactly
+    torch.cuda.synchronize()
+
+
+def _full_size(task_name, opt_name, N, H, seed=7):
+    from judo_amd.controller import make_controller
+
+    ctrl = make_controller(task_name, opt_name)
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.horizon = H * ctrl.task.dt
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.optimizer.seed(seed)
+    assert ctrl.num_timesteps == H
+    return ctrl
+
+
+@pytest.mark.parametrize("task_name,opt_name,N,H", [("cylinder_push", "mppi", 16384, 64), ("fr3_pick", "cem", 32768, 40), ("cartpole", "mppi", 4096, 64)])
+def test_full_size_configs_properties(gpu, task_name, opt_name, N, H):
+    """BASELINE configs 2-4 at their full sizes: properties that need no oracle (finite costs, bounds, bit-exact permutation equivariance of the
+    costs, the same update from permuted candidates, idempotence at sigma = 0, determinism)."""
+    import torch
+
+    ctrl = _full_size(task_name, opt_name, N, H)
+    nominal0 = ctrl.nominal_knots.copy()
+    ctrl.update_action()
+    c1 = ctrl.costs_device.clone()
+    noise1 = ctrl.optimizer.last_noise.clone()
+    assert c1.numel() == N and torch.isfinite(c1).all()
+    r = ctrl.task.actuator_ctrlrange
+    assert (ctrl.nominal_knots >= r[:, 0] - 1e-5).all() and (ctrl.nominal_knots <= r[:, 1] + 1e-5).all()
+    # determinism: same seed, same everything
+    ctrl_b = _full_size(task_name, opt_name, N, H)
+    ctrl_b.update_action()
+    assert torch.equal(ctrl_b.costs_device, c1) and np.array_equal(ctrl_b.nominal_knots, ctrl.nominal_knots)
+    # permutation equivariance: rollouts 1.. permuted -> the costs permute bit for bit, the update is the same up to summation order
+    perm = torch.cat([torch.zeros(1, dtype=torch.long, device=c1.device), 1 + torch.randperm(N - 1, device=c1.device)])
+    ctrl2 = _full_size(task_name, opt_name, N, H)
+    ctrl2.optimizer.injected_noise = noise1[:, :, perm][:, :, 1:].permute(2, 0, 1).contiguous().cpu().numpy()
+    ctrl2.update_action()
+    assert torch.equal(ctrl2.costs_device, c1[perm])
+    np.testing.assert_allclose(ctrl2.nominal_knots, ctrl.nominal_knots, atol=2e-5)
+    # idempotence: no noise -> every rollout is the nominal rollout and the update returns the nominal
+    ctrl3 = _full_size(task_name, opt_name, 4096, H)
+    if opt_name == "cem":
+        ctrl3.optimizer.config.sigma_min = ctrl3.optimizer.config.sigma_max = 0.0
+        ctrl3.optimizer.sigma = np.zeros_like(ctrl3.optimizer.sigma)
+    else:
+        ctrl3.optimizer.config.sigma = 0.0
+    ctrl3.update_action()
+    c3 = ctrl3.costs_device
+    assert torch.equal(c3, c3[0].expand_as(c3)) and float(c3[0]) == float(c1[0])
+    np.testing.assert_allclose(ctrl3.nominal_knots, np.clip(nominal0, r[:, 0], r[:, 1]), atol=1e-6)
+    if task_name == "fr3_pick":
+        st = ctrl.solver_stats()
+        assert st["steps"] >= N * H and st["newton_cap_hits"] < 1e-3 * st["steps"]

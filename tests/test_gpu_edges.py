@@ -54,6 +54,11 @@ def test_small_and_ragged_plan_steps_match_oracle(gpu, task, opt, N, H, K):
 
 
 def test_engine_kernels_reject_more_knots_than_they_hold(gpu):
+    """The C entry point refuses K > 8 on the cooperative kernels (a lane's knots live in 8 registers); the controller routes such a plan step through
+    the materialise path instead (tests/test_gpu_controller.py), so a live num_nodes edit never raises in the control loop."""
+    import torch
+
+    from judo_amd import _lib
     from judo_amd.controller import make_controller
 
     for task in ("leap_cube", "fr3_pick"):
@@ -64,8 +69,15 @@ def test_engine_kernels_reject_more_knots_than_they_hold(gpu):
         ctrl.reset()
         ctrl.current_state = ctrl.task.default_state()
         ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
-        with pytest.raises(ValueError, match="at most 8 knots|exceeds"):
-            ctrl.update_action()
+        assert not ctrl.uses_fused_cost
+        ctrl.update_action()
+        assert np.isfinite(ctrl.nominal_knots).all() and ctrl.nominal_knots.shape == (9, ctrl.nu)
+        K, nu, N, H = 9, ctrl.nu, 8, 8
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device="cuda")  # noqa: E731
+        st = _lib.lib().jh_rollout_cost(ctrl.model.handle, _lib.ptr(z(ctrl.task.nq + ctrl.task.nv)), _lib.ptr(z(K * nu)), _lib.ptr(z(K * nu * N)), N, _lib.ptr(z(K * nu)),
+                                        _lib.ptr(z(H * K)), _lib.ptr(z(2 * nu)), _lib.ptr(z(32)), 0, N, 0, H, K, _lib.ptr(z(N)), None, 0)
+        with pytest.raises(ValueError, match="at most 8 knots"):
+            _lib.check(st, "jh_rollout_cost")
 
 
 @pytest.mark.parametrize("task,N,H", [("leap_cube", 130, 48), ("fr3_pick", 130, 40), ("cylinder_push", 200, 64)])

@@ -159,6 +159,26 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _lib.lib().jh_update_scratch_floats(65536, 4, 16) >= 256 * 66
 
 
+def test_library_limits_agree_with_the_header():
+    from judo_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "judo_amd.h")).read()
+    for name, val in (("JH_MAX_KNOT_DIM", _lib.MAX_KNOT_DIM), ("JH_MAX_ELITES", _lib.MAX_ELITES), ("JH_MAX_TASK_PARAMS", _lib.MAX_TASK_PARAMS)):
+        m = re.search(rf"#define\s+{name}\s+(\d+)", header)
+        assert m and int(m.group(1)) == val, name
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`--gpus 8` under a 1-rank environment must not run (and label) a 1-GPU job: non-zero exit, before any GPU work."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in r.stderr
+    assert not r.stdout.strip()  # no JSON line
+
+
 def test_optimizer_host_state_and_registry():
     from judo_amd import config as c
     from judo_amd import optimizers as o
