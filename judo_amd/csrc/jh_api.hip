@@ -30,7 +30,7 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = 2;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE) ? 3 : 2;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
@@ -80,14 +80,14 @@ extern "C" int jh_model_hist(jh_model* m, int* out /* 24 ints: Newton-iteration 
 }
 
 extern "C" int jh_model_set_kernel(jh_model* m, int generation) {
-  JH_REQUIRE(m && (generation == 1 || generation == 2), "model_set_kernel: generation must be 1 or 2");
+  JH_REQUIRE(m && generation >= 1 && generation <= 3, "model_set_kernel: generation must be 1, 2 or 3");
   m->kernel_gen = generation;
   return JH_OK;
 }
 
 extern "C" int jh_model_limits(const jh_model* m, int* out) {
   JH_REQUIRE(m && out, "model_limits: null pointer");
-  const bool coop = m->kernel_gen == 2 && (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK);
+  const bool coop = m->kernel_gen >= 2 && (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK);
   out[0] = coop ? 8 : JH_MAX_KNOT_DIM / (m->nu > 0 ? m->nu : 1);
   out[1] = JH_MAX_KNOT_DIM;
   out[2] = JH_MAX_ELITES;
@@ -141,7 +141,8 @@ extern "C" int jh_rollout_cost(const jh_model* m, const float* x0, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH)
     return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
-  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 2) return jh_engine3_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
+  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen >= 2) return jh_engine3_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
   return jh_engine_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
 }
@@ -153,7 +154,8 @@ extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0
   JH_REQUIRE(N > 0 && H > 0, "rollout_materialize: N and H must be positive (N=%d H=%d)", N, H);
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) return jh_simple_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
-  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 2) return jh_engine3_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen >= 2) return jh_engine3_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   return jh_engine_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
 }

@@ -1,0 +1,797 @@
+// jh_engine_v5.hip -- leap_cube rollout kernel, second cooperative generation (gfx950): the arithmetic of jh_engine_v2.hip on a register
+// diet, so that more than one wave fits on a SIMD.
+//
+// jh_engine_v2.hip runs one wave per SIMD (487 registers) and is stalled ~75 % of the time on dependent VALU / LDS / DPP chains with
+// nothing to switch to.  Same decomposition here -- 16 lanes (one DPP row) per rollout, lane (c,s) owns link s of finger chain c, its
+// joint, its actuator, its dof rows and <= 2 contacts -- but everything a lane does not need in every instruction lives in LDS:
+//   * per-lane model constants, the lane's spline knots, the warm start, the chain inertia blocks;
+//   * a contact slot keeps frame (9), lever arm (3), cone constants (5), aref / jar / jp (9): the finger-side Jacobian columns are
+//     recomputed from the joint axes / anchors in LDS wherever they are used (J x, J'f, J'WJ), the cube-side rotational columns from the
+//     lever arm and the cube rotation;
+//   * every contact contribution to the gradient and to the arrow Hessian is an LDS float atomic (the cube block as well: no 21-entry
+//     register partials and no 21 row sums per iteration); row sums remain only for the scalars of the convergence test and line search;
+//   * the cube-chain coupling Y = L^-1 Hcb is spread over the chain's four lanes (<= 2 of the 6 columns per lane) instead of being held
+//     whole by every lane; the Schur-complement dot products are shared the same way.
+// The solver itself (primal Newton, exact line search, warm start, termination) is unchanged: results agree with jh_engine_v2.hip to
+// summation order, and the parity suite (tests/test_gpu_leap.py) runs against both.
+#include "jh_coop.h"
+
+using namespace jh_eng;
+using namespace jh_coop;
+
+namespace {
+
+constexpr int G = 16, RPW = 4, WAVE = 64;
+constexpr int NCH = 4, NLK = 4;
+#ifndef JH_V5_LSMAX
+#define JH_V5_LSMAX 16
+#endif
+#ifndef JH_V5_WAVES_PER_EU
+#define JH_V5_WAVES_PER_EU 2
+#endif
+#ifndef JH_V5_WPB
+#define JH_V5_WPB 4  // waves per workgroup: they share one LDS copy of the model image and nothing else
+#endif
+// Waves of a workgroup never exchange data after the image is staged: inside the step loop a "barrier" only has to order one wave's own LDS traffic
+// (a wave's LDS instructions execute in issue order), so it is a compiler fence, not an s_barrier -- rollouts in different waves never wait for each other.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+constexpr int NSLOT = 2;
+constexpr int NCP = 16 * NSLOT;  // contact pool per rollout
+constexpr int MAXHIT = 32;
+constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
+constexpr int MAXG = 72, MAXLG = 8;
+constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
+constexpr int MAXK = 8;
+
+// per-lane model constants staged in LDS (index = lane & 15)
+enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_N = 24 };
+
+struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
+  float pa[NMB][8];   // body origin (0..2) and joint axis in the world (4..6)
+  float xR[NMB][9];
+  float qv[NV], g[NV], p[NV], ws[NV];
+  float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
+  float Mbb[NCH][10];
+  float rhs6[6];
+  int hits[MAXHIT];
+  union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
+    float pool[NCP][POOL_F];
+    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24]; };  // Hcb[c][j*6+q]: chain column j, cube row q
+  };
+  int ncon, nhit;
+};
+
+struct PoolCtx { RS* S; int* overflow; };
+
+__device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos, const float* n, float dist, int body, float mu, float tran) {
+  int i = atomicAdd(&pc.S->ncon, 1);
+  if (i >= NCP) { if (pc.overflow) atomicAdd(pc.overflow, 1); return; }
+  float* e = pc.S->pool[i];
+  e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = dist; e[7] = mu; e[8] = __int_as_float(body); e[9] = tran;
+}
+
+struct LeapSink {
+  PoolCtx pc; int body; float mu, tran;
+  __device__ __forceinline__ void push(const float* pos, const float* n, float dist) { push_contact(pc, pos, n, dist, body, mu, tran); }
+};
+
+// ------------------------------------------------------------------------------------------------ per-lane contact slot (27 registers)
+struct Slot {
+  int link;          // -1 = empty slot, 0 = static geom, 1 + 4*chain + depth = finger link
+  float fr[9];       // contact frame rows (normal, t1, t2), world
+  float rc[3];       // contact point relative to the cube origin, world
+  float aref[3], D0, D1, Dm, mu, fri;
+  float jar[3], jp[3];
+};
+
+// contact-frame image of the relative point velocity for the generalised velocity whose cube part is (xl = linear, world; wang = R_cube *
+// angular part, world) and whose finger part is `vec` (22-vector in LDS).  Normal points from the cube to the hand geom.
+__device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float* qcpos, const float* xl, const float* wang, const float* vec, float* out) {
+  float wx[3]; cross3(wx, wang, s.rc);
+  float w[3] = {-(xl[0] + wx[0]), -(xl[1] + wx[1]), -(xl[2] + wx[2])};
+  if (s.link > 0) {
+    const int ch = (s.link - 1) >> 2, dep = (s.link - 1) & 3;
+    const float pos[3] = {s.rc[0] + qcpos[0], s.rc[1] + qcpos[1], s.rc[2] + qcpos[2]};
+#pragma unroll
+    for (int j = 0; j < NLK; j++) if (j <= dep) {
+      const float* pj = S.pa[1 + 4 * ch + j];
+      const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+      cross3(c3, pj + 4, rb);
+      const float xj = vec[6 + 4 * ch + j];
+      w[0] = fmaf(c3[0], xj, w[0]); w[1] = fmaf(c3[1], xj, w[1]); w[2] = fmaf(c3[2], xj, w[2]);
+    }
+  }
+  out[0] = dot3(s.fr, w); out[1] = dot3(s.fr + 3, w); out[2] = dot3(s.fr + 6, w);
+}
+
+struct DofRows { float fl, fD, fR, faref, lims, laref, lD, jf, jl, pf, pl; };  // fR = 1/fD
+
+__device__ __forceinline__ float cone_cost(const Slot& s) {
+  float f[3], W[6];
+  const float D[3] = {s.D0, s.D1, s.D1};
+  return cone_eval(s.jar, D, s.Dm, s.mu, s.fri, f, W);
+}
+
+__device__ __forceinline__ float dof_rows_cost(const DofRows& dr) {
+  float cs = 0.f;
+  if (dr.fl > 0.f) {
+    const float R = dr.fR, x = dr.jf, fl = dr.fl;
+    if (x <= -R * fl) cs += -0.5f * R * fl * fl - fl * x;
+    else if (x >= R * fl) cs += -0.5f * R * fl * fl + fl * x;
+    else cs += 0.5f * dr.fD * x * x;
+  }
+  if (dr.lims != 0.f && dr.jl < 0.f) cs += 0.5f * dr.lD * dr.jl * dr.jl;
+  return cs;
+}
+
+// slope and curvature of the lane's rows along the search direction at step al (line search)
+__device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr, float al, float* d1, float* d2) {
+  float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NSLOT; k++) {
+    if (sl[k].link < 0) continue;
+    const float* jp = sl[k].jp;
+    const float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
+    const float D[3] = {sl[k].D0, sl[k].D1, sl[k].D1};
+    cone_dir(jar, jp, D, sl[k].Dm, sl[k].mu, sl[k].fri, &g1, &g2);
+  }
+  if (dr.fl > 0.f) {
+    float D = dr.fD, jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
+    if (x <= -lim) g1 -= fl * jp;
+    else if (x >= lim) g1 += fl * jp;
+    else { g1 += D * x * jp; g2 += D * jp * jp; }
+  }
+  if (dr.lims != 0.f) {
+    float jp = dr.pl, x = fmaf(al, jp, dr.jl);
+    if (x < 0.f) { g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; }
+  }
+  *d1 = g1; *d2 = g2;
+}
+
+// 4x4 Cholesky (packed lower) + triangular solves on registers; the diagonal is kept as its reciprocal
+__device__ __forceinline__ void chol4(float* L, float* inv) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = L[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { float r = __frsqrt_rn(fmaxf(s, 1e-30f)); inv[i] = r; L[tri(i, i)] = s * r; }
+      else L[tri(i, j)] = s * inv[j];
+    }
+}
+__device__ __forceinline__ void fwd4(const float* L, const float* inv, float* x) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) { float s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
+    x[i] = s * inv[i]; }
+}
+__device__ __forceinline__ void bwd4(const float* L, const float* inv, float* x) {
+#pragma unroll
+  for (int i = 3; i >= 0; i--) { float s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < 4; k++) s -= L[tri(k, i)] * x[k];
+    x[i] = s * inv[i]; }
+}
+// element j (run-time, wave-nonuniform) of a 4-array held in registers: compare-and-select
+__device__ __forceinline__ float sel4(const float* a, int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
+
+// ------------------------------------------------------------------------------------------------ the kernel
+template <bool MATERIALIZE, int WPB>
+__global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
+                                                   const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
+                                                   const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
+                                                   const float* __restrict__ tp, int N, int n_offset, int H, int K, float* __restrict__ costs,
+                                                   float* __restrict__ knots_out, const float* __restrict__ controls, float* __restrict__ states,
+                                                   float* __restrict__ sensors, int* __restrict__ stats) {
+  __shared__ RS sRS[RPW * WPB];
+  __shared__ float sBody[16 * BODY_F];
+  __shared__ float sTp[16];
+  __shared__ float sGeomF[MAXG * GEOM_F];
+  __shared__ int sGeomI[MAXG * GEOM_I];
+  __shared__ int sLaneG[16 * MAXLG];
+  __shared__ float sLane[16 * LC_N];
+  __shared__ float sKnAll[MAXK * WAVE * WPB];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3;
+  RS& S = sRS[wv * RPW + r];
+  float* sKn = sKnAll + wv * (MAXK * WAVE);
+  const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6];
+  const int oBodyF = HEADER_F, oDofF = oBodyF + nmI * BODY_F, oActF = oDofF + gI[2] * DOF_F, oGeomF = oActF + nuI * ACT_F, oSiteF = oGeomF + ngI * GEOM_F;
+  const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
+  const int oLane = gI[11], lgm = gI[12];
+  for (int i = tid; i < 16 * BODY_F; i += WAVE * WPB) sBody[i] = gF[oBodyF + BODY_F + i];
+  for (int i = tid; i < ngI * GEOM_F; i += WAVE * WPB) sGeomF[i] = gF[oGeomF + i];
+  for (int i = tid; i < ngI * GEOM_I; i += WAVE * WPB) sGeomI[i] = gI[oGeomI + i];
+  for (int i = tid; i < 16 * lgm; i += WAVE * WPB) sLaneG[i] = gI[oLane + i];
+  if (!MATERIALIZE && tid < 9) sTp[tid] = tp[tid];
+  if (tid < 16) {
+    const float* df = gF + oDofF + (6 + l) * DOF_F; const float* af = gF + oActF + l * ACT_F;
+    float* lc = sLane + l * LC_N;
+    lc[LC_DAMP] = df[DF_DAMP]; lc[LC_KVD] = df[DF_KV]; lc[LC_FL] = df[DF_FL]; lc[LC_FB] = df[DF_FB]; lc[LC_FD] = df[DF_FD]; lc[LC_INVW] = df[DF_INVW];
+    lc[LC_LIMITED] = df[DF_LIMITED]; lc[LC_LO] = df[DF_LO]; lc[LC_HI] = df[DF_HI]; lc[LC_LK] = df[DF_LK]; lc[LC_LB] = df[DF_LB];
+    for (int k = 0; k < 5; k++) lc[LC_SI + k] = df[DF_SOLIMP + k];
+    lc[LC_KP] = af[AF_KP]; lc[LC_KV] = af[AF_KV]; lc[LC_CLIM] = af[AF_CLIM]; lc[LC_CLO] = af[AF_CLO]; lc[LC_CHI] = af[AF_CHI];
+  }
+  const float* lc = sLane + l * LC_N;
+  const int n = (blockIdx.x * WPB + wv) * RPW + r;  // rollout handled by this row of 16 lanes
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  const float h = gF[HF_DT], impratio = gF[HF_IMPRATIO], tol = gF[HF_TOL], lstol = gF[HF_LSTOL]; const int cap = (int)gF[HF_MAXITER];
+  const float grav[3] = {gF[HF_GRAV], gF[HF_GRAV + 1], gF[HF_GRAV + 2]};
+  const float cmass = gF[HF_CMASS], cI[3] = {gF[HF_CINERTIA], gF[HF_CINERTIA + 1], gF[HF_CINERTIA + 2]};
+  const float chs[3] = {gF[HF_CSIZE], gF[HF_CSIZE + 1], gF[HF_CSIZE + 2]}, crb = gF[HF_CRBOUND], ctran = gF[HF_CTRAN];
+  const float cK = gF[HF_CK], cB = gF[HF_CB];
+  float csi[5]; for (int k = 0; k < 5; k++) csi[k] = gF[HF_SOLIMP + k];
+  // own cube dof (lanes 0..5): inertia and its inverse; zero elsewhere
+  const float mck = (l < 3 ? cmass : (l == 3 ? cI[0] : (l == 4 ? cI[1] : (l == 5 ? cI[2] : 0.f)))), imck = l < 6 ? 1.f / mck : 0.f;
+  // ---- state: own joint + replicated cube
+  float q, qd, qc[7], vc[6];
+  {
+    const float* xi = x0 + ((MATERIALIZE && x0_batched) ? (size_t)nc * NX : 0);
+    for (int k = 0; k < 7; k++) qc[k] = xi[k];
+    for (int k = 0; k < 6; k++) vc[k] = xi[NQ + k];
+    q = xi[7 + l]; qd = xi[NQ + 6 + l];
+  }
+  // ---- own actuator's spline knots (fused mode): clip(nominal + sigma*noise) -> LDS; global sample 0 keeps the nominal
+  if (!MATERIALIZE) {
+    for (int k = 0; k < MAXK; k++) {
+      float v = 0.f;
+      if (k < K) {
+        int i = k * NU + l;
+        v = nominal[i];
+        if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
+        v = jh_clampf(v, lohi[l], lohi[NU + l]);
+        if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
+      }
+      sKn[k * WAVE + lane] = v;
+    }
+  }
+  S.ws[6 + l] = 0.f; if (l < 6) S.ws[l] = 0.f;
+  int n_iters = 0, n_maxed = 0;
+  float acc = 0.f;
+  __syncthreads();  // the only workgroup barrier: the model image is staged
+
+  for (int hh = 0; hh < H; hh++) {
+    // ================================================================ controls
+    float u;
+    if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + l];
+    else { u = 0.f; for (int k = 0; k < K && k < MAXK; k++) u = fmaf(W[hh * K + k], sKn[k * WAVE + lane], u); }
+    // ================================================================ kinematics (each lane walks its chain up to its own link)
+    float Mrow[NLK], fs_own, a0_own;
+    {
+      float ax[NLK][3], og[NLK][3], Rown[9], pown[3];
+      {
+        float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
+        qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+        float Rc[9]; quat2mat(Rc, qc + 3);
+        float P[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        float sn_own, cs_own; sincosf(q, &sn_own, &cs_own);
+#pragma unroll
+        for (int j = 0; j < NLK; j++) {
+          const float* bf = sBody + (4 * c + j) * BODY_F;
+          float P2[3], R0[9];
+          if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
+          else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
+          const float* al = bf + BF_AXIS;
+          mulMV(ax[j], R0, al);
+          for (int k = 0; k < 3; k++) { og[j][k] = P2[k]; P[k] = P2[k]; }
+          const float sn = quad_get(sn_own, j), cs = quad_get(cs_own, j), t = 1.f - cs, x = al[0], y = al[1], z = al[2];
+          float Rq[9] = {t * x * x + cs, t * x * y - sn * z, t * x * z + sn * y, t * x * y + sn * z, t * y * y + cs, t * y * z - sn * x, t * x * z - sn * y, t * y * z + sn * x, t * z * z + cs};
+          mulMM(R, R0, Rq);
+          if (j == s) { for (int k = 0; k < 3; k++) pown[k] = P2[k]; for (int k = 0; k < 9; k++) Rown[k] = R[k]; }
+        }
+        for (int k = 0; k < 3; k++) { S.pa[1 + l][k] = pown[k]; S.pa[1 + l][4 + k] = s == 0 ? ax[0][k] : (s == 1 ? ax[1][k] : (s == 2 ? ax[2][k] : ax[3][k])); }
+        for (int k = 0; k < 9; k++) S.xR[1 + l][k] = Rown[k];
+        if (l == 0) { for (int k = 0; k < 3; k++) S.pa[0][k] = qc[k]; for (int k = 0; k < 9; k++) S.xR[0][k] = Rc[k]; S.ncon = 0; S.nhit = 0; }
+        S.qv[6 + l] = qd;
+        if (l < 6) S.qv[l] = vc[l];
+      }
+      // sensors of this forward pass (materialise mode): 16 joint positions, then 5 site positions
+      if (MATERIALIZE && sensors) {
+        float* y = sensors + ((size_t)nc * H + hh) * NS;
+        if (live) y[l] = q;
+        WSYNC();
+        if (live && l < nsiteI && l < 5) {
+          int b = gI[oSiteI + l]; float p3[3]; mulMV(p3, S.xR[b], gF + oSiteF + l * SITE_F);
+          for (int k = 0; k < 3; k++) y[16 + 3 * l + k] = p3[k] + S.pa[b][k];
+        }
+      }
+      // ================================================================ chain dynamics: inertia block, bias, smooth force
+      {
+        const float* bf = sBody + (4 * c + s) * BODY_F;
+        float Rk[9], rr[3], cs3[3]; mulMM(Rk, Rown, bf + BF_IR); mulMV(rr, Rown, bf + BF_IPOS);
+        for (int k = 0; k < 3; k++) cs3[k] = pown[k] + rr[k];
+        const float mass = bf[BF_MASS]; const float* di = bf + BF_INERTIA;
+        float wv[3] = {0, 0, 0}, al[3] = {0, 0, 0}, ao[3] = {-grav[0], -grav[1], -grav[2]};
+#pragma unroll
+        for (int j = 0; j < NLK; j++) {
+          float qdj = quad_get(qd, j);
+          if (j <= s) {
+            if (j > 0) {
+              float d[3] = {og[j][0] - og[j - 1][0], og[j][1] - og[j - 1][1], og[j][2] - og[j - 1][2]}, t1[3], t2[3], t3[3];
+              cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d);
+              for (int k = 0; k < 3; k++) ao[k] += t3[k] + t2[k];
+            }
+            float wxa[3]; cross3(wxa, wv, ax[j]);
+            for (int k = 0; k < 3; k++) { al[k] += wxa[k] * qdj; wv[k] += ax[j][k] * qdj; }
+          }
+        }
+        float t1[3], t2[3], t3[3], ac3[3];
+        cross3(t1, wv, rr); cross3(t2, wv, t1); cross3(t3, al, rr);
+        for (int k = 0; k < 3; k++) ac3[k] = ao[k] + t3[k] + t2[k];
+        float Iw[3], Ia[3], gy[3]; inertia_mul(Iw, Rk, di, wv); inertia_mul(Ia, Rk, di, al); cross3(gy, wv, Iw);
+        float Fk[3] = {mass * ac3[0], mass * ac3[1], mass * ac3[2]}, Nk[3] = {Ia[0] + gy[0], Ia[1] + gy[1], Ia[2] + gy[2]};
+        float bias[NLK], Mc[10];
+        for (int k = 0; k < 10; k++) Mc[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NLK; i++) {
+          bias[i] = 0.f;
+          if (i <= s) {
+            float ri[3] = {cs3[0] - og[i][0], cs3[1] - og[i][1], cs3[2] - og[i][2]}, rxF[3], Jvi[3], tB[3];
+            cross3(rxF, ri, Fk);
+            bias[i] = ax[i][0] * (Nk[0] + rxF[0]) + ax[i][1] * (Nk[1] + rxF[1]) + ax[i][2] * (Nk[2] + rxF[2]);
+            cross3(Jvi, ax[i], ri); inertia_mul(tB, Rk, di, ax[i]);
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+              float rj[3] = {cs3[0] - og[j][0], cs3[1] - og[j][1], cs3[2] - og[j][2]}, Jvj[3]; cross3(Jvj, ax[j], rj);
+              Mc[tri(i, j)] = mass * dot3(Jvi, Jvj) + dot3(tB, ax[j]);
+            }
+          }
+        }
+        for (int k = 0; k < 10; k++) Mc[k] = csum(Mc[k]);
+        float bown = 0.f;
+#pragma unroll
+        for (int i = 0; i < NLK; i++) { float b = csum(bias[i]); if (i == s) bown = b; }
+        // position servo on the own joint
+        float cc = u; if (lc[LC_CLIM] != 0.f) cc = jh_clampf(cc, lc[LC_CLO], lc[LC_CHI]);
+        fs_own = -lc[LC_DAMP] * qd - bown + lc[LC_KP] * (cc - q) - lc[LC_KV] * qd;
+        float x4[4], L[10];
+#pragma unroll
+        for (int j = 0; j < NLK; j++) x4[j] = quad_get(fs_own, j);
+        for (int k = 0; k < 10; k++) L[k] = Mc[k];
+        float inv4[4]; chol4(L, inv4); fwd4(L, inv4, x4); bwd4(L, inv4, x4);
+        a0_own = sel4(x4, s);
+#pragma unroll
+        for (int j = 0; j < NLK; j++) { float v = 0.f;
+#pragma unroll
+          for (int i = 0; i < NLK; i++) if (i == s) v = Mc[i >= j ? tri(i, j) : tri(j, i)];
+          Mrow[j] = v; }
+        if (s == 0) for (int k = 0; k < 10; k++) S.Mbb[c][k] = Mc[k];
+      }
+    }
+    // free cube: M = diag(m,m,m,I); own component of the unconstrained acceleration (lanes 0..5)
+    float a0c_own = 0.f;
+    {
+      float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
+      a0c_own = l < 3 ? (l == 0 ? grav[0] : (l == 1 ? grav[1] : grav[2])) : (l == 3 ? -gc[0] / cI[0] : (l == 4 ? -gc[1] / cI[1] : (l == 5 ? -gc[2] / cI[2] : 0.f)));
+    }
+    WSYNC();
+    // ================================================================ collision: broad phase on the lane's geoms, balanced narrow phase
+    {
+      int nh = 0;
+      float Rc[9]; for (int k = 0; k < 9; k++) Rc[k] = S.xR[0][k];
+      const float* pw = S.pa[1 + l]; const float* Rw = S.xR[1 + l];
+      for (int i = 0; i < lgm; i++) {
+        int gid = sLaneG[l * lgm + i];
+        bool hit = false;
+        if (gid >= 0) {
+          const float* gf = sGeomF + gid * GEOM_F;
+          float gp[3];
+          if (sGeomI[gid * GEOM_I] < 0) { gp[0] = gf[GF_POS]; gp[1] = gf[GF_POS + 1]; gp[2] = gf[GF_POS + 2]; }
+          else { mulMV(gp, Rw, gf + GF_POS); gp[0] += pw[0]; gp[1] += pw[1]; gp[2] += pw[2]; }
+          float dc[3] = {gp[0] - qc[0], gp[1] - qc[1], gp[2] - qc[2]}, rs = gf[GF_RBOUND] + crb;
+          hit = dot3(dc, dc) <= rs * rs;
+          if (hit) {
+            float cl[3]; mulMTV(cl, Rc, dc);
+            hit = fabsf(cl[0]) <= chs[0] + gf[GF_RBOUND] && fabsf(cl[1]) <= chs[1] + gf[GF_RBOUND] && fabsf(cl[2]) <= chs[2] + gf[GF_RBOUND];
+            if (hit && sGeomI[gid * GEOM_I + 1] == GBOX) {
+              float gR[9], gl[3];
+              if (sGeomI[gid * GEOM_I] < 0) { for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; } else mulMM(gR, Rw, gf + GF_R);
+              mulMTV(gl, gR, dc);
+              hit = fabsf(gl[0]) <= gf[GF_SIZE] + crb && fabsf(gl[1]) <= gf[GF_SIZE + 1] + crb && fabsf(gl[2]) <= gf[GF_SIZE + 2] + crb;
+            }
+          }
+        }
+        unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+        int pos = nh + __popc(m16 & ((1u << l) - 1u));
+        if (hit && pos < MAXHIT) S.hits[pos] = gid;
+        nh += __popc(m16);
+      }
+      nh = nh < MAXHIT ? nh : MAXHIT;
+      WSYNC();
+      PoolCtx pc{&S, stats};
+      for (int base = 0; __any(base < nh); base += G) {
+        int idx = base + l;
+        if (idx < nh) {
+          int gid = S.hits[idx];
+          const float* gf = sGeomF + gid * GEOM_F; int body = sGeomI[gid * GEOM_I], gtype = sGeomI[gid * GEOM_I + 1];
+          float gp[3], gR[9];
+          if (body < 0) { for (int k = 0; k < 3; k++) gp[k] = gf[GF_POS + k]; for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; }
+          else {
+            float bR[9]; for (int k = 0; k < 9; k++) bR[k] = S.xR[body][k];
+            mulMV(gp, bR, gf + GF_POS); for (int k = 0; k < 3; k++) gp[k] += S.pa[body][k];
+            mulMM(gR, bR, gf + GF_R);
+          }
+          float tran = ctran + gf[GF_TRAN];
+          LeapSink sk{pc, body, gf[GF_MU], tran};
+#ifndef JH_V5_X_NONARROW
+          if (gtype == GBOX) collide_box_box(sk, qc, Rc, chs, gp, gR, gf + GF_SIZE);
+          else collide_box_sphere(sk, qc, Rc, chs, gp, gf[GF_SIZE]);
+#else
+          sk.push(gp, gR, gf[GF_SIZE]);
+#endif
+        }
+      }
+    }
+    WSYNC();
+    // ================================================================ constraint rows: <= 2 contacts per lane + the own dof's friction-loss / limit rows
+    const int ncon = S.ncon < NCP ? S.ncon : NCP;
+    Slot sl[NSLOT];
+    {
+      float wv3[3]; mulMV(wv3, S.xR[0], vc + 3);  // world angular velocity of the cube
+#pragma unroll
+      for (int k = 0; k < NSLOT; k++) {
+        int idx = l + 16 * k;
+        sl[k].link = -1;
+        if (idx < ncon) {
+          const float* e = S.pool[idx];
+          sl[k].rc[0] = e[0] - qc[0]; sl[k].rc[1] = e[1] - qc[1]; sl[k].rc[2] = e[2] - qc[2];
+          sl[k].fr[0] = e[3]; sl[k].fr[1] = e[4]; sl[k].fr[2] = e[5];
+          make_frame(sl[k].fr);
+          float dist = e[6], mu = e[7], tran = e[9]; int body = __float_as_int(e[8]);
+          sl[k].link = body > 0 ? body : 0;
+          float imp = impedance(csi, dist);
+          float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
+          sl[k].D0 = 1.f / R0; sl[k].D1 = 1.f / R1;
+          sl[k].fri = mu; sl[k].mu = mu * sqrtf(R1 / R0);
+          { float m2 = sl[k].mu * sl[k].mu; sl[k].Dm = sl[k].D0 / (m2 * (1.f + m2)); }
+          float vel[3]; slot_Jx(sl[k], S, qc, vc, wv3, S.qv, vel);
+          sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
+        }
+      }
+    }
+    DofRows dr;
+    dr.fl = lc[LC_FL]; dr.fD = lc[LC_FD]; dr.fR = dr.fD > 0.f ? 1.f / dr.fD : 0.f; dr.faref = -lc[LC_FB] * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
+    if (lc[LC_LIMITED] != 0.f) {
+      float dlo = q - lc[LC_LO], dhi = lc[LC_HI] - q, dist = fminf(dlo, dhi);
+      if (dist < 0.f) {
+        float sg = dlo < dhi ? 1.f : -1.f, imp = impedance(lc + LC_SI, dist), R = fmaxf(1e-15f, (1.f - imp) / imp * lc[LC_INVW]);
+        dr.lims = sg; dr.lD = 1.f / R; dr.laref = -lc[LC_LB] * (sg * qd) - lc[LC_LK] * imp * dist;
+      }
+    }
+    // ================================================================ Newton solver (rows distributed over the 16 lanes)
+    float a_own, ac_own;
+    const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
+    const float fsc_own = mck * a0c_own;
+    const float snorm = gsum(fs_own * fs_own * iMd + fsc_own * fsc_own * imck);
+    const bool has_rows = gor((int)(sl[0].link >= 0 || sl[1].link >= 0 || dr.fl > 0.f || dr.lims != 0.f)) != 0;
+    int iters_this = 0;
+    if (!has_rows) { a_own = a0_own; ac_own = a0c_own; }
+    else {
+      // ---- warm start: the better of last step's acceleration (S.ws) and the unconstrained one
+      {
+        const float qws = S.ws[6 + l], wsc_own = l < 6 ? S.ws[l] : 0.f;
+        float xl[3] = {S.ws[0], S.ws[1], S.ws[2]}, xr[3] = {S.ws[3], S.ws[4], S.ws[5]}, wa[3]; mulMV(wa, S.xR[0], xr);
+        float cs = 0.f, jx[3], jar_ws[NSLOT][3];
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+          slot_Jx(sl[k], S, qc, xl, wa, S.ws, jx);
+          for (int rw = 0; rw < 3; rw++) { sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; jar_ws[k][rw] = sl[k].jar[rw]; }
+          cs += cone_cost(sl[k]);
+        }
+        const float jf_ws = qws - dr.faref, jl_ws = dr.lims * qws - dr.laref;
+        dr.jf = jf_ws; dr.jl = jl_ws;
+        cs += dof_rows_cost(dr);
+        float dws = qws - a0_own, md = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLK; j++) md += Mrow[j] * (quad_get(qws, j) - quad_get(a0_own, j));
+        cs += 0.5f * dws * md;
+        { float dcw = wsc_own - a0c_own; cs += 0.5f * dcw * dcw * mck; }
+        const float cost_ws = gsum(cs);
+        S.p[6 + l] = a0_own; if (l < 6) S.p[l] = a0c_own;
+        WSYNC();
+        float xl0[3] = {S.p[0], S.p[1], S.p[2]}, xr0[3] = {S.p[3], S.p[4], S.p[5]}; mulMV(wa, S.xR[0], xr0);
+        cs = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+          slot_Jx(sl[k], S, qc, xl0, wa, S.p, jx);
+          for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw];
+          cs += cone_cost(sl[k]);
+        }
+        dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
+        cs += dof_rows_cost(dr);
+        const float cost_0 = gsum(cs);
+        if (cost_ws < cost_0) {
+          a_own = qws; ac_own = wsc_own;
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar_ws[k][rw];
+          dr.jf = jf_ws; dr.jl = jl_ws;
+        } else { a_own = a0_own; ac_own = a0c_own; }
+        WSYNC();
+      }
+      bool act = true;
+      for (int it = 0; it < cap && __any(act); it++) {
+        // ---- (1) gradient.  Owner lanes: M (a - a0) rows + dof-row forces; contacts: -J'f as LDS float atomics (finger and cube parts)
+        const float da_own = a_own - a0_own, dcl = ac_own - a0c_own;
+        float g_own = 0.f, hd = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLK; j++) g_own += Mrow[j] * quad_get(da_own, j);
+        if (dr.fl > 0.f) {
+          float D = dr.fD, x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+          if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += D * x; hd += D; }
+        }
+        if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
+        if (act) { S.g[6 + l] = g_own; if (l < 6) S.g[l] = mck * dcl; }
+        WSYNC();
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+            const Slot& t = sl[k];
+            float f[3], Wt[6];
+            const float D[3] = {t.D0, t.D1, t.D1};
+            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wt);
+            if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
+            // world force on the hand geom; the cube gets the opposite
+            const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
+            float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
+            // gradient = -J'f: cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
+            atomicAdd(&S.g[0], Fw[0]); atomicAdd(&S.g[1], Fw[1]); atomicAdd(&S.g[2], Fw[2]);
+            atomicAdd(&S.g[3], tb[0]); atomicAdd(&S.g[4], tb[1]); atomicAdd(&S.g[5], tb[2]);
+            if (t.link > 0) {
+              const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
+              const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+#pragma unroll
+              for (int j = 0; j < NLK; j++) if (j <= dep) {
+                const float* pj = S.pa[1 + 4 * ch + j];
+                const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+                cross3(c3, pj + 4, rb);
+                atomicAdd(&S.g[6 + 4 * ch + j], -dot3(c3, Fw));
+              }
+            }
+          }
+        }
+        WSYNC();
+        // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
+        g_own = S.g[6 + l];
+        const float gcl = l < 6 ? S.g[l] : 0.f;
+        const float gn = gsum(g_own * g_own * iMd + gcl * gcl * imck);
+        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        if (!__any(act)) break;
+        if (act) iters_this++;
+        // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
+          for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
+          S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
+          if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
+        }
+        WSYNC();
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+            const Slot& t = sl[k];
+            float f[3], Wk[6];
+            const float D[3] = {t.D0, t.D1, t.D1};
+            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
+            if (Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f) continue;
+            // cube columns in the contact frame
+            float Jc[6][3];
+            for (int q3 = 0; q3 < 3; q3++) {
+              Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
+              float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+              Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
+            }
+#pragma unroll
+            for (int v6 = 0; v6 < 6; v6++) {
+              const float* j3 = Jc[v6];
+              const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+              for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
+            }
+            if (t.link > 0) {
+              const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
+              const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+              float Jb[NLK][3];
+#pragma unroll
+              for (int j = 0; j < NLK; j++) {
+                Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
+                if (j <= dep) {
+                  const float* pj = S.pa[1 + 4 * ch + j];
+                  const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+                  cross3(c3, pj + 4, rb);
+                  Jb[j][0] = dot3(t.fr, c3); Jb[j][1] = dot3(t.fr + 3, c3); Jb[j][2] = dot3(t.fr + 6, c3);
+                }
+              }
+#pragma unroll
+              for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+                const float* j3 = Jb[u4];
+                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+#pragma unroll
+                for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
+              }
+            }
+          }
+        }
+        WSYNC();
+        // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly); the coupling columns Y_q = L^-1 Hcb[:,q] are shared
+        // by the chain's lanes (lane s: columns s and s+4); 6x6 Schur complement on the cube, solved by every lane
+        float L[10], Linv[4], Ya[NLK], Yb[NLK], zb[NLK], xc6[6], pc4[NLK];
+        const bool hasb = s < 2;  // lanes 0,1 of a chain carry a second column (q = 4, 5)
+        {
+          for (int k = 0; k < 10; k++) L[k] = S.Hbb[c][k];
+          chol4(L, Linv);
+          for (int j = 0; j < NLK; j++) { Ya[j] = S.Hcb[c][j * 6 + s]; Yb[j] = hasb ? S.Hcb[c][j * 6 + 4 + s] : 0.f; }
+          fwd4(L, Linv, Ya); fwd4(L, Linv, Yb);
+          for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
+          fwd4(L, Linv, zb);
+          if (act && l < 6) S.rhs6[l] = -gcl;
+        }
+        WSYNC();
+        if (act) {
+          // Schur complement: Hcc[q][r] -= Y_q . Y_r, rhs6[q] -= Y_q . zb; lane s owns q in {s, s+4} and fetches Y_r from its chain-mates
+#pragma unroll
+          for (int r6 = 0; r6 < 6; r6++) {
+            float Yr[NLK];
+#pragma unroll
+            for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
+            const float da = Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3];
+            if (r6 <= s) atomicAdd(&S.Hcc[tri(s, r6)], -da);
+            if (hasb) { const float db = Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3]; if (r6 <= 4 + s) atomicAdd(&S.Hcc[tri(4 + s, r6)], -db); }
+          }
+          atomicAdd(&S.rhs6[s], -(Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3]));
+          if (hasb) atomicAdd(&S.rhs6[4 + s], -(Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3]));
+        }
+        WSYNC();
+        {
+          float Lc[21];
+          for (int k = 0; k < 21; k++) Lc[k] = S.Hcc[k];
+          for (int k = 0; k < 6; k++) xc6[k] = S.rhs6[k];
+          float ci[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+              float sv = Lc[tri(i, j)];
+#pragma unroll
+              for (int k = 0; k < j; k++) sv -= Lc[tri(i, k)] * Lc[tri(j, k)];
+              if (i == j) { float rr = __frsqrt_rn(fmaxf(sv, 1e-30f)); ci[i] = rr; Lc[tri(i, i)] = sv * rr; }
+              else Lc[tri(i, j)] = sv * ci[j];
+            }
+#pragma unroll
+          for (int i = 0; i < 6; i++) { float sv = xc6[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) sv -= Lc[tri(i, k)] * xc6[k];
+            xc6[i] = sv * ci[i]; }
+#pragma unroll
+          for (int i = 5; i >= 0; i--) { float sv = xc6[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) sv -= Lc[tri(k, i)] * xc6[k];
+            xc6[i] = sv * ci[i]; }
+          // back-substitution through the coupling: pc = L^-T (zb - sum_q Y_q x_q); each lane contributes its columns, summed over the chain
+          const float xa = sel4(xc6, s), xb = s == 0 ? xc6[4] : xc6[5];
+#pragma unroll
+          for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
+          bwd4(L, Linv, pc4);
+        }
+        const float p_own = sel4(pc4, s);
+        const float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
+        if (act) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
+        WSYNC();
+        // ---- (5) exact line search along p
+        float Mp_own = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLK; j++) Mp_own += Mrow[j] * pc4[j];
+        const float pMp = gsum(p_own * Mp_own + mck * xcl * xcl);
+        const float pMd = gsum(Mp_own * da_own + mck * xcl * dcl);
+        const float gp = gsum(g_own * p_own + gcl * xcl);
+        if (act && !(gp < 0.f)) act = false;
+        {
+          float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) slot_Jx(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
+        }
+        dr.pf = p_own; dr.pl = dr.lims * p_own;
+        float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
+        for (int ls = 0; ls < JH_V5_LSMAX && __any(lsact); ls++) {
+          float d1, d2;
+          lane_rows_dir(sl, dr, alpha, &d1, &d2);
+          d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
+          if (lsact) {
+            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
+            else {
+              if (d1 < 0.f) { lo = alpha; dlo = d1; if (side < 0) dhi *= 0.5f; side = -1; } else { hi = alpha; dhi = d1; if (side > 0) dlo *= 0.5f; side = 1; }
+              float nx = alpha - d1 * __frcp_rn(d2);
+              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
+              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
+              alpha = nx;
+            }
+          }
+        }
+        // ---- (6) step
+        if (act) {
+          a_own += alpha * p_own; ac_own += alpha * xcl;
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
+          dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
+          if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        }
+        WSYNC();
+      }
+      if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
+    }
+    // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
+    {
+      S.ws[6 + l] = a_own; if (l < 6) { S.ws[l] = ac_own; S.acn[l] = ac_own; }
+      const float da_own = a_own - a0_own;
+      float rhs_own = fs_own, x4[NLK], L[10];
+#pragma unroll
+      for (int j = 0; j < NLK; j++) rhs_own += Mrow[j] * quad_get(da_own, j);
+#pragma unroll
+      for (int j = 0; j < NLK; j++) x4[j] = quad_get(rhs_own, j);
+      for (int k = 0; k < 10; k++) L[k] = S.Mbb[c][k];
+      const float hdk = h * (lc[LC_DAMP] + lc[LC_KVD]);
+#pragma unroll
+      for (int j = 0; j < NLK; j++) L[tri(j, j)] += quad_get(hdk, j);
+      float inv4[4]; chol4(L, inv4); fwd4(L, inv4, x4); bwd4(L, inv4, x4);
+      const float qacc = sel4(x4, s);
+      qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q);
+      WSYNC();
+      for (int k = 0; k < 6; k++) vc[k] = fmaf(h, S.acn[k], vc[k]);  // the cube's inertia is diagonal: its new acceleration is the constrained one itself
+      for (int k = 0; k < 3; k++) qc[k] = fmaf(h, vc[k], qc[k]);
+      float wn = sqrtf(vc[3] * vc[3] + vc[4] * vc[4] + vc[5] * vc[5]), ang = wn * h;
+      if (ang > 0.f) {
+        float sn, cs; sincosf(0.5f * ang, &sn, &cs); float kk = sn / wn;
+        float dq[4] = {cs, vc[3] * kk, vc[4] * kk, vc[5] * kk}, *qq = qc + 3;
+        float r0 = qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2] - qq[3] * dq[3];
+        float r1 = qq[0] * dq[1] + qq[1] * dq[0] + qq[2] * dq[3] - qq[3] * dq[2];
+        float r2 = qq[0] * dq[2] - qq[1] * dq[3] + qq[2] * dq[0] + qq[3] * dq[1];
+        float r3 = qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1] + qq[3] * dq[0];
+        qq[0] = r0; qq[1] = r1; qq[2] = r2; qq[3] = r3;
+      }
+      float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
+      qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+    }
+    if (MATERIALIZE) {
+      if (states && live) {
+        float* o = states + ((size_t)nc * H + hh) * NX;
+        o[7 + l] = q; o[NQ + 6 + l] = qd;
+        if (l < 7) o[l] = qc[l];
+        if (l < 6) o[NQ + l] = vc[l];
+      }
+    } else acc += leap_step_cost(sTp, qc);
+    WSYNC();
+  }
+  if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
+  if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
+}
+
+bool model_is_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 13 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG; }
+
+}  // namespace
+
+int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+  if (!model_is_leap(m)) { jh_set_error("rollout_cost: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
+  JH_REQUIRE(K <= MAXK, "rollout_cost: the cooperative leap kernel keeps at most 8 knots per actuator (K=%d)", K);
+  int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
+  hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
+                     knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                           hipStream_t st) {
+  if (!model_is_leap(m)) { jh_set_error("rollout_materialize: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
+  int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
+  hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
+                     controls, states, sensors, m->d_stats);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}

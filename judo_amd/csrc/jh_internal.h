@@ -24,7 +24,7 @@ struct jh_model {
   size_t nf, ni;
   float* d_f;  // device copy of the float section
   int* d_i;    // device copy of the int section
-  int kernel_gen;  // articulated engine kernel: 2 = cooperative 16-lanes-per-rollout (default; leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
+  int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, several waves per SIMD (leap_cube: v5; fr3_pick: as 2), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
   std::vector<float> h_f;
   std::vector<int> h_i;
@@ -83,6 +83,12 @@ int jh_engine2_rollout_cost(const jh_model* m, const float* x0, const float* nom
                             const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out,
                             hipStream_t st);
 int jh_engine2_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                           hipStream_t st);
+
+// jh_engine_v5.hip: the leap_cube cooperative kernel on a register diet (several waves per SIMD)
+int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st);
+int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st);
 
 // jh_engine_v3.hip: cooperative kernel for fr3_pick (serial arm with a two-finger fork + free box, pyramidal cones)

@@ -194,7 +194,7 @@ def test_leap_two_kernel_generations_agree(gpu):
     e = np.abs(s2 - s1)
     assert np.median(e) < 1e-6 and np.percentile(e[:, -1, :3], 95) < 5e-3
     with pytest.raises(ValueError):
-        b1.model.set_kernel(3)
+        b1.model.set_kernel(4)
 
 
 def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):

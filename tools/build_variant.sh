@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/var_$name
 pids=()
-for s in jh_api jh_simple jh_update jh_engine jh_engine_v2 jh_engine_v3 jh_engine_v4 jh_policy; do
+for s in jh_api jh_simple jh_update jh_engine jh_engine_v2 jh_engine_v5 jh_engine_v3 jh_engine_v4 jh_policy; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Iinclude -Ijudo_amd/csrc "$@" -c judo_amd/csrc/$s.hip -o build/var_$name/$s.o &
   pids+=($!)
 done
