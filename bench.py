@@ -61,12 +61,37 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def cpu_baseline_reference(task: str, ctrl, cores: int, seconds_target: float = 15.0) -> dict | None:
+    """The reference's own CPU path -- `mujoco.rollout.Rollout(nthread=cores)` driven as judo/utils/mj_rollout_backend.py:36-88 drives it -- on a bounded
+    sample of the same workload, when the `mujoco` wheel and the task's MJCF are reachable (oracle/mujoco_probe.py).  None otherwise: MuJoCo is absent
+    from this image and from the GPU box, and the leap / fr3 MJCF need mesh assets that are not in the repository."""
+    from oracle import mujoco_probe as MP
+
+    if task not in MP.MESH_FREE_TASKS or not MP.available(task):
+        return None
+    K, nu, H = ctrl.optimizer.num_nodes, ctrl.nu, ctrl.num_timesteps
+    rng = np.random.default_rng(0)
+    n = 64 * cores
+    while True:
+        U = np.repeat(rng.standard_normal((n, (H + 3) // 4, nu)), 4, axis=1)[:, :H]
+        r = MP.time_reference_rollouts(task, np.asarray(ctrl.task.default_state()), U, cores)
+        if r["seconds"] > seconds_target / 4 or n >= 65536:
+            break
+        n = int(min(65536, max(2 * n, n * (seconds_target / 2) / max(r["seconds"], 1e-3))))
+    return {"value": n / r["seconds"], "unit": "rollouts/s", "cores": cores, "kind": "reference",
+            "sample": f"{n} rollouts x H={H} through mujoco.rollout.Rollout(nthread={cores}) (MuJoCo {r['mujoco']}), {r['seconds']:.1f} s"}
+
+
 def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
-    """Oracle rollouts (threaded C, fp64) on the host cores for a bounded sample of the same workload."""
+    """The reference's CPU rollout when MuJoCo is reachable (kind "reference"); otherwise oracle rollouts (threaded C, fp64; kind "port") on the host
+    cores for a bounded sample of the same workload."""
     from oracle import oracle as O
     from tests.harness import oracle_plan_step
 
     cores = usable_cpus()
+    ref = cpu_baseline_reference(task, ctrl, cores, seconds_target)
+    if ref is not None:
+        return ref
     om = O.Model(task)
     K, nu, H = ctrl.optimizer.num_nodes, ctrl.nu, ctrl.num_timesteps
     rng = np.random.default_rng(0)
@@ -86,7 +111,7 @@ def cpu_baseline(task: str, ctrl, seconds_target: float = 15.0) -> dict:
             break
         n = int(min(65536, max(2 * n, n * (seconds_target / 2) / max(dt, 1e-3))))
     ctrl.optimizer.config.num_rollouts = saved
-    return {"value": total_rollouts / total_t, "unit": "rollouts/s", "cores": cores, "kind": "port",
+    return {"value": total_rollouts / total_t, "unit": "rollouts/s", "cores": cores, "kind": "port", "mujoco": "not installed (oracle/mujoco_probe.py)",
             "sample": f"{total_rollouts} rollouts x H={H} of the same plan step (fp64 oracle engine, {cores} pthreads = usable CPUs of {os.cpu_count()} hardware threads), {total_t:.1f} s"}
 
 

@@ -30,6 +30,12 @@ __device__ __forceinline__ float gsum(float v) {  // sum over the 16 lanes of a 
   v = csum(v); v += dppf<DPP_HALF_MIRROR>(v); v += dppf<DPP_MIRROR>(v);
   return v;
 }
+// sum over the four chains (quads) of a rollout for the same position inside the quad: lanes l, l+4, l+8, l+12 of the row (row rotations by 4 and 8)
+__device__ __forceinline__ float qsum4(float v) {
+  asm volatile("" : "+v"(v));
+  v += dppf<0x124>(v); v += dppf<0x128>(v);
+  return v;
+}
 __device__ __forceinline__ int gor(int v) {
   v |= dppi<DPP_XOR1>(v); v |= dppi<DPP_XOR2>(v); v |= dppi<DPP_HALF_MIRROR>(v); v |= dppi<DPP_MIRROR>(v);
   return v;

@@ -523,8 +523,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += D * x; hd += D; }
         }
         if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
-        if (act) { S.g[6 + l] = g_own; if (l < 6) S.g[l] = mck * dcl; }
+        if (act) S.g[6 + l] = g_own;
         WSYNC();
+        float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
         if (act) {
 #pragma unroll
           for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
@@ -537,8 +538,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
             // gradient = -J'f: cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
-            atomicAdd(&S.g[0], Fw[0]); atomicAdd(&S.g[1], Fw[1]); atomicAdd(&S.g[2], Fw[2]);
-            atomicAdd(&S.g[3], tb[0]); atomicAdd(&S.g[4], tb[1]); atomicAdd(&S.g[5], tb[2]);
+            gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
             if (t.link > 0) {
               const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
               const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
@@ -552,10 +552,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             }
           }
         }
+        float gcl = 0.f;
+#pragma unroll
+        for (int q6 = 0; q6 < 6; q6++) { const float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
+        gcl = fmaf(mck, dcl, gcl);  // lanes 6..15: mck = 0, gcl stays 0
         WSYNC();
         // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
         g_own = S.g[6 + l];
-        const float gcl = l < 6 ? S.g[l] : 0.f;
         const float gn = gsum(g_own * g_own * iMd + gcl * gcl * imck);
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
@@ -632,19 +635,24 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           if (act && l < 6) S.rhs6[l] = -gcl;
         }
         WSYNC();
-        if (act) {
-          // Schur complement: Hcc[q][r] -= Y_q . Y_r, rhs6[q] -= Y_q . zb; lane s owns q in {s, s+4} and fetches Y_r from its chain-mates
+        {
+          // Schur complement: Hcc[q][r] -= sum over chains of Y_q . Y_r, rhs6[q] -= sum of Y_q . zb; lane s of a chain owns q in {s, s+4} and fetches Y_r from
+          // its chain-mates; the four chains' terms are added with two row rotations and the first chain's lane applies the total
 #pragma unroll
           for (int r6 = 0; r6 < 6; r6++) {
             float Yr[NLK];
 #pragma unroll
             for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
-            const float da = Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3];
-            if (r6 <= s) atomicAdd(&S.Hcc[tri(s, r6)], -da);
-            if (hasb) { const float db = Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3]; if (r6 <= 4 + s) atomicAdd(&S.Hcc[tri(4 + s, r6)], -db); }
+            const float da = qsum4(Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3]);
+            const float db = qsum4(Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3]);
+            if (act && c == 0) {
+              if (r6 <= s) S.Hcc[tri(s, r6)] -= da;
+              if (hasb && r6 <= 4 + s) S.Hcc[tri(4 + s, r6)] -= db;
+            }
           }
-          atomicAdd(&S.rhs6[s], -(Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3]));
-          if (hasb) atomicAdd(&S.rhs6[4 + s], -(Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3]));
+          const float ra = qsum4(Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3]);
+          const float rb = qsum4(Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3]);
+          if (act && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
         }
         WSYNC();
         {

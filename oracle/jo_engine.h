@@ -43,7 +43,7 @@ extern "C" {
 #define JO_MAXACT 24
 #define JO_MAXSENSOR 40
 #define JO_MAXSENSORDATA 48
-#define JO_MAXPAIR 160
+#define JO_MAXPAIR 2048
 #define JO_MAXEQ 4
 #define JO_MAXCON 96
 #define JO_MAXEFC 400

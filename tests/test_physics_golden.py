@@ -1,0 +1,47 @@
+"""The physics oracle (oracle/jo_engine.c) against `mj_step` trajectories of MuJoCo itself (tests/golden/physics_<task>.npz, written by
+tools/gen_golden_mujoco.py where the mujoco wheel is installed).  The wheel is absent from the build image and from the GPU box, so the fixtures do not
+exist yet and these tests SKIP: the oracle's physics stays "parity unpinned"  until they run.  One command pins it the day the wheel is reachable."""
+
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+
+@pytest.mark.parametrize("task", ["cartpole", "cylinder_push", "leap_cube", "fr3_pick"])
+def test_oracle_engine_matches_mujoco_trajectories(task):
+    path = os.path.join(GOLDEN, f"physics_{task}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated: the mujoco wheel is not installable here (tools/gen_golden_mujoco.py)")
+    from oracle import oracle as O
+
+    g = np.load(path)
+    om = O.Model(task)
+    s, y = om.rollout(g["x0"], g["controls"])
+    # fp64 on both sides, same algorithm: the first step agrees to solver tolerance, whole trajectories to the growth of that error
+    np.testing.assert_allclose(s[:, 0], g["states"][:, 0], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(y[:, :2], g["sensors"][:, :2], rtol=0, atol=1e-7)  # incl. the one-step sensor lag
+    np.testing.assert_allclose(s, g["states"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(y, g["sensors"], rtol=0, atol=1e-4)
+    sb, yb = om.rollout(g["x0_batched"], g["controls"])
+    np.testing.assert_allclose(sb, g["states_batched"], rtol=0, atol=1e-4)
+
+
+def test_mujoco_probe_reports_absence_honestly():
+    from oracle import mujoco_probe as MP
+
+    if MP.find_mujoco() is None:
+        assert not MP.available()
+        with pytest.raises(RuntimeError):
+            MP.rollout("cartpole", np.zeros(4), np.zeros((1, 2, 1)))
+    else:  # the wheel exists: the probe must reproduce the oracle on the mesh-free tasks (the one-command pin)
+        if MP.reference_xml("cartpole") is None:
+            pytest.skip("mujoco present but the reference MJCF is not reachable")
+        from oracle import oracle as O
+
+        U = np.zeros((2, 8, 1))
+        s, y = MP.rollout("cartpole", np.array([1.0, np.pi, 0.0, 0.0]), U, nthread=1)
+        so, yo = O.Model("cartpole").rollout(np.array([1.0, np.pi, 0.0, 0.0]), U)
+        np.testing.assert_allclose(so, s, atol=1e-6)
