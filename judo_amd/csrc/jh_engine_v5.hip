@@ -29,6 +29,9 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_WAVES_PER_EU
 #define JH_V5_WAVES_PER_EU 2
 #endif
+#ifndef JH_V5_HCC_PRE
+#define JH_V5_HCC_PRE 0  // cube block of the Hessian: 0 = one LDS atomic per contact and entry (default: measured fastest, 57.2 ms), 1 = lane pairs add up first (69.1), 2 = quads add up first (57.7)
+#endif
 #ifndef JH_V5_WPB
 #define JH_V5_WPB 4  // waves per workgroup: they share one LDS copy of the model image and nothing else
 #endif
@@ -435,6 +438,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       for (int k = 0; k < NSLOT; k++) {
         int idx = l + 16 * k;
         sl[k].link = -1;
+        for (int i = 0; i < 9; i++) sl[k].fr[i] = 0.f;  // an empty slot takes part in the quad sums of the Hessian's cube block with zeros
+        sl[k].rc[0] = sl[k].rc[1] = sl[k].rc[2] = 0.f;
         if (idx < ncon) {
           const float* e = S.pool[idx];
           sl[k].rc[0] = e[0] - qc[0]; sl[k].rc[1] = e[1] - qc[1]; sl[k].rc[2] = e[2] - qc[2];
@@ -572,51 +577,64 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
         WSYNC();
-        if (act) {
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
-            const Slot& t = sl[k];
-            float f[3], Wk[6];
+        for (int k = 0; k < NSLOT; k++) {
+          const Slot& t = sl[k];
+          float Wk[6] = {0, 0, 0, 0, 0, 0}, Jc[6][3];
+          bool on = act && t.link >= 0;
+          if (on) {
+            float f[3];
             const float D[3] = {t.D0, t.D1, t.D1};
             cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
-            if (Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f) continue;
-            // cube columns in the contact frame
-            float Jc[6][3];
-            for (int q3 = 0; q3 < 3; q3++) {
-              Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
-              float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
-              Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
+            on = !(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f);
+          }
+          if (!__any(on)) continue;  // (the second slot is empty in most waves)
+          // cube columns in the contact frame
+          for (int q3 = 0; q3 < 3; q3++) {
+            Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
+            float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+            Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
+          }
+          // cube block: every contact of the rollout lands on the same 21 entries.  The lanes of a quad add theirs up first (W = 0 for a lane without
+          // a contact), the quad's first lane issues the atomic: at most 4 instead of 16 lanes collide on an address
+          const bool lead = JH_V5_HCC_PRE == 2 ? s == 0 : (JH_V5_HCC_PRE == 1 ? (s & 1) == 0 : on);
+#pragma unroll
+          for (int v6 = 0; v6 < 6; v6++) {
+            const float* j3 = Jc[v6];
+            const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+            for (int u6 = v6; u6 < 6; u6++) {
+              float v = Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2;
+#if JH_V5_HCC_PRE == 2
+              v = csum(v);
+#elif JH_V5_HCC_PRE == 1
+              asm volatile("" : "+v"(v)); v += dppf<DPP_XOR1>(v);
+#endif
+              if (lead && act) atomicAdd(&S.Hcc[tri(u6, v6)], v);
+            }
+          }
+          if (on && t.link > 0) {
+            const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
+            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+            float Jb[NLK][3];
+#pragma unroll
+            for (int j = 0; j < NLK; j++) {
+              Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
+              if (j <= dep) {
+                const float* pj = S.pa[1 + 4 * ch + j];
+                const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+                cross3(c3, pj + 4, rb);
+                Jb[j][0] = dot3(t.fr, c3); Jb[j][1] = dot3(t.fr + 3, c3); Jb[j][2] = dot3(t.fr + 6, c3);
+              }
             }
 #pragma unroll
-            for (int v6 = 0; v6 < 6; v6++) {
-              const float* j3 = Jc[v6];
+            for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+              const float* j3 = Jb[u4];
               const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
 #pragma unroll
-              for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
-            }
-            if (t.link > 0) {
-              const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
-              const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-              float Jb[NLK][3];
+              for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
 #pragma unroll
-              for (int j = 0; j < NLK; j++) {
-                Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
-                if (j <= dep) {
-                  const float* pj = S.pa[1 + 4 * ch + j];
-                  const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
-                  cross3(c3, pj + 4, rb);
-                  Jb[j][0] = dot3(t.fr, c3); Jb[j][1] = dot3(t.fr + 3, c3); Jb[j][2] = dot3(t.fr + 6, c3);
-                }
-              }
-#pragma unroll
-              for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
-                const float* j3 = Jb[u4];
-                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-                for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
-#pragma unroll
-                for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
-              }
+              for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
             }
           }
         }
