@@ -215,6 +215,7 @@ def main() -> None:
     ap.add_argument("--rollouts", type=int, default=None)
     ap.add_argument("--horizon-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
     args = ap.parse_args()
@@ -255,6 +256,8 @@ def main() -> None:
     ctrl.reset()
     ctrl.current_state = ctrl.task.default_state()
     ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if args.task == "leap_cube" else {}
+    if args.no_self_collision and ctrl.model is not None:
+        ctrl.model.set_self_collision(False)
     ctrl.optimizer.seed(1234)  # the same seed on every rank: each rank slices its shard out of the same noise, the plan does not depend on --gpus
     is_policy = ctrl.task.uses_locomotion_policy
     if is_policy:

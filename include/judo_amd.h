@@ -62,9 +62,15 @@ int jh_model_dims(const jh_model* m, int* dims /* HOST */);
  * Newton iteration cap, out[2] Newton iterations, out[3] physics steps.  HOST pointer. */
 int jh_model_stats(jh_model* m, int* out /* HOST, 4 ints */, int reset);
 
-/* Articulated-body engine kernel generation for this model: 2 (default) = cooperative kernel, 16 lanes per rollout;
+/* Articulated-body engine kernel generation for this model: 3 (default for leap_cube) = cooperative kernel on a register diet, two waves per SIMD,
+ * hand self-collision; 2 (default for fr3_pick) = cooperative kernel, 16 lanes per rollout, one wave per SIMD;
  * 1 = one lane per rollout (kept as an independent second implementation for the parity tests). */
 int jh_model_set_kernel(jh_model* m, int generation);
+
+/* leap_cube on kernel generation 3: model the hand's own contacts (every finger-finger / finger-palm geom pair MuJoCo's filters leave: same welded body,
+ * parent-child, the 18 <exclude> pairs of leap_components/params_and_default.xml:76-101) next to the cube's -- the default, MuJoCo collides them -- or,
+ * with on = 0, the cube's contacts alone (what generations 1 and 2 model). */
+int jh_model_set_self_collision(jh_model* m, int on);
 
 /* Limits of this model's kernels: out[0] = largest knot count K the fused kernel (jh_rollout_cost) accepts -- the cooperative
  * leap_cube / fr3_pick kernels keep a lane's knots in 8 registers, a larger K goes through jh_spline_controls + jh_rollout_materialize +

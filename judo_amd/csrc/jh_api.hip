@@ -30,7 +30,7 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE) ? 3 : 2;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE) ? 3 : 2; m->self_collision = 1;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
@@ -82,6 +82,12 @@ extern "C" int jh_model_hist(jh_model* m, int* out /* 24 ints: Newton-iteration 
 extern "C" int jh_model_set_kernel(jh_model* m, int generation) {
   JH_REQUIRE(m && generation >= 1 && generation <= 3, "model_set_kernel: generation must be 1, 2 or 3");
   m->kernel_gen = generation;
+  return JH_OK;
+}
+
+extern "C" int jh_model_set_self_collision(jh_model* m, int on) {
+  JH_REQUIRE(m != nullptr, "model_set_self_collision: null pointer");
+  m->self_collision = on ? 1 : 0;
   return JH_OK;
 }
 

@@ -22,7 +22,7 @@ enum { DF_DAMP = 0, DF_ARM, DF_FL, DF_FB, DF_FD, DF_INVW, DF_LIMITED, DF_LO, DF_
 // actuator floats
 enum { AF_KP = 0, AF_KV, AF_CLIM, AF_CLO, AF_CHI };
 // geom floats
-enum { GF_SIZE = 0, GF_POS = 3, GF_R = 6, GF_RBOUND = 15, GF_MU = 16, GF_TRAN = 17 };
+enum { GF_SIZE = 0, GF_POS = 3, GF_R = 6, GF_RBOUND = 15, GF_MU = 16 /* max(own, cube's) */, GF_TRAN = 17, GF_MUOWN = 18 };
 
 struct EngineModel {  // views into the LDS copy of the blob
   const float* F;

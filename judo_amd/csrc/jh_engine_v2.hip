@@ -38,7 +38,7 @@ constexpr int NSLOT = JH_V2_NSLOT;
 constexpr int NCP = 16 * NSLOT;  // contact pool per rollout = NSLOT slots per lane
 constexpr int MAXHIT = 32;  // broad-phase survivors per rollout
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
-constexpr int MAXG = 72, MAXLG = 8;  // collision geoms / broad-phase list length per lane staged in LDS
+constexpr int MAXG = 80, MAXLG = 8;  // collision geoms / broad-phase list length per lane staged in LDS
 constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
 
 struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS

@@ -38,11 +38,18 @@ constexpr int NCH = 4, NLK = 4;
 // Waves of a workgroup never exchange data after the image is staged: inside the step loop a "barrier" only has to order one wave's own LDS traffic
 // (a wave's LDS instructions execute in issue order), so it is a compiler fence, not an s_barrier -- rollouts in different waves never wait for each other.
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-constexpr int NSLOT = 2;
+#ifndef JH_V5_NSLOT
+#define JH_V5_NSLOT 2
+#endif
+constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane: the pool holds 16 * NSLOT contacts per rollout
 constexpr int NCP = 16 * NSLOT;  // contact pool per rollout
 constexpr int MAXHIT = 32;
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
 constexpr int MAXG = 72, MAXLG = 8;
+constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1..16 = finger link (1 + 4*chain + depth), 17 = the cube
+constexpr int HITPAIR = 1 << 16;  // broad-phase survivors >= HITPAIR index the hand-hand geom pair list, smaller ones are cube-vs-geom
+constexpr int MAXBPL = 24;        // hand body pairs whose bounding spheres overlap, per rollout and step
+constexpr int NDH = 22 * 23 / 2;  // dense Hessian (packed lower) of a rollout whose contacts couple two finger chains
 constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
 constexpr int MAXK = 8;
 
@@ -56,10 +63,13 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
   float Mbb[NCH][10];
   float rhs6[6];
+  float bs[NMB][4];   // bounding sphere of the hand bodies (0 = all static geometry, 1..16 = finger links), world
   int hits[MAXHIT];
+  int bpl[MAXBPL];
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
     float pool[NCP][POOL_F];
     struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24]; };  // Hcb[c][j*6+q]: chain column j, cube row q
+    struct { float Hd[NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
   };
   int ncon, nhit;
 };
@@ -73,37 +83,66 @@ __device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos
   e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = dist; e[7] = mu; e[8] = __int_as_float(body); e[9] = tran;
 }
 
-struct LeapSink {
-  PoolCtx pc; int body; float mu, tran;
-  __device__ __forceinline__ void push(const float* pos, const float* n, float dist) { push_contact(pc, pos, n, dist, body, mu, tran); }
+struct LeapSink {  // contacts of one geom pair: sides packed as A | B << 8; `flip`: the narrow phase ran with the two geoms swapped (normal B -> A)
+  PoolCtx pc; int sides; float mu, tran; bool flip;
+  __device__ __forceinline__ void push(const float* pos, const float* n, float dist) {
+    const float nn[3] = {flip ? -n[0] : n[0], flip ? -n[1] : n[1], flip ? -n[2] : n[2]};
+    push_contact(pc, pos, nn, dist, sides, mu, tran);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ per-lane contact slot (27 registers)
 struct Slot {
-  int link;          // -1 = empty slot, 0 = static geom, 1 + 4*chain + depth = finger link
+  int la, lb;        // the two sides (normal from A to B): la = -1 empty slot; 0 = static geom, 1 + 4*chain + depth = finger link, CUBE
   float fr[9];       // contact frame rows (normal, t1, t2), world
   float rc[3];       // contact point relative to the cube origin, world
   float aref[3], D0, D1, Dm, mu, fri;
   float jar[3], jp[3];
 };
 
-// contact-frame image of the relative point velocity for the generalised velocity whose cube part is (xl = linear, world; wang = R_cube *
-// angular part, world) and whose finger part is `vec` (22-vector in LDS).  Normal points from the cube to the hand geom.
-__device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float* qcpos, const float* xl, const float* wang, const float* vec, float* out) {
-  float wx[3]; cross3(wx, wang, s.rc);
-  float w[3] = {-(xl[0] + wx[0]), -(xl[1] + wx[1]), -(xl[2] + wx[2])};
-  if (s.link > 0) {
-    const int ch = (s.link - 1) >> 2, dep = (s.link - 1) & 3;
-    const float pos[3] = {s.rc[0] + qcpos[0], s.rc[1] + qcpos[1], s.rc[2] + qcpos[2]};
+// velocity of the point `pos` carried by finger link `code` for the joint-rate vector `vec` (22-vector in LDS), times `sign`, added to w
+__device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos, const float* vec, float sign, float* w) {
+  const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
 #pragma unroll
-    for (int j = 0; j < NLK; j++) if (j <= dep) {
-      const float* pj = S.pa[1 + 4 * ch + j];
-      const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
-      cross3(c3, pj + 4, rb);
-      const float xj = vec[6 + 4 * ch + j];
-      w[0] = fmaf(c3[0], xj, w[0]); w[1] = fmaf(c3[1], xj, w[1]); w[2] = fmaf(c3[2], xj, w[2]);
-    }
+  for (int j = 0; j < NLK; j++) if (j <= dep) {
+    const float* pj = S.pa[1 + 4 * ch + j];
+    const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+    cross3(c3, pj + 4, rb);
+    const float xj = sign * vec[6 + 4 * ch + j];
+    w[0] = fmaf(c3[0], xj, w[0]); w[1] = fmaf(c3[1], xj, w[1]); w[2] = fmaf(c3[2], xj, w[2]);
   }
+}
+// -J'F for the joints of finger link `code` (F = world force on side B; sign = +1 for side B, -1 for side A): LDS float atomics into g
+__device__ __forceinline__ void link_force(RS& S, int code, const float* pos, const float* Fw, float sign) {
+  const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
+#pragma unroll
+  for (int j = 0; j < NLK; j++) if (j <= dep) {
+    const float* pj = S.pa[1 + 4 * ch + j];
+    const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+    cross3(c3, pj + 4, rb);
+    atomicAdd(&S.g[6 + 4 * ch + j], -sign * dot3(c3, Fw));
+  }
+}
+// Jacobian columns (contact frame) of the joints of finger link `code`, times `sign`, added to Jb[j] (j = depth in the chain)
+__device__ __forceinline__ void link_cols(const RS& S, int code, const float* pos, const float* fr, float sign, float (*Jb)[3]) {
+  const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
+#pragma unroll
+  for (int j = 0; j < NLK; j++) if (j <= dep) {
+    const float* pj = S.pa[1 + 4 * ch + j];
+    const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
+    cross3(c3, pj + 4, rb);
+    Jb[j][0] = fmaf(sign, dot3(fr, c3), Jb[j][0]); Jb[j][1] = fmaf(sign, dot3(fr + 3, c3), Jb[j][1]); Jb[j][2] = fmaf(sign, dot3(fr + 6, c3), Jb[j][2]);
+  }
+}
+
+// contact-frame image of the relative point velocity (side B minus side A) for the generalised velocity whose cube part is (xl = linear, world;
+// wang = R_cube * angular part, world) and whose finger part is `vec` (22-vector in LDS)
+__device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float* qcpos, const float* xl, const float* wang, const float* vec, float* out) {
+  float w[3] = {0.f, 0.f, 0.f};
+  const float pos[3] = {s.rc[0] + qcpos[0], s.rc[1] + qcpos[1], s.rc[2] + qcpos[2]};
+  if (s.la == CUBE) { float wx[3]; cross3(wx, wang, s.rc); w[0] = -(xl[0] + wx[0]); w[1] = -(xl[1] + wx[1]); w[2] = -(xl[2] + wx[2]); }
+  else if (s.la > 0) link_vel(S, s.la, pos, vec, -1.f, w);
+  if (s.lb > 0) link_vel(S, s.lb, pos, vec, 1.f, w);
   out[0] = dot3(s.fr, w); out[1] = dot3(s.fr + 3, w); out[2] = dot3(s.fr + 6, w);
 }
 
@@ -132,7 +171,7 @@ __device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr,
   float g1 = 0.f, g2 = 0.f;
 #pragma unroll
   for (int k = 0; k < NSLOT; k++) {
-    if (sl[k].link < 0) continue;
+    if (sl[k].la < 0) continue;
     const float* jp = sl[k].jp;
     const float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
     const float D[3] = {sl[k].D0, sl[k].D1, sl[k].D1};
@@ -204,6 +243,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   const int oBodyF = HEADER_F, oDofF = oBodyF + nmI * BODY_F, oActF = oDofF + gI[2] * DOF_F, oGeomF = oActF + nuI * ACT_F, oSiteF = oGeomF + ngI * GEOM_F;
   const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
   const int oLane = gI[11], lgm = gI[12];
+  const int oBP = gI[15], oBS = gI[16], nBP = gI[17], oGP = oBP + 4 * nBP;  // hand self-collision: body pairs, body bounding spheres, geom pairs
   for (int i = tid; i < 16 * BODY_F; i += WAVE * WPB) sBody[i] = gF[oBodyF + BODY_F + i];
   for (int i = tid; i < ngI * GEOM_F; i += WAVE * WPB) sGeomF[i] = gF[oGeomF + i];
   for (int i = tid; i < ngI * GEOM_I; i += WAVE * WPB) sGeomI[i] = gI[oGeomI + i];
@@ -254,6 +294,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   S.ws[6 + l] = 0.f; if (l < 6) S.ws[l] = 0.f;
   int n_iters = 0, n_maxed = 0;
   float acc = 0.f;
+#ifdef JH_V5_COUNT
+  int cnt_dense = 0, cnt_it = 0, cnt_l2 = 0, cnt_bp = 0, cnt_hh = 0;
+#endif
   __syncthreads();  // the only workgroup barrier: the model image is staged
 
   for (int hh = 0; hh < H; hh++) {
@@ -371,11 +414,16 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       a0c_own = l < 3 ? (l == 0 ? grav[0] : (l == 1 ? grav[1] : grav[2])) : (l == 3 ? -gc[0] / cI[0] : (l == 4 ? -gc[1] / cI[1] : (l == 5 ? -gc[2] / cI[2] : 0.f)));
     }
     WSYNC();
-    // ================================================================ collision: broad phase on the lane's geoms, balanced narrow phase
+    // ================================================================ collision: broad phase (cube vs the lane's geoms; hand body pairs), balanced narrow phase
     {
       int nh = 0;
       float Rc[9]; for (int k = 0; k < 9; k++) Rc[k] = S.xR[0][k];
       const float* pw = S.pa[1 + l]; const float* Rw = S.xR[1 + l];
+      {  // bounding sphere of the own link for the hand's self-collision
+        const float* b4 = gF + oBS + 4 * (1 + l); float cw[3]; mulMV(cw, Rw, b4);
+        S.bs[1 + l][0] = cw[0] + pw[0]; S.bs[1 + l][1] = cw[1] + pw[1]; S.bs[1 + l][2] = cw[2] + pw[2]; S.bs[1 + l][3] = b4[3];
+        if (l < 4) S.bs[0][l] = gF[oBS + l];
+      }
       for (int i = 0; i < lgm; i++) {
         int gid = sLaneG[l * lgm + i];
         bool hit = false;
@@ -402,29 +450,99 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (hit && pos < MAXHIT) S.hits[pos] = gid;
         nh += __popc(m16);
       }
+      WSYNC();
+#ifndef JH_V5_NO_SELF
+      // hand self-collision, level 1: body pairs whose bounding spheres overlap (106 candidate pairs after MuJoCo's static filters, 16 per pass)
+      int nbl = 0;
+      for (int base = 0; base < nBP; base += G) {
+        const int pi = base + l;
+        bool hit = false;
+        if (pi < nBP) {
+          const int ba = gI[oBP + 4 * pi], bb = gI[oBP + 4 * pi + 1];
+          const float* sa = S.bs[ba]; const float* sb = S.bs[bb];
+          const float d[3] = {sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2]}, rs = sa[3] + sb[3];
+          hit = dot3(d, d) <= rs * rs;
+        }
+        unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+        int pos = nbl + __popc(m16 & ((1u << l) - 1u));
+        if (hit && pos < MAXBPL) S.bpl[pos] = pi;
+        nbl += __popc(m16);
+      }
+      nbl = nbl < MAXBPL ? nbl : MAXBPL;
+#ifdef JH_V5_COUNT
+      if (l == 0 && live) cnt_bp += nbl;
+      const int nh_cube = nh;
+#endif
+      WSYNC();
+      // level 2: the geom pairs of those body pairs, 16 at a time per rollout: bounding spheres of the two geoms
+      for (int i = 0; __any(i < nbl); i++) {
+        int start = 0, count = 0, ba = 0, bb = 0;
+        if (i < nbl) { const int pi = S.bpl[i]; ba = gI[oBP + 4 * pi]; bb = gI[oBP + 4 * pi + 1]; start = gI[oBP + 4 * pi + 2]; count = gI[oBP + 4 * pi + 3]; }
+        for (int j0 = 0; __any(j0 < count); j0 += G) {
+#ifdef JH_V5_COUNT
+          if (lane == 0) cnt_l2++;
+#endif
+          const int j = j0 + l;
+          bool hit = false;
+          if (j < count) {
+            const int ga = gI[oGP + 2 * (start + j)], gb = gI[oGP + 2 * (start + j) + 1];
+            const float* fa = sGeomF + ga * GEOM_F; const float* fb = sGeomF + gb * GEOM_F;
+            float ca[3], cb[3];
+            if (ba == 0) { ca[0] = fa[GF_POS]; ca[1] = fa[GF_POS + 1]; ca[2] = fa[GF_POS + 2]; }
+            else { mulMV(ca, S.xR[ba], fa + GF_POS); ca[0] += S.pa[ba][0]; ca[1] += S.pa[ba][1]; ca[2] += S.pa[ba][2]; }
+            mulMV(cb, S.xR[bb], fb + GF_POS); cb[0] += S.pa[bb][0]; cb[1] += S.pa[bb][1]; cb[2] += S.pa[bb][2];
+            const float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]}, rs = fa[GF_RBOUND] + fb[GF_RBOUND];
+            hit = dot3(d, d) <= rs * rs;
+          }
+          unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+          int pos = nh + __popc(m16 & ((1u << l) - 1u));
+          if (hit && pos < MAXHIT) S.hits[pos] = HITPAIR + start + j;
+          nh += __popc(m16);
+        }
+      }
+#ifdef JH_V5_COUNT
+      if (l == 0 && live) cnt_hh += nh - nh_cube;
+#endif
+#endif
       nh = nh < MAXHIT ? nh : MAXHIT;
       WSYNC();
+      // narrow phase: survivor i goes to lane i; side A is the cube or the first geom of a hand pair, side B a hand geom
       PoolCtx pc{&S, stats};
       for (int base = 0; __any(base < nh); base += G) {
         int idx = base + l;
         if (idx < nh) {
-          int gid = S.hits[idx];
-          const float* gf = sGeomF + gid * GEOM_F; int body = sGeomI[gid * GEOM_I], gtype = sGeomI[gid * GEOM_I + 1];
-          float gp[3], gR[9];
-          if (body < 0) { for (int k = 0; k < 3; k++) gp[k] = gf[GF_POS + k]; for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; }
+          const int hid = S.hits[idx];
+          int ga = -1, gb = hid;
+          if (hid >= HITPAIR) { ga = gI[oGP + 2 * (hid - HITPAIR)]; gb = gI[oGP + 2 * (hid - HITPAIR) + 1]; }
+          // side B
+          const float* fb = sGeomF + gb * GEOM_F; const int bodyb = sGeomI[gb * GEOM_I], tb = sGeomI[gb * GEOM_I + 1];
+          float pB[3], RB[9];
+          if (bodyb < 0) { for (int k = 0; k < 3; k++) pB[k] = fb[GF_POS + k]; for (int k = 0; k < 9; k++) RB[k] = fb[GF_R + k]; }
+          else { mulMV(pB, S.xR[bodyb], fb + GF_POS); for (int k = 0; k < 3; k++) pB[k] += S.pa[bodyb][k]; mulMM(RB, S.xR[bodyb], fb + GF_R); }
+          // side A
+          float pA[3], RA[9], hA[3], mua, trana; int ta, codea;
+          if (ga < 0) { for (int k = 0; k < 3; k++) { pA[k] = qc[k]; hA[k] = chs[k]; } for (int k = 0; k < 9; k++) RA[k] = Rc[k]; mua = 0.f; trana = ctran; ta = GBOX; codea = CUBE; }
           else {
-            float bR[9]; for (int k = 0; k < 9; k++) bR[k] = S.xR[body][k];
-            mulMV(gp, bR, gf + GF_POS); for (int k = 0; k < 3; k++) gp[k] += S.pa[body][k];
-            mulMM(gR, bR, gf + GF_R);
+            const float* fa = sGeomF + ga * GEOM_F; const int bodya = sGeomI[ga * GEOM_I];
+            if (bodya < 0) { for (int k = 0; k < 3; k++) pA[k] = fa[GF_POS + k]; for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; }
+            else { mulMV(pA, S.xR[bodya], fa + GF_POS); for (int k = 0; k < 3; k++) pA[k] += S.pa[bodya][k]; mulMM(RA, S.xR[bodya], fa + GF_R); }
+            for (int k = 0; k < 3; k++) hA[k] = fa[GF_SIZE + k];
+            mua = fa[GF_MUOWN]; trana = fa[GF_TRAN]; ta = sGeomI[ga * GEOM_I + 1]; codea = bodya < 0 ? 0 : bodya;
           }
-          float tran = ctran + gf[GF_TRAN];
-          LeapSink sk{pc, body, gf[GF_MU], tran};
-#ifndef JH_V5_X_NONARROW
-          if (gtype == GBOX) collide_box_box(sk, qc, Rc, chs, gp, gR, gf + GF_SIZE);
-          else collide_box_sphere(sk, qc, Rc, chs, gp, gf[GF_SIZE]);
-#else
-          sk.push(gp, gR, gf[GF_SIZE]);
-#endif
+          // contact parameters: friction = the larger of the two geoms' (the cube's is folded into GF_MU), R from the two bodies' inverse weights
+          const float mu = ga < 0 ? fb[GF_MU] : fmaxf(mua, fb[GF_MUOWN]);
+          LeapSink sk{pc, codea | ((bodyb < 0 ? 0 : bodyb) << 8), mu, trana + fb[GF_TRAN], false};
+          if (ta == GBOX && tb == GBOX) collide_box_box(sk, pA, RA, hA, pB, RB, fb + GF_SIZE);
+          else if (ta == GBOX) collide_box_sphere(sk, pA, RA, hA, pB, fb[GF_SIZE]);
+          else if (tb == GBOX) { sk.flip = true; collide_box_sphere(sk, pB, RB, fb + GF_SIZE, pA, hA[0]); }
+          else {  // two spheres (fingertips)
+            const float d[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]}; const float dn = sqrtf(dot3(d, d)), dist = dn - hA[0] - fb[GF_SIZE];
+            if (dist < 0.f && dn > 1e-9f) {
+              const float n3[3] = {d[0] / dn, d[1] / dn, d[2] / dn}, m = hA[0] + 0.5f * dist;
+              const float pos3[3] = {pA[0] + m * n3[0], pA[1] + m * n3[1], pA[2] + m * n3[2]};
+              sk.push(pos3, n3, dist);
+            }
+          }
         }
       }
     }
@@ -437,16 +555,16 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
       for (int k = 0; k < NSLOT; k++) {
         int idx = l + 16 * k;
-        sl[k].link = -1;
-        for (int i = 0; i < 9; i++) sl[k].fr[i] = 0.f;  // an empty slot takes part in the quad sums of the Hessian's cube block with zeros
+        sl[k].la = -1; sl[k].lb = 0;
+        for (int i = 0; i < 9; i++) sl[k].fr[i] = 0.f;
         sl[k].rc[0] = sl[k].rc[1] = sl[k].rc[2] = 0.f;
         if (idx < ncon) {
           const float* e = S.pool[idx];
           sl[k].rc[0] = e[0] - qc[0]; sl[k].rc[1] = e[1] - qc[1]; sl[k].rc[2] = e[2] - qc[2];
           sl[k].fr[0] = e[3]; sl[k].fr[1] = e[4]; sl[k].fr[2] = e[5];
           make_frame(sl[k].fr);
-          float dist = e[6], mu = e[7], tran = e[9]; int body = __float_as_int(e[8]);
-          sl[k].link = body > 0 ? body : 0;
+          float dist = e[6], mu = e[7], tran = e[9]; const int sides = __float_as_int(e[8]);
+          sl[k].la = sides & 0xFF; sl[k].lb = sides >> 8;
           float imp = impedance(csi, dist);
           float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
           sl[k].D0 = 1.f / R0; sl[k].D1 = 1.f / R1;
@@ -466,12 +584,20 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         dr.lims = sg; dr.lD = 1.f / R; dr.laref = -lc[LC_LB] * (sg * qd) - lc[LC_LK] * imp * dist;
       }
     }
+    // a contact between links of two different finger chains couples their blocks: no arrow structure for this rollout in this step
+    bool anyslot = false, cross = false;
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      anyslot |= sl[k].la >= 0;
+      cross |= sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2);
+    }
+    const bool dense_row = gor((int)cross) != 0;
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     float a_own, ac_own;
     const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
     const float fsc_own = mck * a0c_own;
     const float snorm = gsum(fs_own * fs_own * iMd + fsc_own * fsc_own * imck);
-    const bool has_rows = gor((int)(sl[0].link >= 0 || sl[1].link >= 0 || dr.fl > 0.f || dr.lims != 0.f)) != 0;
+    const bool has_rows = gor((int)(anyslot || dr.fl > 0.f || dr.lims != 0.f)) != 0;
     int iters_this = 0;
     if (!has_rows) { a_own = a0_own; ac_own = a0c_own; }
     else {
@@ -481,7 +607,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float xl[3] = {S.ws[0], S.ws[1], S.ws[2]}, xr[3] = {S.ws[3], S.ws[4], S.ws[5]}, wa[3]; mulMV(wa, S.xR[0], xr);
         float cs = 0.f, jx[3], jar_ws[NSLOT][3];
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+        for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
           slot_Jx(sl[k], S, qc, xl, wa, S.ws, jx);
           for (int rw = 0; rw < 3; rw++) { sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; jar_ws[k][rw] = sl[k].jar[rw]; }
           cs += cone_cost(sl[k]);
@@ -500,7 +626,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float xl0[3] = {S.p[0], S.p[1], S.p[2]}, xr0[3] = {S.p[3], S.p[4], S.p[5]}; mulMV(wa, S.xR[0], xr0);
         cs = 0.f;
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+        for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
           slot_Jx(sl[k], S, qc, xl0, wa, S.p, jx);
           for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw];
           cs += cone_cost(sl[k]);
@@ -511,7 +637,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (cost_ws < cost_0) {
           a_own = qws; ac_own = wsc_own;
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar_ws[k][rw];
+          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar_ws[k][rw];
           dr.jf = jf_ws; dr.jl = jl_ws;
         } else { a_own = a0_own; ac_own = a0c_own; }
         WSYNC();
@@ -533,28 +659,20 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
         if (act) {
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) {
+          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
             const Slot& t = sl[k];
             float f[3], Wt[6];
             const float D[3] = {t.D0, t.D1, t.D1};
             cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wt);
             if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
-            // world force on the hand geom; the cube gets the opposite
+            // world force on side B; side A gets the opposite.  gradient = -J'f with J = J_B - J_A
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
-            float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
-            // gradient = -J'f: cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
-            gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
-            if (t.link > 0) {
-              const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
-              const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-#pragma unroll
-              for (int j = 0; j < NLK; j++) if (j <= dep) {
-                const float* pj = S.pa[1 + 4 * ch + j];
-                const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
-                cross3(c3, pj + 4, rb);
-                atomicAdd(&S.g[6 + 4 * ch + j], -dot3(c3, Fw));
-              }
-            }
+            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+            if (t.la == CUBE) {  // cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
+              float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
+              gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
+            } else if (t.la > 0) link_force(S, t.la, pos, Fw, -1.f);
+            if (t.lb > 0) link_force(S, t.lb, pos, Fw, 1.f);
           }
         }
         float gcl = 0.f;
@@ -568,8 +686,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
-        // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks
-        if (act) {
+        // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
+        // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
+        const bool aact = act && !dense_row;
+        if (aact) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
@@ -580,8 +700,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
           const Slot& t = sl[k];
-          float Wk[6] = {0, 0, 0, 0, 0, 0}, Jc[6][3];
-          bool on = act && t.link >= 0;
+          float Wk[6] = {0, 0, 0, 0, 0, 0};
+          bool on = aact && t.la >= 0;
           if (on) {
             float f[3];
             const float D[3] = {t.D0, t.D1, t.D1};
@@ -589,52 +709,42 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             on = !(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f);
           }
           if (!__any(on)) continue;  // (the second slot is empty in most waves)
-          // cube columns in the contact frame
-          for (int q3 = 0; q3 < 3; q3++) {
-            Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
-            float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
-            Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
-          }
-          // cube block: every contact of the rollout lands on the same 21 entries.  The lanes of a quad add theirs up first (W = 0 for a lane without
-          // a contact), the quad's first lane issues the atomic: at most 4 instead of 16 lanes collide on an address
-          const bool lead = JH_V5_HCC_PRE == 2 ? s == 0 : (JH_V5_HCC_PRE == 1 ? (s & 1) == 0 : on);
+          if (on) {
+            const bool cube = t.la == CUBE;
+            float Jc[6][3];
+            if (cube) {  // cube columns in the contact frame
+              for (int q3 = 0; q3 < 3; q3++) {
+                Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
+                float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+                Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
+              }
 #pragma unroll
-          for (int v6 = 0; v6 < 6; v6++) {
-            const float* j3 = Jc[v6];
-            const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+              for (int v6 = 0; v6 < 6; v6++) {
+                const float* j3 = Jc[v6];
+                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
 #pragma unroll
-            for (int u6 = v6; u6 < 6; u6++) {
-              float v = Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2;
-#if JH_V5_HCC_PRE == 2
-              v = csum(v);
-#elif JH_V5_HCC_PRE == 1
-              asm volatile("" : "+v"(v)); v += dppf<DPP_XOR1>(v);
-#endif
-              if (lead && act) atomicAdd(&S.Hcc[tri(u6, v6)], v);
-            }
-          }
-          if (on && t.link > 0) {
-            const int ch = (t.link - 1) >> 2, dep = (t.link - 1) & 3;
-            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-            float Jb[NLK][3];
-#pragma unroll
-            for (int j = 0; j < NLK; j++) {
-              Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
-              if (j <= dep) {
-                const float* pj = S.pa[1 + 4 * ch + j];
-                const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]}; float c3[3];
-                cross3(c3, pj + 4, rb);
-                Jb[j][0] = dot3(t.fr, c3); Jb[j][1] = dot3(t.fr + 3, c3); Jb[j][2] = dot3(t.fr + 6, c3);
+                for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
               }
             }
+            if (t.lb > 0) {  // finger columns: side B, minus side A when that is a link of the same chain (hand self-contact)
+              const int ch = (t.lb - 1) >> 2;
+              const int dep = (t.lb - 1) & 3;
+              const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+              float Jb[NLK][3];
+              for (int j = 0; j < NLK; j++) Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
+              link_cols(S, t.lb, pos, t.fr, 1.f, Jb);
+              if (!cube && t.la > 0) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
 #pragma unroll
-            for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
-              const float* j3 = Jb[u4];
-              const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+              for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+                const float* j3 = Jb[u4];
+                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
 #pragma unroll
-              for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+                for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+                if (cube) {
 #pragma unroll
-              for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
+                  for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
+                }
+              }
             }
           }
         }
@@ -650,7 +760,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           fwd4(L, Linv, Ya); fwd4(L, Linv, Yb);
           for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
           fwd4(L, Linv, zb);
-          if (act && l < 6) S.rhs6[l] = -gcl;
+          if (aact && l < 6) S.rhs6[l] = -gcl;
         }
         WSYNC();
         {
@@ -663,14 +773,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
             const float da = qsum4(Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3]);
             const float db = qsum4(Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3]);
-            if (act && c == 0) {
+            if (aact && c == 0) {
               if (r6 <= s) S.Hcc[tri(s, r6)] -= da;
               if (hasb && r6 <= 4 + s) S.Hcc[tri(4 + s, r6)] -= db;
             }
           }
           const float ra = qsum4(Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3]);
           const float rb = qsum4(Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3]);
-          if (act && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
+          if (aact && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
         }
         WSYNC();
         {
@@ -704,10 +814,134 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
           bwd4(L, Linv, pc4);
         }
-        const float p_own = sel4(pc4, s);
-        const float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
-        if (act) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
+        float p_own = sel4(pc4, s);
+        float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
+        if (aact) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
         WSYNC();
+        // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
+        // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
+#ifndef JH_V5_NO_DENSE
+#ifdef JH_V5_COUNT
+        if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
+#endif
+        if (__any(act && dense_row)) {
+          const bool dact = act && dense_row;
+          if (dact) for (int e = l; e < NDH; e += G) S.Hd[e] = 0.f;
+          WSYNC();
+          if (dact) {
+#pragma unroll
+            for (int j = 0; j < NLK; j++) if (j <= s) S.Hd[tri(6 + l, 6 + 4 * c + j)] = Mrow[j] + (j == s ? hd : 0.f);
+            if (l < 6) { S.Hd[tri(l, l)] = mck; S.g[l] = gcl; }
+          }
+          WSYNC();
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) {
+            const Slot& t = sl[k];
+            if (!(dact && t.la >= 0)) continue;
+            float f[3], Wk[6];
+            const float D[3] = {t.D0, t.D1, t.D1};
+            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
+            if (Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f) continue;
+            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+            // three column blocks: X0 = cube (6 columns at dof 0) or side-A link (4 columns at its chain), X1 = side-B link (4 columns)
+            float X0[6][3], X1[NLK][3];
+            for (int j = 0; j < 6; j++) X0[j][0] = X0[j][1] = X0[j][2] = 0.f;
+            for (int j = 0; j < NLK; j++) X1[j][0] = X1[j][1] = X1[j][2] = 0.f;
+            int o0 = 0, n0 = 0, o1 = 0, n1 = 0;
+            if (t.la == CUBE) {
+              n0 = 6;
+              for (int q3 = 0; q3 < 3; q3++) {
+                X0[q3][0] = -t.fr[q3]; X0[q3][1] = -t.fr[3 + q3]; X0[q3][2] = -t.fr[6 + q3];
+                float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+                X0[3 + q3][0] = -dot3(t.fr, c3); X0[3 + q3][1] = -dot3(t.fr + 3, c3); X0[3 + q3][2] = -dot3(t.fr + 6, c3);
+              }
+            } else if (t.la > 0) { o0 = 6 + 4 * ((t.la - 1) >> 2); n0 = 1 + ((t.la - 1) & 3); link_cols(S, t.la, pos, t.fr, -1.f, X0); }
+            if (t.lb > 0) {
+              o1 = 6 + 4 * ((t.lb - 1) >> 2); n1 = 1 + ((t.lb - 1) & 3);
+              if (t.la != CUBE && t.la > 0 && o1 == o0) { link_cols(S, t.lb, pos, t.fr, 1.f, X0); n0 = n0 > n1 ? n0 : n1; n1 = 0; }  // same chain: one block
+              else link_cols(S, t.lb, pos, t.fr, 1.f, X1);
+            }
+            if (n1 > 0 && n0 > 0 && o1 < o0) {  // keep the blocks in dof order (X0 before X1) so that every entry lands in the lower triangle
+              for (int j = 0; j < NLK; j++) for (int q = 0; q < 3; q++) { const float tmp = X0[j][q]; X0[j][q] = X1[j][q]; X1[j][q] = tmp; }
+              int ti = o0; o0 = o1; o1 = ti; ti = n0; n0 = n1; n1 = ti;
+            }
+#pragma unroll
+            for (int u = 0; u < 6; u++) if (u < n0) {
+              const float* j3 = X0[u];
+              const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+              for (int v = 0; v <= u; v++) atomicAdd(&S.Hd[tri(o0 + u, o0 + v)], X0[v][0] * G0 + X0[v][1] * G1 + X0[v][2] * G2);
+#pragma unroll
+              for (int v = 0; v < NLK; v++) if (v < n1) atomicAdd(&S.Hd[tri(o1 + v, o0 + u)], X1[v][0] * G0 + X1[v][1] * G1 + X1[v][2] * G2);
+            }
+#pragma unroll
+            for (int u = 0; u < NLK; u++) if (u < n1) {
+              const float* j3 = X1[u];
+              const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+              for (int v = 0; v <= u; v++) atomicAdd(&S.Hd[tri(o1 + u, o1 + v)], X1[v][0] * G0 + X1[v][1] * G1 + X1[v][2] * G2);
+            }
+          }
+          WSYNC();
+          // Cholesky by rows: lane l keeps rows l and 16 + l (l < 6) of the factor in registers.  Column k: every lane reads row k's finished entries
+          // L[k][0..k-1] from LDS (published as they were finished), forms the pivot redundantly and finishes its own rows' entry of column k --
+          // one LDS round trip per column, all reads of a column independent of each other
+          const int r1 = 16 + l;
+          const bool two = l < 6;
+          float h0[16], h1[NV];
+#pragma unroll
+          for (int j = 0; j < 16; j++) h0[j] = (dact && j <= l) ? S.Hd[tri(l, j)] : 0.f;
+#pragma unroll
+          for (int j = 0; j < NV; j++) h1[j] = (dact && two && j <= r1) ? S.Hd[tri(r1, j)] : 0.f;
+#pragma unroll
+          for (int kk = 0; kk < NV; kk++) {
+            float dp = 0.f, s0 = kk < 16 ? h0[kk < 16 ? kk : 0] : 0.f, s1 = h1[kk];
+            const float hkk = dact ? S.Hd[tri(kk, kk)] : 1.f;
+#pragma unroll
+            for (int j = 0; j < kk; j++) {
+              const float t = dact ? S.Hd[tri(kk, j)] : 0.f;
+              dp = fmaf(t, t, dp);
+              if (kk < 16) s0 = fmaf(-h0[j < 16 ? j : 0], t, s0);
+              s1 = fmaf(-h1[j], t, s1);
+            }
+            const float rk = __frsqrt_rn(fmaxf(hkk - dp, 1e-30f));
+            if (kk < 16) h0[kk < 16 ? kk : 0] = kk <= l ? s0 * rk : 0.f;
+            h1[kk] = (two && kk <= r1) ? s1 * rk : 0.f;
+            if (dact) {
+              if (kk < 16 && l > kk) S.Hd[tri(l, kk)] = h0[kk < 16 ? kk : 0];
+              if (two && r1 > kk) S.Hd[tri(r1, kk)] = h1[kk];
+              if (l == 0) S.dinv[kk] = rk;
+            }
+            WSYNC();
+          }
+          // L y = -g: the owner of row k publishes y_k, every lane takes it out of its own rows' right-hand sides
+          float b0 = dact ? -S.g[l] : 0.f, b1 = (dact && two) ? -S.g[r1] : 0.f;
+#pragma unroll
+          for (int kk = 0; kk < NV; kk++) {
+            if (dact && (kk < 16 ? l == kk : r1 == kk)) S.p[kk] = (kk < 16 ? b0 : b1) * S.dinv[kk];
+            WSYNC();
+            const float yk = dact ? S.p[kk] : 0.f;
+            if (kk < 16) b0 -= (l > kk ? h0[kk < 16 ? kk : 0] : 0.f) * yk;
+            b1 -= ((two && r1 > kk) ? h1[kk] : 0.f) * yk;
+          }
+          // L' x = y, in place: the owner of row k finishes x_k and takes it out of the entries above
+#pragma unroll
+          for (int kk = NV - 1; kk >= 0; kk--) {
+            if (dact && (kk < 16 ? l == kk : r1 == kk)) {
+              const float xk = S.p[kk] * S.dinv[kk];
+              S.p[kk] = xk;
+#pragma unroll
+              for (int j = 0; j < kk; j++) S.p[j] -= (kk < 16 ? h0[j < 16 ? j : 0] : h1[j]) * xk;
+            }
+            WSYNC();
+          }
+          if (dact) {
+            p_own = S.p[6 + l]; xcl = l < 6 ? S.p[l] : 0.f;
+            for (int k = 0; k < 6; k++) xc6[k] = S.p[k];
+            for (int j = 0; j < NLK; j++) pc4[j] = S.p[6 + 4 * c + j];
+          }
+        }
+#endif
         // ---- (5) exact line search along p
         float Mp_own = 0.f;
 #pragma unroll
@@ -719,7 +953,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         {
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) slot_Jx(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
+          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) slot_Jx(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
@@ -742,7 +976,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act) {
           a_own += alpha * p_own; ac_own += alpha * xcl;
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].link >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
+          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
           dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         }
@@ -792,6 +1026,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     } else acc += leap_step_cost(sTp, qc);
     WSYNC();
   }
+#ifdef JH_V5_COUNT
+  if (stats) { if (lane == 0) { atomicAdd(stats + 24, cnt_dense); atomicAdd(stats + 25, cnt_it); atomicAdd(stats + 26, cnt_l2); atomicAdd(stats + 28, H); } if (l == 0 && live) { atomicAdd(stats + 27, cnt_bp); atomicAdd(stats + 29, cnt_hh); } }
+#endif
   if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
 }

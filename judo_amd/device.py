@@ -50,8 +50,12 @@ class GpuModel:
         self.handle = handle
 
     def set_kernel(self, generation: int) -> None:
-        """Select the articulated-engine kernel generation (2 = cooperative, default; 1 = one lane per rollout)."""
+        """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: leap_cube default; 2 = cooperative: fr3_pick default; 1 = one lane per rollout)."""
         _lib.check(_lib.lib().jh_model_set_kernel(self.handle, int(generation)), "jh_model_set_kernel")
+
+    def set_self_collision(self, on: bool) -> None:
+        """leap_cube, kernel generation 3: model the hand's own contacts too (default) or the cube's alone."""
+        _lib.check(_lib.lib().jh_model_set_self_collision(self.handle, int(bool(on))), "jh_model_set_self_collision")
 
     @property
     def max_fused_knots(self) -> int:

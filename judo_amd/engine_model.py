@@ -191,7 +191,7 @@ def fuse_fixed_bodies(desc: dict) -> dict:
     return fuse_fixed_bodies(d)
 
 
-def generic_pairs(desc: dict, fused: dict, st: dict) -> list[tuple[int, int]]:
+def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = None) -> list[tuple[int, int]]:
     """Candidate box-box / box-sphere pairs for the generic (reference-kernel) contact path, MuJoCo's static filters
     applied on the ORIGINAL bodies: same welded body, parent-child (unless the parent is welded to the world), excludes.
     leap_cube: restricted to pairs that involve the cube (hand self-collision is out of scope this round)."""
@@ -225,8 +225,9 @@ def generic_pairs(desc: dict, fused: dict, st: dict) -> list[tuple[int, int]]:
                 continue
             if (weld_parent(ba) == wb and wb != 0) or (weld_parent(bb) == wa and wa != 0):
                 continue
-            if desc.get("family", desc["task"]) == "leap_cube" and free_fused not in (ga["body"], gb["body"]):
-                continue
+            leap = desc.get("family", desc["task"]) == "leap_cube"
+            if (leap if cube_only is None else cube_only) and free_fused not in (ga["body"], gb["body"]):
+                continue  # (the one-lane reference kernel and jh_engine_v2.hip model the cube's contacts only; jh_engine_v5.hip adds the hand's own)
             out.append((a, b))
     # order by importance for the fixed-capacity contact pools: pairs with the free body first, then pairs against static
     # geometry, pairs between two articulated bodies (e.g. the two fingers' pad stacks) last -- those are the ones dropped on overflow
@@ -357,7 +358,7 @@ def pack_engine_model(desc: dict) -> bytes:
         rb = size[0] if g["type"] == "sphere" else float(np.linalg.norm(size))
         mu = max(MINMU, max(g["friction"][0], mu_cube))
         I += [mb, GBOX if g["type"] == "box" else GSPHERE]
-        F += [*size, *pos, *R.reshape(-1), rb, mu, bodyw_geom(g), 0, 0]
+        F += [*size, *pos, *R.reshape(-1), rb, mu, bodyw_geom(g), max(MINMU, g["friction"][0]), 0]
     # ---- sites + sensors
     for s in sites:
         b = s["body"]
@@ -393,6 +394,45 @@ def pack_engine_model(desc: dict) -> bytes:
         I[11], I[12] = len(I), lgm
         for x in lists:
             I += x + [-1] * (lgm - len(x))
+        # hand self-collision (jh_engine_v5.hip): candidate geom pairs between hand bodies after MuJoCo's static filters (same welded body, parent-child,
+        # the 18 excludes), grouped by body pair; a bounding sphere per body (static geometry: one sphere in world coordinates)
+        oidx = {id(g): i for i, g in enumerate(others)}
+        og = [g for g in desc["geoms"] if g["type"] in ("box", "sphere")]
+        hh = [(a, b) for a, b in generic_pairs(orig, dict(desc, geoms=og), st, cube_only=False) if st["free"] not in (og[a]["body"], og[b]["body"])]
+        code = lambda g: 0 if st["is_static"][g["body"]] else midx[g["body"]]  # noqa: E731   0 = static, 1..16 = finger links
+        groups: dict[tuple[int, int], list[tuple[int, int]]] = {}
+        for a, b in hh:
+            ga, gb = og[a], og[b]
+            if code(ga) > code(gb):
+                ga, gb = gb, ga
+            groups.setdefault((code(ga), code(gb)), []).append((oidx[id(ga)], oidx[id(gb)]))
+        I[15], I[17] = len(I), len(groups)
+        start = 0
+        for (ca, cb), lst in groups.items():
+            I += [ca, cb, start, len(lst)]
+            start += len(lst)
+        for lst in groups.values():
+            for a, b in lst:
+                I += [a, b]
+        I[16] = len(F)
+        for c in range(17):  # per hand body (0 = all static geometry, in world coordinates): bounding sphere and bounding box of its collision geoms, body frame
+            gs = [g for g in others if code(g) == c]
+            corners = []
+            for g in gs:
+                if c == 0:
+                    bpos, bquat = _static_world_pose(desc, g["body"])
+                    gp, gR = bpos + quat_to_mat(bquat) @ np.array(g["pos"]), quat_to_mat(quat_mul(bquat, g["quat"]))
+                else:
+                    gp, gR = np.array(g["pos"]), quat_to_mat(g["quat"])
+                hs = np.array([g["size"][0]] * 3) if g["type"] == "sphere" else np.array(g["size"][:3])
+                for sx in (-1, 1):
+                    for sy in (-1, 1):
+                        for sz in (-1, 1):
+                            corners.append(gp + gR @ (hs * np.array([sx, sy, sz])))
+            corners = np.array(corners)
+            lo, hi = corners.min(0), corners.max(0)
+            ctr, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+            F += [*ctr, float(np.linalg.norm(half)), *half, 0.0]
     # ---- generic sections (reference kernel): every collision geom incl. the cube, explicit candidate pairs, joint
     # equalities, sensor frames with orientation, geom-distance sensors
     allg = [g for g in desc["geoms"] if g["type"] in ("box", "sphere")]

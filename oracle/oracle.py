@@ -94,13 +94,12 @@ def load_description(task: str) -> dict:
         return json.load(f)
 
 
-def collision_pairs(desc: dict, scope: str = "task") -> list[tuple[int, int]]:
-    """Candidate geom pairs after MuJoCo's static filters.
+def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
+    """Candidate geom pairs after MuJoCo's static filters (same welded body, parent-child unless the parent is the world, explicit excludes)
+    that have a supported narrow phase.
 
-    scope "task": the pairs the build models for this task (DESIGN.md "contacts modelled"):
-      leap_cube  -> cube geom vs every hand geom (hand self-collision is out of scope this round)
-      others     -> every pair that survives the filters and has a supported narrow-phase.
-    """
+    scope "all" (default): every such pair -- for leap_cube that includes the hand's self-collision (finger-finger, finger-palm), which
+    jh_engine_v5.hip models; scope "cube": leap_cube only, the cube's contacts alone (what jh_engine.hip / jh_engine_v2.hip model)."""
     bodies, geoms = desc["bodies"], desc["geoms"]
     nb = len(bodies)
     njnt_body = [0] * nb
@@ -133,7 +132,7 @@ def collision_pairs(desc: dict, scope: str = "task") -> list[tuple[int, int]]:
                 continue
             if (geoms[g1]["type"], geoms[g2]["type"]) not in supported:
                 continue
-            if desc.get("family", desc["task"]) == "leap_cube" and scope == "task":
+            if desc.get("family", desc["task"]) == "leap_cube" and scope in ("cube", "task"):
                 cube = next(i for i, g in enumerate(geoms) if g["name"] == "cube")
                 if cube not in (g1, g2):
                     continue
@@ -144,7 +143,7 @@ def collision_pairs(desc: dict, scope: str = "task") -> list[tuple[int, int]]:
 class Model:
     """Owns a C `jo_model`."""
 
-    def __init__(self, task: str, desc: dict | None = None, pairs: list[tuple[int, int]] | None = None) -> None:
+    def __init__(self, task: str, desc: dict | None = None, pairs: list[tuple[int, int]] | None = None, scope: str = "all") -> None:
         L = lib()
         self.task = task
         self.desc = d = desc if desc is not None else load_description(task)
@@ -168,7 +167,7 @@ class Model:
             assert r >= 0
             if g.get("priority", 0):
                 assert L.jo_set_geom_priority(self.ptr, r, int(g["priority"])) == 0
-        self.pairs = pairs if pairs is not None else collision_pairs(d)
+        self.pairs = pairs if pairs is not None else collision_pairs(d, scope)
         for g1, g2 in self.pairs:
             assert L.jo_add_pair(self.ptr, g1, g2) >= 0
         for s in d["sites"]:

@@ -185,6 +185,7 @@ def test_leap_two_kernel_generations_agree(gpu):
     om, knots, U, _ = _mppi_controls(N, seed=9)
     x0 = np.concatenate([LEAP_QPOS_HOME, np.zeros(22)])
     b2 = GpuRolloutBackend("leap_cube", N)
+    b2.model.set_self_collision(False)  # the one-lane kernel models the cube's contacts only
     s2, y2, _ = b2.rollout(x0, U)
     b1 = GpuRolloutBackend("leap_cube", N)
     b1.model.set_kernel(1)
@@ -206,19 +207,26 @@ def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):
     from oracle import oracle as O
 
     t = LeapCubeDown()
-    om = O.Model("leap_cube_down")
+    om = O.Model("leap_cube_down", scope="cube")  # generations 1 and 2 model the cube's contacts only
     rng = np.random.default_rng(3)
     N, H = 64, 48
     U = t.reset_command[None, None] + 0.3 * np.repeat(rng.standard_normal((N, 4, 16)), H // 4, axis=1)
     x0 = t.default_state()
     rs, rsens = om.rollout(x0, U)
-    for gen in (2, 1):
+    for gen in (3, 2, 1):
         be = GpuRolloutBackend(t.gpu_model(), N)
         be.model.set_kernel(gen)
+        be.model.set_self_collision(False)
         gs, gsens, _ = be.rollout(x0, U)
         e = np.abs(gs - rs)
         assert np.median(e) < 1e-5 and np.percentile(e[:, -1, :3], 95) < 5e-3, gen
         np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=1e-4)
+    # the default kernel with the hand's own contacts against the oracle with every pair (palm-down: the fingers close under the palm)
+    oa = O.Model("leap_cube_down")
+    ra, _ = oa.rollout(x0, U)
+    ga, _, _ = GpuRolloutBackend(t.gpu_model(), N).rollout(x0, U)
+    ea = np.abs(ga - ra)
+    assert np.median(ea) < 1e-5 and np.percentile(ea[:, -1, :3], 95) < 5e-3
     ctrl = make_controller("leap_cube_down", "mppi")
     assert ctrl.optimizer.config.num_rollouts == 64 and ctrl.task.config.w_rot == 0.05
     ctrl.update_action()

@@ -1,0 +1,110 @@
+"""leap_cube hand self-collision (finger-finger, finger-palm: every geom pair MuJoCo's static filters leave, judo/models/xml/leap_components/
+params_and_default.xml:76-101 lists the 18 excluded body pairs) on the default leap kernel (jh_engine_v5.hip), against the fp64 oracle with the same pairs.
+The MPPI workload around the home pose almost never closes the hand on itself, so the controls here drive the fingers across each other and into the palm."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tangled_states(N, seed, frac=0.6):
+    """Hand configurations `frac` of the way from the home pose to uniformly random joint angles (the fingers cross each other and dig into the palm),
+    small random velocities, the cube parked 0.3 m above the hand (no cube contacts: the hand's own are what is under test)."""
+    from judo_amd.tasks import LEAP_QPOS_HOME
+    from oracle import oracle as O
+
+    om = O.Model("leap_cube")
+    rng = np.random.default_rng(seed)
+    r = np.array([a["ctrlrange"] for a in om.desc["actuators"]])
+    q = r[:, 0] + (r[:, 1] - r[:, 0]) * rng.uniform(0.0, 1.0, (N, 16))
+    q = LEAP_QPOS_HOME[7:] + frac * (q - LEAP_QPOS_HOME[7:])
+    xs = np.zeros((N, 45))
+    xs[:, :7] = LEAP_QPOS_HOME[:7]
+    xs[:, 2] += 0.3
+    xs[:, 7:23] = q
+    xs[:, 23:] = 0.2 * rng.standard_normal((N, 22))
+    return om, xs, q
+
+
+def _contact_kinds(om, x, u):
+    """(cube contacts, hand contacts within one finger chain or against the palm, contacts between two finger chains) in the oracle's forward pass."""
+    f = om.forward(x[:23], x[23:], u)
+    d = om.desc
+    body = [g["body"] for g in d["geoms"]]
+    names = [b["name"] for b in d["bodies"]]
+    cube = names.index("cube")
+    chain = {}
+    for b, n in enumerate(names):
+        chain[b] = {"if": 0, "mf": 1, "rf": 2, "th": 3}.get(n[:2], -1) if n not in ("cube",) else -2
+    nc = ns = nx = 0
+    for row in f["contacts"]:
+        ba, bb = body[int(row[13])], body[int(row[14])]
+        if cube in (ba, bb):
+            nc += 1
+        elif chain[ba] >= 0 and chain[bb] >= 0 and chain[ba] != chain[bb]:
+            nx += 1
+        else:
+            ns += 1
+    return nc, ns, nx
+
+
+def test_self_collision_single_steps_match_oracle(gpu):
+    """One mj_step from hand configurations in which the fingers touch each other or the palm; the states with a contact between two finger
+    chains take the kernel's dense Hessian path, the others the arrow path."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from oracle import oracle as O
+
+    om, xs, q = _tangled_states(600, seed=5)
+    us = q[:, None, :]
+    kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(len(xs))])
+    ok = kinds.sum(1) <= 32  # within the kernel's contact capacity per rollout
+    within, across = ok & (kinds[:, 1] > 0) & (kinds[:, 2] == 0), ok & (kinds[:, 2] > 0)
+    assert within.sum() > 10 and across.sum() > 100, (within.sum(), across.sum())
+    nxt, _ = om.rollout(xs, us)
+    be = GpuRolloutBackend("leap_cube", len(xs))
+    g1, _, _ = be.rollout(xs, us)
+    assert np.isfinite(g1).all()
+    # deep random penetrations: accelerations of 1e3..1e5 rad/s^2 on 1e-5 kg m^2 links, velocities of tens of rad/s after one step: the error is stated
+    # relative to the velocity scale of the rollout (solver tolerance 1e-4 of the force scale on both sides of the comparison)
+    scale = np.maximum(1.0, np.abs(nxt[:, 0, 23:]).max(axis=1, keepdims=True))
+    e = np.abs(g1[:, 0] - nxt[:, 0])
+    e[:, 23:] /= scale
+    for sel, name in ((within, "arrow path"), (across, "dense path"), (ok & (kinds.sum(1) == 0), "no contact")):
+        ev = e[sel][:, 23:]
+        assert np.median(ev) < 2e-5 and np.percentile(ev, 95) < 2e-2, (name, np.median(ev), np.percentile(ev, 95))
+    # the same steps WITHOUT the hand's own contacts are far off: the cube-only model moves the fingers through each other
+    oc = O.Model("leap_cube", scope="cube")
+    rc, _ = oc.rollout(xs[across], us[across])
+    miss = np.abs(rc[:, 0] - nxt[across, 0])[:, 23:] / scale[across]
+    assert np.percentile(miss, 75) > 50 * np.percentile(e[across][:, 23:], 75)
+    # switching the hand's own contacts off reproduces exactly that cube-only model
+    be.model.set_self_collision(False)
+    g0, _, _ = be.rollout(xs[across], us[across])
+    assert np.median(np.abs(g0[:, 0] - rc[:, 0])[:, 23:] / scale[across]) < 2e-5
+    be.model.set_self_collision(True)
+    st = be.model.stats()
+    assert st["contact_overflow"] <= int((~ok).sum()) * 64
+
+
+def test_self_collision_rollouts_match_oracle(gpu):
+    """24 steps from the tangled configurations with the servos holding the pose: the fingers push each other apart."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from oracle import oracle as O
+
+    om, xs, q = _tangled_states(256, seed=11, frac=0.5)
+    kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(len(xs))])
+    keep = (kinds.sum(1) <= 24) & (kinds.sum(1) > 0)
+    xs, q = xs[keep], q[keep]
+    assert len(xs) > 40
+    H = 24
+    U = np.repeat(q[:, None, :], H, axis=1)
+    rs, _ = om.rollout(xs, U)
+    rc, _ = O.Model("leap_cube", scope="cube").rollout(xs, U)
+    gs, _, _ = GpuRolloutBackend("leap_cube", len(xs)).rollout(xs, U)
+    assert np.isfinite(gs).all()
+    err = np.abs(gs - rs)[:, :, 7:23]  # joint angles
+    gap = np.abs(rc - rs)[:, :, 7:23]  # what ignoring the hand's self-collision costs
+    assert np.median(gap[:, -1].max(1)) > 1e-2
+    assert np.median(err[:, -1].max(1)) < 0.05 * np.median(gap[:, -1].max(1))
+    assert np.percentile(err[:, -1], 90) < 5e-3

@@ -38,11 +38,14 @@ JOINT_DEFAULTS = dict(
     solreffriction="0.02 1", solimpfriction="0.9 0.95 0.001 0.5 2",
 )
 
-# Collision-mesh substitutes: {mesh name: primitive in the geom's own frame}.  The tip sphere is placed so
-# that its far end reaches the reference's own `trace_*_tip` site (leap_hand.xml:118,163,208,250).
+# Collision-mesh substitutes: {mesh name: primitive (or list of primitives) in the geom's own frame}.  The fingertip meshes `tip` / `thumb_tip` are
+# replaced by the primitives the reference itself uses for the same fingertip in its mesh-free hand model
+# (judo/models/xml/caltech_leap_components/leap_rh.xml:131-132,175-176,219-220,259-260: a cylinder r = 14 mm, half length 7 mm, and a sphere r = 14 mm
+# 7 mm further out); the cylinder is taken as a second sphere of the same radius (sphere-swept segment: the two overlap into a capsule-like tip whose
+# far end sits at the reference's `trace_*_tip` site, leap_hand.xml:120,252).
 MESH_SUBSTITUTES = {
-    "tip": dict(type="sphere", size=[0.012], pos=[0.0, -0.0365, 0.0145], quat=[1, 0, 0, 0]),
-    "thumb_tip": dict(type="sphere", size=[0.012], pos=[0.0, -0.0465, -0.0145], quat=[1, 0, 0, 0]),
+    "tip": [dict(type="sphere", size=[0.014], pos=[0.0, -0.027, 0.0145], quat=[1, 0, 0, 0]), dict(type="sphere", size=[0.014], pos=[0.0, -0.034, 0.0145], quat=[1, 0, 0, 0])],
+    "thumb_tip": [dict(type="sphere", size=[0.014], pos=[0.0, -0.0375, -0.01425], quat=[1, 0, 0, 0]), dict(type="sphere", size=[0.014], pos=[0.0, -0.0445, -0.01425], quat=[1, 0, 0, 0])],
     # fr3 link hulls: capsules along the link axes (radius ~ hull half-width of the FR3 links), not used by
     # the shipped fr3_pick cost except through contacts; fingers' mesh hull -> box over the finger body.
     "link0_coll": dict(type="capsule", size=[0.07, 0.06], pos=[-0.04, 0, 0.06], quat=[0.7071068, 0, 0.7071068, 0]),
@@ -321,18 +324,26 @@ def compile_model(xml_name: str, task: str) -> dict:
             for g in geoms_here:
                 if g["contype"] == 0 and g["conaffinity"] == 0:
                     continue  # visual-only
+                parts = [g]
                 if g["type"] == "mesh":
-                    sub = MESH_SUBSTITUTES.get(g["mesh"])
-                    if sub is None:
+                    subs = MESH_SUBSTITUTES.get(g["mesh"])
+                    if subs is None:
                         raise KeyError(f"collision mesh {g['mesh']} has no substitute")
-                    # substitute is expressed in the mesh geom's frame
-                    g["pos"] = [g["pos"][i] + quat_rot(g["quat"], sub["pos"])[i] for i in range(3)]
-                    g["quat"] = qnorm(quat_mul(g["quat"], sub["quat"]))
-                    g["type"], g["size"] = sub["type"], list(sub["size"])
-                    g["substitute_for_mesh"] = g["mesh"]
-                for k in ("mesh", "density", "mass", "contype", "conaffinity"):
-                    g.pop(k, None)
-                model["geoms"].append(g)
+                    subs = subs if isinstance(subs, list) else [subs]
+                    parts = []
+                    for i_sub, sub in enumerate(subs):  # substitutes are expressed in the mesh geom's frame
+                        gg = dict(g)
+                        gg["pos"] = [g["pos"][i] + quat_rot(g["quat"], sub["pos"])[i] for i in range(3)]
+                        gg["quat"] = qnorm(quat_mul(g["quat"], sub["quat"]))
+                        gg["type"], gg["size"] = sub["type"], list(sub["size"])
+                        gg["substitute_for_mesh"] = g["mesh"]
+                        if len(subs) > 1:
+                            gg["name"] = f"{g['name']}_{i_sub + 1}"
+                        parts.append(gg)
+                for gg in parts:
+                    for k in ("mesh", "density", "mass", "contype", "conaffinity"):
+                        gg.pop(k, None)
+                    model["geoms"].append(gg)
             walk(b, bid, cc)
 
     wb = root.find("worldbody")

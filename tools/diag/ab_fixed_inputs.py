@@ -22,6 +22,9 @@ if mode == "record":
 else:
     d = np.load(path)
     c.record_kernel_events = True
+    if os.environ.get("KERNEL_GEN"): c.model.set_kernel(int(os.environ["KERNEL_GEN"]))
+    if os.environ.get("SELF") is not None: c.model.set_self_collision(os.environ["SELF"] == "1")
+    noms = []
     for rep in range(int(os.environ.get("REPS", "1"))):
         c.kernel_events.clear()
         for i in range(S):
@@ -29,6 +32,13 @@ else:
             c.nominal_knots = d["knots"][i].copy(); c.times = d["times"][i].copy(); c.update_spline(c.times, c.nominal_knots); c.time = float(d["t"][i])
             if OPT == "cem": c.optimizer.sigma = d["sigma"][i].copy()
             c.update_action()
+            if rep == 0: noms.append(c.nominal_knots.copy())
         torch.cuda.synchronize()
         k = np.array([a.elapsed_time(b) for a, b in c.kernel_events])
-        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')} lstol={EM.SOLVER_LS_TOL:g} tol={EM.SOLVER_TOL:g}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {c.model.stats()['newton_iters'] / (NR * HS * S):.3f}")
+        if os.environ.get("OUT") and rep == 0: np.save(os.environ["OUT"], np.stack(noms))
+        if os.environ.get("REF") and rep == 0:
+            dn = np.abs(np.stack(noms) - np.load(os.environ["REF"]))
+            print(f"  returned nominal vs {os.environ['REF']}: max {dn.max():.2e} rad, 99th percentile {np.percentile(dn, 99):.2e}, median {np.median(dn):.2e}")
+        st = c.model.stats()
+        print(f"  contacts dropped above the pool {st['contact_overflow']} ({st['contact_overflow'] / max(st['steps'], 1):.2e} per step), Newton cap hits {st['newton_cap_hits']}")
+        print(f"{os.environ.get('JUDO_AMD_LIB', 'default')} lstol={EM.SOLVER_LS_TOL:g} tol={EM.SOLVER_TOL:g}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {st['newton_iters'] / (NR * HS * S):.3f}")
