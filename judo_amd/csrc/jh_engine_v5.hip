@@ -45,7 +45,7 @@ constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane: the pool holds 16
 constexpr int NCP = 16 * NSLOT;  // contact pool per rollout
 constexpr int MAXHIT = 32;
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
-constexpr int MAXG = 72, MAXLG = 8;
+constexpr int MAXG = 80, MAXLG = 8;
 constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1..16 = finger link (1 + 4*chain + depth), 17 = the cube
 constexpr int HITPAIR = 1 << 16;  // broad-phase survivors >= HITPAIR index the hand-hand geom pair list, smaller ones are cube-vs-geom
 constexpr int MAXBPL = 24;        // hand body pairs whose bounding spheres overlap, per rollout and step
@@ -137,11 +137,12 @@ __device__ __forceinline__ void link_cols(const RS& S, int code, const float* po
 
 // contact-frame image of the relative point velocity (side B minus side A) for the generalised velocity whose cube part is (xl = linear, world;
 // wang = R_cube * angular part, world) and whose finger part is `vec` (22-vector in LDS)
+template <bool SELF>
 __device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float* qcpos, const float* xl, const float* wang, const float* vec, float* out) {
   float w[3] = {0.f, 0.f, 0.f};
   const float pos[3] = {s.rc[0] + qcpos[0], s.rc[1] + qcpos[1], s.rc[2] + qcpos[2]};
-  if (s.la == CUBE) { float wx[3]; cross3(wx, wang, s.rc); w[0] = -(xl[0] + wx[0]); w[1] = -(xl[1] + wx[1]); w[2] = -(xl[2] + wx[2]); }
-  else if (s.la > 0) link_vel(S, s.la, pos, vec, -1.f, w);
+  if (!SELF || s.la == CUBE) { float wx[3]; cross3(wx, wang, s.rc); w[0] = -(xl[0] + wx[0]); w[1] = -(xl[1] + wx[1]); w[2] = -(xl[2] + wx[2]); }
+  else if (SELF && s.la > 0) link_vel(S, s.la, pos, vec, -1.f, w);
   if (s.lb > 0) link_vel(S, s.lb, pos, vec, 1.f, w);
   out[0] = dot3(s.fr, w); out[1] = dot3(s.fr + 3, w); out[2] = dot3(s.fr + 6, w);
 }
@@ -221,7 +222,7 @@ __device__ __forceinline__ void bwd4(const float* L, const float* inv, float* x)
 __device__ __forceinline__ float sel4(const float* a, int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-template <bool MATERIALIZE, int WPB>
+template <bool MATERIALIZE, int WPB, bool SELF>
 __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
                                                    const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
                                                    const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         nh += __popc(m16);
       }
       WSYNC();
-#ifndef JH_V5_NO_SELF
+      if constexpr (SELF) {
       // hand self-collision, level 1: body pairs whose bounding spheres overlap (106 candidate pairs after MuJoCo's static filters, 16 per pass)
       int nbl = 0;
       for (int base = 0; base < nBP; base += G) {
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_hh += nh - nh_cube;
 #endif
-#endif
+      }
       nh = nh < MAXHIT ? nh : MAXHIT;
       WSYNC();
       // narrow phase: survivor i goes to lane i; side A is the cube or the first geom of a hand pair, side B a hand geom
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (idx < nh) {
           const int hid = S.hits[idx];
           int ga = -1, gb = hid;
-          if (hid >= HITPAIR) { ga = gI[oGP + 2 * (hid - HITPAIR)]; gb = gI[oGP + 2 * (hid - HITPAIR) + 1]; }
+          if (SELF && hid >= HITPAIR) { ga = gI[oGP + 2 * (hid - HITPAIR)]; gb = gI[oGP + 2 * (hid - HITPAIR) + 1]; }
           // side B
           const float* fb = sGeomF + gb * GEOM_F; const int bodyb = sGeomI[gb * GEOM_I], tb = sGeomI[gb * GEOM_I + 1];
           float pB[3], RB[9];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           else { mulMV(pB, S.xR[bodyb], fb + GF_POS); for (int k = 0; k < 3; k++) pB[k] += S.pa[bodyb][k]; mulMM(RB, S.xR[bodyb], fb + GF_R); }
           // side A
           float pA[3], RA[9], hA[3], mua, trana; int ta, codea;
-          if (ga < 0) { for (int k = 0; k < 3; k++) { pA[k] = qc[k]; hA[k] = chs[k]; } for (int k = 0; k < 9; k++) RA[k] = Rc[k]; mua = 0.f; trana = ctran; ta = GBOX; codea = CUBE; }
+          if (!SELF || ga < 0) { for (int k = 0; k < 3; k++) { pA[k] = qc[k]; hA[k] = chs[k]; } for (int k = 0; k < 9; k++) RA[k] = Rc[k]; mua = 0.f; trana = ctran; ta = GBOX; codea = CUBE; }
           else {
             const float* fa = sGeomF + ga * GEOM_F; const int bodya = sGeomI[ga * GEOM_I];
             if (bodya < 0) { for (int k = 0; k < 3; k++) pA[k] = fa[GF_POS + k]; for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; }
@@ -530,10 +531,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             mua = fa[GF_MUOWN]; trana = fa[GF_TRAN]; ta = sGeomI[ga * GEOM_I + 1]; codea = bodya < 0 ? 0 : bodya;
           }
           // contact parameters: friction = the larger of the two geoms' (the cube's is folded into GF_MU), R from the two bodies' inverse weights
-          const float mu = ga < 0 ? fb[GF_MU] : fmaxf(mua, fb[GF_MUOWN]);
+          const float mu = (!SELF || ga < 0) ? fb[GF_MU] : fmaxf(mua, fb[GF_MUOWN]);
           LeapSink sk{pc, codea | ((bodyb < 0 ? 0 : bodyb) << 8), mu, trana + fb[GF_TRAN], false};
-          if (ta == GBOX && tb == GBOX) collide_box_box(sk, pA, RA, hA, pB, RB, fb + GF_SIZE);
-          else if (ta == GBOX) collide_box_sphere(sk, pA, RA, hA, pB, fb[GF_SIZE]);
+          if ((!SELF || ta == GBOX) && tb == GBOX) collide_box_box(sk, pA, RA, hA, pB, RB, fb + GF_SIZE);
+          else if (!SELF || ta == GBOX) collide_box_sphere(sk, pA, RA, hA, pB, fb[GF_SIZE]);
           else if (tb == GBOX) { sk.flip = true; collide_box_sphere(sk, pB, RB, fb + GF_SIZE, pA, hA[0]); }
           else {  // two spheres (fingertips)
             const float d[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]}; const float dn = sqrtf(dot3(d, d)), dist = dn - hA[0] - fb[GF_SIZE];
@@ -564,13 +565,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           sl[k].fr[0] = e[3]; sl[k].fr[1] = e[4]; sl[k].fr[2] = e[5];
           make_frame(sl[k].fr);
           float dist = e[6], mu = e[7], tran = e[9]; const int sides = __float_as_int(e[8]);
-          sl[k].la = sides & 0xFF; sl[k].lb = sides >> 8;
+          sl[k].la = SELF ? (sides & 0xFF) : CUBE; sl[k].lb = sides >> 8;
           float imp = impedance(csi, dist);
           float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
           sl[k].D0 = 1.f / R0; sl[k].D1 = 1.f / R1;
           sl[k].fri = mu; sl[k].mu = mu * sqrtf(R1 / R0);
           { float m2 = sl[k].mu * sl[k].mu; sl[k].Dm = sl[k].D0 / (m2 * (1.f + m2)); }
-          float vel[3]; slot_Jx(sl[k], S, qc, vc, wv3, S.qv, vel);
+          float vel[3]; slot_Jx<SELF>(sl[k], S, qc, vc, wv3, S.qv, vel);
           sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
         }
       }
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
     for (int k = 0; k < NSLOT; k++) {
       anyslot |= sl[k].la >= 0;
-      cross |= sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2);
+      cross |= SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2);
     }
     const bool dense_row = gor((int)cross) != 0;
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float cs = 0.f, jx[3], jar_ws[NSLOT][3];
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
-          slot_Jx(sl[k], S, qc, xl, wa, S.ws, jx);
+          slot_Jx<SELF>(sl[k], S, qc, xl, wa, S.ws, jx);
           for (int rw = 0; rw < 3; rw++) { sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; jar_ws[k][rw] = sl[k].jar[rw]; }
           cs += cone_cost(sl[k]);
         }
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         cs = 0.f;
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
-          slot_Jx(sl[k], S, qc, xl0, wa, S.p, jx);
+          slot_Jx<SELF>(sl[k], S, qc, xl0, wa, S.p, jx);
           for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw];
           cs += cone_cost(sl[k]);
         }
@@ -668,10 +669,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             // world force on side B; side A gets the opposite.  gradient = -J'f with J = J_B - J_A
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-            if (t.la == CUBE) {  // cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
+            if (!SELF || t.la == CUBE) {  // cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
               float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
               gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
-            } else if (t.la > 0) link_force(S, t.la, pos, Fw, -1.f);
+            } else if (SELF && t.la > 0) link_force(S, t.la, pos, Fw, -1.f);
             if (t.lb > 0) link_force(S, t.lb, pos, Fw, 1.f);
           }
         }
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           }
           if (!__any(on)) continue;  // (the second slot is empty in most waves)
           if (on) {
-            const bool cube = t.la == CUBE;
+            const bool cube = !SELF || t.la == CUBE;
             float Jc[6][3];
             if (cube) {  // cube columns in the contact frame
               for (int q3 = 0; q3 < 3; q3++) {
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
               float Jb[NLK][3];
               for (int j = 0; j < NLK; j++) Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
               link_cols(S, t.lb, pos, t.fr, 1.f, Jb);
-              if (!cube && t.la > 0) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
+              if (SELF && !cube && t.la > 0) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
 #pragma unroll
               for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
                 const float* j3 = Jb[u4];
@@ -820,7 +821,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         WSYNC();
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
         // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
-#ifndef JH_V5_NO_DENSE
+#ifndef JH_V5_X_NODENSE
+        if constexpr (SELF) {
 #ifdef JH_V5_COUNT
         if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
 #endif
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             for (int j = 0; j < NLK; j++) pc4[j] = S.p[6 + 4 * c + j];
           }
         }
+}
 #endif
         // ---- (5) exact line search along p
         float Mp_own = 0.f;
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         {
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) slot_Jx(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
+          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) slot_Jx<SELF>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
@@ -1042,8 +1045,12 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
   if (!model_is_leap(m)) { jh_set_error("rollout_cost: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
   JH_REQUIRE(K <= MAXK, "rollout_cost: the cooperative leap kernel keeps at most 8 knots per actuator (K=%d)", K);
   int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
-  hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                     knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+  if (m->self_collision && m->h_i[17] > 0)
+    hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+  else
+    hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -1052,9 +1059,14 @@ int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, c
                            hipStream_t st) {
   if (!model_is_leap(m)) { jh_set_error("rollout_materialize: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
   int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
-  hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
-                     controls, states, sensors, m->d_stats);
+  if (m->self_collision && m->h_i[17] > 0)
+    hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
+                       controls, states, sensors, m->d_stats);
+  else
+    hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
+                       controls, states, sensors, m->d_stats);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
