@@ -63,7 +63,8 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
   float Mbb[NCH][10];
   float rhs6[6];
-  float bs[NMB][4];   // bounding sphere of the hand bodies (0 = all static geometry, 1..16 = finger links), world
+  float bs[NMB][4];   // bounding sphere of the hand bodies (0 = all static geometry, 1..16 = finger links): world centre, radius (the centre is the
+                      // bounding box's too; its half sizes and axes come from the model image and the body rotation)
   int hits[MAXHIT];
   int bpl[MAXBPL];
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
@@ -99,6 +100,26 @@ struct Slot {
   float aref[3], D0, D1, Dm, mu, fri;
   float jar[3], jp[3];
 };
+
+// two oriented boxes (centre, rotation, half sizes): false when one of the six face axes separates them (a conservative cull: the nine edge axes are
+// left to the narrow phase)
+__device__ __forceinline__ bool obb_face_overlap(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb, const float* hb) {
+  const float d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  float C[9];  // C = |Ra' Rb|
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[3 * i + j] = fabsf(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float da = fabsf(d[0] * Ra[i] + d[1] * Ra[3 + i] + d[2] * Ra[6 + i]);
+    ok = ok && da <= ha[i] + hb[0] * C[3 * i] + hb[1] * C[3 * i + 1] + hb[2] * C[3 * i + 2];
+    const float db = fabsf(d[0] * Rb[i] + d[1] * Rb[3 + i] + d[2] * Rb[6 + i]);
+    ok = ok && db <= hb[i] + ha[0] * C[i] + ha[1] * C[3 + i] + ha[2] * C[6 + i];
+  }
+  return ok;
+}
 
 // velocity of the point `pos` carried by finger link `code` for the joint-rate vector `vec` (22-vector in LDS), times `sign`, added to w
 __device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos, const float* vec, float sign, float* w) {
@@ -236,6 +257,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   __shared__ int sGeomI[MAXG * GEOM_I];
   __shared__ int sLaneG[16 * MAXLG];
   __shared__ float sLane[16 * LC_N];
+  __shared__ int sBP[SELF ? 4 * 112 : 4];    // hand body pairs (side A, side B, first geom pair, number of geom pairs)
+  __shared__ float sBB[SELF ? 17 * 8 : 4];   // per hand body: bounding-box centre (body frame), bounding radius, half sizes
   __shared__ float sKnAll[MAXK * WAVE * WPB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3;
   RS& S = sRS[wv * RPW + r];
@@ -250,6 +273,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   for (int i = tid; i < ngI * GEOM_I; i += WAVE * WPB) sGeomI[i] = gI[oGeomI + i];
   for (int i = tid; i < 16 * lgm; i += WAVE * WPB) sLaneG[i] = gI[oLane + i];
   if (!MATERIALIZE && tid < 9) sTp[tid] = tp[tid];
+  if constexpr (SELF) {
+    for (int i = tid; i < 4 * nBP && i < 4 * 112; i += WAVE * WPB) sBP[i] = gI[oBP + i];
+    for (int i = tid; i < 17 * 8; i += WAVE * WPB) sBB[i] = gF[oBS + i];
+  }
   if (tid < 16) {
     const float* df = gF + oDofF + (6 + l) * DOF_F; const float* af = gF + oActF + l * ACT_F;
     float* lc = sLane + l * LC_N;
@@ -420,10 +447,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       int nh = 0;
       float Rc[9]; for (int k = 0; k < 9; k++) Rc[k] = S.xR[0][k];
       const float* pw = S.pa[1 + l]; const float* Rw = S.xR[1 + l];
-      {  // bounding sphere of the own link for the hand's self-collision
-        const float* b4 = gF + oBS + 4 * (1 + l); float cw[3]; mulMV(cw, Rw, b4);
-        S.bs[1 + l][0] = cw[0] + pw[0]; S.bs[1 + l][1] = cw[1] + pw[1]; S.bs[1 + l][2] = cw[2] + pw[2]; S.bs[1 + l][3] = b4[3];
-        if (l < 4) S.bs[0][l] = gF[oBS + l];
+      if constexpr (SELF) {  // bounding volume of the own link for the hand's self-collision
+        const float* b8 = sBB + 8 * (1 + l); float cw[3]; mulMV(cw, Rw, b8);
+        S.bs[1 + l][0] = cw[0] + pw[0]; S.bs[1 + l][1] = cw[1] + pw[1]; S.bs[1 + l][2] = cw[2] + pw[2]; S.bs[1 + l][3] = b8[3];
+        if (l < 4) S.bs[0][l] = sBB[l];
       }
       for (int i = 0; i < lgm; i++) {
         int gid = sLaneG[l * lgm + i];
@@ -459,10 +486,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         const int pi = base + l;
         bool hit = false;
         if (pi < nBP) {
-          const int ba = gI[oBP + 4 * pi], bb = gI[oBP + 4 * pi + 1];
+          const int ba = sBP[4 * pi], bb = sBP[4 * pi + 1];
           const float* sa = S.bs[ba]; const float* sb = S.bs[bb];
           const float d[3] = {sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2]}, rs = sa[3] + sb[3];
           hit = dot3(d, d) <= rs * rs;
+          if (hit) {  // the two bodies' bounding boxes (static geometry: axis-aligned in the world)
+            const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            float Ra[9]; for (int k = 0; k < 9; k++) Ra[k] = ba == 0 ? I9[k] : S.xR[ba][k];
+            hit = obb_face_overlap(sa, Ra, sBB + 8 * ba + 4, sb, S.xR[bb], sBB + 8 * bb + 4);
+          }
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nbl + __popc(m16 & ((1u << l) - 1u));
@@ -478,7 +510,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       // level 2: the geom pairs of those body pairs, 16 at a time per rollout: bounding spheres of the two geoms
       for (int i = 0; __any(i < nbl); i++) {
         int start = 0, count = 0, ba = 0, bb = 0;
-        if (i < nbl) { const int pi = S.bpl[i]; ba = gI[oBP + 4 * pi]; bb = gI[oBP + 4 * pi + 1]; start = gI[oBP + 4 * pi + 2]; count = gI[oBP + 4 * pi + 3]; }
+        if (i < nbl) { const int pi = S.bpl[i]; ba = sBP[4 * pi]; bb = sBP[4 * pi + 1]; start = sBP[4 * pi + 2]; count = sBP[4 * pi + 3]; }
         for (int j0 = 0; __any(j0 < count); j0 += G) {
 #ifdef JH_V5_COUNT
           if (lane == 0) cnt_l2++;
@@ -494,6 +526,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             mulMV(cb, S.xR[bb], fb + GF_POS); cb[0] += S.pa[bb][0]; cb[1] += S.pa[bb][1]; cb[2] += S.pa[bb][2];
             const float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]}, rs = fa[GF_RBOUND] + fb[GF_RBOUND];
             hit = dot3(d, d) <= rs * rs;
+            if (hit) {  // the geoms' own boxes (a sphere counts as the cube around it)
+              float RA[9], RB[9];
+              if (ba == 0) { for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; } else mulMM(RA, S.xR[ba], fa + GF_R);
+              mulMM(RB, S.xR[bb], fb + GF_R);
+              const bool sphA = sGeomI[ga * GEOM_I + 1] != GBOX, sphB = sGeomI[gb * GEOM_I + 1] != GBOX;
+              const float hA[3] = {fa[GF_SIZE], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 1], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 2]};
+              const float hB[3] = {fb[GF_SIZE], sphB ? fb[GF_SIZE] : fb[GF_SIZE + 1], sphB ? fb[GF_SIZE] : fb[GF_SIZE + 2]};
+              hit = obb_face_overlap(ca, RA, hA, cb, RB, hB);
+            }
           }
           unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
           int pos = nh + __popc(m16 & ((1u << l) - 1u));
