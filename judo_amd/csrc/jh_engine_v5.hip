@@ -14,6 +14,8 @@
 //     whole by every lane; the Schur-complement dot products are shared the same way.
 // The solver itself (primal Newton, exact line search, warm start, termination) is unchanged: results agree with jh_engine_v2.hip to
 // summation order, and the parity suite (tests/test_gpu_leap.py) runs against both.
+#include <type_traits>
+
 #include "jh_coop.h"
 
 using namespace jh_eng;
@@ -685,6 +687,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         WSYNC();
       }
       bool act = true;
+      // The Newton loop exists twice: waves in which some rollout needs the dense direction this step run the copy that contains it, all others a copy
+      // without that code (the register needs of the rare path would otherwise make the allocator spill inside every iteration of every rollout)
+      auto newton_loop = [&](auto dense_tag) __attribute__((always_inline)) {
+      constexpr bool DENSE = decltype(dense_tag)::value;
       for (int it = 0; it < cap && __any(act); it++) {
         // ---- (1) gradient.  Owner lanes: M (a - a0) rows + dof-row forces; contacts: -J'f as LDS float atomics (finger and cube parts)
         const float da_own = a_own - a0_own, dcl = ac_own - a0c_own;
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act) iters_this++;
         // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
-        const bool aact = act && !dense_row;
+        const bool aact = act && !(DENSE && dense_row);
         if (aact) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
         // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
 #ifndef JH_V5_X_NODENSE
-        if constexpr (SELF) {
+        if constexpr (SELF && DENSE) {
 #ifdef JH_V5_COUNT
         if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
 #endif
@@ -1026,6 +1032,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
         WSYNC();
       }
+      };
+      if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
