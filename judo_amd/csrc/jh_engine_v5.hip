@@ -14,6 +14,8 @@
 //     whole by every lane; the Schur-complement dot products are shared the same way.
 // The solver itself (primal Newton, exact line search, warm start, termination) is unchanged: results agree with jh_engine_v2.hip to
 // summation order, and the parity suite (tests/test_gpu_leap.py) runs against both.
+#include <type_traits>
+
 #include "jh_coop.h"
 
 using namespace jh_eng;
@@ -49,6 +51,7 @@ constexpr int MAXG = 80, MAXLG = 8;
 constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1..16 = finger link (1 + 4*chain + depth), 17 = the cube
 constexpr int HITPAIR = 1 << 16;  // broad-phase survivors >= HITPAIR index the hand-hand geom pair list, smaller ones are cube-vs-geom
 constexpr int MAXBPL = 24;        // hand body pairs whose bounding spheres overlap, per rollout and step
+constexpr int NDH = 22 * 23 / 2;  // dense Hessian (packed lower) of a rollout whose contacts couple two finger chains
 constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
 constexpr int MAXK = 8;
 
@@ -69,6 +72,7 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
     float pool[NCP][POOL_F];
     struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24]; };  // Hcb[c][j*6+q]: chain column j, cube row q
+    struct { float Hd[NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
   };
   int ncon, nhit;
 };
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
       WSYNC();
       if constexpr (SELF) {
+#ifndef JH_V5_X_NOL1
       // hand self-collision, level 1: body pairs whose bounding spheres overlap (106 candidate pairs after MuJoCo's static filters, 16 per pass)
       int nbl = 0;
       for (int base = 0; base < nBP; base += G) {
@@ -505,6 +510,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       const int nh_cube = nh;
 #endif
       WSYNC();
+#ifdef JH_V5_X_NOL2
+      nbl = 0;
+#endif
       // level 2: the geom pairs of those body pairs, 16 at a time per rollout: bounding spheres of the two geoms
       for (int i = 0; __any(i < nbl); i++) {
         int start = 0, count = 0, ba = 0, bb = 0;
@@ -542,6 +550,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_hh += nh - nh_cube;
+#endif
 #endif
       }
       nh = nh < MAXHIT ? nh : MAXHIT;
@@ -624,9 +633,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         dr.lims = sg; dr.lD = 1.f / R; dr.laref = -lc[LC_LB] * (sg * qd) - lc[LC_LK] * imp * dist;
       }
     }
-    bool anyslot = false;
+    // a contact between links of two different finger chains couples their blocks: no arrow structure for this rollout in this step
+    bool anyslot = false, cross = false;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) anyslot |= sl[k].la >= 0;
+    for (int k = 0; k < NSLOT; k++) {
+      anyslot |= sl[k].la >= 0;
+      cross |= SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2);
+    }
+    const bool dense_row = gor((int)cross) != 0;
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     float a_own, ac_own;
     const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
@@ -678,6 +692,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         WSYNC();
       }
       bool act = true;
+      // The Newton loop exists twice: waves in which some rollout needs the dense direction this step run the copy that contains it, all others a copy
+      // without that code (the register needs of the rare path would otherwise make the allocator spill inside every iteration of every rollout)
+      auto newton_loop = [&](auto dense_tag) __attribute__((always_inline)) {
+      constexpr bool DENSE = decltype(dense_tag)::value;
       for (int it = 0; it < cap && __any(act); it++) {
         // ---- (1) gradient.  Owner lanes: M (a - a0) rows + dof-row forces; contacts: -J'f as LDS float atomics (finger and cube parts)
         const float da_own = a_own - a0_own, dcl = ac_own - a0c_own;
@@ -721,13 +739,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
-        // ---- (3) Newton matrix: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A contact
-        // between links of two different finger chains (hand self-collision) would couple their blocks and break the arrow structure; its two diagonal
-        // blocks Ja'W Ja and Jb'W Jb are kept and the coupling -Ja'W Jb dropped.  The matrix stays positive definite and within a factor 2 of the Hessian
-        // (|x - y|^2 <= 2|x|^2 + 2|y|^2), gradient, line search and termination test stay exact: the solver converges to the same minimiser, such a
-        // rollout just takes a few more iterations (measured: DESIGN.md section 5).  An exact dense 22 x 22 path was built first and measured 4-5x the
-        // cost of an arrow iteration for every wave that contained one such rollout (132 ms instead of 58 ms per plan step); it is not in the tree.
-        if (act) {
+        // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
+        // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
+        const bool aact = act && !(DENSE && dense_row);
+        if (aact) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
@@ -739,7 +754,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         for (int k = 0; k < NSLOT; k++) {
           const Slot& t = sl[k];
           float Wk[6] = {0, 0, 0, 0, 0, 0};
-          bool on = act && t.la >= 0;
+          bool on = aact && t.la >= 0;
           if (on) {
             float f[3];
             const float D[3] = {t.D0, t.D1, t.D1};
@@ -764,27 +779,23 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
                 for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
               }
             }
-            if (t.lb > 0) {  // finger columns: side B's chain block; side A's joins it when both links sit in the same chain, else it gets its own block (no coupling)
+            if (t.lb > 0) {  // finger columns: side B, minus side A when that is a link of the same chain (hand self-contact)
+              const int ch = (t.lb - 1) >> 2;
+              const int dep = (t.lb - 1) & 3;
               const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-              const bool linkA = SELF && !cube && t.la > 0;
-              const bool same = linkA && ((t.la - 1) >> 2) == ((t.lb - 1) >> 2);
-              for (int pass = 0; pass < ((linkA && !same) ? 2 : 1); pass++) {
-                const int code = pass == 0 ? t.lb : t.la;
-                const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
-                float Jb[NLK][3];
-                for (int j = 0; j < NLK; j++) Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
-                link_cols(S, code, pos, t.fr, 1.f, Jb);  // (the sign of a whole block does not matter in Jb'W Jb)
-                if (same) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
+              float Jb[NLK][3];
+              for (int j = 0; j < NLK; j++) Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
+              link_cols(S, t.lb, pos, t.fr, 1.f, Jb);
+              if (SELF && !cube && t.la > 0) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
 #pragma unroll
-                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
-                  const float* j3 = Jb[u4];
-                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+              for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+                const float* j3 = Jb[u4];
+                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
 #pragma unroll
-                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
-                  if (cube) {
+                for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+                if (cube) {
 #pragma unroll
-                    for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
-                  }
+                  for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
                 }
               }
             }
@@ -802,7 +813,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           fwd4(L, Linv, Ya); fwd4(L, Linv, Yb);
           for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
           fwd4(L, Linv, zb);
-          if (act && l < 6) S.rhs6[l] = -gcl;
+          if (aact && l < 6) S.rhs6[l] = -gcl;
         }
         WSYNC();
         {
@@ -815,14 +826,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
             for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
             const float da = qsum4(Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3]);
             const float db = qsum4(Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3]);
-            if (act && c == 0) {
+            if (aact && c == 0) {
               if (r6 <= s) S.Hcc[tri(s, r6)] -= da;
               if (hasb && r6 <= 4 + s) S.Hcc[tri(4 + s, r6)] -= db;
             }
           }
           const float ra = qsum4(Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3]);
           const float rb = qsum4(Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3]);
-          if (act && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
+          if (aact && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
         }
         WSYNC();
         {
@@ -858,8 +869,134 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
         float p_own = sel4(pc4, s);
         float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
-        if (act) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
+        if (aact) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
         WSYNC();
+        // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
+        // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
+#ifndef JH_V5_X_NODENSE
+        if constexpr (SELF && DENSE) {
+#ifdef JH_V5_COUNT
+        if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
+#endif
+        if (__any(act && dense_row)) {
+          const bool dact = act && dense_row;
+          if (dact) for (int e = l; e < NDH; e += G) S.Hd[e] = 0.f;
+          WSYNC();
+          if (dact) {
+#pragma unroll
+            for (int j = 0; j < NLK; j++) if (j <= s) S.Hd[tri(6 + l, 6 + 4 * c + j)] = Mrow[j] + (j == s ? hd : 0.f);
+            if (l < 6) { S.Hd[tri(l, l)] = mck; S.g[l] = gcl; }
+          }
+          WSYNC();
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) {
+            const Slot& t = sl[k];
+            if (!(dact && t.la >= 0)) continue;
+            float f[3], Wk[6];
+            const float D[3] = {t.D0, t.D1, t.D1};
+            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
+            if (Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f) continue;
+            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+            // three column blocks: X0 = cube (6 columns at dof 0) or side-A link (4 columns at its chain), X1 = side-B link (4 columns)
+            float X0[6][3], X1[NLK][3];
+            for (int j = 0; j < 6; j++) X0[j][0] = X0[j][1] = X0[j][2] = 0.f;
+            for (int j = 0; j < NLK; j++) X1[j][0] = X1[j][1] = X1[j][2] = 0.f;
+            int o0 = 0, n0 = 0, o1 = 0, n1 = 0;
+            if (t.la == CUBE) {
+              n0 = 6;
+              for (int q3 = 0; q3 < 3; q3++) {
+                X0[q3][0] = -t.fr[q3]; X0[q3][1] = -t.fr[3 + q3]; X0[q3][2] = -t.fr[6 + q3];
+                float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+                X0[3 + q3][0] = -dot3(t.fr, c3); X0[3 + q3][1] = -dot3(t.fr + 3, c3); X0[3 + q3][2] = -dot3(t.fr + 6, c3);
+              }
+            } else if (t.la > 0) { o0 = 6 + 4 * ((t.la - 1) >> 2); n0 = 1 + ((t.la - 1) & 3); link_cols(S, t.la, pos, t.fr, -1.f, X0); }
+            if (t.lb > 0) {
+              o1 = 6 + 4 * ((t.lb - 1) >> 2); n1 = 1 + ((t.lb - 1) & 3);
+              if (t.la != CUBE && t.la > 0 && o1 == o0) { link_cols(S, t.lb, pos, t.fr, 1.f, X0); n0 = n0 > n1 ? n0 : n1; n1 = 0; }  // same chain: one block
+              else link_cols(S, t.lb, pos, t.fr, 1.f, X1);
+            }
+            if (n1 > 0 && n0 > 0 && o1 < o0) {  // keep the blocks in dof order (X0 before X1) so that every entry lands in the lower triangle
+              for (int j = 0; j < NLK; j++) for (int q = 0; q < 3; q++) { const float tmp = X0[j][q]; X0[j][q] = X1[j][q]; X1[j][q] = tmp; }
+              int ti = o0; o0 = o1; o1 = ti; ti = n0; n0 = n1; n1 = ti;
+            }
+#pragma unroll
+            for (int u = 0; u < 6; u++) if (u < n0) {
+              const float* j3 = X0[u];
+              const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+              for (int v = 0; v <= u; v++) atomicAdd(&S.Hd[tri(o0 + u, o0 + v)], X0[v][0] * G0 + X0[v][1] * G1 + X0[v][2] * G2);
+#pragma unroll
+              for (int v = 0; v < NLK; v++) if (v < n1) atomicAdd(&S.Hd[tri(o1 + v, o0 + u)], X1[v][0] * G0 + X1[v][1] * G1 + X1[v][2] * G2);
+            }
+#pragma unroll
+            for (int u = 0; u < NLK; u++) if (u < n1) {
+              const float* j3 = X1[u];
+              const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+              for (int v = 0; v <= u; v++) atomicAdd(&S.Hd[tri(o1 + u, o1 + v)], X1[v][0] * G0 + X1[v][1] * G1 + X1[v][2] * G2);
+            }
+          }
+          WSYNC();
+          // Cholesky by rows: lane l keeps rows l and 16 + l (l < 6) of the factor in registers.  Column k: every lane reads row k's finished entries
+          // L[k][0..k-1] from LDS (published as they were finished), forms the pivot redundantly and finishes its own rows' entry of column k --
+          // one LDS round trip per column, all reads of a column independent of each other
+          const int r1 = 16 + l;
+          const bool two = l < 6;
+          float h0[16], h1[NV];
+#pragma unroll
+          for (int j = 0; j < 16; j++) h0[j] = (dact && j <= l) ? S.Hd[tri(l, j)] : 0.f;
+#pragma unroll
+          for (int j = 0; j < NV; j++) h1[j] = (dact && two && j <= r1) ? S.Hd[tri(r1, j)] : 0.f;
+#pragma unroll
+          for (int kk = 0; kk < NV; kk++) {
+            float dp = 0.f, s0 = kk < 16 ? h0[kk < 16 ? kk : 0] : 0.f, s1 = h1[kk];
+            const float hkk = dact ? S.Hd[tri(kk, kk)] : 1.f;
+#pragma unroll
+            for (int j = 0; j < kk; j++) {
+              const float t = dact ? S.Hd[tri(kk, j)] : 0.f;
+              dp = fmaf(t, t, dp);
+              if (kk < 16) s0 = fmaf(-h0[j < 16 ? j : 0], t, s0);
+              s1 = fmaf(-h1[j], t, s1);
+            }
+            const float rk = __frsqrt_rn(fmaxf(hkk - dp, 1e-30f));
+            if (kk < 16) h0[kk < 16 ? kk : 0] = kk <= l ? s0 * rk : 0.f;
+            h1[kk] = (two && kk <= r1) ? s1 * rk : 0.f;
+            if (dact) {
+              if (kk < 16 && l > kk) S.Hd[tri(l, kk)] = h0[kk < 16 ? kk : 0];
+              if (two && r1 > kk) S.Hd[tri(r1, kk)] = h1[kk];
+              if (l == 0) S.dinv[kk] = rk;
+            }
+            WSYNC();
+          }
+          // L y = -g: the owner of row k publishes y_k, every lane takes it out of its own rows' right-hand sides
+          float b0 = dact ? -S.g[l] : 0.f, b1 = (dact && two) ? -S.g[r1] : 0.f;
+#pragma unroll
+          for (int kk = 0; kk < NV; kk++) {
+            if (dact && (kk < 16 ? l == kk : r1 == kk)) S.p[kk] = (kk < 16 ? b0 : b1) * S.dinv[kk];
+            WSYNC();
+            const float yk = dact ? S.p[kk] : 0.f;
+            if (kk < 16) b0 -= (l > kk ? h0[kk < 16 ? kk : 0] : 0.f) * yk;
+            b1 -= ((two && r1 > kk) ? h1[kk] : 0.f) * yk;
+          }
+          // L' x = y, in place: the owner of row k finishes x_k and takes it out of the entries above
+#pragma unroll
+          for (int kk = NV - 1; kk >= 0; kk--) {
+            if (dact && (kk < 16 ? l == kk : r1 == kk)) {
+              const float xk = S.p[kk] * S.dinv[kk];
+              S.p[kk] = xk;
+#pragma unroll
+              for (int j = 0; j < kk; j++) S.p[j] -= (kk < 16 ? h0[j < 16 ? j : 0] : h1[j]) * xk;
+            }
+            WSYNC();
+          }
+          if (dact) {
+            p_own = S.p[6 + l]; xcl = l < 6 ? S.p[l] : 0.f;
+            for (int k = 0; k < 6; k++) xc6[k] = S.p[k];
+            for (int j = 0; j < NLK; j++) pc4[j] = S.p[6 + 4 * c + j];
+          }
+        }
+}
+#endif
         // ---- (5) exact line search along p
         float Mp_own = 0.f;
 #pragma unroll
@@ -900,6 +1037,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
         WSYNC();
       }
+      };
+      if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
