@@ -259,7 +259,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   __shared__ int sGeomI[MAXG * GEOM_I];
   __shared__ int sLaneG[16 * MAXLG];
   __shared__ float sLane[16 * LC_N];
-  __shared__ int sBP[SELF ? 4 * 112 : 4];    // hand body pairs (side A, side B, first geom pair, number of geom pairs)
+  __shared__ int sBP[SELF ? 2 * 112 : 4];    // hand body pairs (side A, side B): every geom of A is a candidate against every geom of B
+  __shared__ int sBG[SELF ? 2 * 17 : 4];     // per hand body: first collision geom, number of geoms (contiguous in the geom table)
   __shared__ float sBB[SELF ? 17 * 8 : 4];   // per hand body: bounding-box centre (body frame), bounding radius, half sizes
   __shared__ float sKnAll[MAXK * WAVE * WPB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3;
@@ -269,14 +270,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   const int oBodyF = HEADER_F, oDofF = oBodyF + nmI * BODY_F, oActF = oDofF + gI[2] * DOF_F, oGeomF = oActF + nuI * ACT_F, oSiteF = oGeomF + ngI * GEOM_F;
   const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
   const int oLane = gI[11], lgm = gI[12];
-  const int oBP = gI[15], oBS = gI[16], nBP = gI[17], oGP = oBP + 4 * nBP;  // hand self-collision: body pairs, body bounding spheres, geom pairs
+  const int oBP = gI[15], oBS = gI[16], nBP = gI[17], oBG = oBP + 2 * nBP;  // hand self-collision: body pairs, body bounding volumes, per-body geom ranges
   for (int i = tid; i < 16 * BODY_F; i += WAVE * WPB) sBody[i] = gF[oBodyF + BODY_F + i];
   for (int i = tid; i < ngI * GEOM_F; i += WAVE * WPB) sGeomF[i] = gF[oGeomF + i];
   for (int i = tid; i < ngI * GEOM_I; i += WAVE * WPB) sGeomI[i] = gI[oGeomI + i];
   for (int i = tid; i < 16 * lgm; i += WAVE * WPB) sLaneG[i] = gI[oLane + i];
   if (!MATERIALIZE && tid < 9) sTp[tid] = tp[tid];
   if constexpr (SELF) {
-    for (int i = tid; i < 4 * nBP && i < 4 * 112; i += WAVE * WPB) sBP[i] = gI[oBP + i];
+    for (int i = tid; i < 2 * nBP && i < 2 * 112; i += WAVE * WPB) sBP[i] = gI[oBP + i];
+    for (int i = tid; i < 2 * 17; i += WAVE * WPB) sBG[i] = gI[oBG + i];
     for (int i = tid; i < 17 * 8; i += WAVE * WPB) sBB[i] = gF[oBS + i];
   }
   if (tid < 16) {
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         const int pi = base + l;
         bool hit = false;
         if (pi < nBP) {
-          const int ba = sBP[4 * pi], bb = sBP[4 * pi + 1];
+          const int ba = sBP[2 * pi], bb = sBP[2 * pi + 1];
           const float* sa = S.bs[ba]; const float* sb = S.bs[bb];
           const float d[3] = {sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2]}, rs = sa[3] + sb[3];
           hit = dot3(d, d) <= rs * rs;
@@ -510,21 +512,38 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       const int nh_cube = nh;
 #endif
       WSYNC();
-#ifdef JH_V5_X_NOL2
-      nbl = 0;
-#endif
-      // level 2: the geom pairs of those body pairs, 16 at a time per rollout: bounding spheres of the two geoms
+      // level 2, per surviving body pair: (a) every geom of either body against the OTHER body's bounding box (one pass: lanes 0..nA-1 take A's geoms,
+      // the next nB lanes B's; nA + nB <= 16) -- usually nothing of one side comes near the other and the pair is done; (b) the near geoms of A against
+      // the near geoms of B (bounding spheres, then the six face axes of their boxes)
       for (int i = 0; __any(i < nbl); i++) {
-        int start = 0, count = 0, ba = 0, bb = 0;
-        if (i < nbl) { const int pi = S.bpl[i]; ba = sBP[4 * pi]; bb = sBP[4 * pi + 1]; start = sBP[4 * pi + 2]; count = sBP[4 * pi + 3]; }
-        for (int j0 = 0; __any(j0 < count); j0 += G) {
 #ifdef JH_V5_COUNT
-          if (lane == 0) cnt_l2++;
+        if (lane == 0) cnt_l2++;
 #endif
-          const int j = j0 + l;
+        int ba = 0, bb = 0, ga0 = 0, na = 0, gb0 = 0, nb = 0;
+        if (i < nbl) { const int pi = S.bpl[i]; ba = sBP[2 * pi]; bb = sBP[2 * pi + 1]; ga0 = sBG[2 * ba]; na = sBG[2 * ba + 1]; gb0 = sBG[2 * bb]; nb = sBG[2 * bb + 1]; }
+        bool near = false;
+        if (l < na + nb) {
+          const bool isA = l < na;
+          const int g = isA ? ga0 + l : gb0 + (l - na), own = isA ? ba : bb, oth = isA ? bb : ba;
+          const float* gf = sGeomF + g * GEOM_F;
+          float cw[3];
+          if (own == 0) { cw[0] = gf[GF_POS]; cw[1] = gf[GF_POS + 1]; cw[2] = gf[GF_POS + 2]; }
+          else { mulMV(cw, S.xR[own], gf + GF_POS); cw[0] += S.pa[own][0]; cw[1] += S.pa[own][1]; cw[2] += S.pa[own][2]; }
+          const float dw[3] = {cw[0] - S.bs[oth][0], cw[1] - S.bs[oth][1], cw[2] - S.bs[oth][2]};
+          float dl[3];
+          if (oth == 0) { dl[0] = dw[0]; dl[1] = dw[1]; dl[2] = dw[2]; } else mulMTV(dl, S.xR[oth], dw);
+          const float* hb = sBB + 8 * oth + 4;
+          const float ex = fmaxf(fabsf(dl[0]) - hb[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hb[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hb[2], 0.f);
+          near = ex * ex + ey * ey + ez * ez <= gf[GF_RBOUND] * gf[GF_RBOUND];
+        }
+        const unsigned m16 = (unsigned)((__ballot(near) >> (16 * r)) & 0xFFFFull);
+        const unsigned mB = (m16 >> na) & ((1u << nb) - 1u);
+        unsigned rem = mB != 0 ? (m16 & ((1u << na) - 1u)) : 0u;
+        while (__any(rem != 0)) {
+          const int ia = rem != 0 ? __ffs(rem) - 1 : 0;
           bool hit = false;
-          if (j < count) {
-            const int ga = gI[oGP + 2 * (start + j)], gb = gI[oGP + 2 * (start + j) + 1];
+          const int ga = ga0 + ia, gb = gb0 + l;
+          if (rem != 0 && l < nb && ((mB >> l) & 1u)) {
             const float* fa = sGeomF + ga * GEOM_F; const float* fb = sGeomF + gb * GEOM_F;
             float ca[3], cb[3];
             if (ba == 0) { ca[0] = fa[GF_POS]; ca[1] = fa[GF_POS + 1]; ca[2] = fa[GF_POS + 2]; }
@@ -542,10 +561,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
               hit = obb_face_overlap(ca, RA, hA, cb, RB, hB);
             }
           }
-          unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
-          int pos = nh + __popc(m16 & ((1u << l) - 1u));
-          if (hit && pos < MAXHIT) S.hits[pos] = HITPAIR + start + j;
-          nh += __popc(m16);
+          const unsigned h16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+          const int pos = nh + __popc(h16 & ((1u << l) - 1u));
+          if (hit && pos < MAXHIT) S.hits[pos] = HITPAIR + (ga << 8 | gb);
+          nh += __popc(h16);
+          rem &= rem - 1u;
         }
       }
 #ifdef JH_V5_COUNT
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (idx < nh) {
           const int hid = S.hits[idx];
           int ga = -1, gb = hid;
-          if (SELF && hid >= HITPAIR) { ga = gI[oGP + 2 * (hid - HITPAIR)]; gb = gI[oGP + 2 * (hid - HITPAIR) + 1]; }
+          if (SELF && hid >= HITPAIR) { ga = (hid - HITPAIR) >> 8; gb = (hid - HITPAIR) & 0xFF; }
           // side B
           const float* fb = sGeomF + gb * GEOM_F; const int bodyb = sGeomI[gb * GEOM_I], tb = sGeomI[gb * GEOM_I + 1];
           float pB[3], RB[9];

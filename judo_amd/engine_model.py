@@ -217,8 +217,8 @@ def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = No
         for b in range(a + 1, len(geoms)):
             ga, gb = geoms[a], geoms[b]
             ta, tb = ga["type"], gb["type"]
-            if not ((ta == "box" and tb in ("box", "sphere")) or (ta == "sphere" and tb == "box")):
-                continue
+            if not ((ta == "box" and tb in ("box", "sphere")) or (ta == "sphere" and tb == "box") or (ta == "sphere" and tb == "sphere" and cube_only is False)):
+                continue  # (sphere-sphere: the fingertips of two fingers; only jh_engine_v5.hip collides the hand with itself)
             ba, bb = ga["orig_body"], gb["orig_body"]
             wa, wb = weld(ba), weld(bb)
             if wa == wb or tuple(sorted((ba, bb))) in excl:
@@ -406,14 +406,21 @@ def pack_engine_model(desc: dict) -> bytes:
             if code(ga) > code(gb):
                 ga, gb = gb, ga
             groups.setdefault((code(ga), code(gb)), []).append((oidx[id(ga)], oidx[id(gb)]))
-        I[15], I[17] = len(I), len(groups)
-        start = 0
+        # MuJoCo's static filters act on bodies and every collision geom of the hand has the same contype / conaffinity: a surviving body pair collides
+        # all of A's geoms with all of B's, and the geoms of a body are contiguous in `others` -> the image carries the body pairs and one
+        # (first geom, count) range per body, no geom-pair table
+        rng = {}
+        for c in range(17):
+            idxs = [i for i, g in enumerate(others) if code(g) == c]
+            assert idxs == list(range(idxs[0], idxs[0] + len(idxs))), "geoms of a body must be contiguous"
+            rng[c] = (idxs[0], len(idxs))
         for (ca, cb), lst in groups.items():
-            I += [ca, cb, start, len(lst)]
-            start += len(lst)
-        for lst in groups.values():
-            for a, b in lst:
-                I += [a, b]
+            assert len(lst) == rng[ca][1] * rng[cb][1] and rng[ca][1] + rng[cb][1] <= 16, (ca, cb, len(lst))
+        I[15], I[17] = len(I), len(groups)
+        for (ca, cb) in groups:
+            I += [ca, cb]
+        for c in range(17):
+            I += list(rng[c])
         I[16] = len(F)
         for c in range(17):  # per hand body (0 = all static geometry, in world coordinates): bounding sphere and bounding box of its collision geoms, body frame
             gs = [g for g in others if code(g) == c]

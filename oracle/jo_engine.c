@@ -469,6 +469,15 @@ static int collide_box_sphere(const double* pb, const double* Rb, const double* 
   return 1;
 }
 
+/* two spheres (MuJoCo's mjc_SphereSphere: normal along the centre line from the first to the second, position midway through the overlap) */
+static int collide_sphere_sphere(const double* c1, double r1, const double* c2, double r2, double margin, rawcon* out) {
+  double d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}; double l = norm3(d), dist = l - r1 - r2;
+  if (dist >= margin || l < 1e-12) return 0;
+  for (int k = 0; k < 3; k++) { out->n[k] = d[k] / l; out->pos[k] = c1[k] + (r1 + 0.5 * dist) * d[k] / l; }
+  out->dist = dist;
+  return 1;
+}
+
 /* two cylinders with parallel axes whose heights overlap: radial contact (the only cylinder case in the four models,
  * cylinder_push.xml:23,30; MuJoCo itself routes cylinder-cylinder through its general convex collider) */
 static int collide_cyl_cyl_parallel(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin, rawcon* out) {
@@ -571,6 +580,7 @@ static void collision(const jo_model* m, jo_data* d) {
     if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_BOX) n = collide_box_box(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
     else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_SPHERE) n = collide_box_sphere(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2][0], margin, rc);
     else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], d->geom_xpos[g1], m->geom_size[g1][0], margin, rc); flip = 1; }
+    else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_SPHERE) n = collide_sphere_sphere(d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2], m->geom_size[g2][0], margin, rc);
     else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) n = collide_cyl_cyl_parallel(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
     for (int i = 0; i < n; i++) {
       if (d->ncon >= JO_MAXCON) { d->con_overflow++; break; }

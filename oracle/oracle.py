@@ -116,7 +116,7 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
         return weld(bodies[w]["parent"]) if w > 0 else 0
 
     excl = {tuple(sorted(e)) for e in desc["excludes"]}
-    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("cylinder", "cylinder"),
+    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("sphere", "sphere"), ("cylinder", "cylinder"),
                  ("plane", "sphere"), ("plane", "capsule"), ("plane", "box"), ("sphere", "plane"), ("capsule", "plane"), ("box", "plane")}
     pairs = []
     for g1 in range(len(geoms)):
