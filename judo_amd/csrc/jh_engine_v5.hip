@@ -759,9 +759,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
+        float xc6[6], pc4[NLK], p_own = 0.f, xcl = 0.f;
+        if constexpr (!DENSE) {
         // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
-        const bool aact = act && !(DENSE && dense_row);
+        const bool aact = act;
         if (aact) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         WSYNC();
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly); the coupling columns Y_q = L^-1 Hcb[:,q] are shared
         // by the chain's lanes (lane s: columns s and s+4); 6x6 Schur complement on the cube, solved by every lane
-        float L[10], Linv[4], Ya[NLK], Yb[NLK], zb[NLK], xc6[6], pc4[NLK];
+        float L[10], Linv[4], Ya[NLK], Yb[NLK], zb[NLK];
         const bool hasb = s < 2;  // lanes 0,1 of a chain carry a second column (q = 4, 5)
         {
           for (int k = 0; k < 10; k++) L[k] = S.Hbb[c][k];
@@ -887,19 +889,21 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
           bwd4(L, Linv, pc4);
         }
-        float p_own = sel4(pc4, s);
-        float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
+        p_own = sel4(pc4, s);
+        xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
         if (aact) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
+        }
         WSYNC();
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
         // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
 #ifndef JH_V5_X_NODENSE
         if constexpr (SELF && DENSE) {
 #ifdef JH_V5_COUNT
-        if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
+        if (lane == 0) { cnt_it++; cnt_dense += 1; }
 #endif
-        if (__any(act && dense_row)) {
-          const bool dact = act && dense_row;
+        {
+          const bool dact = act;  // this copy of the loop runs for waves in which some rollout has a contact between two finger chains: all of the wave's
+                                  // rollouts then take the dense direction (running the arrow factorisation next to it would cost more than it saves)
           if (dact) for (int e = l; e < NDH; e += G) S.Hd[e] = 0.f;
           WSYNC();
           if (dact) {
