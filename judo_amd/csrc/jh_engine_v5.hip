@@ -71,7 +71,8 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   int bpl[MAXBPL];
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
     float pool[NCP][POOL_F];
-    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24]; };  // Hcb[c][j*6+q]: chain column j, cube row q
+    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[NCH][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[b][ib*4+ia]: block (chain b, chain a) of a
+                                                                           // contact-coupled pair a < b (hand self-collision), stored with the higher chain
     struct { float Hd[NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
   };
   int ncon, nhit;
@@ -654,13 +655,27 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
     }
     // a contact between links of two different finger chains couples their blocks: no arrow structure for this rollout in this step
-    bool anyslot = false, cross = false;
+    // Which finger chains are coupled by contacts between their links (hand self-collision): a 4 x 4 bit matrix per rollout, bit 4a + b for chains a < b.
+    // If the coupling is a matching (every chain touches at most one other: 99 % of the coupled steps of the headline workload, mostly middle-ring) the
+    // arrow elimination runs in two stages -- first chain of a pair, then its partner with the first one's Schur update, then the cube; any other
+    // pattern takes the dense direction.  lo = partner with the lower index (this chain is eliminated second), hi = partner eliminated after this chain.
+    bool anyslot = false; int cmask = 0;
 #pragma unroll
     for (int k = 0; k < NSLOT; k++) {
       anyslot |= sl[k].la >= 0;
-      cross |= SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2);
+      if (SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2)) cmask |= 1 << (4 * ((sl[k].la - 1) >> 2) + ((sl[k].lb - 1) >> 2));
     }
-    const bool dense_row = gor((int)cross) != 0;
+    int my_lo = -1, my_hi = -1; bool dense_row = false;
+    if constexpr (SELF) {
+      cmask = gor(cmask);
+      int deg = 0;
+#pragma unroll
+      for (int o = 0; o < NCH; o++) {
+        if (o < c && (cmask >> (4 * o + c)) & 1) { my_lo = o; deg++; }
+        if (o > c && (cmask >> (4 * c + o)) & 1) { my_hi = o; deg++; }
+      }
+      dense_row = gor((int)(deg > 1)) != 0;
+    }
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     float a_own, ac_own;
     const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
@@ -759,15 +774,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
-        float xc6[6], pc4[NLK], p_own = 0.f, xcl = 0.f;
-        if constexpr (!DENSE) {
         // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
-        const bool aact = act;
+        const bool aact = act && !(DENSE && dense_row);
         if (aact) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
+          if (SELF) for (int k = 0; k < 4; k++) S.Hx[c][s * 4 + k] = 0.f;
           S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
@@ -801,14 +815,16 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
                 for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
               }
             }
-            if (t.lb > 0) {  // finger columns: side B, minus side A when that is a link of the same chain (hand self-contact)
-              const int ch = (t.lb - 1) >> 2;
-              const int dep = (t.lb - 1) & 3;
+            if (t.lb > 0) {  // finger columns: side B; side A joins the same block when both links sit in one chain, else its chain gets its own block and the
+                             // pair's coupling block -Jb'W Ja goes to Hx (stored with the higher chain, which is always B's)
+              const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
               const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+              const bool linkA = SELF && !cube && t.la > 0;
+              const bool same = linkA && ((t.la - 1) >> 2) == ch;
               float Jb[NLK][3];
               for (int j = 0; j < NLK; j++) Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
               link_cols(S, t.lb, pos, t.fr, 1.f, Jb);
-              if (SELF && !cube && t.la > 0) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
+              if (same) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
 #pragma unroll
               for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
                 const float* j3 = Jb[u4];
@@ -820,22 +836,64 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
                   for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
                 }
               }
+              if (linkA && !same) {
+                const int cha = (t.la - 1) >> 2, depa = (t.la - 1) & 3;
+                float Ja[NLK][3];
+                for (int j = 0; j < NLK; j++) Ja[j][0] = Ja[j][1] = Ja[j][2] = 0.f;
+                link_cols(S, t.la, pos, t.fr, 1.f, Ja);
+#pragma unroll
+                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= depa) {
+                  const float* j3 = Ja[u4];
+                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[cha][tri(u4, v4)], Ja[v4][0] * G0 + Ja[v4][1] * G1 + Ja[v4][2] * G2);
+#pragma unroll
+                  for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[ch][v4 * 4 + u4], -(Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2));
+                }
+              }
             }
           }
         }
         WSYNC();
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly); the coupling columns Y_q = L^-1 Hcb[:,q] are shared
         // by the chain's lanes (lane s: columns s and s+4); 6x6 Schur complement on the cube, solved by every lane
-        float L[10], Linv[4], Ya[NLK], Yb[NLK], zb[NLK];
+        float L[10], Linv[4], Ya[NLK], Yb[NLK], zb[NLK], xc6[6], pc4[NLK];
         const bool hasb = s < 2;  // lanes 0,1 of a chain carry a second column (q = 4, 5)
-        {
+        auto factor_block = [&]() __attribute__((always_inline)) {
           for (int k = 0; k < 10; k++) L[k] = S.Hbb[c][k];
           chol4(L, Linv);
           for (int j = 0; j < NLK; j++) { Ya[j] = S.Hcb[c][j * 6 + s]; Yb[j] = hasb ? S.Hcb[c][j * 6 + 4 + s] : 0.f; }
           fwd4(L, Linv, Ya); fwd4(L, Linv, Yb);
           for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
           fwd4(L, Linv, zb);
-          if (aact && l < 6) S.rhs6[l] = -gcl;
+        };
+        factor_block();
+        if (aact && l < 6) S.rhs6[l] = -gcl;
+        float Xs[NLK] = {0.f, 0.f, 0.f, 0.f};  // column s of X = L^-1 H(a,b) for the first chain a of a coupled pair (b = my_hi)
+        if constexpr (SELF) {
+          if (__any(aact && my_hi >= 0)) {
+            // first chain of a pair: its elimination updates the partner's blocks -- Hbb(b) -= X'X, Hcb(b) -= X'Y, g(b) += X'zb (so that the partner's
+            // zb becomes L_b^-1 (-g_b - X'zb_a)) -- before the partner factorises
+            if (aact && my_hi >= 0) {
+              for (int j = 0; j < NLK; j++) Xs[j] = S.Hx[my_hi][s * 4 + j];  // H(a,b)[ia][ib = s] = H(b,a)[ib = s][ia]
+              fwd4(L, Linv, Xs);
+            }
+#pragma unroll
+            for (int j = 0; j < NLK; j++) {
+              const float v = Xs[0] * quad_get(Xs[0], j) + Xs[1] * quad_get(Xs[1], j) + Xs[2] * quad_get(Xs[2], j) + Xs[3] * quad_get(Xs[3], j);
+              if (aact && my_hi >= 0 && j <= s) S.Hbb[my_hi][tri(s, j)] -= v;
+            }
+#pragma unroll
+            for (int q6 = 0; q6 < 6; q6++) {
+              float v = 0.f;
+#pragma unroll
+              for (int j = 0; j < NLK; j++) v += Xs[j] * (q6 < 4 ? quad_get(Ya[j], q6) : quad_get(Yb[j], q6 - 4));
+              if (aact && my_hi >= 0) S.Hcb[my_hi][s * 6 + q6] -= v;
+            }
+            if (aact && my_hi >= 0) S.g[6 + 4 * my_hi + s] += Xs[0] * zb[0] + Xs[1] * zb[1] + Xs[2] * zb[2] + Xs[3] * zb[3];
+            WSYNC();
+            if (my_lo >= 0) factor_block();  // second chain of a pair: factorise the updated blocks
+          }
         }
         WSYNC();
         {
@@ -887,23 +945,34 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           const float xa = sel4(xc6, s), xb = s == 0 ? xc6[4] : xc6[5];
 #pragma unroll
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
+          if constexpr (SELF) {
+            if (__any(aact && my_hi >= 0)) {
+              // p_a = L_a^-T (zb_a - Y_a x_c - X p_b): the partner finishes first and publishes p_b
+              float pb4[NLK];
+              for (int j = 0; j < NLK; j++) pb4[j] = pc4[j];
+              bwd4(L, Linv, pb4);
+              if (aact && my_lo >= 0) S.p[6 + l] = sel4(pb4, s);
+              WSYNC();
+              const float pbs = (aact && my_hi >= 0) ? S.p[6 + 4 * my_hi + s] : 0.f;
+#pragma unroll
+              for (int j = 0; j < NLK; j++) pc4[j] -= csum(Xs[j] * pbs);
+            }
+          }
           bwd4(L, Linv, pc4);
         }
-        p_own = sel4(pc4, s);
-        xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
+        float p_own = sel4(pc4, s);
+        float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
         if (aact) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
-        }
         WSYNC();
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
         // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
 #ifndef JH_V5_X_NODENSE
         if constexpr (SELF && DENSE) {
 #ifdef JH_V5_COUNT
-        if (lane == 0) { cnt_it++; cnt_dense += 1; }
+        if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
 #endif
-        {
-          const bool dact = act;  // this copy of the loop runs for waves in which some rollout has a contact between two finger chains: all of the wave's
-                                  // rollouts then take the dense direction (running the arrow factorisation next to it would cost more than it saves)
+        if (__any(act && dense_row)) {
+          const bool dact = act && dense_row;
           if (dact) for (int e = l; e < NDH; e += G) S.Hd[e] = 0.f;
           WSYNC();
           if (dact) {

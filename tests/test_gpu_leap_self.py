@@ -38,15 +38,21 @@ def _contact_kinds(om, x, u):
     for b, n in enumerate(names):
         chain[b] = {"if": 0, "mf": 1, "rf": 2, "th": 3}.get(n[:2], -1) if n not in ("cube",) else -2
     nc = ns = nx = 0
+    deg = [0, 0, 0, 0]
+    pairs = set()
     for row in f["contacts"]:
         ba, bb = body[int(row[13])], body[int(row[14])]
         if cube in (ba, bb):
             nc += 1
         elif chain[ba] >= 0 and chain[bb] >= 0 and chain[ba] != chain[bb]:
             nx += 1
+            pairs.add((min(chain[ba], chain[bb]), max(chain[ba], chain[bb])))
         else:
             ns += 1
-    return nc, ns, nx
+    for a, b in pairs:
+        deg[a] += 1
+        deg[b] += 1
+    return nc, ns, nx, int(max(deg) > 1)  # last: the coupled chains do not form a matching (the kernel's dense direction)
 
 
 def test_self_collision_single_steps_match_oracle(gpu):
@@ -58,9 +64,10 @@ def test_self_collision_single_steps_match_oracle(gpu):
     om, xs, q = _tangled_states(600, seed=5)
     us = q[:, None, :]
     kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(len(xs))])
-    ok = kinds.sum(1) <= 32  # within the kernel's contact capacity per rollout
+    ok = kinds[:, :3].sum(1) <= 32  # within the kernel's contact capacity per rollout
     within, across = ok & (kinds[:, 1] > 0) & (kinds[:, 2] == 0), ok & (kinds[:, 2] > 0)
-    assert within.sum() > 10 and across.sum() > 100, (within.sum(), across.sum())
+    paired, tangled = across & (kinds[:, 3] == 0), across & (kinds[:, 3] == 1)
+    assert within.sum() > 10 and paired.sum() > 50 and tangled.sum() > 20, (within.sum(), paired.sum(), tangled.sum())
     nxt, _ = om.rollout(xs, us)
     be = GpuRolloutBackend("leap_cube", len(xs))
     g1, _, _ = be.rollout(xs, us)
@@ -70,7 +77,7 @@ def test_self_collision_single_steps_match_oracle(gpu):
     scale = np.maximum(1.0, np.abs(nxt[:, 0, 23:]).max(axis=1, keepdims=True))
     e = np.abs(g1[:, 0] - nxt[:, 0])
     e[:, 23:] /= scale
-    for sel, name in ((within, "arrow path"), (across, "dense path"), (ok & (kinds.sum(1) == 0), "no contact")):
+    for sel, name in ((within, "arrow"), (paired, "two-stage arrow (one coupled pair of chains per matching)"), (tangled, "dense direction"), (ok & (kinds[:, :3].sum(1) == 0), "no contact")):
         ev = e[sel][:, 23:]
         assert np.median(ev) < 2e-5 and np.percentile(ev, 95) < 2e-2, (name, np.median(ev), np.percentile(ev, 95))
     # the same steps WITHOUT the hand's own contacts are far off: the cube-only model moves the fingers through each other
@@ -94,7 +101,7 @@ def test_self_collision_rollouts_match_oracle(gpu):
 
     om, xs, q = _tangled_states(256, seed=11, frac=0.5)
     kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(len(xs))])
-    keep = (kinds.sum(1) <= 24) & (kinds.sum(1) > 0)
+    keep = (kinds[:, :3].sum(1) <= 24) & (kinds[:, :3].sum(1) > 0)
     xs, q = xs[keep], q[keep]
     assert len(xs) > 40
     H = 24
