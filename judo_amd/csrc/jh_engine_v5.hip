@@ -730,8 +730,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       // The Newton loop exists twice: waves in which some rollout needs the dense direction this step run the copy that contains it, all others a copy
       // without that code (the register needs of the rare path would otherwise make the allocator spill inside every iteration of every rollout)
       auto newton_loop = [&](auto dense_tag) __attribute__((always_inline)) {
-      constexpr int MODE = decltype(dense_tag)::value;  // 0: no finger-finger coupling in this wave; 1: coupled pairs (two-stage elimination); 2: + dense direction
-      constexpr bool DENSE = MODE == 2, PAIRS = MODE >= 1;
+      constexpr bool DENSE = decltype(dense_tag)::value;
       for (int it = 0; it < cap && __any(act); it++) {
         // ---- (1) gradient.  Owner lanes: M (a - a0) rows + dof-row forces; contacts: -J'f as LDS float atomics (finger and cube parts)
         const float da_own = a_own - a0_own, dcl = ac_own - a0c_own;
@@ -782,7 +781,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
-          if (SELF && PAIRS) for (int k = 0; k < 4; k++) S.Hx[c][s * 4 + k] = 0.f;
+          if (SELF) for (int k = 0; k < 4; k++) S.Hx[c][s * 4 + k] = 0.f;
           S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
@@ -837,7 +836,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
                   for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
                 }
               }
-              if (PAIRS && linkA && !same) {
+              if (linkA && !same) {
                 const int cha = (t.la - 1) >> 2, depa = (t.la - 1) & 3;
                 float Ja[NLK][3];
                 for (int j = 0; j < NLK; j++) Ja[j][0] = Ja[j][1] = Ja[j][2] = 0.f;
@@ -871,7 +870,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         factor_block();
         if (aact && l < 6) S.rhs6[l] = -gcl;
         float Xs[NLK] = {0.f, 0.f, 0.f, 0.f};  // column s of X = L^-1 H(a,b) for the first chain a of a coupled pair (b = my_hi)
-        if constexpr (SELF && PAIRS) {
+        if constexpr (SELF) {
           if (__any(aact && my_hi >= 0)) {
             // first chain of a pair: its elimination updates the partner's blocks -- Hbb(b) -= X'X, Hcb(b) -= X'Y, g(b) += X'zb (so that the partner's
             // zb becomes L_b^-1 (-g_b - X'zb_a)) -- before the partner factorises
@@ -946,7 +945,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           const float xa = sel4(xc6, s), xb = s == 0 ? xc6[4] : xc6[5];
 #pragma unroll
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
-          if constexpr (SELF && PAIRS) {
+          if constexpr (SELF) {
             if (__any(aact && my_hi >= 0)) {
               // p_a = L_a^-T (zb_a - Y_a x_c - X p_b): the partner finishes first and publishes p_b
               float pb4[NLK];
@@ -1132,10 +1131,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         WSYNC();
       }
       };
-      // three copies of the loop, chosen per wave and step: each carries only the code (and the register needs) of what can occur in it
-      if (SELF && __any(dense_row)) newton_loop(std::integral_constant<int, 2>{});
-      else if (SELF && __any(cmask != 0)) newton_loop(std::integral_constant<int, 1>{});
-      else newton_loop(std::integral_constant<int, 0>{});
+      if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
