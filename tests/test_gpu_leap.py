@@ -224,10 +224,13 @@ def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):
     # the default kernel with the hand's own contacts against the oracle with every pair (palm-down: the fingers close under the palm)
     oa = O.Model("leap_cube_down")
     ra, _ = oa.rollout(x0, U)
-    ga, _, _ = GpuRolloutBackend(t.gpu_model(), N).rollout(x0, U)
+    bea = GpuRolloutBackend(t.gpu_model(), N)
+    bea.model.set_kernel(3)
+    bea.model.set_self_collision(True)  # (the task caches its model object: undo the switches of the loop above)
+    ga, _, _ = bea.rollout(x0, U)
     ea = np.abs(ga - ra)
     gap = np.abs(rs - ra)  # what leaving the hand's own contacts out costs on the same controls (p95 of the cube position at the horizon: 2 cm)
-    assert np.median(ea) < 1e-5 and np.percentile(ea[:, -1, :3], 75) < 5e-3 and np.percentile(ea[:, -1, :3], 90) < np.percentile(gap[:, -1, :3], 90)
+    assert np.median(ea) < 1e-5 and np.percentile(ea[:, -1, :3], 75) < 5e-3 and np.percentile(ea[:, -1, :3], 90) < 0.5 * np.percentile(gap[:, -1, :3], 90)
     ctrl = make_controller("leap_cube_down", "mppi")
     assert ctrl.optimizer.config.num_rollouts == 64 and ctrl.task.config.w_rot == 0.05
     ctrl.update_action()
