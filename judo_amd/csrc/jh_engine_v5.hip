@@ -327,6 +327,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   S.ws[6 + l] = 0.f; if (l < 6) S.ws[l] = 0.f;
   int n_iters = 0, n_maxed = 0;
   float acc = 0.f;
+#ifdef JH_V5_TICKS  // shader-clock totals per phase (diagnostic builds; tools/diag/profile_v5.py): 0 kinematics+dynamics, 1 broad phase, 2 narrow phase, 3 rows+warm start,
+                     // 4 gradient, 5 Newton matrix, 6 factorisation+direction, 7 line search+step and integration
+  long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
+#define V5_TICK(slot) { long long t__ = clock64(); cyc[slot] += t__ - t0; t0 = t__; }
+#else
+#define V5_TICK(slot)
+#endif
 #ifdef JH_V5_COUNT
   int cnt_dense = 0, cnt_it = 0, cnt_l2 = 0, cnt_bp = 0, cnt_hh = 0;
 #endif
@@ -447,6 +454,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       a0c_own = l < 3 ? (l == 0 ? grav[0] : (l == 1 ? grav[1] : grav[2])) : (l == 3 ? -gc[0] / cI[0] : (l == 4 ? -gc[1] / cI[1] : (l == 5 ? -gc[2] / cI[2] : 0.f)));
     }
     WSYNC();
+    V5_TICK(0)
     // ================================================================ collision: broad phase (cube vs the lane's geoms; hand body pairs), balanced narrow phase
     {
       int nh = 0;
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
       nh = nh < MAXHIT ? nh : MAXHIT;
       WSYNC();
+      V5_TICK(1)
       // narrow phase: survivor i goes to lane i; side A is the cube or the first geom of a hand pair, side B a hand geom
       PoolCtx pc{&S, stats};
       for (int base = 0; __any(base < nh); base += G) {
@@ -617,6 +626,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
     }
     WSYNC();
+    V5_TICK(2)
     // ================================================================ constraint rows: <= 2 contacts per lane + the own dof's friction-loss / limit rows
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
     Slot sl[NSLOT];
@@ -727,6 +737,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         WSYNC();
       }
       bool act = true;
+      V5_TICK(3)
       // The Newton loop exists twice: waves in which some rollout needs the dense direction this step run the copy that contains it, all others a copy
       // without that code (the register needs of the rare path would otherwise make the allocator spill inside every iteration of every rollout)
       auto newton_loop = [&](auto dense_tag) __attribute__((always_inline)) {
@@ -768,6 +779,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         for (int q6 = 0; q6 < 6; q6++) { const float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
         gcl = fmaf(mck, dcl, gcl);  // lanes 6..15: mck = 0, gcl stays 0
         WSYNC();
+        V5_TICK(4)
         // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
         g_own = S.g[6 + l];
         const float gn = gsum(g_own * g_own * iMd + gcl * gcl * imck);
@@ -855,6 +867,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           }
         }
         WSYNC();
+        V5_TICK(5)
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly); the coupling columns Y_q = L^-1 Hcb[:,q] are shared
         // by the chain's lanes (lane s: columns s and s+4); 6x6 Schur complement on the cube, solved by every lane
         float L[10], Linv[4], Ya[NLK], Yb[NLK], zb[NLK], xc6[6], pc4[NLK];
@@ -1090,6 +1103,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
 }
 #endif
+        V5_TICK(6)
         // ---- (5) exact line search along p
         float Mp_own = 0.f;
 #pragma unroll
@@ -1166,6 +1180,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
       qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
     }
+    V5_TICK(7)
     if (MATERIALIZE) {
       if (states && live) {
         float* o = states + ((size_t)nc * H + hh) * NX;
@@ -1178,6 +1193,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   }
 #ifdef JH_V5_COUNT
   if (stats) { if (lane == 0) { atomicAdd(stats + 24, cnt_dense); atomicAdd(stats + 25, cnt_it); atomicAdd(stats + 26, cnt_l2); atomicAdd(stats + 28, H); } if (l == 0 && live) { atomicAdd(stats + 27, cnt_bp); atomicAdd(stats + 29, cnt_hh); } }
+#endif
+#ifdef JH_V5_TICKS
+  if (lane == 0 && stats) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)cyc[k]);
 #endif
   if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
