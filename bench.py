@@ -40,6 +40,7 @@ WORKLOADS = {
     "spot_navigate": ("mppi", 65536, 100),
 }
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILE = "r02_traffic.json"
 
 
 def usable_cpus() -> int:
@@ -307,11 +308,12 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
     # measurement of this exact launch (profiles/, separate --pmc passes) is reported when the workload matches.
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01b_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    self_on = bool(ctrl.model is not None and ctrl.model.self_collision)
     if world == 1 and (N, H) == WORKLOADS[args.task][1:] and os.path.exists(tfile):
-        t = json.load(open(tfile)).get(args.task)
+        t = json.load(open(tfile)).get(args.task if self_on or args.task != "leap_cube" else "leap_cube_cube_only")
         if t:
-            traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r01b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            traffic, traffic_src = t["hbm_bytes_per_launch"], f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
     if rank == 0:
         ms = np.array(per_step) * 1e3
@@ -329,7 +331,8 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
-                       "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters},
+                       "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters,
+                       "hand_self_collision": self_on if args.task.startswith("leap") else None},
             "plan_step_ms": {"mean": float(ms.mean()), "std": float(ms.std()), "median": float(np.median(ms)), "iqr": float(np.percentile(ms, 75) - np.percentile(ms, 25)),
                              "min": float(ms.min()), "max": float(ms.max())},
             "physics_steps_per_s": N * H * substeps * args.steps / elapsed,
