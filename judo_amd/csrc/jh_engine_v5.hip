@@ -71,8 +71,8 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   int bpl[MAXBPL];
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
     float pool[NCP][POOL_F];
-    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[NCH][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[b][ib*4+ia]: block (chain b, chain a) of a
-                                                                           // contact-coupled pair a < b (hand self-collision), stored with the higher chain
+    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[6][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[pidx(a,b)][ib*4+ia]: block (chain b, chain a)
+                                                                         // of a contact-coupled pair of chains a < b (hand self-collision)
     struct { float Hd[NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
   };
   int ncon, nhit;
@@ -245,6 +245,41 @@ __device__ __forceinline__ void bwd4(const float* L, const float* inv, float* x)
 // element j (run-time, wave-nonuniform) of a 4-array held in registers: compare-and-select
 __device__ __forceinline__ float sel4(const float* a, int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
 
+// Elimination order of the four finger chains when contacts couple them (hand self-collision).  `cmask` has bit 4a + b for every coupled pair a < b.
+// A coupling graph without a cycle is eliminated leaf first: every chain is eliminated when at most one of its neighbours is left (its parent, which
+// receives the Schur update); `level` is the stage at which chain c goes, `maxlev` the last stage of the rollout.  Returns false for a graph with a
+// cycle (elimination would create a block between two chains that had none): those rollouts take the dense direction.
+__device__ __forceinline__ int pidx(int a, int b) { return a * (7 - a) / 2 + (b - a - 1); }  // index of the chain pair a < b: 01 02 03 12 13 23
+__device__ __forceinline__ bool chain_elim_order(int cmask, int c, int& level, int& parent, int& maxlev) {
+  int adj[NCH] = {0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < NCH; a++)
+#pragma unroll
+    for (int b = a + 1; b < NCH; b++) if ((cmask >> (4 * a + b)) & 1) { adj[a] |= 1 << b; adj[b] |= 1 << a; }
+  int rem = 0xF; bool ok = true;
+  level = 0; parent = -1; maxlev = 0;
+#pragma unroll
+  for (int st = 0; st < NCH; st++) {
+    int elig = 0, pr[NCH] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int a = 0; a < NCH; a++) if ((rem >> a) & 1) {
+      const int nbm = adj[a] & rem, deg = __popc(nbm);
+      if (deg == 0) elig |= 1 << a;
+      else if (deg == 1) {
+        const int nb = __ffs(nbm) - 1;
+        const int anb = nb == 0 ? adj[0] : (nb == 1 ? adj[1] : (nb == 2 ? adj[2] : adj[3]));
+        if (__popc(anb & rem) > 1 || a < nb) { elig |= 1 << a; pr[a] = nb; }
+      }
+    }
+    if (rem != 0 && elig == 0) ok = false;
+    if (elig != 0) maxlev = st;
+#pragma unroll
+    for (int a = 0; a < NCH; a++) if (((elig >> a) & 1) && a == c) { level = st; parent = pr[a]; }
+    rem &= ~elig;
+  }
+  return ok;
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
 template <bool MATERIALIZE, int WPB, bool SELF>
 __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #define V5_TICK(slot)
 #endif
 #ifdef JH_V5_COUNT
-  int cnt_dense = 0, cnt_it = 0, cnt_l2 = 0, cnt_bp = 0, cnt_hh = 0;
+  int cnt_dense = 0, cnt_it = 0, cnt_l2 = 0, cnt_bp = 0, cnt_hh = 0, cnt_cls[4] = {0, 0, 0, 0};
 #endif
   __syncthreads();  // the only workgroup barrier: the model image is staged
 
@@ -664,27 +699,27 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         dr.lims = sg; dr.lD = 1.f / R; dr.laref = -lc[LC_LB] * (sg * qd) - lc[LC_LK] * imp * dist;
       }
     }
-    // a contact between links of two different finger chains couples their blocks: no arrow structure for this rollout in this step
     // Which finger chains are coupled by contacts between their links (hand self-collision): a 4 x 4 bit matrix per rollout, bit 4a + b for chains a < b.
-    // If the coupling is a matching (every chain touches at most one other: 99 % of the coupled steps of the headline workload, mostly middle-ring) the
-    // arrow elimination runs in two stages -- first chain of a pair, then its partner with the first one's Schur update, then the cube; any other
-    // pattern takes the dense direction.  lo = partner with the lower index (this chain is eliminated second), hi = partner eliminated after this chain.
+    // Without a cycle in that graph (every coupled step of the headline workload: one pair, mostly middle-ring, or a chain touching both neighbours) the
+    // arrow elimination runs in stages, leaf chains first: a chain is eliminated when at most one coupled neighbour is left (its parent `par`, whose
+    // blocks take the Schur update and which factorises at a later stage `lvl`); then the cube.  A graph with a cycle takes the dense direction.
     bool anyslot = false; int cmask = 0;
 #pragma unroll
     for (int k = 0; k < NSLOT; k++) {
       anyslot |= sl[k].la >= 0;
       if (SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2)) cmask |= 1 << (4 * ((sl[k].la - 1) >> 2) + ((sl[k].lb - 1) >> 2));
     }
-    int my_lo = -1, my_hi = -1; bool dense_row = false;
+    int lvl = 0, par = -1, nlev = 0; bool dense_row = false;
     if constexpr (SELF) {
       cmask = gor(cmask);
-      int deg = 0;
-#pragma unroll
-      for (int o = 0; o < NCH; o++) {
-        if (o < c && (cmask >> (4 * o + c)) & 1) { my_lo = o; deg++; }
-        if (o > c && (cmask >> (4 * c + o)) & 1) { my_hi = o; deg++; }
+      if (__any(cmask != 0)) dense_row = !chain_elim_order(cmask, c, lvl, par, nlev);
+#ifdef JH_V5_COUNT
+      if (l == 0 && live) {
+        int dmax = 0;
+        for (int a = 0; a < NCH; a++) { int d = 0; for (int b = 0; b < NCH; b++) if (b != a) d += (cmask >> (a < b ? 4 * a + b : 4 * b + a)) & 1; dmax = d > dmax ? d : dmax; }
+        cnt_cls[cmask == 0 ? 0 : (dense_row ? 3 : (dmax <= 1 ? 1 : 2))]++;
       }
-      dense_row = gor((int)(deg > 1)) != 0;
+#endif
     }
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     float a_own, ac_own;
@@ -793,7 +828,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
-          if (SELF) for (int k = 0; k < 4; k++) S.Hx[c][s * 4 + k] = 0.f;
+          if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
           S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
@@ -828,7 +863,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
               }
             }
             if (t.lb > 0) {  // finger columns: side B; side A joins the same block when both links sit in one chain, else its chain gets its own block and the
-                             // pair's coupling block -Jb'W Ja goes to Hx (stored with the higher chain, which is always B's)
+                             // pair's coupling block -Jb'W Ja goes to Hx (B's chain is always the higher one)
               const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
               const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
               const bool linkA = SELF && !cube && t.la > 0;
@@ -860,7 +895,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
                   for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[cha][tri(u4, v4)], Ja[v4][0] * G0 + Ja[v4][1] * G1 + Ja[v4][2] * G2);
 #pragma unroll
-                  for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[ch][v4 * 4 + u4], -(Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2));
+                  for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[pidx(cha, ch)][v4 * 4 + u4], -(Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2));
                 }
               }
             }
@@ -882,30 +917,34 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         };
         factor_block();
         if (aact && l < 6) S.rhs6[l] = -gcl;
-        float Xs[NLK] = {0.f, 0.f, 0.f, 0.f};  // column s of X = L^-1 H(a,b) for the first chain a of a coupled pair (b = my_hi)
+        float Xs[NLK] = {0.f, 0.f, 0.f, 0.f};  // column s of X = L^-1 H(a,P) of a chain a with a parent P
         if constexpr (SELF) {
-          if (__any(aact && my_hi >= 0)) {
-            // first chain of a pair: its elimination updates the partner's blocks -- Hbb(b) -= X'X, Hcb(b) -= X'Y, g(b) += X'zb (so that the partner's
-            // zb becomes L_b^-1 (-g_b - X'zb_a)) -- before the partner factorises
-            if (aact && my_hi >= 0) {
-              for (int j = 0; j < NLK; j++) Xs[j] = S.Hx[my_hi][s * 4 + j];  // H(a,b)[ia][ib = s] = H(b,a)[ib = s][ia]
+#pragma unroll 1
+          for (int st = 1; st < NCH; st++) {
+            if (!__any(aact && nlev >= st)) break;
+            // chains of stage st - 1 with a parent: their elimination updates the parent's blocks -- Hbb(P) -= X'X, Hcb(P) -= X'Y, g(P) += X'zb (so that the
+            // parent's zb becomes L_P^-1 (-g_P - X'zb_a)) -- before the parent factorises at its own stage (atomics: two leaves may share a parent)
+            const bool me = aact && lvl == st - 1 && par >= 0;
+            if (me) {
+              const float* hx = par > c ? S.Hx[pidx(c, par)] : S.Hx[pidx(par, c)];
+              for (int j = 0; j < NLK; j++) Xs[j] = par > c ? hx[s * 4 + j] : hx[j * 4 + s];  // H(a,P)[ia = j][iP = s]
               fwd4(L, Linv, Xs);
             }
 #pragma unroll
             for (int j = 0; j < NLK; j++) {
               const float v = Xs[0] * quad_get(Xs[0], j) + Xs[1] * quad_get(Xs[1], j) + Xs[2] * quad_get(Xs[2], j) + Xs[3] * quad_get(Xs[3], j);
-              if (aact && my_hi >= 0 && j <= s) S.Hbb[my_hi][tri(s, j)] -= v;
+              if (me && j <= s) atomicAdd(&S.Hbb[par][tri(s, j)], -v);
             }
 #pragma unroll
             for (int q6 = 0; q6 < 6; q6++) {
               float v = 0.f;
 #pragma unroll
               for (int j = 0; j < NLK; j++) v += Xs[j] * (q6 < 4 ? quad_get(Ya[j], q6) : quad_get(Yb[j], q6 - 4));
-              if (aact && my_hi >= 0) S.Hcb[my_hi][s * 6 + q6] -= v;
+              if (me) atomicAdd(&S.Hcb[par][s * 6 + q6], -v);
             }
-            if (aact && my_hi >= 0) S.g[6 + 4 * my_hi + s] += Xs[0] * zb[0] + Xs[1] * zb[1] + Xs[2] * zb[2] + Xs[3] * zb[3];
+            if (me) atomicAdd(&S.g[6 + 4 * par + s], Xs[0] * zb[0] + Xs[1] * zb[1] + Xs[2] * zb[2] + Xs[3] * zb[3]);
             WSYNC();
-            if (my_lo >= 0) factor_block();  // second chain of a pair: factorise the updated blocks
+            if (lvl == st) factor_block();  // the updated blocks
           }
         }
         WSYNC();
@@ -959,16 +998,23 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #pragma unroll
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
           if constexpr (SELF) {
-            if (__any(aact && my_hi >= 0)) {
-              // p_a = L_a^-T (zb_a - Y_a x_c - X p_b): the partner finishes first and publishes p_b
-              float pb4[NLK];
-              for (int j = 0; j < NLK; j++) pb4[j] = pc4[j];
-              bwd4(L, Linv, pb4);
-              if (aact && my_lo >= 0) S.p[6 + l] = sel4(pb4, s);
-              WSYNC();
-              const float pbs = (aact && my_hi >= 0) ? S.p[6 + 4 * my_hi + s] : 0.f;
+            if (__any(aact && nlev > 0)) {
+              // p_a = L_a^-T (zb_a - Y_a x_c - X p_P): parents finish first (last stage first) and publish their part of the direction
+#pragma unroll 1
+              for (int st = NCH - 1; st >= 0; st--) {
+                if (!__any(aact && nlev >= st)) continue;
+                const bool me = aact && lvl == st;
+                const float pbs = (me && par >= 0) ? S.p[6 + 4 * par + s] : 0.f;
 #pragma unroll
-              for (int j = 0; j < NLK; j++) pc4[j] -= csum(Xs[j] * pbs);
+                for (int j = 0; j < NLK; j++) pc4[j] -= csum(Xs[j] * pbs);
+                if (st > 0) {
+                  float pb4[NLK];
+                  for (int j = 0; j < NLK; j++) pb4[j] = pc4[j];
+                  bwd4(L, Linv, pb4);
+                  if (me) S.p[6 + l] = sel4(pb4, s);
+                  WSYNC();
+                }
+              }
             }
           }
           bwd4(L, Linv, pc4);
@@ -1192,7 +1238,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     WSYNC();
   }
 #ifdef JH_V5_COUNT
-  if (stats) { if (lane == 0) { atomicAdd(stats + 24, cnt_dense); atomicAdd(stats + 25, cnt_it); atomicAdd(stats + 26, cnt_l2); atomicAdd(stats + 28, H); } if (l == 0 && live) { atomicAdd(stats + 27, cnt_bp); atomicAdd(stats + 29, cnt_hh); } }
+  if (stats) { if (lane == 0) { atomicAdd(stats + 24, cnt_dense); atomicAdd(stats + 25, cnt_it); atomicAdd(stats + 26, cnt_l2); atomicAdd(stats + 28, H); } if (l == 0 && live) { atomicAdd(stats + 27, cnt_bp); atomicAdd(stats + 29, cnt_hh); for (int k = 0; k < 4; k++) atomicAdd(stats + 30 + k, cnt_cls[k]); } }
 #endif
 #ifdef JH_V5_TICKS
   if (lane == 0 && stats) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)cyc[k]);

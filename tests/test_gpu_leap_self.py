@@ -49,25 +49,44 @@ def _contact_kinds(om, x, u):
             pairs.add((min(chain[ba], chain[bb]), max(chain[ba], chain[bb])))
         else:
             ns += 1
-    for a, b in pairs:
+    root = list(range(4))
+
+    def find(a):
+        while root[a] != a:
+            a = root[a]
+        return a
+
+    cycle = False
+    for a, b in sorted(pairs):
         deg[a] += 1
         deg[b] += 1
-    return nc, ns, nx, int(max(deg) > 1)  # last: the coupled chains do not form a matching (the kernel's dense direction)
+        ra, rb = find(a), find(b)
+        cycle |= ra == rb
+        root[ra] = rb
+    # last: 0 = the coupled chains form a matching, 1 = some chain touches two others but the coupling graph has no cycle (both: staged arrow
+    # elimination), 2 = a cycle (the kernel's dense direction)
+    return nc, ns, nx, 2 if cycle else int(max(deg) > 1)
 
 
 def test_self_collision_single_steps_match_oracle(gpu):
-    """One mj_step from hand configurations in which the fingers touch each other or the palm; the states with a contact between two finger
-    chains take the kernel's dense Hessian path, the others the arrow path."""
+    """One mj_step from hand configurations in which the fingers touch each other or the palm: contacts within a chain or against the palm keep the
+    arrow structure, contacts between chains take the staged arrow elimination (one pair; a chain touching two others) or, when the coupling graph
+    has a cycle, the dense direction."""
     from judo_amd.rollout_backend import GpuRolloutBackend
     from oracle import oracle as O
 
     om, xs, q = _tangled_states(600, seed=5)
-    us = q[:, None, :]
     kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(len(xs))])
+    # coupling graphs with a cycle (the thumb and two fingers all touching each other) are rare even here: pick them out of a larger draw
+    _, xs2, q2 = _tangled_states(12000, seed=6, frac=0.7)
+    kinds2 = np.array([_contact_kinds(om, xs2[i], q2[i]) for i in range(len(xs2))])
+    cyc = (kinds2[:, 3] == 2) & (kinds2[:, :3].sum(1) <= 32)
+    xs, q, kinds = np.concatenate([xs, xs2[cyc]]), np.concatenate([q, q2[cyc]]), np.concatenate([kinds, kinds2[cyc]])
+    us = q[:, None, :]
     ok = kinds[:, :3].sum(1) <= 32  # within the kernel's contact capacity per rollout
     within, across = ok & (kinds[:, 1] > 0) & (kinds[:, 2] == 0), ok & (kinds[:, 2] > 0)
-    paired, tangled = across & (kinds[:, 3] == 0), across & (kinds[:, 3] == 1)
-    assert within.sum() > 10 and paired.sum() > 50 and tangled.sum() > 20, (within.sum(), paired.sum(), tangled.sum())
+    paired, forest, tangled = across & (kinds[:, 3] == 0), across & (kinds[:, 3] == 1), across & (kinds[:, 3] == 2)
+    assert within.sum() > 10 and paired.sum() > 50 and forest.sum() > 20 and tangled.sum() > 20, (within.sum(), paired.sum(), forest.sum(), tangled.sum())
     nxt, _ = om.rollout(xs, us)
     be = GpuRolloutBackend("leap_cube", len(xs))
     g1, _, _ = be.rollout(xs, us)
@@ -77,7 +96,8 @@ def test_self_collision_single_steps_match_oracle(gpu):
     scale = np.maximum(1.0, np.abs(nxt[:, 0, 23:]).max(axis=1, keepdims=True))
     e = np.abs(g1[:, 0] - nxt[:, 0])
     e[:, 23:] /= scale
-    for sel, name in ((within, "arrow"), (paired, "two-stage arrow (one coupled pair of chains per matching)"), (tangled, "dense direction"), (ok & (kinds[:, :3].sum(1) == 0), "no contact")):
+    for sel, name in ((within, "arrow"), (paired, "staged arrow, coupled pairs"), (forest, "staged arrow, a chain with two coupled neighbours"), (tangled, "dense direction"),
+                      (ok & (kinds[:, :3].sum(1) == 0), "no contact")):
         ev = e[sel][:, 23:]
         assert np.median(ev) < 2e-5 and np.percentile(ev, 95) < 2e-2, (name, np.median(ev), np.percentile(ev, 95))
     # the same steps WITHOUT the hand's own contacts are far off: the cube-only model moves the fingers through each other
