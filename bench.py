@@ -217,6 +217,7 @@ def main() -> None:
     ap.add_argument("--horizon-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
+    ap.add_argument("--no-cube-only", action="store_true", help="leap_cube: skip the extra cube-contacts-only steps run after the timed region")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
     args = ap.parse_args()
@@ -278,6 +279,9 @@ def main() -> None:
         t_plan += 1.0 / ctrl.controller_cfg.control_freq
     ctrl.record_kernel_events = True
     ctrl.kernel_events.clear()
+    ctrl.solver_warnings = False
+    if not is_policy:
+        ctrl.solver_stats()  # zero the kernels' counters: the line reports the timed steps alone
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -296,6 +300,33 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])) if ctrl.kernel_events else float("nan")
+    solver = None
+    if not is_policy and ctrl.model is not None and args.task not in ("cartpole", "cylinder_push"):
+        st = ctrl.solver_stats()
+        if st["steps"] > 0:  # (32-bit counters: fine for the default run lengths, they wrap after ~4e9 rollout-iterations)
+            solver = {"newton_iters_per_step": st["newton_iters"] / st["steps"], "newton_cap_hits_per_step": st["newton_cap_hits"] / st["steps"],
+                      "contacts_dropped_per_step": st["contact_overflow"] / st["steps"]}
+            if st.get("wave_steps"):
+                solver["wave_newton_iters_per_step"] = st["wave_newton_iters"] / st["wave_steps"]
+                solver["lock_step_inflation"] = solver["wave_newton_iters_per_step"] / max(solver["newton_iters_per_step"], 1e-9)
+    # leap_cube: the same loop continued with the hand's own contacts switched off (the model round 1 measured), outside the timed region
+    cube_only = None
+    if args.task == "leap_cube" and world == 1 and ctrl.model is not None and ctrl.model.self_collision and not args.no_cube_only:
+        ctrl.model.set_self_collision(False)
+        ctrl.kernel_events.clear()
+        n_extra = min(args.steps, 10)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(n_extra):
+            ctrl.time = t_plan
+            ctrl.update_action()
+            t_plan += 1.0 / ctrl.controller_cfg.control_freq
+        torch.cuda.synchronize()
+        tc = (time.perf_counter() - tc) / n_extra
+        cube_only = {"ms_per_step": tc * 1e3, "rollouts_per_s": N / tc, "steps": n_extra,
+                     "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])),
+                     "note": "hand self-collision off (cube contacts only): the model of round 1's 81.8 ms line; continues the plan of the timed steps"}
+        ctrl.model.set_self_collision(True)
     n_local = ctrl.last_shard.count
     substeps = ctrl.task.physics_substeps
     if is_policy:  # per control step the tree kernel reads state + control + warm start and writes state + warm start; H launches inside the timed region
@@ -342,6 +373,10 @@ def main() -> None:
                          "traffic_source": traffic_src,
                          "note": "latency/VALU-issue-bound by construction (H serial physics steps, ~1e5 flop per step against a few hundred algorithmic bytes per rollout); see DESIGN.md section 6"},
         }
+        if solver:
+            line["solver"] = solver
+        if cube_only:
+            line["cube_only"] = cube_only
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_policy(ctrl) if is_policy else cpu_baseline(args.task, ctrl)
         print(json.dumps(line))

@@ -59,8 +59,10 @@ int jh_model_dims(const jh_model* m, int* dims /* HOST */);
 
 /* Diagnostics accumulated by the articulated-body kernels since the last reset (synchronises the device):
  * out[0] contacts dropped because a rollout exceeded the per-rollout contact capacity, out[1] constraint solves that hit the
- * Newton iteration cap, out[2] Newton iterations, out[3] physics steps.  HOST pointer. */
-int jh_model_stats(jh_model* m, int* out /* HOST, 4 ints */, int reset);
+ * Newton iteration cap, out[2] Newton iterations (summed over rollouts), out[3] physics steps (summed over rollouts); leap_cube kernel generation 3 also:
+ * out[4] Newton iterations executed by wavefronts (four rollouts advance in lock step: per step the maximum over the four), out[5] physics steps
+ * summed over wavefronts; out[6], out[7] reserved (0).  The counters are 32-bit and wrap: reset them at least every ~10^9 rollout-steps.  HOST pointer. */
+int jh_model_stats(jh_model* m, int* out /* HOST, 8 ints */, int reset);
 
 /* Articulated-body engine kernel generation for this model: 3 (default for leap_cube) = cooperative kernel on a register diet, two waves per SIMD,
  * hand self-collision; 2 (default for fr3_pick) = cooperative kernel, 16 lanes per rollout, one wave per SIMD;

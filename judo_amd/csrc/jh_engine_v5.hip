@@ -360,7 +360,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     }
   }
   S.ws[6 + l] = 0.f; if (l < 6) S.ws[l] = 0.f;
-  int n_iters = 0, n_maxed = 0;
+  int n_iters = 0, n_maxed = 0, n_wave_iters = 0;  // (the last: iterations this wave ran -- per step the maximum over its four rollouts)
   float acc = 0.f;
 #ifdef JH_V5_TICKS  // shader-clock totals per phase (diagnostic builds; tools/diag/profile_v5.py): 0 kinematics+dynamics, 1 broad phase, 2 narrow phase, 3 rows+warm start,
                      // 4 gradient, 5 Newton matrix, 6 factorisation+direction, 7 line search+step and integration
@@ -821,6 +821,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
+        n_wave_iters++;
         // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
         const bool aact = act && !(DENSE && dense_row);
@@ -1245,6 +1246,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #endif
   if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }
+  if (stats && lane == 0 && live) { atomicAdd(stats + 20, n_wave_iters); atomicAdd(stats + 21, H); }
 }
 
 bool model_is_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 13 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG; }

@@ -68,9 +68,10 @@ class GpuModel:
 
     def stats(self, reset: bool = True) -> dict:
         """Diagnostic counters of the articulated-body kernels (synchronises)."""
-        out = (C.c_int * 4)()
+        out = (C.c_int * 8)()
         _lib.check(_lib.lib().jh_model_stats(self.handle, out, int(reset)), "jh_model_stats")
-        return {"contact_overflow": out[0], "newton_cap_hits": out[1], "newton_iters": out[2], "steps": out[3]}
+        u = [v & 0xFFFFFFFF for v in out]  # 32-bit counters: unsigned
+        return {"contact_overflow": u[0], "newton_cap_hits": u[1], "newton_iters": u[2], "steps": u[3], "wave_newton_iters": u[4], "wave_steps": u[5]}
 
     def __del__(self) -> None:
         try:

@@ -7,7 +7,7 @@ root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 task=leap_cube
-cmd="python $root/bench.py --task $task --steps 3 --warmup 2 --no-cpu-baseline $3"
+cmd="python $root/bench.py --task $task --steps 3 --warmup 2 --no-cpu-baseline --no-cube-only $3"
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/${task}_stats -o $task -- $cmd > $out/${task}_bench_under_rocprof.json 2> $out/${task}_stats.log
 i=0
 for pmc in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM SQ_ACTIVE_INST_MISC"; do
