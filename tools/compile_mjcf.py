@@ -319,8 +319,24 @@ def compile_model(xml_name: str, task: str) -> dict:
                 elif len(massive) == 1:
                     g, m, I = massive[0]
                     rec.update(mass=m, ipos=list(g["pos"]), iquat=list(g["quat"]), inertia=I)
-                else:
-                    raise NotImplementedError(f"body {name}: multi-geom inertia not needed by the four models")
+                else:  # several massive geoms: total mass, centre of mass, inertia about it (parallel axes), principal frame -- what MuJoCo's compiler does
+                    import numpy as _np
+
+                    def rotm(q):
+                        return _np.array([quat_rot(q, e) for e in ([1, 0, 0], [0, 1, 0], [0, 0, 1])]).T
+
+                    mt = sum(m for _, m, _ in massive)
+                    com = sum(m * _np.array(g["pos"]) for g, m, _ in massive) / mt
+                    It = _np.zeros((3, 3))
+                    for g, m, I in massive:
+                        R = rotm(g["quat"])
+                        d = _np.array(g["pos"]) - com
+                        It += R @ _np.diag(I) @ R.T + m * (d @ d * _np.eye(3) - _np.outer(d, d))
+                    w, V = _np.linalg.eigh(It)
+                    w, V = w[::-1], V[:, ::-1]  # MuJoCo orders the principal moments descending
+                    if _np.linalg.det(V) < 0:
+                        V[:, 2] = -V[:, 2]
+                    rec.update(mass=float(mt), ipos=[float(x) for x in com], iquat=qnorm(mat_to_quat(V.tolist())), inertia=[float(x) for x in w])
             for g in geoms_here:
                 if g["contype"] == 0 and g["conaffinity"] == 0:
                     continue  # visual-only

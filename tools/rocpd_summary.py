@@ -22,6 +22,16 @@ for db in sys.argv[1:]:
         print(f"{'kernel':<100} {'calls':>6} {'total_us':>16} {'avg_us':>14} {'pct':>7}")
         for n, c, t, a, p in rows:
             print(f"{short(n):<100} {c:>6} {t:>16.1f} {a:>14.1f} {p:>7.3f}")
+    if rows:  # the dominant kernel, dispatch by dispatch (the bench times its last K launches: warm-up launches come first)
+        top = max(rows, key=lambda r: r[2])[0]
+        try:
+            d = [r[0] / 1e3 for r in cur.execute("select duration from kernels where name = ? order by start", (top,))]
+            print(f"dispatches of {short(top)[:60]} [us]: " + " ".join(f"{x:.0f}" for x in d))
+            for k in (3, 20):
+                if len(d) > k:
+                    print(f"  mean of the last {k}: {sum(d[-k:]) / k:.1f} us")
+        except sqlite3.OperationalError:
+            pass
     try:
         rows = list(cur.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(vgpr_count), avg(accum_vgpr_count), avg(sgpr_count), avg(scratch_size), avg(lds_block_size) from counters_collection group by kernel_name, counter_name order by avg(value) desc"))
     except sqlite3.OperationalError:
