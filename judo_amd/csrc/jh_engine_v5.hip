@@ -39,6 +39,14 @@ constexpr int NCH = 4, NLK = 4;
 #endif
 // Waves of a workgroup never exchange data after the image is staged: inside the step loop a "barrier" only has to order one wave's own LDS traffic
 // (a wave's LDS instructions execute in issue order), so it is a compiler fence, not an s_barrier -- rollouts in different waves never wait for each other.
+// OPAQUE(x): the compiler forgets what it knows about x, so nothing derived from it is hoisted out of the enclosing loop.  Used on the contact slots at the top of
+// every Newton iteration: otherwise the slots' Jacobian columns, lever arms and LDS addresses (all invariant over the iterations) are computed once before
+// the loop, do not fit in the register file and are spilled and reloaded in every iteration.
+#define OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef JH_V5_OPAQUE
+#define JH_V5_OPAQUE -1  // -1: per instantiation (3 with the hand's own contacts, 2 without: measured fastest, tools/diag/ab_variants.sh); 0 = off, 1 = the sides, 2 = + lever arm, 3 = + frame,
+                         // 4 = 3 and again before the Hessian assembly and before the line search
+#endif
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #ifndef JH_V5_NSLOT
 #define JH_V5_NSLOT 2
@@ -775,10 +783,22 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       V5_TICK(3)
       // The Newton loop exists twice: waves in which some rollout needs the dense direction this step run the copy that contains it, all others a copy
       // without that code (the register needs of the rare path would otherwise make the allocator spill inside every iteration of every rollout)
+      constexpr int OPQ = JH_V5_OPAQUE >= 0 ? JH_V5_OPAQUE : (SELF ? 3 : 2);
+      auto forget_slots = [&]() __attribute__((always_inline)) {
+        if constexpr (OPQ > 0) {
+#pragma unroll
+          for (int k = 0; k < NSLOT; k++) {
+            OPAQUE(sl[k].la); OPAQUE(sl[k].lb);
+            if constexpr (OPQ > 1) { OPAQUE(sl[k].rc[0]); OPAQUE(sl[k].rc[1]); OPAQUE(sl[k].rc[2]); }
+            if constexpr (OPQ > 2) { for (int q9 = 0; q9 < 9; q9++) OPAQUE(sl[k].fr[q9]); }
+          }
+        }
+      };
       auto newton_loop = [&](auto dense_tag) __attribute__((always_inline)) {
       constexpr bool DENSE = decltype(dense_tag)::value;
       for (int it = 0; it < cap && __any(act); it++) {
         // ---- (1) gradient.  Owner lanes: M (a - a0) rows + dof-row forces; contacts: -J'f as LDS float atomics (finger and cube parts)
+        forget_slots();
         const float da_own = a_own - a0_own, dcl = ac_own - a0c_own;
         float g_own = 0.f, hd = 0.f;
 #pragma unroll
@@ -824,6 +844,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         n_wave_iters++;
         // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
+        if constexpr (OPQ > 3) forget_slots();
         const bool aact = act && !(DENSE && dense_row);
         if (aact) {
 #pragma unroll
@@ -1152,6 +1173,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #endif
         V5_TICK(6)
         // ---- (5) exact line search along p
+        if constexpr (OPQ > 3) forget_slots();
         float Mp_own = 0.f;
 #pragma unroll
         for (int j = 0; j < NLK; j++) Mp_own += Mrow[j] * pc4[j];

@@ -356,6 +356,12 @@ def compile_model(xml_name: str, task: str) -> dict:
                         if len(subs) > 1:
                             gg["name"] = f"{g['name']}_{i_sub + 1}"
                         parts.append(gg)
+                if g["type"] == "cylinder" and task == "caltech_leap_cube":
+                    # fingertip cylinders (MuJoCo collides them with its general convex routine, not with a primitive pair function): taken as a sphere of the
+                    # same radius at the cylinder's centre, which with the tip's own sphere 7 mm further out makes the capsule-like tip described above
+                    gg = dict(g)
+                    gg["type"], gg["size"], gg["substitute_for_cylinder"] = "sphere", [g["size"][0]], list(g["size"])
+                    parts = [gg]
                 for gg in parts:
                     for k in ("mesh", "density", "mass", "contype", "conaffinity"):
                         gg.pop(k, None)
@@ -405,6 +411,10 @@ def compile_model(xml_name: str, task: str) -> dict:
                 rec.update(objtype=s.get("objtype"), obj=(site_id if s.get("objtype") == "site" else body_id)[s.get("objname")], dim=3)
                 if s.get("refname") is not None:  # value expressed in the reference frame (framepos: R_ref' (p - p_ref))
                     rec.update(reftype=s.get("reftype"), ref=(site_id if s.get("reftype") == "site" else body_id)[s.get("refname")])
+            elif s.tag == "framequat":  # orientation of the object frame relative to the reference frame: q_ref^-1 * q_obj
+                rec.update(objtype=s.get("objtype"), obj=(site_id if s.get("objtype") == "site" else body_id)[s.get("objname")], dim=4)
+                if s.get("refname") is not None:
+                    rec.update(reftype=s.get("reftype"), ref=(site_id if s.get("reftype") == "site" else body_id)[s.get("refname")])
             elif s.tag == "jointpos":
                 rec.update(obj=joint_id[s.get("joint")], dim=1)
             elif s.tag == "distance":
@@ -420,10 +430,10 @@ def compile_model(xml_name: str, task: str) -> dict:
 def main() -> None:
     os.makedirs(OUT_DIR, exist_ok=True)
     for xml_name, task in (("cartpole.xml", "cartpole"), ("cylinder_push.xml", "cylinder_push"), ("leap_cube.xml", "leap_cube"), ("fr3_pick.xml", "fr3_pick"),
-                           ("leap_cube_palm_down.xml", "leap_cube_down"), ("spot_primitive/robot.xml", "spot")):
+                           ("leap_cube_palm_down.xml", "leap_cube_down"), ("caltech_leap_cube.xml", "caltech_leap_cube"), ("spot_primitive/robot.xml", "spot")):
         m = compile_model(xml_name, task)
-        if task == "leap_cube_down":
-            m["family"] = "leap_cube"  # same components, palm-down hand pose: runs on the leap_cube kernels
+        if task in ("leap_cube_down", "caltech_leap_cube"):
+            m["family"] = "leap_cube"  # same hand topology (palm-down pose / the Caltech primitive hand): runs on the leap_cube kernels
         path = os.path.join(OUT_DIR, task + ".json")
         with open(path, "w") as f:
             json.dump(m, f, indent=None, separators=(",", ":"))
