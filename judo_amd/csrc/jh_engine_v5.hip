@@ -43,6 +43,9 @@ constexpr int NCH = 4, NLK = 4;
 // every Newton iteration: otherwise the slots' Jacobian columns, lever arms and LDS addresses (all invariant over the iterations) are computed once before
 // the loop, do not fit in the register file and are spilled and reloaded in every iteration.
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef JH_V5_OPAQUE_LANE
+#define JH_V5_OPAQUE_LANE 1
+#endif
 #ifndef JH_V5_OPAQUE
 #define JH_V5_OPAQUE -1  // -1: per instantiation (3 with the hand's own contacts, 2 without: measured fastest, tools/diag/ab_variants.sh); 0 = off, 1 = the sides, 2 = + lever arm, 3 = + frame,
                          // 4 = 3 and again before the Hessian assembly and before the line search
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   __shared__ int sBG[SELF ? 2 * 17 : 4];     // per hand body: first collision geom, number of geoms (contiguous in the geom table)
   __shared__ float sBB[SELF ? 17 * 8 : 4];   // per hand body: bounding-box centre (body frame), bounding radius, half sizes
   __shared__ float sKnAll[MAXK * WAVE * WPB];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, r = lane >> 4, c = l >> 2, s = l & 3;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane >> 4;
+  int l = lane & 15, c = l >> 2, s = l & 3;  // (not const: see the top of the step loop)
   RS& S = sRS[wv * RPW + r];
   float* sKn = sKnAll + wv * (MAXK * WAVE);
   const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6];
@@ -383,6 +387,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   __syncthreads();  // the only workgroup barrier: the model image is staged
 
   for (int hh = 0; hh < H; hh++) {
+#if JH_V5_OPAQUE_LANE
+    // the model constants of a lane (sBody, sLane, ...) do not change over the steps: left alone the compiler loads them once before the loop, runs out of
+    // registers and reloads them from scratch memory in every step instead of from LDS
+    OPAQUE(l); c = l >> 2; s = l & 3;
+    const float* lc = sLane + l * LC_N;
+#endif
     // ================================================================ controls
     float u;
     if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + l];
