@@ -61,9 +61,12 @@ constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
 constexpr int MAXG = 80, MAXLG = 8;
 constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1..16 = finger link (1 + 4*chain + depth), 17 = the cube
 constexpr int HITPAIR = 1 << 16;  // broad-phase survivors >= HITPAIR index the hand-hand geom pair list, smaller ones are cube-vs-geom
+constexpr int MAXBP = 128;         // hand body pairs in the model image (leap_cube 106, caltech_leap_cube 122)
 constexpr int MAXBPL = 24;        // hand body pairs whose bounding spheres overlap, per rollout and step
 constexpr int NDH = 22 * 23 / 2;  // dense Hessian (packed lower) of a rollout whose contacts couple two finger chains
-constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NX = 45, NMB = 17;
+constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NS_CALTECH = 23, NX = 45, NMB = 17;
+constexpr int NBC = 20;  // hand bodies of the self-collision tables: 0 = static geometry, 1..16 = finger links, 17..19 = further groups of static geometry (engine_model.py)
+__device__ __forceinline__ bool static_code(int b) { return b == 0 || b >= NMB; }
 constexpr int MAXK = 8;
 
 // per-lane model constants staged in LDS (index = lane & 15)
@@ -76,7 +79,7 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
   float Mbb[NCH][10];
   float rhs6[6];
-  float bs[NMB][4];   // bounding sphere of the hand bodies (0 = all static geometry, 1..16 = finger links): world centre, radius (the centre is the
+  float bs[NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
                       // bounding box's too; its half sizes and axes come from the model image and the body rotation)
   int hits[MAXHIT];
   int bpl[MAXBPL];
@@ -306,15 +309,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   __shared__ int sGeomI[MAXG * GEOM_I];
   __shared__ int sLaneG[16 * MAXLG];
   __shared__ float sLane[16 * LC_N];
-  __shared__ int sBP[SELF ? 2 * 112 : 4];    // hand body pairs (side A, side B): every geom of A is a candidate against every geom of B
-  __shared__ int sBG[SELF ? 2 * 17 : 4];     // per hand body: first collision geom, number of geoms (contiguous in the geom table)
-  __shared__ float sBB[SELF ? 17 * 8 : 4];   // per hand body: bounding-box centre (body frame), bounding radius, half sizes
+  __shared__ int sBP[SELF ? 2 * MAXBP : 4];    // hand body pairs (side A, side B): every geom of A is a candidate against every geom of B
+  __shared__ int sBG[SELF ? 2 * NBC : 4];    // per hand body: first collision geom, number of geoms (contiguous in the geom table)
+  __shared__ float sBB[SELF ? NBC * 8 : 4];  // per hand body: bounding-box centre (body frame; static geometry: world), bounding radius, half sizes
   __shared__ float sKnAll[MAXK * WAVE * WPB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane >> 4;
   int l = lane & 15, c = l >> 2, s = l & 3;  // (not const: see the top of the step loop)
   RS& S = sRS[wv * RPW + r];
   float* sKn = sKnAll + wv * (MAXK * WAVE);
-  const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6];
+  const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6], nsI = gI[7], oRef = gI[18];
   const int oBodyF = HEADER_F, oDofF = oBodyF + nmI * BODY_F, oActF = oDofF + gI[2] * DOF_F, oGeomF = oActF + nuI * ACT_F, oSiteF = oGeomF + ngI * GEOM_F;
   const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
   const int oLane = gI[11], lgm = gI[12];
@@ -325,9 +328,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   for (int i = tid; i < 16 * lgm; i += WAVE * WPB) sLaneG[i] = gI[oLane + i];
   if (!MATERIALIZE && tid < 9) sTp[tid] = tp[tid];
   if constexpr (SELF) {
-    for (int i = tid; i < 2 * nBP && i < 2 * 112; i += WAVE * WPB) sBP[i] = gI[oBP + i];
-    for (int i = tid; i < 2 * 17; i += WAVE * WPB) sBG[i] = gI[oBG + i];
-    for (int i = tid; i < 17 * 8; i += WAVE * WPB) sBB[i] = gF[oBS + i];
+    for (int i = tid; i < 2 * nBP && i < 2 * MAXBP; i += WAVE * WPB) sBP[i] = gI[oBP + i];
+    for (int i = tid; i < 2 * NBC; i += WAVE * WPB) sBG[i] = gI[oBG + i];
+    for (int i = tid; i < NBC * 8; i += WAVE * WPB) sBB[i] = gF[oBS + i];
   }
   if (tid < 16) {
     const float* df = gF + oDofF + (6 + l) * DOF_F; const float* af = gF + oActF + l * ACT_F;
@@ -429,12 +432,22 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
       // sensors of this forward pass (materialise mode): 16 joint positions, then 5 site positions
       if (MATERIALIZE && sensors) {
-        float* y = sensors + ((size_t)nc * H + hh) * NS;
+        float* y = sensors + ((size_t)nc * H + hh) * nsI;
         if (live) y[l] = q;
         WSYNC();
-        if (live && l < nsiteI && l < 5) {
-          int b = gI[oSiteI + l]; float p3[3]; mulMV(p3, S.xR[b], gF + oSiteF + l * SITE_F);
-          for (int k = 0; k < 3; k++) y[16 + 3 * l + k] = p3[k] + S.pa[b][k];
+        if (nsI == NS) {  // leap_cube / leap_cube_down: five site positions
+          if (live && l < nsiteI && l < 5) {
+            int b = gI[oSiteI + l]; float p3[3]; mulMV(p3, S.xR[b], gF + oSiteF + l * SITE_F);
+            for (int k = 0; k < 3; k++) y[16 + 3 * l + k] = p3[k] + S.pa[b][k];
+          }
+        } else if (live && l < 7) {  // caltech_leap_cube: cube position in the (world-fixed) grasp-site frame, cube orientation relative to the goal body's
+          const float* rf = gF + oRef;  // [p_ref(3), R_ref(9), q_ref(4)]
+          if (l < 3) y[16 + l] = rf[3 + l] * (qc[0] - rf[0]) + rf[6 + l] * (qc[1] - rf[1]) + rf[9 + l] * (qc[2] - rf[2]);
+          else {
+            const float a0 = rf[12], a1 = -rf[13], a2 = -rf[14], a3 = -rf[15], b0 = qc[3], b1 = qc[4], b2 = qc[5], b3 = qc[6];  // conj(q_ref) * q_cube
+            const float qo[4] = {a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3, a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2, a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1, a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0};
+            y[16 + l] = l == 3 ? qo[0] : (l == 4 ? qo[1] : (l == 5 ? qo[2] : qo[3]));
+          }
         }
       }
       // ================================================================ chain dynamics: inertia block, bias, smooth force
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       if constexpr (SELF) {  // bounding volume of the own link for the hand's self-collision
         const float* b8 = sBB + 8 * (1 + l); float cw[3]; mulMV(cw, Rw, b8);
         S.bs[1 + l][0] = cw[0] + pw[0]; S.bs[1 + l][1] = cw[1] + pw[1]; S.bs[1 + l][2] = cw[2] + pw[2]; S.bs[1 + l][3] = b8[3];
-        if (l < 4) S.bs[0][l] = sBB[l];
+        if (l < 4) { S.bs[0][l] = sBB[l]; for (int b = NMB; b < NBC; b++) S.bs[b][l] = sBB[8 * b + l]; }
       }
       for (int i = 0; i < lgm; i++) {
         int gid = sLaneG[l * lgm + i];
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           hit = dot3(d, d) <= rs * rs;
           if (hit) {  // the two bodies' bounding boxes (static geometry: axis-aligned in the world)
             const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            float Ra[9]; for (int k = 0; k < 9; k++) Ra[k] = ba == 0 ? I9[k] : S.xR[ba][k];
+            float Ra[9]; for (int k = 0; k < 9; k++) Ra[k] = static_code(ba) ? I9[k] : S.xR[ba][k];  // (side A is the static one of a pair, if any)
             hit = obb_face_overlap(sa, Ra, sBB + 8 * ba + 4, sb, S.xR[bb], sBB + 8 * bb + 4);
           }
         }
@@ -589,11 +602,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           const int g = isA ? ga0 + l : gb0 + (l - na), own = isA ? ba : bb, oth = isA ? bb : ba;
           const float* gf = sGeomF + g * GEOM_F;
           float cw[3];
-          if (own == 0) { cw[0] = gf[GF_POS]; cw[1] = gf[GF_POS + 1]; cw[2] = gf[GF_POS + 2]; }
+          if (static_code(own)) { cw[0] = gf[GF_POS]; cw[1] = gf[GF_POS + 1]; cw[2] = gf[GF_POS + 2]; }
           else { mulMV(cw, S.xR[own], gf + GF_POS); cw[0] += S.pa[own][0]; cw[1] += S.pa[own][1]; cw[2] += S.pa[own][2]; }
           const float dw[3] = {cw[0] - S.bs[oth][0], cw[1] - S.bs[oth][1], cw[2] - S.bs[oth][2]};
           float dl[3];
-          if (oth == 0) { dl[0] = dw[0]; dl[1] = dw[1]; dl[2] = dw[2]; } else mulMTV(dl, S.xR[oth], dw);
+          if (static_code(oth)) { dl[0] = dw[0]; dl[1] = dw[1]; dl[2] = dw[2]; } else mulMTV(dl, S.xR[oth], dw);
           const float* hb = sBB + 8 * oth + 4;
           const float ex = fmaxf(fabsf(dl[0]) - hb[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hb[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hb[2], 0.f);
           near = ex * ex + ey * ey + ez * ez <= gf[GF_RBOUND] * gf[GF_RBOUND];
@@ -608,14 +621,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           if (rem != 0 && l < nb && ((mB >> l) & 1u)) {
             const float* fa = sGeomF + ga * GEOM_F; const float* fb = sGeomF + gb * GEOM_F;
             float ca[3], cb[3];
-            if (ba == 0) { ca[0] = fa[GF_POS]; ca[1] = fa[GF_POS + 1]; ca[2] = fa[GF_POS + 2]; }
+            if (static_code(ba)) { ca[0] = fa[GF_POS]; ca[1] = fa[GF_POS + 1]; ca[2] = fa[GF_POS + 2]; }
             else { mulMV(ca, S.xR[ba], fa + GF_POS); ca[0] += S.pa[ba][0]; ca[1] += S.pa[ba][1]; ca[2] += S.pa[ba][2]; }
             mulMV(cb, S.xR[bb], fb + GF_POS); cb[0] += S.pa[bb][0]; cb[1] += S.pa[bb][1]; cb[2] += S.pa[bb][2];
             const float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]}, rs = fa[GF_RBOUND] + fb[GF_RBOUND];
             hit = dot3(d, d) <= rs * rs;
             if (hit) {  // the geoms' own boxes (a sphere counts as the cube around it)
               float RA[9], RB[9];
-              if (ba == 0) { for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; } else mulMM(RA, S.xR[ba], fa + GF_R);
+              if (static_code(ba)) { for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; } else mulMM(RA, S.xR[ba], fa + GF_R);
               mulMM(RB, S.xR[bb], fb + GF_R);
               const bool sphA = sGeomI[ga * GEOM_I + 1] != GBOX, sphB = sGeomI[gb * GEOM_I + 1] != GBOX;
               const float hA[3] = {fa[GF_SIZE], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 1], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 2]};
@@ -1281,7 +1294,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   if (stats && lane == 0 && live) { atomicAdd(stats + 20, n_wave_iters); atomicAdd(stats + 21, H); }
 }
 
-bool model_is_leap(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && m->ns == 31 && m->h_i.size() > 13 && m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG; }
+bool model_is_leap(const jh_model* m) {
+  return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && (m->ns == NS || (m->ns == NS_CALTECH && m->h_i.size() > 18 && m->h_i[18] > 0)) && m->h_i.size() > 17 &&
+         m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG && m->h_i[17] <= MAXBP;
+}
 
 }  // namespace
 

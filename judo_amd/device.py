@@ -48,7 +48,7 @@ class GpuModel:
         st = _lib.lib().jh_model_create(buf, len(blob), self.device.index or 0, C.byref(handle))
         _lib.check(st, "jh_model_create")
         self.handle = handle
-        self.self_collision = self.task.startswith("leap")  # library default: on where the kernel models it
+        self.self_collision = self.desc.get("family", self.task) == "leap_cube"  # library default: on where the kernel models it
 
     def set_kernel(self, generation: int) -> None:
         """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: leap_cube default; 2 = cooperative: fr3_pick default; 1 = one lane per rollout)."""
@@ -57,7 +57,7 @@ class GpuModel:
     def set_self_collision(self, on: bool) -> None:
         """leap_cube, kernel generation 3: model the hand's own contacts too (default) or the cube's alone."""
         _lib.check(_lib.lib().jh_model_set_self_collision(self.handle, int(bool(on))), "jh_model_set_self_collision")
-        self.self_collision = bool(on) and self.task.startswith("leap")
+        self.self_collision = bool(on) and self.desc.get("family", self.task) == "leap_cube"
 
     @property
     def max_fused_knots(self) -> int:

@@ -187,11 +187,36 @@ def fuse_fixed_bodies(desc: dict) -> dict:
         for g in coll:
             g["body"] = remap[g["body"]]
     for sn in d["sensors"]:
-        if sn["type"] in ("framepos", "framezaxis") and sn.get("objtype") == "body":
+        if sn["type"] in ("framepos", "framezaxis", "framequat") and sn.get("objtype") == "body":
             sn["obj"] = remap[sn["obj"]]
     d["excludes"] = [[remap[a], remap[c2]] for a, c2 in d["excludes"] if a != b and c2 != b]
     d.setdefault("fused", []).append(body["name"])
     return fuse_fixed_bodies(d)
+
+
+def sensor_reference_frames(desc: dict) -> list[float] | None:
+    """World pose of the (static) reference frames of `framepos ... reftype=site` / `framequat ... reftype=body` sensors, resolved on the description as
+    compiled (before static bodies are fused away): [p_ref(3), R_ref(9), q_ref(4)], or None when no sensor has a reference frame on the engine's models
+    (caltech_leap_cube: cube position in the frame of `grasp_site` on the hand mount, cube orientation relative to the mocap goal body at its model pose --
+    the pose every rollout thread's MjData starts with, judo/utils/mj_rollout_backend.py:38-43)."""
+    weld = lambda b: all(j["body"] != b for j in desc["joints"]) and (desc["bodies"][b]["parent"] < 0 or weld(desc["bodies"][b]["parent"]))  # noqa: E731
+    p_ref, R_ref, q_ref, found = np.zeros(3), np.eye(3), np.array([1.0, 0, 0, 0]), False
+    for sn in desc["sensors"]:
+        if sn["type"] == "framepos" and sn.get("reftype") == "site" and sn.get("objtype") == "body":
+            site = desc["sites"][sn["ref"]]
+            if not weld(site["body"]):
+                raise NotImplementedError("framepos relative to a moving site")
+            bp, bq = _static_world_pose(desc, site["body"])
+            p_ref = bp + quat_to_mat(bq) @ np.array(site["pos"])
+            R_ref = quat_to_mat(quat_mul(bq, site.get("quat", [1, 0, 0, 0])))
+            found = True
+        elif sn["type"] == "framequat":
+            if sn.get("reftype") == "body":
+                if not weld(sn["ref"]):
+                    raise NotImplementedError("framequat relative to a moving body")
+                q_ref = np.array(_static_world_pose(desc, sn["ref"])[1], dtype=np.float64)
+            found = True
+    return [*p_ref, *R_ref.reshape(-1), *q_ref] if found else None
 
 
 def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = None) -> list[tuple[int, int]]:
@@ -245,6 +270,7 @@ def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = No
 
 def pack_engine_model(desc: dict) -> bytes:
     orig = desc
+    ref_frames = sensor_reference_frames(orig)
     dofw_o, bodyw_o = inverse_weights(orig)
     desc = fuse_fixed_bodies(orig)
     st = engine_structure(desc)
@@ -365,12 +391,19 @@ def pack_engine_model(desc: dict) -> bytes:
     # ---- sites + sensors
     for s in sites:
         b = s["body"]
-        if st["is_static"][b]:
-            raise NotImplementedError("site on a static body")
+        if st["is_static"][b]:  # world-fixed site: body index -1, world position
+            bp, bq = _static_world_pose(desc, b)
+            I += [-1]
+            F += list(bp + quat_to_mat(bq) @ np.array(s["pos"]))
+            continue
         I += [midx[b]]
         F += list(s["pos"])
     for s in sens:
-        if s["type"] == "framepos" and s["objtype"] == "site":
+        if s["type"] == "framepos" and s.get("reftype") is not None and s["objtype"] == "body":
+            I += [6, midx[s["obj"]], s["adr"]]  # body position in the static reference frame (tail block I[18])
+        elif s["type"] == "framequat":
+            I += [7, midx[s["obj"]], s["adr"]]  # body orientation relative to the static reference quaternion
+        elif s["type"] == "framepos" and s["objtype"] == "site":
             I += [0, s["obj"], s["adr"]]
         elif s["type"] == "framepos":
             I += [1, midx[s["obj"]], s["adr"]]
@@ -402,34 +435,58 @@ def pack_engine_model(desc: dict) -> bytes:
         oidx = {id(g): i for i, g in enumerate(others)}
         og = [g for g in desc["geoms"] if g["type"] in ("box", "sphere")]
         hh = [(a, b) for a, b in generic_pairs(orig, dict(desc, geoms=og), st, cube_only=False) if st["free"] not in (og[a]["body"], og[b]["body"])]
-        code = lambda g: 0 if st["is_static"][g["body"]] else midx[g["body"]]  # noqa: E731   0 = static, 1..16 = finger links
+        # hand "bodies" of the self-collision tables: 1..16 = finger links; the static geometry is one body (0) when all of it collides with the same links
+        # (leap_cube: the palm), else one body per set of static geoms with the same partners (caltech_leap_cube: floor + hand mount, palm): 0, 17, 18, 19
+        link_code = lambda g: midx[g["body"]]  # noqa: E731
+        partners: dict[int, set] = {}
+        for a, b in hh:
+            for x, y in ((og[a], og[b]), (og[b], og[a])):
+                if st["is_static"][x["body"]] and not st["is_static"][y["body"]]:
+                    partners.setdefault(x["body"], set()).add(link_code(y))
+        sgroups: list[frozenset] = []
+        for g in others:
+            if st["is_static"][g["body"]]:
+                key = frozenset(partners.get(g["body"], ()))
+                if key not in sgroups:
+                    sgroups.append(key)
+        if len(sgroups) > 4:
+            raise NotImplementedError("more than four groups of static collision geometry")
+        SCODES = [0, 17, 18, 19]
+        NBC = 20  # body codes in the image (jh_engine_v5.hip NBC)
+        code = lambda g: SCODES[sgroups.index(frozenset(partners.get(g["body"], ())))] if st["is_static"][g["body"]] else link_code(g)  # noqa: E731
+        is_static_code = lambda c: c == 0 or c > 16  # noqa: E731
         groups: dict[tuple[int, int], list[tuple[int, int]]] = {}
         for a, b in hh:
             ga, gb = og[a], og[b]
-            if code(ga) > code(gb):
+            if is_static_code(code(gb)) or (not is_static_code(code(ga)) and code(ga) > code(gb)):  # side A: static geometry, else the lower link
                 ga, gb = gb, ga
+            if is_static_code(code(gb)):
+                continue  # (static against static never collides)
             groups.setdefault((code(ga), code(gb)), []).append((oidx[id(ga)], oidx[id(gb)]))
         # MuJoCo's static filters act on bodies and every collision geom of the hand has the same contype / conaffinity: a surviving body pair collides
         # all of A's geoms with all of B's, and the geoms of a body are contiguous in `others` -> the image carries the body pairs and one
         # (first geom, count) range per body, no geom-pair table
         rng = {}
-        for c in range(17):
+        for c in range(NBC):
             idxs = [i for i, g in enumerate(others) if code(g) == c]
-            assert idxs == list(range(idxs[0], idxs[0] + len(idxs))), "geoms of a body must be contiguous"
-            rng[c] = (idxs[0], len(idxs))
+            assert not idxs or idxs == list(range(idxs[0], idxs[0] + len(idxs))), "geoms of a body must be contiguous"
+            rng[c] = (idxs[0], len(idxs)) if idxs else (0, 0)
         for (ca, cb), lst in groups.items():
             assert len(lst) == rng[ca][1] * rng[cb][1] and rng[ca][1] + rng[cb][1] <= 16, (ca, cb, len(lst))
         I[15], I[17] = len(I), len(groups)
         for (ca, cb) in groups:
             I += [ca, cb]
-        for c in range(17):
+        for c in range(NBC):
             I += list(rng[c])
         I[16] = len(F)
-        for c in range(17):  # per hand body (0 = all static geometry, in world coordinates): bounding sphere and bounding box of its collision geoms, body frame
+        for c in range(NBC):  # per hand body (static geometry: in world coordinates): bounding sphere and bounding box of its collision geoms, body frame
             gs = [g for g in others if code(g) == c]
+            if not gs:
+                F += [0.0] * 8
+                continue
             corners = []
             for g in gs:
-                if c == 0:
+                if is_static_code(c):
                     bpos, bquat = _static_world_pose(desc, g["body"])
                     gp, gR = bpos + quat_to_mat(bquat) @ np.array(g["pos"]), quat_to_mat(quat_mul(bquat, g["quat"]))
                 else:
@@ -448,7 +505,13 @@ def pack_engine_model(desc: dict) -> bytes:
     allg = [g for g in desc["geoms"] if g["type"] in ("box", "sphere")]
     gidx = {id(g): i for i, g in enumerate(allg)}
     pairs_all = generic_pairs(orig, dict(desc, geoms=allg), st)
-    frames = [dict(body=midx[sx["body"]], pos=sx["pos"], quat=sx.get("quat", [1, 0, 0, 0])) for sx in sites]
+    frames = []
+    for sx in sites:
+        if st["is_static"][sx["body"]]:  # world-fixed frame
+            bp, bq = _static_world_pose(desc, sx["body"])
+            frames.append(dict(body=-1, pos=list(bp + quat_to_mat(bq) @ np.array(sx["pos"])), quat=list(quat_mul(bq, sx.get("quat", [1, 0, 0, 0])))))
+        else:
+            frames.append(dict(body=midx[sx["body"]], pos=sx["pos"], quat=sx.get("quat", [1, 0, 0, 0])))
     dists = [sx for sx in sens if sx["type"] == "distance"]
     eqs = desc["equalities"]
     I[13], I[14] = len(I), len(F)
@@ -495,7 +558,11 @@ def pack_engine_model(desc: dict) -> bytes:
         F += [sx["cutoff"]]
     idist = 0
     for sx in sens:  # generic sensor table: (type, object, aux, address)
-        if sx["type"] == "framepos" and sx.get("objtype") == "site":
+        if sx["type"] == "framepos" and sx.get("reftype") is not None and sx["objtype"] == "body":
+            I += [6, midx[sx["obj"]], 0, sx["adr"]]
+        elif sx["type"] == "framequat":
+            I += [7, midx[sx["obj"]], 0, sx["adr"]]
+        elif sx["type"] == "framepos" and sx.get("objtype") == "site":
             I += [0, sx["obj"], 0, sx["adr"]]
         elif sx["type"] == "framepos":
             I += [1, midx[sx["obj"]], 0, sx["adr"]]
@@ -509,6 +576,9 @@ def pack_engine_model(desc: dict) -> bytes:
             I += [4, idist, 0, sx["adr"]]
             idist += 1
     I += glists
+    if ref_frames is not None:  # reference frames of the sensors (jh_engine_v5.hip, caltech_leap_cube layout)
+        I[18] = len(F)
+        F += ref_frames
     ntp = 9 if desc.get("family", desc["task"]) == "leap_cube" else 22
     return _pack(TASK_KIND[desc.get("family", desc["task"])], lay, ntp, F, I)
 

@@ -298,6 +298,36 @@ class LeapCubeDown(LeapCube):
         return np.concatenate([LEAP_DOWN_QPOS_HOME, np.zeros(22)])
 
 
+CALTECH_LEAP_QPOS_HOME = np.array(
+    [0.11, 0.005, 0.04, 1.0, 0.0, 0.0, 0.0, 0.5, -0.75, 0.75, 0.25, 0.5, 0.0, 0.75, 0.25, 0.5, 0.75, 0.75, 0.25, 0.65, 0.9, 0.75, 0.6]
+)  # judo/tasks/caltech_leap_cube.py:13-21
+
+
+@dataclass
+class CaltechLeapCubeConfig(LeapCubeConfig):
+    pass
+
+
+class CaltechLeapCube(LeapCube):
+    """The Caltech LEAP hand (judo/tasks/caltech_leap_cube.py:31-51): the same 16-joint hand built from primitive geoms, palm up at the origin, cone
+    `impratio` 1, the cube above the grasp site; sensordata is the 16 joint positions, the cube position in the grasp-site frame and the cube
+    orientation relative to the goal body.  Runs on the leap_cube kernels (generation 3) with its own model constants."""
+
+    name = "caltech_leap_cube"
+    config_t = CaltechLeapCubeConfig
+
+    def __init__(self) -> None:
+        Task.__init__(self)
+        self.goal_pos = np.array([0.11, 0.005, 0.03])
+        self.goal_quat = np.array([1.0, 0.0, 0.0, 0.0])
+        self.qpos_home = CALTECH_LEAP_QPOS_HOME
+        self.reset_command = CALTECH_LEAP_QPOS_HOME[7:].copy()
+        self.reset()
+
+    def default_state(self) -> np.ndarray:
+        return np.concatenate([CALTECH_LEAP_QPOS_HOME, np.zeros(22)])
+
+
 # ------------------------------------------------------------------------------------------------ fr3_pick
 FR3_QPOS_HOME = np.array([0.7, 0, 0.02, 1, 0, 0, 0, 0, -0.7854, 0.0, -2.3562, 0.0, 1.5708, 0.7854, 0.04, 0.04])  # fr3_pick.py:16-22
 
@@ -403,6 +433,7 @@ _registered_tasks: dict[str, tuple[type, type]] = {
     CylinderPush.name: (CylinderPush, CylinderPushConfig),
     LeapCube.name: (LeapCube, LeapCubeConfig),
     LeapCubeDown.name: (LeapCubeDown, LeapCubeDownConfig),
+    CaltechLeapCube.name: (CaltechLeapCube, CaltechLeapCubeConfig),
     FR3Pick.name: (FR3Pick, FR3PickConfig),
 }
 

@@ -150,7 +150,7 @@ int jo_add_actuator(jo_model* m, int joint, double kp, double kv, int ctrllimite
 int jo_add_sensor(jo_model* m, int type, int obj, int obj2, double cutoff) {
   if (m->nsensor >= JO_MAXSENSOR) return -1;
   int s = m->nsensor++;
-  int dim = (type == JO_SENS_JOINTPOS || type == JO_SENS_DISTANCE) ? 1 : 3;
+  int dim = (type == JO_SENS_JOINTPOS || type == JO_SENS_DISTANCE) ? 1 : (type == JO_SENS_FRAMEQUAT_BODY ? 4 : 3);
   if (m->nsensordata + dim > JO_MAXSENSORDATA) return -1;
   m->sensor_type[s] = type; m->sensor_obj[s] = obj; m->sensor_obj2[s] = obj2; m->sensor_cutoff[s] = cutoff; m->sensor_adr[s] = m->nsensordata;
   m->nsensordata += dim;
@@ -920,7 +920,18 @@ static void sensors(const jo_model* m, jo_data* d) {
       case JO_SENS_FRAMEXAXIS_SITE: col(o, d->xmat[m->site_body[obj]], 0); break;
       case JO_SENS_FRAMEYAXIS_SITE: col(o, d->xmat[m->site_body[obj]], 1); break;
       case JO_SENS_FRAMEZAXIS_SITE: col(o, d->xmat[m->site_body[obj]], 2); break;
-      case JO_SENS_FRAMEPOS_BODY: copy3(o, d->xpos[obj]); break;
+      case JO_SENS_FRAMEPOS_BODY: /* obj2 >= 0: in the frame of that reference site, as above */
+        copy3(o, d->xpos[obj]);
+        if (m->sensor_obj2[s] >= 0) {
+          int rs = m->sensor_obj2[s]; const double* R = d->xmat[m->site_body[rs]];
+          double dv[3] = {o[0] - d->site_xpos[rs][0], o[1] - d->site_xpos[rs][1], o[2] - d->site_xpos[rs][2]};
+          for (int k = 0; k < 3; k++) o[k] = R[k] * dv[0] + R[3 + k] * dv[1] + R[6 + k] * dv[2];
+        }
+        break;
+      case JO_SENS_FRAMEQUAT_BODY: {
+        if (m->sensor_obj2[s] >= 0) { const double* qr = d->xquat[m->sensor_obj2[s]]; double qc[4] = {qr[0], -qr[1], -qr[2], -qr[3]}; quat_mul(o, qc, d->xquat[obj]); }
+        else memcpy(o, d->xquat[obj], 4 * sizeof(double));
+      } break;
       case JO_SENS_JOINTPOS: o[0] = d->qpos[m->jnt_qposadr[obj]]; break;
       case JO_SENS_FRAMEZAXIS_BODY: col(o, d->xmat[obj], 2); break;
       case JO_SENS_DISTANCE: { /* min over the box geoms of body obj and body obj2, clipped at the cutoff */

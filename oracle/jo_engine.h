@@ -53,7 +53,8 @@ enum { JO_GEOM_PLANE = 0, JO_GEOM_SPHERE = 2, JO_GEOM_CAPSULE = 3, JO_GEOM_CYLIN
 enum { JO_INT_EULER = 0, JO_INT_IMPLICITFAST = 3 };
 enum { JO_CONE_PYRAMIDAL = 0, JO_CONE_ELLIPTIC = 1 };
 enum { JO_SENS_FRAMEPOS_SITE = 0, JO_SENS_FRAMEPOS_BODY = 1, JO_SENS_JOINTPOS = 2, JO_SENS_FRAMEZAXIS_BODY = 3, JO_SENS_DISTANCE = 4,
-       JO_SENS_FRAMEXAXIS_SITE = 5, JO_SENS_FRAMEYAXIS_SITE = 6, JO_SENS_FRAMEZAXIS_SITE = 7 }; /* site axes: sites carry no rotation of their own here (identity site quat) */
+       JO_SENS_FRAMEXAXIS_SITE = 5, JO_SENS_FRAMEYAXIS_SITE = 6, JO_SENS_FRAMEZAXIS_SITE = 7,
+       JO_SENS_FRAMEQUAT_BODY = 8 /* orientation of body obj relative to body obj2 (or the world): conj(q_ref) * q_obj, mj_sensorPos mjSENS_FRAMEQUAT */ }; /* site axes: sites carry no rotation of their own here (identity site quat) */
 enum { JO_EFC_EQUALITY = 0, JO_EFC_FRICTION = 1, JO_EFC_LIMIT = 2, JO_EFC_CONTACT_FRICTIONLESS = 3, JO_EFC_CONTACT_PYRAMIDAL = 4, JO_EFC_CONTACT_ELLIPTIC = 5 };
 
 typedef struct jo_model {

@@ -25,7 +25,7 @@ _LIB = None
 
 JNT = {"free": 0, "slide": 2, "hinge": 3}
 GEOM = {"plane": 0, "sphere": 2, "capsule": 3, "cylinder": 5, "box": 6}
-SENS = {"framepos_site": 0, "framepos_body": 1, "jointpos": 2, "framezaxis_body": 3, "distance": 4, "framexaxis_site": 5, "frameyaxis_site": 6, "framezaxis_site": 7}
+SENS = {"framepos_site": 0, "framepos_body": 1, "jointpos": 2, "framezaxis_body": 3, "distance": 4, "framexaxis_site": 5, "frameyaxis_site": 6, "framezaxis_site": 7, "framequat_body": 8}
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
@@ -180,12 +180,15 @@ class Model:
             if s["type"] == "framepos":
                 ref = -1
                 if s.get("reftype") is not None:  # position in the frame of a reference site
-                    assert s["objtype"] == "site" and s["reftype"] == "site" and list(d["sites"][s["ref"]]["quat"]) == [1.0, 0.0, 0.0, 0.0]
+                    assert s["reftype"] == "site" and list(d["sites"][s["ref"]]["quat"]) == [1.0, 0.0, 0.0, 0.0]
                     ref = s["ref"]
                 r = L.jo_add_sensor(self.ptr, SENS["framepos_site" if s["objtype"] == "site" else "framepos_body"], s["obj"], ref, 0.0)
             elif s["type"] in ("framexaxis", "frameyaxis", "framezaxis") and s.get("objtype") == "site":
                 assert list(d["sites"][s["obj"]]["quat"]) == [1.0, 0.0, 0.0, 0.0] and s.get("reftype") is None
                 r = L.jo_add_sensor(self.ptr, SENS[s["type"] + "_site"], s["obj"], -1, 0.0)
+            elif s["type"] == "framequat":
+                assert s["objtype"] == "body" and s.get("reftype") in (None, "body")
+                r = L.jo_add_sensor(self.ptr, SENS["framequat_body"], s["obj"], s["ref"] if s.get("reftype") else -1, 0.0)
             elif s["type"] == "jointpos":
                 r = L.jo_add_sensor(self.ptr, SENS["jointpos"], s["obj"], -1, 0.0)
             elif s["type"] == "framezaxis":

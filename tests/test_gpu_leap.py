@@ -235,3 +235,51 @@ def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):
     assert ctrl.optimizer.config.num_rollouts == 64 and ctrl.task.config.w_rot == 0.05
     ctrl.update_action()
     assert np.isfinite(ctrl.nominal_knots).all()
+
+
+def test_caltech_leap_cube_runs_on_the_leap_kernel(gpu):
+    """caltech_leap_cube (judo/tasks/caltech_leap_cube.py, judo/models/xml/caltech_leap_cube.xml): the hand built from primitive geoms, cone impratio 1, a
+    box floor, static geometry with two different exclude sets (floor + mount, palm), 23 sensor values (joint positions, cube position in the grasp-site
+    frame, cube orientation relative to the goal body).  States and sensors of the default kernel against the oracle, with and without the hand's own
+    contacts; the older kernel generations refuse the model."""
+    from judo_amd.controller import make_controller
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.tasks import CaltechLeapCube
+    from oracle import oracle as O
+
+    t = CaltechLeapCube()
+    assert t.nsensordata == 23 and t.nu == 16
+    rng = np.random.default_rng(4)
+    N, H = 64, 48
+    U = t.reset_command[None, None] + 0.4 * np.repeat(rng.standard_normal((N, 4, 16)), H // 4, axis=1)
+    x0 = t.default_state()
+    for scope, self_on in (("all", True), ("cube", False)):
+        om = O.Model("caltech_leap_cube", scope=scope)
+        rs, rsens = om.rollout(x0, U)
+        be = GpuRolloutBackend(t.gpu_model(), N)
+        be.model.set_self_collision(self_on)
+        gs, gsens, _ = be.rollout(x0, U)
+        assert gsens.shape == (N, H, 23)
+        e = np.abs(gs - rs)
+        assert np.median(e) < 1e-5 and np.percentile(e[:, -1, :3], 90) < 5e-3, (scope, np.median(e), np.percentile(e[:, -1, :3], 90))
+        np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=1e-4)  # all 23 sensor values of the first steps
+        es = np.abs(gsens - rsens)
+        assert np.median(es) < 1e-5 and np.percentile(es[:, -1, 16:19], 90) < 5e-3
+        # sensor values are consistent with the states of the same forward pass: y[16:19] = cube position - grasp site, y[19:23] = cube quaternion (goal at identity)
+        np.testing.assert_allclose(gsens[:, 1:, 16:19], gs[:, :-1, 0:3] - np.array([0.11, 0.005, 0.03]), atol=2e-6)
+        np.testing.assert_allclose(gsens[:, 1:, 19:23], gs[:, :-1, 3:7], atol=2e-6)
+    st = be.model.stats()
+    assert st["contact_overflow"] == 0
+    be.model.set_self_collision(True)
+    for gen in (2, 1):
+        b2 = GpuRolloutBackend(t.gpu_model(), N)
+        b2.model.set_kernel(gen)
+        with pytest.raises(RuntimeError):
+            b2.rollout(x0, U)
+        b2.model.set_kernel(3)
+    ctrl = make_controller("caltech_leap_cube", "mppi")
+    assert ctrl.optimizer.config.num_rollouts == 32 and ctrl.controller_cfg.spline_order == "cubic"
+    for _ in range(2):
+        ctrl.update_action()
+    assert np.isfinite(ctrl.nominal_knots).all()
+    assert ctrl.traces is None or ctrl.traces.size == 0  # no sensor is named trace*: nothing to draw (judo/controller/controller.py:96-101)

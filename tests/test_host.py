@@ -437,3 +437,34 @@ def test_tree_create_rejects_images_outside_the_kernel_instantiation():
     wrong = bytes(blob[: 16 + 4 * nf]) + ints.tobytes()
     rc, msg = create(wrong)
     assert rc < 0 and "chain" in msg
+
+
+def test_caltech_leap_cube_model_and_oracle_sensors():
+    """caltech_leap_cube: the packed image carries the reference frames of its two frame sensors and four groups of hand bodies for the
+    self-collision tables; the oracle evaluates `framepos reftype=site` and `framequat reftype=body` as mj_sensorPos does."""
+    import struct
+
+    from judo_amd.models import load_description, pack_model
+    from judo_amd.tasks import CaltechLeapCube, get_registered_tasks
+    from oracle import oracle as O
+
+    assert "caltech_leap_cube" in get_registered_tasks()
+    d = load_description("caltech_leap_cube")
+    assert d["option"]["impratio"] == 1.0 and d["nsensordata"] == 23 and sum(g["type"] == "sphere" for g in d["geoms"]) == 8
+    b = pack_model(d)
+    h = struct.unpack("<16I", b[:64])
+    nf, ni = h[8], h[9]
+    F = np.frombuffer(b[64 : 64 + 4 * nf], dtype=np.float32)
+    I = np.frombuffer(b[64 + 4 * nf : 64 + 4 * (nf + ni)], dtype=np.int32)
+    assert h[6] == 23 and I[7] == 23 and 0 < I[17] <= 128 and I[18] > 0
+    np.testing.assert_allclose(F[I[18] : I[18] + 16], [0.11, 0.005, 0.03, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0], atol=1e-7)  # grasp site, goal body
+    om = O.Model("caltech_leap_cube")
+    t = CaltechLeapCube()
+    x = t.default_state()
+    q = np.array([0.5, 0.5, -0.5, 0.5])
+    x[3:7] = q
+    x[0:3] = [0.13, -0.02, 0.08]
+    y = om.forward(x[:23], x[23:], np.zeros(16))["sensordata"]
+    np.testing.assert_allclose(y[:16], x[7:23], atol=1e-12)
+    np.testing.assert_allclose(y[16:19], x[0:3] - np.array([0.11, 0.005, 0.03]), atol=1e-12)
+    np.testing.assert_allclose(y[19:23], q, atol=1e-12)
