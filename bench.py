@@ -217,6 +217,7 @@ def main() -> None:
     ap.add_argument("--horizon-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
+    ap.add_argument("--settle", type=float, default=0.4, help="seconds of untimed plan steps on a throw-away plan before the W warm-up steps (runtime one-offs)")
     ap.add_argument("--no-cube-only", action="store_true", help="leap_cube: skip the extra cube-contacts-only steps run after the timed region")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
@@ -272,12 +273,21 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
+    ctrl.record_kernel_events = True  # (already during the warm-up: the first timed HIP event costs ~40 ms of one-off initialisation)
+    # settle: some 0.1 s into a process's first GPU work the ROCm runtime spends one ~35 ms stall (seen in about half of the runs, at a random early plan step);
+    # plan steps on a throw-away plan until --settle seconds have passed keep it out of the W + K steps, which then start from the initial state again
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        ctrl.update_action()
+    torch.cuda.synchronize()
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.optimizer.seed(1234)
     t_plan = 0.0
     for _ in range(args.warmup):
         ctrl.time = t_plan
         ctrl.update_action()
         t_plan += 1.0 / ctrl.controller_cfg.control_freq
-    ctrl.record_kernel_events = True
     ctrl.kernel_events.clear()
     ctrl.solver_warnings = False
     if not is_policy:
@@ -309,23 +319,27 @@ def main() -> None:
             if st.get("wave_steps"):
                 solver["wave_newton_iters_per_step"] = st["wave_newton_iters"] / st["wave_steps"]
                 solver["lock_step_inflation"] = solver["wave_newton_iters_per_step"] / max(solver["newton_iters_per_step"], 1e-9)
-    # leap_cube: the same loop continued with the hand's own contacts switched off (the model round 1 measured), outside the timed region
+    # leap_cube: the same measurement restarted with the hand's own contacts switched off (the model round 1 measured), outside the timed region
     cube_only = None
     if args.task == "leap_cube" and world == 1 and ctrl.model is not None and ctrl.model.self_collision and not args.no_cube_only:
         ctrl.model.set_self_collision(False)
-        ctrl.kernel_events.clear()
-        n_extra = min(args.steps, 10)
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        for _ in range(n_extra):
-            ctrl.time = t_plan
+        ctrl.reset()
+        ctrl.current_state = ctrl.task.default_state()
+        ctrl.optimizer.seed(1234)
+        n_extra, tq = min(args.steps, 10), 0.0
+        for i in range(args.warmup + n_extra):
+            if i == args.warmup:
+                ctrl.kernel_events.clear()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+            ctrl.time = tq
             ctrl.update_action()
-            t_plan += 1.0 / ctrl.controller_cfg.control_freq
+            tq += 1.0 / ctrl.controller_cfg.control_freq
         torch.cuda.synchronize()
         tc = (time.perf_counter() - tc) / n_extra
-        cube_only = {"ms_per_step": tc * 1e3, "rollouts_per_s": N / tc, "steps": n_extra,
+        cube_only = {"ms_per_step": tc * 1e3, "rollouts_per_s": N / tc, "steps": n_extra, "warmup": args.warmup,
                      "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])),
-                     "note": "hand self-collision off (cube contacts only): the model of round 1's 81.8 ms line; continues the plan of the timed steps"}
+                     "note": "hand self-collision off (the cube's contacts only): the model of round 1's 81.8 ms line, restarted from the same state and seed"}
         ctrl.model.set_self_collision(True)
     n_local = ctrl.last_shard.count
     substeps = ctrl.task.physics_substeps
@@ -348,6 +362,8 @@ def main() -> None:
 
     if rank == 0:
         ms = np.array(per_step) * 1e3
+        if os.environ.get("JUDO_BENCH_STEPS"):
+            print("plan steps [ms]: " + " ".join(f"{x:.2f}" for x in ms), file=sys.stderr)
         line = {
             "metric": "rollouts/sec + plan-step ms, leap_cube MPPI 65536xH64" if args.task == "leap_cube" else f"rollouts/sec + plan-step ms, {args.task}",
             "value": N * args.steps / elapsed,

@@ -1,6 +1,7 @@
 // jh_engine.hip -- generic articulated-body rollout engine, ONE LANE PER ROLLOUT (reference kernel): leap_cube and fr3_pick, gfx950.
-// (leap_cube's production kernel is the cooperative jh_engine_v2.hip; this one is model-generic: explicit geom pairs with
-// arbitrary sides, pyramidal or elliptic cones, joint equalities, geom-distance sensors.)
+// This is the CROSS-CHECK implementation (jh_model_set_kernel(m, 1)), not a production path: leap_cube runs on the cooperative jh_engine_v5.hip (generation 3;
+// jh_engine_v2.hip is generation 2), fr3_pick on jh_engine_v3.hip.  It is model-generic -- explicit geom pairs with arbitrary sides, pyramidal or elliptic cones,
+// joint equalities, geom-distance sensors -- and leap_cube's contacts here are the cube's only (no hand self-collision).
 //
 // One lane owns one rollout.  Per step (MuJoCo's pipeline, restated -- see oracle/jo_engine.c for the fp64 checker and
 // DESIGN.md section 5 for the derivation):

@@ -1,6 +1,6 @@
 """GPU parity tests of the articulated-body engine (leap_cube) against the fp64 oracle, through the C ABI.
 
-Contact dynamics are chaotic and the solver runs in fp32 (Hessian in fp64), so trajectory-level agreement is stated as
+Contact dynamics are chaotic and the solvers run in fp32 (only the one-lane cross-check kernel, generation 1, keeps its Hessian in fp64), so trajectory-level agreement is stated as
 distribution tolerances (median / percentile / rank) plus hard per-step tolerances; every tolerance is an fp32 tolerance
 against the build's own fp64 restatement of MuJoCo's algorithm (parity at the MuJoCo boundary itself is unpinned)."""
 

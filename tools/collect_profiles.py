@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copy what tools/profile_round2.sh left under gpurun_out/prof_<tag>/ into profiles/<tag>_* (tracked) and derive profiles/<tag>_traffic.json
+(HBM bytes per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes) which bench.py reports as roofline.traffic.
+usage: tools/collect_profiles.py <tag>"""
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+traffic = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --task <task> --steps 5 --warmup 3 "
+                     "--no-cpu-baseline --no-cube-only` (tools/profile_round2.sh; summaries in profiles/%s_<case>_rocprofv3_summary.txt).  Counter unit = KB "
+                     "(calibrated in round 1 on torch.randn's 16 MiB write: WRITE_SIZE = 16384.0); the guide's x2 FETCH_SIZE correction applies to 16 B/lane "
+                     "streams and is NOT applied (4 B/lane accesses).  Almost all of it is register spill traffic (scratch), not rollout data." % tag}
+for name in sorted(os.listdir(src)):
+    p = os.path.join(src, name)
+    if name.endswith("_summary.txt"):
+        case = name[: -len("_summary.txt")]
+        shutil.copy(p, os.path.join(dst, f"{tag}_{case}_rocprofv3_summary.txt"))
+        txt = open(p).read()
+        vals = {}
+        for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+            m = re.search(r"^(\S.*?)\s+" + cn + r"\s+(\d+)\s+([\d.]+)\s", txt, re.M)
+            if m:
+                vals[cn], kern = float(m.group(3)), m.group(1)
+        ms = re.findall(r"mean of the last 20: ([\d.]+) us", txt)
+        if vals:
+            traffic[case] = {"kernel": re.sub(r"\(float const\*.*", "", kern).strip(), "kernel_ms_default_bench_last20": float(ms[-1]) / 1e3 if ms else None,
+                             "FETCH_SIZE_KB_per_launch": vals.get("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": vals.get("WRITE_SIZE"),
+                             "hbm_bytes_per_launch": int(1024 * (vals.get("FETCH_SIZE", 0) + vals.get("WRITE_SIZE", 0)))}
+    elif name.endswith("_bench_under_rocprof.json") or (name.startswith("bench_") and name.endswith(".json")):
+        lines = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_{name}"), "w").write(lines[-1] + "\n")
+json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in traffic.items() if k != "method"}, indent=1))
+sweep = os.path.join(ROOT, "gpurun_out", "sweep", "sweep.txt")
+if os.path.exists(sweep):
+    shutil.copy(sweep, os.path.join(dst, f"{tag}_tolerance_sweep.txt"))
