@@ -169,7 +169,7 @@ def materialize_line(args, torch, world: int, rank: int) -> None:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if SHARED_GPU_TEST else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = ev0.elapsed_time(ev1) / args.steps
@@ -188,13 +188,18 @@ def materialize_line(args, torch, world: int, rank: int) -> None:
         torch.distributed.destroy_process_group()
 
 
+# Test hook (tests/test_gpu_nccl.py on a one-GPU box): all ranks share cuda:0 and rendezvous over gloo; everything else -- the launcher, the rank environment, the
+# shard-local kernels, the per-rank record exchange, barrier + max-over-ranks timing, rank 0's line -- is the code the multi-GPU run executes.
+SHARED_GPU_TEST = os.environ.get("JUDO_BENCH_SHARED_GPU") == "1"
+
+
 def launch_ranks(n: int, n_devices: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this script as N ranks, one per GPU, over RCCL
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`).  Returns the exit status."""
     import socket
     import subprocess
 
-    if n_devices < n:
+    if n_devices < n and not SHARED_GPU_TEST:
         print(f"bench.py: --gpus {n} but only {n_devices} GPU(s) are visible; refusing to run a smaller job under that label", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -236,13 +241,18 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, torch.cuda.device_count()))
+    if SHARED_GPU_TEST:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if SHARED_GPU_TEST:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if args.mode == "materialize":
         return materialize_line(args, torch, world, rank)
@@ -276,10 +286,20 @@ def main() -> None:
     ctrl.record_kernel_events = True  # (already during the warm-up: the first timed HIP event costs ~40 ms of one-off initialisation)
     # settle: some 0.1 s into a process's first GPU work the ROCm runtime spends one ~35 ms stall (seen in about half of the runs, at a random early plan step);
     # plan steps on a throw-away plan until --settle seconds have passed keep it out of the W + K steps, which then start from the initial state again
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle:
+    if args.settle > 0:
+        ctrl.update_action()  # (one-off initialisation)
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter()
         ctrl.update_action()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        n_settle = int(min(2000, max(0, np.ceil(args.settle / max(time.perf_counter() - t_settle, 1e-5)) - 1)))
+        if world > 1:  # every plan step is a collective: all ranks must run the same number of them
+            t = torch.tensor([n_settle], dtype=torch.int64, device="cpu" if SHARED_GPU_TEST else "cuda")
+            dist.broadcast(t, 0)
+            n_settle = int(t.item())
+        for _ in range(n_settle):
+            ctrl.update_action()
+        torch.cuda.synchronize()
     ctrl.reset()
     ctrl.current_state = ctrl.task.default_state()
     ctrl.optimizer.seed(1234)
@@ -306,7 +326,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if SHARED_GPU_TEST else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])) if ctrl.kernel_events else float("nan")

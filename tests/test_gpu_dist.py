@@ -77,3 +77,27 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
         # vs one process only the reduction is regrouped (two block records instead of one): fp32 summation order in the MPPI average
         np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=5e-6 if opt == "mppi" else 0)
         np.testing.assert_allclose(r0["sig"], sig1, rtol=1e-6, atol=1e-7)
+
+
+def test_bench_two_ranks_sharing_the_gpu(gpu):
+    """`python bench.py --gpus 2` end to end on a one-GPU box: the launcher spawns two ranks (test hook: both on cuda:0, gloo rendezvous), the settle / warm-up /
+    timed steps run the same number of collectives on both, rank 0 prints one contract line for the two-rank job whose plan matches the one-rank run's."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JUDO_BENCH_SHARED_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--task", "leap_cube", "--rollouts", "1024", "--horizon-steps", "8", "--steps", "3", "--warmup", "1",
+               "--settle", "0.05", "--no-cpu-baseline", "--no-cube-only"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1, r.stdout[-2000:]
+        lines[n] = json.loads(js[0])
+    assert lines[2]["n_gpus"] == 2 and lines[1]["n_gpus"] == 1 and lines[2]["steps"] == 3 and lines[2]["value"] > 0
+    assert lines[2]["config"]["parallelism"] == "rollout-shard x2" and lines[2]["config"]["rollouts"] == 1024
+    assert "cpu_baseline" not in lines[2] and "roofline" in lines[2]
