@@ -43,6 +43,9 @@ constexpr int NCH = 4, NLK = 4;
 // every Newton iteration: otherwise the slots' Jacobian columns, lever arms and LDS addresses (all invariant over the iterations) are computed once before
 // the loop, do not fit in the register file and are spilled and reloaded in every iteration.
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef JH_V5_PARK
+#define JH_V5_PARK 1
+#endif
 #ifndef JH_V5_OPAQUE_LANE
 #define JH_V5_OPAQUE_LANE 1
 #endif
@@ -79,10 +82,17 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
   float Mbb[NCH][10];
   float rhs6[6];
-  float bs[NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
-                      // bounding box's too; its half sizes and axes come from the model image and the body rotation)
-  int hits[MAXHIT];
-  int bpl[MAXBPL];
+  union {
+    struct {
+      float bs[NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
+                          // bounding box's too; its half sizes and axes come from the model image and the body rotation)
+      int hits[MAXHIT];
+      int bpl[MAXBPL];
+    };
+    // the collision arrays are dead from the constraint rows on: the step-level state the Newton loop does not touch is parked here instead of being held in
+    // registers (or spilled to scratch memory by the compiler) across the loop.  The joint velocity and the cube's velocity are in qv already.
+    struct { float pk_q[G], pk_fs[G], pk_cq[4], pk_acc; };
+  };
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
     float pool[NCP][POOL_F];
     struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[6][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[pidx(a,b)][ib*4+ia]: block (chain b, chain a)
@@ -752,6 +762,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
 #endif
     }
+#if JH_V5_PARK
+    S.pk_q[l] = q; S.pk_fs[l] = fs_own;
+    if (l == 0) { S.pk_cq[0] = qc[3]; S.pk_cq[1] = qc[4]; S.pk_cq[2] = qc[5]; S.pk_cq[3] = qc[6]; S.pk_acc = acc; }
+#endif
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     float a_own, ac_own;
     const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
@@ -1243,6 +1257,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
       S.ws[6 + l] = a_own; if (l < 6) { S.ws[l] = ac_own; S.acn[l] = ac_own; }
+#if JH_V5_PARK
+      q = S.pk_q[l]; qd = S.qv[6 + l]; fs_own = S.pk_fs[l];  // (own entries: no other lane wrote them)
+#endif
       const float da_own = a_own - a0_own;
       float rhs_own = fs_own, x4[NLK], L[10];
 #pragma unroll
@@ -1257,6 +1274,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       const float qacc = sel4(x4, s);
       qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q);
       WSYNC();
+#if JH_V5_PARK
+      for (int k = 0; k < 6; k++) vc[k] = S.qv[k];
+      for (int k = 0; k < 4; k++) qc[3 + k] = S.pk_cq[k];
+      if (!MATERIALIZE) acc = S.pk_acc;
+#endif
       for (int k = 0; k < 6; k++) vc[k] = fmaf(h, S.acn[k], vc[k]);  // the cube's inertia is diagonal: its new acceleration is the constrained one itself
       for (int k = 0; k < 3; k++) qc[k] = fmaf(h, vc[k], qc[k]);
       float wn = sqrtf(vc[3] * vc[3] + vc[4] * vc[4] + vc[5] * vc[5]), ang = wn * h;
