@@ -43,8 +43,8 @@ HEADER_I, HEADER_F = 24, 24
 # stops at |slope| <= SOLVER_LS_TOL * |slope at 0| (MuJoCo's ls_tolerance default is 0.01 too; 1e-3 costs 2.4 % more on fixed plan inputs
 # and does not save a single Newton iteration, tools/diag/ab_fixed_inputs.py).
 # tol = 1e-5 is where the returned MPPI nominal stops moving with the tolerance on the recorded 40 plan steps of the headline workload
-# (profiles/r02_tolerance_sweep.txt: against tol 1e-6 with a 48-contact pool, 26 of the 40 plans pick another winner at 1e-3, 5 at 1e-4, 4 at 1e-5
-# and 4 at 1e-6 -- the rest is the 32-contact pool); it costs 2.7 % over 1e-4 (6.86 instead of 6.57 iterations per step).
+# (profiles/r02_tolerance_sweep.txt: against tol 1e-6 with a 48-contact pool, 25 of the 40 plans pick another winner at 1e-3, 5 at 1e-4, 2 at 1e-5
+# and 2 at 1e-6 -- the rest is the 32-contact pool); it costs 2.7 % over 1e-4 (6.86 instead of 6.57 iterations per step).
 SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-5, 20, 1e-2
 # diagnostics: (phase, repeats) read only by -DJH_V2_ABLATE builds of the cooperative kernel (tools/diag/time_ablate.py)
 ABLATE = (0, 1)
