@@ -55,9 +55,10 @@ def test_leap_single_step_matches_oracle(gpu):
     be = GpuRolloutBackend("leap_cube", len(xs))
     g1, s1, _ = be.rollout(xs, us)
     e = np.abs(g1[:, 0] - nxt)
-    # positions move by h * velocity error; velocities carry the solver error
-    assert np.median(e[:, 23:]) < 1e-6 and np.percentile(e[:, 23:], 99) < 2e-3 and np.percentile(e[:, 23:], 99.9) < 5e-2
-    assert e[:, :23].max() < 5e-3 and np.percentile(e[:, :23], 99.9) < 5e-4
+    # positions move by h * velocity error; velocities carry the solver error (Newton tolerance 1e-5, fp32).  Observed (tools/diag/leap_parity_margins.py):
+    # velocity median 4e-8, 99th percentile 3e-6, 99.9th 9e-6, max 1.4e-3 (one stiff contact); position max 7e-6
+    assert np.median(e[:, 23:]) < 1e-6 and np.percentile(e[:, 23:], 99) < 1e-4 and np.percentile(e[:, 23:], 99.9) < 5e-4 and e[:, 23:].max() < 3e-2
+    assert e[:, :23].max() < 3e-4 and np.percentile(e[:, :23], 99.9) < 5e-6
     # sensors are those of the forward pass at the start of the step (pre-integration state)
     np.testing.assert_allclose(s1[:, 0], rsens[:, 1:].reshape(-1, 31), atol=2e-6)
     st = be.model.stats()
@@ -76,12 +77,13 @@ def test_leap_rollouts_and_costs_match_oracle(gpu):
     be = GpuRolloutBackend("leap_cube", N)
     gs, gsens, _ = be.rollout(x0, U)
     assert gs.shape == rs.shape and gsens.shape == rsens.shape and np.isfinite(gs).all()
-    np.testing.assert_allclose(gs[:, :5], rs[:, :5], atol=3e-4)  # cube ballistic, fingers under friction-loss rows: solver tolerance 1e-4
+    np.testing.assert_allclose(gs[:, :5], rs[:, :5], atol=5e-5)  # cube ballistic, fingers under friction-loss rows (observed 2.4e-6)
     err = np.abs(gs - rs)
-    assert np.median(err[:, -1, :3]) < 1e-5 and np.percentile(err[:, -1, :3], 95) < 5e-3  # cube position at the horizon
+    # cube position at the horizon (64 steps of contact dynamics): observed median 6e-9, 95th percentile 9e-8
+    assert np.median(err[:, -1, :3]) < 1e-6 and np.percentile(err[:, -1, :3], 95) < 1e-5
     cr = -O.reward_leap(rs, GOAL["goal_quat"])
     cg = -LeapCube().reward(gs, gsens, U, GOAL)
-    assert np.median(np.abs(cr - cg)) < 1e-5 and np.percentile(np.abs(cr - cg), 95) < 2e-3
+    assert np.median(np.abs(cr - cg)) < 2e-6 and np.percentile(np.abs(cr - cg), 95) < 1e-5  # observed 7e-8 / 2.4e-7 (max 7e-4: one rollout through a stiff contact)
     rank = np.corrcoef(np.argsort(np.argsort(cr)), np.argsort(np.argsort(cg)))[0, 1]
     assert rank > 0.995
 
@@ -112,12 +114,12 @@ def test_leap_plan_step_matches_oracle(gpu):
     np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
     costs = -ctrl.rewards_local
     d = np.abs(costs + ref["rewards"])
-    assert np.median(d) < 1e-5 and np.percentile(d, 95) < 2e-3
+    assert np.median(d) < 2e-6 and np.percentile(d, 95) < 1e-5  # observed 6e-8 / 3e-7
     # lambda = 0.0025 amplifies cost differences by 400x in the exponent: the stated tolerance on the returned nominal
-    # knots (rad, range ~2.5 rad) is 2e-2 against the fp64 oracle, 2e-4 against an exact update on the GPU's own costs
+    # knots (rad, range ~2.5 rad) is 2e-4 against the fp64 oracle (observed 1.1e-6), 1e-5 against an exact update on the GPU's own costs (observed 1.6e-7)
     exp = O.mppi_update(ref["knots"], -costs.astype(np.float64), 0.0025)
-    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=2e-4)
-    np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=2e-4)
     ctrl.update_traces()
     E, S, H = 1, len(ctrl.trace_sensors), ctrl.num_timesteps
     assert ctrl.traces.shape == (E * S * (H - 1), 2, 3) and np.isfinite(ctrl.traces).all()
