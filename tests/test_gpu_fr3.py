@@ -53,11 +53,13 @@ def test_fr3_rollout_backend_matches_oracle(gpu, x0_kind):
     be = GpuRolloutBackend("fr3_pick", N)
     gs, gsens, _ = be.rollout(x0, U)
     assert gs.shape == (N, H, 31) and gsens.shape == (N, H, 14) and np.isfinite(gs).all()
-    np.testing.assert_allclose(gs[:, 0], rs[:, 0], atol=5e-4)  # one step: servo gains of 4500 on fp32 positions
+    # observed (tools/diag/fr3_parity_margins.py): first step 9e-7, all entries median 3e-9, joint / cube positions at the 40-step horizon 95th percentile 7e-7,
+    # sensors median 2e-8, 99th percentile 2e-5 (the box-box distance sensors)
+    np.testing.assert_allclose(gs[:, 0], rs[:, 0], atol=2e-5)  # one step: servo gains of 4500 on fp32 positions
     e = np.abs(gs - rs)
-    assert np.median(e) < 1e-5 and np.percentile(e[:, -1, :16], 95) < 5e-3
+    assert np.median(e) < 2e-7 and np.percentile(e[:, -1, :16], 95) < 2e-5
     es = np.abs(gsens - rsens)
-    assert np.median(es) < 1e-5 and np.percentile(es, 99) < 5e-3
+    assert np.median(es) < 1e-6 and np.percentile(es, 99) < 5e-4
     st = be.model.stats()
     # closing the empty gripper slams the two pad stacks together: for 1-2 steps the oracle itself sees up to 72 contacts (36 box
     # pairs), above the kernel capacity (48 finger-finger + 32 other contacts); the dropped points are redundant pad-pad contacts (parity above is unaffected)
@@ -100,7 +102,7 @@ def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
     np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
     costs = -ctrl.rewards_local
     d = np.abs(costs + ref["rewards"])
-    assert np.median(d) < 2e-4 and np.percentile(d, 95) < 2e-2  # costs are sums of O(1..40) terms
+    assert np.median(d) < 2e-4 and np.percentile(d, 95) < 1.5e-2  # costs are sums of O(1..40) terms of size O(1..100); observed median 2e-6..5e-5, 95th percentile 2e-3..6e-3
     exp_nom, exp_sig, _ = O.cem_update(ref["knots"], -costs.astype(np.float64), 3, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
     np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=1e-4, atol=1e-6)
