@@ -43,6 +43,18 @@ constexpr int NCH = 4, NLK = 4;
 // every Newton iteration: otherwise the slots' Jacobian columns, lever arms and LDS addresses (all invariant over the iterations) are computed once before
 // the loop, do not fit in the register file and are spilled and reloaded in every iteration.
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef JH_V5_RSPAD
+#define JH_V5_RSPAD 8
+#endif
+#ifndef JH_V5_LCN
+#define JH_V5_LCN 25
+#endif
+#ifndef JH_V5_BFS
+#define JH_V5_BFS 33   // row stride of the LDS copy of the body records (BODY_F = 32 floats each): odd, the four chains' rows in different banks
+#endif
+#ifndef JH_V5_PAS
+#define JH_V5_PAS 9    // row stride of S.pa
+#endif
 #ifndef JH_V5_PARK
 #define JH_V5_PARK 1
 #endif
@@ -73,10 +85,10 @@ __device__ __forceinline__ bool static_code(int b) { return b == 0 || b >= NMB; 
 constexpr int MAXK = 8;
 
 // per-lane model constants staged in LDS (index = lane & 15)
-enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_N = 24 };
+enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_N = JH_V5_LCN };  // (row stride of the LDS table: odd, so that the 16 lanes' rows start in 16 different banks)
 
 struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
-  float pa[NMB][8];   // body origin (0..2) and joint axis in the world (4..6)
+  float pa[NMB][JH_V5_PAS];   // body origin (0..2) and joint axis in the world (4..6); odd row stride: lanes reading 16 different bodies hit 16 different banks
   float xR[NMB][9];
   float qv[NV], g[NV], p[NV], ws[NV];
   float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
@@ -100,6 +112,9 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
     struct { float Hd[NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
   };
   int ncon, nhit;
+#if JH_V5_RSPAD > 0
+  float pad_[JH_V5_RSPAD];  // record size = 16 banks modulo 64: the same field of a wave's four rollouts starts in four disjoint groups of 16 banks
+#endif
 };
 
 struct PoolCtx { RS* S; int* overflow; };
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
                                                    float* __restrict__ knots_out, const float* __restrict__ controls, float* __restrict__ states,
                                                    float* __restrict__ sensors, int* __restrict__ stats) {
   __shared__ RS sRS[RPW * WPB];
-  __shared__ float sBody[16 * BODY_F];
+  __shared__ float sBody[16 * JH_V5_BFS];
   __shared__ float sTp[16];
   __shared__ float sGeomF[MAXG * GEOM_F];
   __shared__ int sGeomI[MAXG * GEOM_I];
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
   const int oLane = gI[11], lgm = gI[12];
   const int oBP = gI[15], oBS = gI[16], nBP = gI[17], oBG = oBP + 2 * nBP;  // hand self-collision: body pairs, body bounding volumes, per-body geom ranges
-  for (int i = tid; i < 16 * BODY_F; i += WAVE * WPB) sBody[i] = gF[oBodyF + BODY_F + i];
+  for (int i = tid; i < 16 * BODY_F; i += WAVE * WPB) sBody[(i / BODY_F) * JH_V5_BFS + i % BODY_F] = gF[oBodyF + BODY_F + i];
   for (int i = tid; i < ngI * GEOM_F; i += WAVE * WPB) sGeomF[i] = gF[oGeomF + i];
   for (int i = tid; i < ngI * GEOM_I; i += WAVE * WPB) sGeomI[i] = gI[oGeomI + i];
   for (int i = tid; i < 16 * lgm; i += WAVE * WPB) sLaneG[i] = gI[oLane + i];
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float sn_own, cs_own; sincosf(q, &sn_own, &cs_own);
 #pragma unroll
         for (int j = 0; j < NLK; j++) {
-          const float* bf = sBody + (4 * c + j) * BODY_F;
+          const float* bf = sBody + (4 * c + j) * JH_V5_BFS;
           float P2[3], R0[9];
           if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
           else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       }
       // ================================================================ chain dynamics: inertia block, bias, smooth force
       {
-        const float* bf = sBody + (4 * c + s) * BODY_F;
+        const float* bf = sBody + (4 * c + s) * JH_V5_BFS;
         float Rk[9], rr[3], cs3[3]; mulMM(Rk, Rown, bf + BF_IR); mulMV(rr, Rown, bf + BF_IPOS);
         for (int k = 0; k < 3; k++) cs3[k] = pown[k] + rr[k];
         const float mass = bf[BF_MASS]; const float* di = bf + BF_INERTIA;
