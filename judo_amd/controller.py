@@ -105,7 +105,11 @@ class Controller:
         self._lohi_cache: tuple = (None, None)
         self._bufs: _PlanBuffers | None = None
         self._bufs_key: tuple | None = None
-        self._noise_buf: torch.Tensor | None = None
+        self._noise_bufs: list[torch.Tensor] | None = None
+        self._noise_cur = 0
+        self._noise_ahead = None
+        self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
+        self._prefetch_args = None
         self.keep_candidates = False
         self.force_materialize = False  # True: always take the materialise path (rollout arrays + Task.reward), e.g. to inspect trajectories
         self.last_rollout = None  # (states, sensors, controls) device tensors of the last materialised iteration
@@ -269,16 +273,41 @@ class Controller:
             self._bufs, self._bufs_key = _PlanBuffers(self.device, *key), key
         return self._bufs
 
+    def _noise_buffer(self, shape: tuple[int, int, int]) -> torch.Tensor:
+        """The next of two persistent (K, nu, N) noise buffers (the other one still backs the lazy `rewards` / `candidate_knots` of the last plan step)."""
+        if self._noise_bufs is None or tuple(self._noise_bufs[0].shape) != shape:
+            self._noise_bufs = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._noise_ahead = None
+        self._noise_cur ^= 1
+        return self._noise_bufs[self._noise_cur]
+
     def _draw_noise(self, n_local: int, n_offset: int) -> torch.Tensor:
-        """The optimizer's noise for this shard, drawn into a persistent (K, nu, N) buffer when it comes from the device generator."""
+        """The optimizer's noise for this shard, drawn into a persistent (K, nu, N) buffer when it comes from the device generator -- or taken from the
+        draw `_prefetch_noise` enqueued behind the last iteration's download (same generator, same order of draws: the same numbers, earlier)."""
         opt = self.optimizer
         if opt.injected_noise is None:
             K, nu = opt.num_nodes, self.nu
             total = max(int(opt.num_rollouts), n_offset + n_local)
-            if self._noise_buf is None or tuple(self._noise_buf.shape) != (K, nu, total):
-                self._noise_buf = torch.empty((K, nu, total), dtype=torch.float32, device=self.device)
-            return opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buf)
+            ahead, self._noise_ahead = self._noise_ahead, None
+            if ahead is not None and ahead[0] == (K, nu, total, n_local, n_offset) and ahead[1] is opt._generator and ahead[1] is not None:
+                opt.last_noise = ahead[2]
+                return ahead[2]
+            return opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, total)))
+        self._noise_ahead = None
         return opt.draw_noise(n_local, n_offset, self.device)
+
+    def _prefetch_noise(self, n_local: int, n_offset: int) -> None:
+        """Enqueue the next iteration's noise draw now (behind the download of this one's result): it leaves the critical path of the next plan step.
+        Only for the library's own `draw_noise` with the device generator; a reseed, an injected noise array or a changed shape discards the draw."""
+        opt = self.optimizer
+        if not self.prefetch_noise or opt.injected_noise is not None or type(opt).draw_noise is not Optimizer.draw_noise or opt._generator is None:
+            return
+        K, nu = opt.num_nodes, self.nu
+        total = max(int(opt.num_rollouts), n_offset + n_local)
+        keep = opt.last_noise
+        noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, total)))
+        opt.last_noise = keep
+        self._noise_ahead = ((K, nu, total, n_local, n_offset), opt._generator, noise)
 
     # ---- the plan step -------------------------------------------------------------------------------------------
     @property
@@ -308,6 +337,7 @@ class Controller:
             raise ValueError(f"num_nodes * nu = {K * nu} exceeds the update kernels' limit of {_lib.MAX_KNOT_DIM} (include/judo_amd.h JH_MAX_KNOT_DIM)")
         world, rank = world_info(self.group)
         shard: Shard = shard_rollouts(N, world, rank)
+        self._prefetch_args = None
 
         # time shift (host; needs the previous plan's spline)
         new_times = self.time + self.spline_timesteps
@@ -385,6 +415,8 @@ class Controller:
         _lib.check(L.jh_download_begin(b.out_host_ptr, b.out.data_ptr(), 4 * n, self._stream), "jh_download_begin")
         if behind is not None:
             behind()
+        if self._prefetch_args is not None:
+            self._prefetch_noise(*self._prefetch_args)
         _lib.check(L.jh_download_end(), "jh_download_end")
         return b.out_np[:n].astype(np.float64)
 
@@ -398,6 +430,7 @@ class Controller:
         sigma_raw = sigma_n * scale[None, :]
         self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm))
         noise = self._draw_noise(shard.count, shard.offset)  # (K, nu, shard.count), possibly a view into the full draw
+        self._prefetch_args = (shard.count, shard.offset)
         ldn, noise_p = int(noise.stride(1)), noise.data_ptr()
         self._last_sigma_raw, self._last_nominal_before = sigma_raw, nominal_raw.copy()
         if self.keep_candidates and b.knots_out is None:

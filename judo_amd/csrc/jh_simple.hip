@@ -56,16 +56,15 @@ __device__ __forceinline__ float impedance_pow(const float* si, float dist) {
 struct Cartpole {
   static constexpr int NX = 4, NU = 1, NS = 6, NP = CP_NPARAM, NTP = 6;
   float x, th, xd, thd;
-  __device__ void load(const float* x0) { x = x0[0]; th = x0[1]; xd = x0[2]; thd = x0[3]; }
+  float sn, cs;  // sin / cos of the pole angle, carried: one sincos per step serves the step's dynamics, the cost after it and the sensors
+  __device__ void load(const float* x0) { x = x0[0]; th = x0[1]; xd = x0[2]; thd = x0[3]; sincosf(th, &sn, &cs); }
   __device__ void store(float* o) const { o[0] = x; o[1] = th; o[2] = xd; o[3] = thd; }
   // framepos of the sites trace_cart (cart origin) and trace_pole (pole tip), cartpole.xml:27,31,41-42
   __device__ void sensors(const float* P, float* s) const {
-    float sn, cs; sincosf(th, &sn, &cs);
     s[0] = x; s[1] = 0.f; s[2] = 0.f; s[3] = x + P[CP_TIP] * sn; s[4] = 0.f; s[5] = P[CP_TIP] * cs;
   }
   __device__ void step(const float* P, const float* u) {
     const float h = P[CP_DT], mp = P[CP_MPOLE], l = P[CP_L];
-    float sn, cs; sincosf(th, &sn, &cs);
     // joint-space inertia and its inverse
     float m11 = P[CP_MCART] + mp, m12 = mp * l * cs, m22 = P[CP_IPOLE] + mp * l * l;
     // bias = Coriolis/centrifugal + gravity; passive = -damping*v; actuator = clamp(kp*(clamp(u) - x) - kv*xd)
@@ -95,14 +94,15 @@ struct Cartpole {
     // Euler with implicit damping: (M + h*D) a = qfrc_smooth + qfrc_constraint
     float a11 = m11 + h * P[CP_DAMP_X], a22 = m22 + h * P[CP_DAMP_TH];
     float r1 = f1 + fc, r2 = f2;
-    float det = a11 * a22 - m12 * m12;
-    float ax = (a22 * r1 - m12 * r2) / det, ath = (a11 * r2 - m12 * r1) / det;
+    float idet = __builtin_amdgcn_rcpf(a11 * a22 - m12 * m12);  // (v_rcp_f32, 1 ulp: the step is a chain of dependent instructions, a full division is ten of them)
+    float ax = (a22 * r1 - m12 * r2) * idet, ath = (a11 * r2 - m12 * r1) * idet;
     xd = fmaf(h, ax, xd); thd = fmaf(h, ath, thd);
     x = fmaf(h, xd, x); th = fmaf(h, thd, th);
+    sincosf(th, &sn, &cs);
   }
   // running cost of judo/tasks/cartpole.py:61-78 (w = w_vertical,w_centered,w_velocity,w_control,p_vertical,p_centered)
   __device__ float cost(const float* w, const float* u) const {
-    float cv = cosf(th) - 1.f;
+    float cv = cs - 1.f;
     return w[0] * (sqrtf(cv * cv + w[4] * w[4]) - w[4]) + w[1] * (sqrtf(x * x + w[5] * w[5]) - w[5]) +
            w[2] * 0.5f * (xd * xd + thd * thd) + w[3] * 0.5f * u[0] * u[0];
   }
