@@ -205,12 +205,7 @@ class GpuMPPI(FusedOptimizer[MPPIConfig]):
         return self.config.temperature
 
     def knot_sigma(self) -> np.ndarray:
-        K = self.num_nodes
-        if self.use_noise_ramp:
-            s = self.noise_ramp * ramp_linspace(1 / K, 1, K)[:, None] * self.sigma
-        else:
-            s = np.full((K, 1), self.sigma)
-        return np.broadcast_to(s, (K, self.nu)).astype(np.float64)
+        return _ramped_sigma(self)
 
     def update_nominal_knots(self, sampled_knots: np.ndarray, rewards: np.ndarray) -> np.ndarray:
         return self._update_via_device(sampled_knots, rewards)[0]
@@ -229,6 +224,17 @@ class GpuMPPI(FusedOptimizer[MPPIConfig]):
         K = K or self.num_nodes
         st = _lib.lib().jh_mppi_merge(_lib.ptr(recs), G, K, self.nu, float(self.temperature), _lib.ptr(nominal_out), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_mppi_merge")
+
+
+def _ramped_sigma(opt) -> np.ndarray:
+    """(K, nu) per-knot sigma of MPPI / PS (mppi.py:44-52): a function of four config values, cached on the optimizer (it is asked for in every iteration)."""
+    key = (opt.num_nodes, opt.nu, bool(opt.use_noise_ramp), float(opt.noise_ramp), float(opt.sigma))
+    hit = getattr(opt, "_sigma_cache", None)
+    if hit is None or hit[0] != key:
+        K = opt.num_nodes
+        s = opt.noise_ramp * ramp_linspace(1 / K, 1, K)[:, None] * opt.sigma if opt.use_noise_ramp else np.full((K, 1), opt.sigma)
+        hit = opt._sigma_cache = (key, np.broadcast_to(s, (K, opt.nu)).astype(np.float64))
+    return hit[1].copy()
 
 
 class _EliteOptimizer(FusedOptimizer[OptimizerConfigT]):
@@ -326,12 +332,7 @@ class GpuPS(_EliteOptimizer[PredictiveSamplingConfig]):
         return self.config.sigma
 
     def knot_sigma(self) -> np.ndarray:
-        K = self.num_nodes
-        if self.use_noise_ramp:
-            s = self.noise_ramp * ramp_linspace(1 / K, 1, K)[:, None] * self.sigma
-        else:
-            s = np.full((K, 1), self.sigma)
-        return np.broadcast_to(s, (K, self.nu)).astype(np.float64)
+        return _ramped_sigma(self)
 
     def update_nominal_knots(self, sampled_knots: np.ndarray, rewards: np.ndarray) -> np.ndarray:
         return self._update_via_device(sampled_knots, rewards)[0]
