@@ -66,7 +66,8 @@ int jh_model_stats(jh_model* m, int* out /* HOST, 8 ints */, int reset);
 
 /* Articulated-body engine kernel generation for this model: 3 (default for leap_cube) = cooperative kernel on a register diet, two waves per SIMD,
  * hand self-collision; 2 (default for fr3_pick) = cooperative kernel, 16 lanes per rollout, one wave per SIMD;
- * 1 = one lane per rollout (kept as an independent second implementation for the parity tests). */
+ * 1 = one lane per rollout (kept as an independent second implementation for the parity tests).  "leap_cube" is the model family: leap_cube, leap_cube_down
+ * and caltech_leap_cube (the last one only on generation 3: its sensor layout and static-geometry groups exist there alone). */
 int jh_model_set_kernel(jh_model* m, int generation);
 
 /* leap_cube on kernel generation 3: model the hand's own contacts (every finger-finger / finger-palm geom pair MuJoCo's filters leave: same welded body,
