@@ -31,9 +31,6 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_WAVES_PER_EU
 #define JH_V5_WAVES_PER_EU 2
 #endif
-#ifndef JH_V5_HCC_PRE
-#define JH_V5_HCC_PRE 0  // cube block of the Hessian: 0 = one LDS atomic per contact and entry (default: measured fastest, 57.2 ms), 1 = lane pairs add up first (69.1), 2 = quads add up first (57.7)
-#endif
 #ifndef JH_V5_WPB
 #define JH_V5_WPB 4  // waves per workgroup: they share one LDS copy of the model image and nothing else
 #endif
