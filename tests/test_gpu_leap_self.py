@@ -8,13 +8,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _tangled_states(N, seed, frac=0.6):
+def _tangled_states(N, seed, frac=0.6, task="leap_cube"):
     """Hand configurations `frac` of the way from the home pose to uniformly random joint angles (the fingers cross each other and dig into the palm),
     small random velocities, the cube parked 0.3 m above the hand (no cube contacts: the hand's own are what is under test)."""
-    from judo_amd.tasks import LEAP_QPOS_HOME
+    from judo_amd.tasks import CALTECH_LEAP_QPOS_HOME
+    from judo_amd.tasks import LEAP_QPOS_HOME as LEAP_HOME
     from oracle import oracle as O
 
-    om = O.Model("leap_cube")
+    LEAP_QPOS_HOME = CALTECH_LEAP_QPOS_HOME if task == "caltech_leap_cube" else LEAP_HOME
+    om = O.Model(task)
     rng = np.random.default_rng(seed)
     r = np.array([a["ctrlrange"] for a in om.desc["actuators"]])
     q = r[:, 0] + (r[:, 1] - r[:, 0]) * rng.uniform(0.0, 1.0, (N, 16))
@@ -140,3 +142,31 @@ def test_self_collision_rollouts_match_oracle(gpu):
     assert np.median(gap[:, -1].max(1)) > 1e-2
     assert np.median(err[:, -1].max(1)) < 0.05 * np.median(gap[:, -1].max(1))
     assert np.percentile(err[:, -1], 90) < 5e-3
+
+
+def test_caltech_self_collision_single_steps_match_oracle(gpu):
+    """caltech_leap_cube: tangled hand configurations against the oracle -- the primitive hand has three static bodies with collision geoms (floor, mount, palm) in
+    two groups of different partners, which the self-collision tables carry as hand bodies 0 and 17."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+
+    om, xs, q = _tangled_states(500, seed=21, task="caltech_leap_cube")
+    names = [b["name"] for b in om.desc["bodies"]]
+    body = [g["body"] for g in om.desc["geoms"]]
+    static = {names.index(n) for n in ("floor", "leap_mount", "palm_right")}
+    n_static = n_hand = 0
+    ok = np.ones(len(xs), dtype=bool)
+    for i in range(len(xs)):
+        f = om.forward(xs[i, :23], xs[i, 23:], q[i])
+        ok[i] = f["ncon"] <= 32
+        for row in f["contacts"]:
+            ba, bb = body[int(row[13])], body[int(row[14])]
+            n_static += (ba in static) != (bb in static)
+            n_hand += 1
+    assert n_static > 100 and n_hand > 1000 and ok.sum() > 300, (n_static, n_hand, ok.sum())
+    us = q[:, None, :]
+    nxt, _ = om.rollout(xs, us)
+    g1, _, _ = GpuRolloutBackend("caltech_leap_cube", len(xs)).rollout(xs, us)
+    assert np.isfinite(g1).all()
+    scale = np.maximum(1.0, np.abs(nxt[:, 0, 23:]).max(axis=1, keepdims=True))
+    e = (np.abs(g1[:, 0] - nxt[:, 0])[:, 23:] / scale)[ok]
+    assert np.median(e) < 2e-5 and np.percentile(e, 95) < 2e-2, (np.median(e), np.percentile(e, 95))

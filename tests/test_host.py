@@ -468,3 +468,33 @@ def test_caltech_leap_cube_model_and_oracle_sensors():
     np.testing.assert_allclose(y[:16], x[7:23], atol=1e-12)
     np.testing.assert_allclose(y[16:19], x[0:3] - np.array([0.11, 0.005, 0.03]), atol=1e-12)
     np.testing.assert_allclose(y[19:23], q, atol=1e-12)
+
+
+def test_hand_self_collision_pair_tables():
+    """MuJoCo's static collision filters on the leap models (same welded body, parent-child unless the parent is welded to the world, the <exclude> pairs, judo/models/xml/
+    leap_components/params_and_default.xml:76-101): the oracle's geom pair list and the body-pair table of the packed image describe the same candidate set."""
+    import struct
+
+    from judo_amd.models import load_description, pack_model
+    from oracle import oracle as O
+
+    for task, n_all, n_cube, n_body_pairs, n_excl in (("leap_cube", 1950, 75, 106, 18), ("leap_cube_down", 1950, 75, 106, 18), ("caltech_leap_cube", 1955, 74, 122, 35)):
+        d = load_description(task)
+        assert len(d["excludes"]) == n_excl
+        pa, pc = O.collision_pairs(d, scope="all"), O.collision_pairs(d, scope="cube")
+        assert (len(pa), len(pc)) == (n_all, n_cube) and set(pc) <= set(pa)
+        names = [b["name"] for b in d["bodies"]]
+        cube = names.index("cube")
+        body = [g["body"] for g in d["geoms"]]
+        assert all(cube in (body[a], body[b]) for a, b in pc) and not any(cube in (body[a], body[b]) for a, b in set(pa) - set(pc))
+        excl = {frozenset(e) for e in d["excludes"]}
+        hand = set(pa) - set(pc)
+        assert not any(frozenset((body[a], body[b])) in excl or body[a] == body[b] for a, b in hand)
+        b = pack_model(d)
+        h = struct.unpack("<16I", b[:64])
+        I = np.frombuffer(b[64 + 4 * h[8] : 64 + 4 * (h[8] + h[9])], dtype=np.int32)
+        assert I[17] == n_body_pairs
+        # every body pair of the image expands to (geoms of A) x (geoms of B): the sum over the pairs is the oracle's hand pair count
+        bp = I[I[15] : I[15] + 2 * I[17]].reshape(-1, 2)
+        rng = I[I[15] + 2 * I[17] : I[15] + 2 * I[17] + 40].reshape(20, 2)
+        assert int(sum(rng[a, 1] * rng[c, 1] for a, c in bp)) == len(hand)
