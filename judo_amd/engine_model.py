@@ -45,7 +45,9 @@ HEADER_I, HEADER_F = 24, 24
 # tol = 1e-5 is where the returned MPPI nominal stops moving with the tolerance on the recorded 40 plan steps of the headline workload
 # (profiles/r02_tolerance_sweep.txt: against tol 1e-6 with a 48-contact pool, 25 of the 40 plans pick another winner at 1e-3, 5 at 1e-4, 2 at 1e-5
 # and 2 at 1e-6 -- the rest is the 32-contact pool); it costs 2.7 % over 1e-4 (6.86 instead of 6.57 iterations per step).
-SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-5, 20, 1e-2
+# 50 iterations instead of round 1's 20: the random-state sweep tools/diag/fuzz_leap.py has states on which the fp64 oracle needs 21-31; on the headline workload the
+# higher cap costs nothing measurable (4e-4 solves per step used to stop at 20).
+SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL = 1e-5, 50, 1e-2
 # diagnostics: (phase, repeats) read only by -DJH_V2_ABLATE builds of the cooperative kernel (tools/diag/time_ablate.py)
 ABLATE = (0, 1)
 
