@@ -68,11 +68,12 @@ constexpr int NCH = 4, NLK = 4;
 #endif
 constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane: the pool holds 16 * NSLOT contacts per rollout
 constexpr int NCP = 16 * NSLOT;  // contact pool per rollout
-constexpr int MAXHIT = 32;
+constexpr int MAXHIT = 64;  // broad-phase survivors (candidate geom pairs) per rollout and step; 16 bits each.  More than that are counted as dropped contacts
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
 constexpr int MAXG = 80, MAXLG = 8;
 constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1..16 = finger link (1 + 4*chain + depth), 17 = the cube
-constexpr int HITPAIR = 1 << 16;  // broad-phase survivors >= HITPAIR index the hand-hand geom pair list, smaller ones are cube-vs-geom
+constexpr int HITPAIR = 1 << 15;  // broad-phase survivors >= HITPAIR are hand-hand geom pairs (ga << 7 | gb, geom ids < 128), smaller ones are cube-vs-geom
+static_assert(MAXG <= 128, "hand geom pairs are packed into 14 bits");
 constexpr int MAXBP = 128;         // hand body pairs in the model image (leap_cube 106, caltech_leap_cube 122)
 constexpr int MAXBPL = 24;        // hand body pairs whose bounding spheres overlap, per rollout and step
 constexpr int NDH = 22 * 23 / 2;  // dense Hessian (packed lower) of a rollout whose contacts couple two finger chains
@@ -95,7 +96,7 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
     struct {
       float bs[NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
                           // bounding box's too; its half sizes and axes come from the model image and the body rotation)
-      int hits[MAXHIT];
+      unsigned short hits[MAXHIT];
       int bpl[MAXBPL];
     };
     // the collision arrays are dead from the constraint rows on: the step-level state the Newton loop does not touch is parked here instead of being held in
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nh + __popc(m16 & ((1u << l) - 1u));
-        if (hit && pos < MAXHIT) S.hits[pos] = gid;
+        if (hit && pos < MAXHIT) S.hits[pos] = (unsigned short)gid;
         nh += __popc(m16);
       }
       WSYNC();
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           }
           const unsigned h16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
           const int pos = nh + __popc(h16 & ((1u << l) - 1u));
-          if (hit && pos < MAXHIT) S.hits[pos] = HITPAIR + (ga << 8 | gb);
+          if (hit && pos < MAXHIT) S.hits[pos] = (unsigned short)(HITPAIR + (ga << 7 | gb));
           nh += __popc(h16);
           rem &= rem - 1u;
         }
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
 #endif
 #endif
       }
-      nh = nh < MAXHIT ? nh : MAXHIT;
+      if (nh > MAXHIT) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT); nh = MAXHIT; }  // (candidate pairs lost: counted with the dropped contacts)
       WSYNC();
       V5_TICK(1)
       // narrow phase: survivor i goes to lane i; side A is the cube or the first geom of a hand pair, side B a hand geom
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (idx < nh) {
           const int hid = S.hits[idx];
           int ga = -1, gb = hid;
-          if (SELF && hid >= HITPAIR) { ga = (hid - HITPAIR) >> 8; gb = (hid - HITPAIR) & 0xFF; }
+          if (SELF && hid >= HITPAIR) { ga = (hid - HITPAIR) >> 7; gb = (hid - HITPAIR) & 0x7F; }
           // side B
           const float* fb = sGeomF + gb * GEOM_F; const int bodyb = sGeomI[gb * GEOM_I], tb = sGeomI[gb * GEOM_I + 1];
           float pB[3], RB[9];

@@ -170,3 +170,32 @@ def test_caltech_self_collision_single_steps_match_oracle(gpu):
     scale = np.maximum(1.0, np.abs(nxt[:, 0, 23:]).max(axis=1, keepdims=True))
     e = (np.abs(g1[:, 0] - nxt[:, 0])[:, 23:] / scale)[ok]
     assert np.median(e) < 2e-5 and np.percentile(e, 95) < 2e-2, (np.median(e), np.percentile(e, 95))
+
+
+def test_random_states_with_the_cube_jammed_into_the_hand(gpu):
+    """Random-state sweep (tools/diag/fuzz_leap.py, shortened): tangled hand configurations with the cube inside the hand at a random attitude -- cube contacts, the hand's own
+    contacts and both at once, ~20 contacts per state, hard solves (the oracle needs up to 30 Newton iterations on some: the kernel's iteration cap is 50).  One physics step."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+
+    N = 1200
+    rng = np.random.default_rng(123)
+    om, xs, q = _tangled_states(N, seed=99, frac=0.5)
+    home = xs[0, :3].copy()
+    home[2] -= 0.3
+    xs[:, :3] = home + rng.uniform(-0.03, 0.03, (N, 3))
+    quat = rng.standard_normal((N, 4))
+    xs[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    xs[:, 23:29] = rng.standard_normal((N, 6)) * np.array([0.2, 0.2, 0.2, 2, 2, 2])
+    kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(N)])
+    ok = kinds[:, :3].sum(1) <= 32  # within the kernel's contact pool
+    assert ok.sum() > 800 and (ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)).sum() > 80
+    U = q[:, None, :]
+    ref, _ = om.rollout(xs, U)
+    be = GpuRolloutBackend("leap_cube", N)
+    g, _, _ = be.rollout(xs, U)
+    assert np.isfinite(g).all()
+    scale = np.maximum(1.0, np.abs(ref[:, 0, 23:]).max(axis=1, keepdims=True))
+    ev = (np.abs(g[:, 0] - ref[:, 0])[:, 23:] / scale).max(1)
+    for name, sel in (("cube only", ok & (kinds[:, 0] > 0) & (kinds[:, 1] + kinds[:, 2] == 0)), ("cube and coupled chains", ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)), ("all", ok)):
+        assert np.median(ev[sel]) < 5e-6 and np.percentile(ev[sel], 95) < 1e-4 and ev[sel].max() < 5e-2, (name, np.median(ev[sel]), np.percentile(ev[sel], 95), ev[sel].max())
+    assert be.model.stats()["newton_cap_hits"] == 0
