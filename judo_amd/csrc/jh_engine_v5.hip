@@ -75,7 +75,7 @@ constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1.
 constexpr int HITPAIR = 1 << 15;  // broad-phase survivors >= HITPAIR are hand-hand geom pairs (ga << 7 | gb, geom ids < 128), smaller ones are cube-vs-geom
 static_assert(MAXG <= 128, "hand geom pairs are packed into 14 bits");
 constexpr int MAXBP = 128;         // hand body pairs in the model image (leap_cube 106, caltech_leap_cube 122)
-constexpr int MAXBPL = 24;        // hand body pairs whose bounding spheres overlap, per rollout and step
+constexpr int MAXBPL = 96;        // hand body pairs whose bounding volumes overlap, per rollout and step (one byte each: pair indices < MAXBP <= 256)
 constexpr int NDH = 22 * 23 / 2;  // dense Hessian (packed lower) of a rollout whose contacts couple two finger chains
 constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NS_CALTECH = 23, NX = 45, NMB = 17;
 constexpr int NBC = 20;  // hand bodies of the self-collision tables: 0 = static geometry, 1..16 = finger links, 17..19 = further groups of static geometry (engine_model.py)
@@ -97,7 +97,7 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
       float bs[NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
                           // bounding box's too; its half sizes and axes come from the model image and the body rotation)
       unsigned short hits[MAXHIT];
-      int bpl[MAXBPL];
+      unsigned char bpl[MAXBPL];
     };
     // the collision arrays are dead from the constraint rows on: the step-level state the Newton loop does not touch is parked here instead of being held in
     // registers (or spilled to scratch memory by the compiler) across the loop.  The joint velocity and the cube's velocity are in qv already.
@@ -601,10 +601,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nbl + __popc(m16 & ((1u << l) - 1u));
-        if (hit && pos < MAXBPL) S.bpl[pos] = pi;
+        if (hit && pos < MAXBPL) S.bpl[pos] = (unsigned char)pi;
         nbl += __popc(m16);
       }
-      nbl = nbl < MAXBPL ? nbl : MAXBPL;
+      if (nbl > MAXBPL) { if (l == 0 && live && stats) atomicAdd(stats, nbl - MAXBPL); nbl = MAXBPL; }  // (counted with the dropped contacts)
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_bp += nbl;
       const int nh_cube = nh;
