@@ -302,6 +302,8 @@ class GpuCEM(_EliteOptimizer[CrossEntropyMethodConfig]):
         """Node-count change: sigma is re-interpolated linearly in time with extrapolation (cem.py:44-53)."""
         if len(self.sigma) != self.num_nodes:
             old_times, new_times = np.asarray(old_times, dtype=np.float64), np.asarray(new_times, dtype=np.float64)
+            if len(old_times) != len(self.sigma):  # (scipy's interp1d raises the same way in the reference)
+                raise ValueError(f"CEM sigma has {len(self.sigma)} rows but the previous plan has {len(old_times)} knots: x and y arrays must be equal in length along the interpolation axis")
             i = np.clip(np.searchsorted(old_times, new_times, side="right") - 1, 0, len(old_times) - 2)
             a = ((new_times - old_times[i]) / (old_times[i + 1] - old_times[i]))[:, None]
             self.sigma = self.sigma[i] + a * (self.sigma[i + 1] - self.sigma[i])

@@ -1,0 +1,65 @@
+"""Random configurations of the plan step (optimizer, rollout count, knot count, spline order, horizon, iterations, normaliser, ramp, temperature, elites, traces) on the
+closed-form tasks, three consecutive plan steps each, against the oracle's update_action (pinned to the reference's own Controller by tests/test_controller_golden.py)."""
+import sys, traceback
+import numpy as np
+sys.path.insert(0, ".")
+from judo_amd.controller import make_controller
+from oracle import oracle as O
+from tests.harness import oracle_reward, oracle_update_action
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = []
+for case in range(n_cases):
+    task_name = ["cartpole", "cylinder_push"][rng.integers(2)]
+    opt_name = ["mppi", "cem", "ps"][rng.integers(3)]
+    N = int(rng.choice([2, 3, 5, 17, 64, 65, 200, 513]))
+    K = int(rng.integers(2, 11))
+    order = ["zero", "linear", "cubic"][rng.integers(3)]
+    if order == "cubic" and K < 4: order = "linear"
+    if order == "linear" and K < 2: order = "zero"
+    Hs = int(rng.integers(3, 70))
+    iters = int(rng.integers(1, 4))
+    norm = ["none", "min_max", "running"][rng.integers(3)]
+    desc = f"{task_name} {opt_name} N={N} K={K} {order} H={Hs} iters={iters} {norm}"
+    try:
+        ctrl = make_controller(task_name, opt_name)
+        cfg = ctrl.optimizer.config
+        cfg.num_rollouts, cfg.num_nodes = N, K
+        cfg.use_noise_ramp = bool(rng.integers(2)); cfg.noise_ramp = float(rng.uniform(1, 4))
+        if opt_name == "mppi": cfg.temperature = float(10 ** rng.uniform(-2.5, 0)); cfg.sigma = float(rng.uniform(0.05, 0.5))
+        if opt_name == "ps": cfg.sigma = float(rng.uniform(0.05, 0.5))
+        if opt_name == "cem": cfg.num_elites = int(rng.integers(1, min(N, 8) + 1)); cfg.sigma_min = 0.05; cfg.sigma_max = float(rng.uniform(0.3, 1.0))
+        if opt_name == "cem": ctrl.optimizer = type(ctrl.optimizer)(cfg, ctrl.nu)  # (sigma state sized for the new knot count)
+        cc = ctrl.controller_cfg
+        cc.horizon, cc.spline_order, cc.max_opt_iters, cc.action_normalizer, cc.max_num_traces = Hs * ctrl.task.dt, order, iters, norm, int(rng.integers(0, 6))
+        ctrl.controller_cfg = cc
+        ctrl.reset()
+        x0 = ctrl.task.default_state() + 0.05 * rng.standard_normal(ctrl.task.nq + ctrl.task.nv)
+        nu = ctrl.nu; om = O.Model(task_name); r = ctrl.task.actuator_ctrlrange
+        state = dict(times=ctrl.times.copy(), nominal_knots=ctrl.nominal_knots.copy(), normalizer=O.OracleNormalizer(norm, nu, r[:, 0], r[:, 1]))
+        if opt_name == "cem": state["sigma"] = np.asarray(ctrl.optimizer.sigma, dtype=np.float64).copy()
+        err = 0.0
+        for step in range(3):
+            noises = [rng.standard_normal((N - 1, K, nu)).astype(np.float32) for _ in range(iters)]
+            ctrl.optimizer.injected_noise = list(noises)
+            ctrl.current_state, ctrl.time = x0.copy(), 0.05 * step
+            ctrl.update_action()
+            ref = oracle_update_action(opt_name, cfg, cc, nu, ctrl.task.dt, r, om.rollout, lambda s, y, u: oracle_reward(ctrl.task, s, y, u, ctrl.system_metadata), state, x0, 0.05 * step, noises)
+            e_nom = np.abs(ctrl.nominal_knots - ref["nominal"]).max()
+            e_rew = (np.abs(ctrl.rewards - ref["rewards"]) / (1 + np.abs(ref["rewards"]))).max()
+            e_sig = np.abs(np.asarray(ctrl.optimizer.sigma) - state["sigma"]).max() if opt_name == "cem" else 0.0
+            # an argmax / elite choice may flip when two candidates are closer than the fp32 rollout error: judge the nominal only when the oracle's own ranking is unambiguous
+            srt = np.sort(ref["rewards"])[::-1]; k = 1 if opt_name == "ps" else (cfg.num_elites if opt_name == "cem" else 0)
+            ambiguous = k > 0 and len(srt) > k and (srt[k - 1] - srt[k]) < 10 * np.abs(ctrl.rewards - ref["rewards"]).max()
+            err = max(err, e_rew, 0.0 if ambiguous else max(e_nom, e_sig))
+            if ambiguous:  # keep both sides on the same plan
+                state["nominal_knots"] = ctrl.nominal_knots.copy()
+                if opt_name == "cem": state["sigma"] = np.asarray(ctrl.optimizer.sigma, dtype=np.float64).copy()
+        worst.append((err, desc))
+    except Exception as ex:
+        worst.append((float("inf"), desc + " EXC " + "".join(traceback.format_exception_only(type(ex), ex)).strip()[:200]))
+worst.sort(key=lambda t: -t[0])
+print(f"{n_cases} cases; worst:")
+for e, dsc in worst[:12]:
+    print(f"  {e:.2e}  {dsc}")
+print("median case error %.2e" % np.median([w[0] for w in worst]))
