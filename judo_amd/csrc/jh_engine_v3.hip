@@ -479,7 +479,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         if (hit && pos < MAXHIT) S.hits[pos] = p;
         nh += __popc(m16);
       }
-      nh = nh < MAXHIT ? nh : MAXHIT;
+      if (nh > MAXHIT) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT); nh = MAXHIT; }  // candidate pairs beyond the list: counted with the dropped contacts
       __syncthreads();
       for (int base = 0; __any(base < nh); base += G) {
         const int idx = base + l;
