@@ -414,7 +414,7 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         if (hit && pos < MAXHIT) S.hits[pos] = gid;
         nh += __popc(m16);
       }
-      if (nh > MAXHIT) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT); nh = MAXHIT; }  // candidate pairs beyond the list: counted with the dropped contacts
+      nh = nh < MAXHIT ? nh : MAXHIT;
 #ifdef JH_ENGINE_PROFILE
 #ifndef JH_V2_LSHIST
       if (l == 0 && live && stats) atomicAdd(stats + 48 + (nh < 15 ? nh : 15), 1);

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, NMB = 10;
-constexpr int NCP = 32, NSL = NCP / G, MAXHIT = 32, RAW_F = 8, JW = NVT * 3;
+constexpr int NCP = 32, NSL = NCP / G, MAXHIT = 64, RAW_F = 8, JW = NVT * 3;  // MAXHIT: broad-phase survivors (candidate pairs) per rollout and step, 16 bits each
 constexpr int MAXDT = 32;  // box pairs behind the distance sensors
 #ifndef JH_V3_NFS
 #define JH_V3_NFS 3
@@ -49,7 +49,7 @@ struct __attribute__((aligned(16))) RS3 {  // per-rollout shared state
   float fW[NCP][9];                             // frame (while rows are built), then f[3], W[6] of the current Newton iterate
   float y[16];                                  // sensordata of the forward pass
   float kn[NU][8];                              // spline knots per actuator (kept out of the register file: they are read once per step)
-  int hits[MAXHIT];
+  unsigned short hits[MAXHIT];
   int ncon, nhit, nff;
 };
 
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nh + __popc(m16 & ((1u << l) - 1u));
-        if (hit && pos < MAXHIT) S.hits[pos] = p;
+        if (hit && pos < MAXHIT) S.hits[pos] = (unsigned short)p;
         nh += __popc(m16);
       }
       if (nh > MAXHIT) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT); nh = MAXHIT; }  // candidate pairs beyond the list: counted with the dropped contacts
