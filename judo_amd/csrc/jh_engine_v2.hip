@@ -414,6 +414,9 @@ __global__ __launch_bounds__(WAVE, JH_V2_WAVES_PER_EU) void k_leap_v2(const floa
         if (hit && pos < MAXHIT) S.hits[pos] = gid;
         nh += __popc(m16);
       }
+      // (Survivors beyond the list are dropped without being counted, as in round 1.  Counting them here -- one global atomic -- changes this kernel's results on
+      // leap_cube_down from the second step on although the arithmetic is untouched: suspected code-generation issue of the 487-register build (SGPR spills under
+      // divergent control flow).  Generation 2 is kept exactly as it was validated; generation 3 counts and holds 64.)
       nh = nh < MAXHIT ? nh : MAXHIT;
 #ifdef JH_ENGINE_PROFILE
 #ifndef JH_V2_LSHIST
