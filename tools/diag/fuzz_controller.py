@@ -45,6 +45,12 @@ for case in range(n_cases):
             ctrl.current_state, ctrl.time = x0.copy(), 0.05 * step
             ctrl.update_action()
             ref = oracle_update_action(opt_name, cfg, cc, nu, ctrl.task.dt, r, om.rollout, lambda s, y, u: oracle_reward(ctrl.task, s, y, u, ctrl.system_metadata), state, x0, 0.05 * step, noises)
+            adrs = [sx["adr"] for sx in ctrl.trace_sensors]
+            if adrs and cc.max_num_traces > 0:  # traces: the elites chosen by the GPU's own rewards, their sensor rows from the oracle's rollouts
+                exp = O.trace_segments(ref["sensors"], ctrl.rewards, adrs, cc.max_num_traces)
+                tr = ctrl.traces
+                assert tr.shape == exp.shape, (tr.shape, exp.shape)
+                err = max(err, float(np.abs(tr - exp).max()) if tr.size else 0.0)
             e_nom = np.abs(ctrl.nominal_knots - ref["nominal"]).max()
             e_rew = (np.abs(ctrl.rewards - ref["rewards"]) / (1 + np.abs(ref["rewards"]))).max()
             e_sig = np.abs(np.asarray(ctrl.optimizer.sigma) - state["sigma"]).max() if opt_name == "cem" else 0.0
