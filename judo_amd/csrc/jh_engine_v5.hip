@@ -68,7 +68,10 @@ constexpr int NCH = 4, NLK = 4;
 #endif
 constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane: the pool holds 16 * NSLOT contacts per rollout
 constexpr int NCP = 16 * NSLOT;  // contact pool per rollout
-constexpr int MAXHIT = 64;  // broad-phase survivors (candidate geom pairs) per rollout and step; 16 bits each.  More than that are counted as dropped contacts
+#ifndef JH_V5_MAXHIT
+#define JH_V5_MAXHIT 64
+#endif
+constexpr int MAXHIT = JH_V5_MAXHIT;  // broad-phase survivors (candidate geom pairs) per rollout and step; 16 bits each.  More than that are counted as dropped contacts
 constexpr int POOL_F = 10;  // pos3, normal3, dist, mu, body, tran
 constexpr int MAXG = 80, MAXLG = 8;
 constexpr int CUBE = 17;          // contact side codes: 0 = static geometry, 1..16 = finger link (1 + 4*chain + depth), 17 = the cube
