@@ -80,6 +80,11 @@ int jh_model_set_self_collision(jh_model* m, int on);
  * jh_task_reward, which have no such limit; out[1] = JH_MAX_KNOT_DIM; out[2] = JH_MAX_ELITES; out[3] = contact capacity per rollout
  * (0 = the model has at most one contact).  HOST pointer. */
 int jh_model_limits(const jh_model* m, int* out /* HOST, 4 ints */);
+/* out[0] of jh_model_limits is an upper bound over all horizons.  The one-lane kernels (cartpole, cylinder_push, kernel generation 1) stage W (H x K) and
+ * their lanes' knots in LDS, so their largest fused K also depends on the horizon: this returns the K up to which jh_rollout_cost accepts a launch of H
+ * steps (>= 0), or a negative jh_status.  A Controller asks before every plan step and takes the materialise path above it (a live num_nodes / horizon
+ * edit, judo/optimizers/base.py:15-21, must not raise out of update_action). */
+int jh_model_max_fused_knots(const jh_model* m, int H);
 
 /* Plan-step I/O in one call each (the two transfers of a plan step: < 2 KB down, the new nominal knots up): an asynchronous copy of `nbytes` from
  * pinned HOST memory to the device on `stream`; and an asynchronous copy from the device to pinned HOST memory followed by a wait for `stream`
@@ -87,7 +92,8 @@ int jh_model_limits(const jh_model* m, int* out /* HOST, 4 ints */);
 int jh_upload_async(void* dst_device, const void* src_host, size_t nbytes, void* stream);
 int jh_download_wait(void* dst_host, const void* src_device, size_t nbytes, void* stream);
 /* The same in two halves: `begin` enqueues the copy and marks its end on `stream`; work enqueued afterwards (the trace records of update_traces)
- * runs behind it; `end` waits for the mark only.  One transfer in flight per host thread. */
+ * runs behind it; `end` waits for the mark only.  Marks are kept per host thread and stream (a thread may drive controllers on several GPUs) and `end`
+ * waits for the oldest mark of the calling thread that has not been waited for yet; a stream carries one mark at a time. */
 int jh_download_begin(void* dst_host, const void* src_device, size_t nbytes, void* stream);
 int jh_download_end(void);
 

@@ -322,7 +322,11 @@ class Controller:
         above what the fused kernel of this model holds in registers (a live `num_nodes` edit must not kill the control loop)."""
         if self.force_materialize or type(self.task).reward is not Task.reward or self.model is None or not self.uses_fused_optimizer:
             return False
-        return self.optimizer.num_nodes <= self.model.max_fused_knots
+        # the fused kernel neither maps controls through `task_to_sim_ctrl` nor hands trajectories to `post_rollout` (controller.py:262-277): a plugin
+        # task that keeps the shipped reward but overrides either hook goes through the materialise path, where both are called
+        if type(self.task).post_rollout is not Task.post_rollout or type(self.task).task_to_sim_ctrl is not Task.task_to_sim_ctrl:
+            return False
+        return self.optimizer.num_nodes <= self.model.max_fused_knots_at(self.num_timesteps)
 
     def update_action(self) -> None:
         lib = _lib.lib()
@@ -433,9 +437,13 @@ class Controller:
         self._prefetch_args = (shard.count, shard.offset)
         ldn, noise_p = int(noise.stride(1)), noise.data_ptr()
         self._last_sigma_raw, self._last_nominal_before = sigma_raw, nominal_raw.copy()
-        if self.keep_candidates and b.knots_out is None:
-            b.knots_out = torch.empty((K, nu, shard.count), dtype=torch.float32, device=self.device)
-        knots_out = b.knots_out if self.keep_candidates else None
+        knots_out = None
+        if self.keep_candidates:
+            # the rollout kernels write candidate (k, u) of local rollout n at [(k * nu + u) * ldn + n] with the NOISE's row stride (include/judo_amd.h):
+            # a sharded draw is a column view of the full (K, nu, total) draw, so the buffer gets rows of that length and the shard's columns are handed out
+            if b.knots_out is None or b.knots_out.shape[2] != ldn:
+                b.knots_out = torch.empty((K, nu, ldn), dtype=torch.float32, device=self.device)
+            knots_out = b.knots_out[:, :, : shard.count]
         if self.record_kernel_events:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -663,6 +671,7 @@ class Controller:
         else:
             knots = recs[ok, 2:].astype(np.float64).reshape(len(ok), st["K"], st["nu"])
             U = evaluate(st["order"], st["times"], knots, st["times"][0] + self.task.dt * np.arange(H))
+            U = np.asarray(self.task.task_to_sim_ctrl(U), dtype=np.float64)  # the plant sees the mapped controls (controller.py:262-263)
             _, sensors, _ = GpuRolloutBackend(self.model, len(ok)).rollout(st["x0"], U)
             pts = np.stack([sensors[:, :, s["adr"] : s["adr"] + 3] for s in self.trace_sensors], axis=2)
         segs = np.stack([pts[:, :-1], pts[:, 1:]], axis=-2)  # (E, H-1, S, 2, 3)

@@ -93,14 +93,27 @@ extern "C" int jh_model_set_self_collision(jh_model* m, int on) {
   return JH_OK;
 }
 
+static int max_fused_knots(const jh_model* m, int H) {
+  const bool coop = m->kernel_gen >= 2 && (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK);
+  int k = JH_MAX_KNOT_DIM / (m->nu > 0 ? m->nu : 1);
+  if (coop) return k < 8 ? k : 8;
+  // the one-lane kernels stage W (H x K) and 64 lanes' knots in LDS: the launcher's 64 KiB budget bounds K as well
+  const int lds_k = (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) ? jh_simple_max_knots(m, H) : jh_engine_max_knots(m, H);
+  return k < lds_k ? k : lds_k;
+}
+
 extern "C" int jh_model_limits(const jh_model* m, int* out) {
   JH_REQUIRE(m && out, "model_limits: null pointer");
-  const bool coop = m->kernel_gen >= 2 && (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK);
-  out[0] = coop ? 8 : JH_MAX_KNOT_DIM / (m->nu > 0 ? m->nu : 1);
+  out[0] = max_fused_knots(m, 1);  // upper bound over all horizons; jh_model_max_fused_knots(m, H) is the figure for a given H
   out[1] = JH_MAX_KNOT_DIM;
   out[2] = JH_MAX_ELITES;
   out[3] = (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK) ? 32 : 0;
   return JH_OK;
+}
+
+extern "C" int jh_model_max_fused_knots(const jh_model* m, int H) {
+  JH_REQUIRE(m != nullptr && H >= 1, "model_max_fused_knots: null model or H < 1");
+  return max_fused_knots(m, H);
 }
 
 extern "C" int jh_upload_async(void* dst, const void* src, size_t nbytes, void* stream) {
@@ -116,19 +129,40 @@ extern "C" int jh_download_wait(void* dst, const void* src, size_t nbytes, void*
   return JH_OK;
 }
 
-static thread_local hipEvent_t g_dl_event = nullptr;
+// One completion mark per (host thread, stream): an event belongs to the device it was created on, so a thread that drives controllers on several GPUs
+// (one stream each) needs one per stream, created with that stream's device current.  `end` waits for the marks in the order they were set.
+namespace {
+struct DlMark { void* stream; hipEvent_t ev; };
+thread_local std::vector<DlMark> g_dl_marks;     // events owned by this thread, one per stream it has downloaded on
+thread_local std::vector<hipEvent_t> g_dl_pending;  // marks set by `begin` and not yet waited for, oldest first
+}  // namespace
 
 extern "C" int jh_download_begin(void* dst, const void* src, size_t nbytes, void* stream) {
   JH_REQUIRE(dst && src, "download_begin: null pointer");
-  if (!g_dl_event) JH_HIP(hipEventCreateWithFlags(&g_dl_event, hipEventDisableTiming));
+  hipEvent_t ev = nullptr;
+  for (const DlMark& mk : g_dl_marks) if (mk.stream == stream) ev = mk.ev;
+  if (!ev) {
+    int cur = 0, dev = 0;
+    JH_HIP(hipGetDevice(&cur));
+    dev = cur;
+    if (stream) { hipDevice_t sd; if (hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess) dev = (int)sd; else (void)hipGetLastError(); }
+    if (dev != cur) JH_HIP(hipSetDevice(dev));
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (dev != cur) (void)hipSetDevice(cur);
+    JH_HIP(e);
+    g_dl_marks.push_back({stream, ev});
+  }
   JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  JH_HIP(hipEventRecord(g_dl_event, (hipStream_t)stream));
+  JH_HIP(hipEventRecord(ev, (hipStream_t)stream));
+  g_dl_pending.push_back(ev);
   return JH_OK;
 }
 
 extern "C" int jh_download_end(void) {
-  JH_REQUIRE(g_dl_event != nullptr, "download_end without download_begin");
-  JH_HIP(hipEventSynchronize(g_dl_event));
+  JH_REQUIRE(!g_dl_pending.empty(), "download_end without download_begin");
+  hipEvent_t ev = g_dl_pending.front();
+  g_dl_pending.erase(g_dl_pending.begin());
+  JH_HIP(hipEventSynchronize(ev));
   return JH_OK;
 }
 

@@ -992,6 +992,12 @@ int launch_materialize(const jh_model* m, const float* x0, int x0_batched, const
 
 }  // namespace
 
+// largest K for which launch_cost's LDS staging (model image, W, the lanes' knots, task constants) fits the 64 KiB it may ask for
+int jh_engine_max_knots(const jh_model* m, int H) {
+  const long room = 16 * 1024 - (long)(m->nf + m->ni) - JH_MAX_TASK_PARAMS;
+  return room <= 0 ? 0 : (int)(room / ((long)H + (long)m->nu * kBlock));
+}
+
 int jh_engine_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                            const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
                            float* knots_out, hipStream_t st) {

@@ -68,6 +68,8 @@ enum {
 int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                            const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
                            float* knots_out, hipStream_t st);
+int jh_simple_max_knots(const jh_model* m, int H);  // largest fused K at horizon H (LDS staging budget of the launcher)
+int jh_engine_max_knots(const jh_model* m, int H);
 int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
                           float* sensors, hipStream_t st);
 int jh_simple_reward(const jh_model* m, const float* states, const float* controls, const float* tp, int N, int H, float* rewards, hipStream_t st);

@@ -321,6 +321,11 @@ int launch_cost(const jh_model* m, const float* x0, const float* nominal, const 
 
 }  // namespace
 
+// largest K for which launch_cost's LDS staging (W, the lanes' knots, model / task constants, x0) fits the 64 KiB it may ask for
+template <class T>
+static int max_knots(int H) { return (int)((16 * 1024 - T::NP - T::NTP - T::NX) / ((size_t)H + (size_t)T::NU * kBlock)); }
+int jh_simple_max_knots(const jh_model* m, int H) { return m->kind == JH_TASK_CARTPOLE ? max_knots<Cartpole>(H) : max_knots<CylinderPush>(H); }
+
 int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                            const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
                            float* knots_out, hipStream_t st) {

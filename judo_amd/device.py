@@ -48,16 +48,22 @@ class GpuModel:
         st = _lib.lib().jh_model_create(buf, len(blob), self.device.index or 0, C.byref(handle))
         _lib.check(st, "jh_model_create")
         self.handle = handle
+        self.kernel_generation = 3 if self.desc.get("family", self.task) == "leap_cube" else 2  # library defaults (jh_model_create)
+        self._self_collision_requested = True
         self.self_collision = self.desc.get("family", self.task) == "leap_cube"  # library default: on where the kernel models it
 
     def set_kernel(self, generation: int) -> None:
         """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: leap_cube default; 2 = cooperative: fr3_pick default; 1 = one lane per rollout)."""
         _lib.check(_lib.lib().jh_model_set_kernel(self.handle, int(generation)), "jh_model_set_kernel")
+        self.kernel_generation = int(generation)
+        # only generation 3 of the leap family models the hand's own contacts: what bench.py / tests report must follow the kernel actually selected
+        self.self_collision = self._self_collision_requested and self.kernel_generation == 3 and self.desc.get("family", self.task) == "leap_cube"
 
     def set_self_collision(self, on: bool) -> None:
         """leap_cube, kernel generation 3: model the hand's own contacts too (default) or the cube's alone."""
         _lib.check(_lib.lib().jh_model_set_self_collision(self.handle, int(bool(on))), "jh_model_set_self_collision")
-        self.self_collision = bool(on) and self.desc.get("family", self.task) == "leap_cube"
+        self._self_collision_requested = bool(on)
+        self.self_collision = bool(on) and self.kernel_generation == 3 and self.desc.get("family", self.task) == "leap_cube"
 
     @property
     def max_fused_knots(self) -> int:
@@ -65,6 +71,13 @@ class GpuModel:
         out = (C.c_int * 4)()
         _lib.check(_lib.lib().jh_model_limits(self.handle, out), "jh_model_limits")
         return int(out[0])
+
+    def max_fused_knots_at(self, H: int) -> int:
+        """Largest K `jh_rollout_cost` accepts for a launch of H steps (the one-lane kernels stage W and the knots in LDS: it depends on H)."""
+        k = int(_lib.lib().jh_model_max_fused_knots(self.handle, int(H)))
+        if k < 0:
+            _lib.check(k, "jh_model_max_fused_knots")
+        return k
 
     def stats(self, reset: bool = True) -> dict:
         """Diagnostic counters of the articulated-body kernels (synchronises)."""

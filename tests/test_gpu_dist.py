@@ -32,10 +32,13 @@ def _plan(task, opt, N, noise, group=None):
         ctrl.optimizer.seed(77)   # device noise: every rank draws all rollouts' noise from the same seed and keeps its shard's columns
     else:
         ctrl.optimizer.injected_noise = noise
+    ctrl.keep_candidates = True   # the clipped candidates of the shard, written by the rollout kernel with the row stride of the (possibly full-width) noise draw
     ctrl.update_action()
     torch.cuda.synchronize()
     sig = np.asarray(ctrl.optimizer.sigma, dtype=np.float64) if opt == "cem" else np.zeros(1)
-    return ctrl.nominal_knots.copy(), sig, ctrl.last_shard, -ctrl.rewards_local
+    cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
+    assert cand.shape[0] == ctrl.last_shard.count
+    return ctrl.nominal_knots.copy(), sig, ctrl.last_shard, -ctrl.rewards_local, cand
 
 
 def _worker(rank, world, port, cases, out_dir):
@@ -48,9 +51,9 @@ def _worker(rank, world, port, cases, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
         noise = None if seed < 0 else np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
-        nom, sig, shard, costs = _plan(task, opt, N, noise, group=dist.group.WORLD)
+        nom, sig, shard, costs, cand = _plan(task, opt, N, noise, group=dist.group.WORLD)
         assert (shard.world, shard.rank) == (world, rank) and shard.count in (N // world, N // world + 1)
-        np.savez(os.path.join(out_dir, f"case{i}_rank{rank}.npz"), nom=nom, sig=sig, costs=costs)
+        np.savez(os.path.join(out_dir, f"case{i}_rank{rank}.npz"), nom=nom, sig=sig, costs=costs, cand=cand)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,7 +68,7 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
     mp.spawn(_worker, args=(world, port, cases, str(tmp_path)), nprocs=world, join=True)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
         noise = None if seed < 0 else np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
-        nom1, sig1, _, costs1 = _plan(task, opt, N, noise)
+        nom1, sig1, _, costs1, cand1 = _plan(task, opt, N, noise)
         r0, r1 = np.load(tmp_path / f"case{i}_rank0.npz"), np.load(tmp_path / f"case{i}_rank1.npz")
         np.testing.assert_array_equal(r0["nom"], r1["nom"])  # identical on every rank without a broadcast
         np.testing.assert_array_equal(r0["sig"], r1["sig"])
@@ -74,6 +77,9 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
         assert costs2.shape == costs1.shape
         # every kernel is bit-reproducible and independent of where a rollout sits in its wave (test_gpu_edges.py): the costs are identical
         np.testing.assert_array_equal(costs2, costs1)
+        # the kept candidates of the two shards are the single process's, rank-major (a sharded device draw is a column view of the full draw:
+        # the kernel's row stride is the full width, the buffer must have it too -- ADVICE round 2)
+        np.testing.assert_array_equal(np.concatenate([r0["cand"], r1["cand"]]), cand1)
         # vs one process only the reduction is regrouped (two block records instead of one): fp32 summation order in the MPPI average
         np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=5e-6 if opt == "mppi" else 0)
         np.testing.assert_allclose(r0["sig"], sig1, rtol=1e-6, atol=1e-7)
