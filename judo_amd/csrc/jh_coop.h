@@ -209,6 +209,11 @@ __device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const
   float va[4], vb[4], vg[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) { va[q] = ca + s1[q] * e1a + s2[q] * e2a; vb[q] = cbb + s1[q] * e1b + s2[q] * e2b; vg[q] = cg + s1[q] * e1g + s2[q] * e2g; }
+  // Degenerate alignments are the rule, not the exception, in the shipped models: the gripper's two pad stacks are mirror images (equal rectangles face to
+  // face, vertices ON each other's edges), and in fp32 such a vertex lands exactly on the boundary in one coordinate and a few ulps outside in the other.
+  // The three sets must therefore tile the boundary without a hole: (a) closed (<=), (b) open in the edge parameter but CLOSED in the other rectangle
+  // coordinate, (c) open.  With (b) open in both, a vertex outside in `a` and exactly on `b = hb` belonged to no set: a closed gripper lost 8 of its 16
+  // face-to-face pad contacts that way (found against the oracle's Sutherland-Hodgman clipping, which has no such hole).
 #pragma unroll
   for (int q = 0; q < 4; q++) if (fabsf(va[q]) <= ha && fabsf(vb[q]) <= hb) emit(va[q], vb[q], vg[q]);   // (a)
 #pragma unroll
@@ -217,8 +222,8 @@ __device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const
     const float da = va[qn] - va[q], db = vb[qn] - vb[q], dg = vg[qn] - vg[q];
 #pragma unroll
     for (int sgn = -1; sgn <= 1; sgn += 2) {
-      if (da != 0.f) { float t = (sgn * ha - va[q]) / da; float bb2 = vb[q] + t * db; if (t > 0.f && t < 1.f && fabsf(bb2) < hb) emit(sgn * ha, bb2, vg[q] + t * dg); }
-      if (db != 0.f) { float t = (sgn * hb - vb[q]) / db; float aa2 = va[q] + t * da; if (t > 0.f && t < 1.f && fabsf(aa2) < ha) emit(aa2, sgn * hb, vg[q] + t * dg); }
+      if (da != 0.f) { float t = (sgn * ha - va[q]) / da; float bb2 = vb[q] + t * db; if (t > 0.f && t < 1.f && fabsf(bb2) <= hb) emit(sgn * ha, bb2, vg[q] + t * dg); }
+      if (db != 0.f) { float t = (sgn * hb - vb[q]) / db; float aa2 = va[q] + t * da; if (t > 0.f && t < 1.f && fabsf(aa2) <= ha) emit(aa2, sgn * hb, vg[q] + t * dg); }
     }
   }
   const float det = e1a * e2b - e1b * e2a;                                                               // (c)

@@ -30,9 +30,18 @@ constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, N
 constexpr int NCP = 32, NSL = NCP / G, MAXHIT = 64, RAW_F = 8, JW = NVT * 3;  // MAXHIT: broad-phase survivors (candidate pairs) per rollout and step, 16 bits each
 constexpr int MAXDT = 32;  // box pairs behind the distance sensors
 #ifndef JH_V3_NFS
-#define JH_V3_NFS 3
+#define JH_V3_NFS 6
 #endif
-constexpr int NFS = JH_V3_NFS, NFF = NFS * G;  // finger-finger contacts: kept in registers of their owner lanes (3 per lane), never in the LDS Jacobian
+constexpr int NFS = JH_V3_NFS, NFF = NFS * G;  // finger-finger contacts: kept in registers of their owner lanes (6 per lane = 96 per rollout), never in the LDS Jacobian
+#ifndef JH_V3_NOISE
+#define JH_V3_NOISE 1.2e-7f  // one fp32 ulp (2^-23), relative: the resolution of the iterate
+#endif
+#ifndef JH_V3_LSCAP
+#define JH_V3_LSCAP 12  // line-search evaluations per Newton iteration
+#endif
+#ifndef JH_V3_WPE
+#define JH_V3_WPE 1   // waves per SIMD the register allocation aims at
+#endif
 constexpr int LF = 8, RF = 9;       // moving-body indices of the two fingers (arm dofs 7 / 8 = lanes 13 / 14)
 
 struct __attribute__((aligned(16))) RS3 {  // per-rollout shared state
@@ -71,7 +80,12 @@ struct Sink3 {  // contact sink of the narrow phase
 };
 
 struct Slot3 { bool valid; float D, mu, aref[3], jar[3], jp[3]; };
-struct SlotF : Slot3 { float J13[3], J14[3]; };  // finger-finger contact: the only non-zero Jacobian columns are the two finger slides
+// finger-finger contact: the only non-zero Jacobian columns are the two finger slides, and because the two slide axes are antiparallel (checked at create:
+// jh_model_is_fr3) those two columns are EQUAL -- side A on one finger, side B on the other: s13 a13 = s14 a14.  The contact therefore sees the arm only through
+// the scalar a13 + a14 (the closing acceleration of the gripper): jar = Jf (a13 + a14) - aref and jp = Jf (p13 + p14) are recomputed where they are used, and
+// a slot is 8 registers instead of 17.  That is what lets 6 slots per lane -- 96 pad-against-pad contacts per rollout, more than the 82 a closed empty gripper
+// produces (fr3_components/fr3.xml:84-116) -- fit where 3 did.  D = 0 marks an empty slot (every term of a pyramid row carries D).
+struct SlotF { float D, mu, aref[3], Jf[3]; };
 struct DofRows3 { float fl, fD, fR, faref, lims, laref, lD, jf, jl, pf, pl; };
 
 // four one-sided rows x_k = jar_n +- mu jar_t1, jar_n +- mu jar_t2: slope and curvature along jp
@@ -95,10 +109,13 @@ __device__ __forceinline__ void contact_Jx(const RS3& S, int c, const float* xc,
   out[0] = o0; out[1] = o1; out[2] = o2;
 }
 
-__device__ __forceinline__ float lane_rows_cost(const Slot3* sl, const SlotF* sf, const DofRows3& dr, bool eq_lane, float eD, float ejar) {
+__device__ __forceinline__ float lane_rows_cost(const Slot3* sl, const SlotF* sf, float sff, const DofRows3& dr, bool eq_lane, float eD, float ejar) {
   float cs = 0.f;
 #pragma unroll
-  for (int k = 0; k < NFS; k++) if (sf[k].valid) { float f[3], W[6]; cs += pyramid_eval(sf[k].jar, sf[k].D, sf[k].mu, f, W); }
+  for (int k = 0; k < NFS; k++) if (sf[k].D > 0.f) {  // sff = a13 + a14 of the point the cost is taken at
+    const float jar[3] = {fmaf(sf[k].Jf[0], sff, -sf[k].aref[0]), fmaf(sf[k].Jf[1], sff, -sf[k].aref[1]), fmaf(sf[k].Jf[2], sff, -sf[k].aref[2])};
+    float f[3], W[6]; cs += pyramid_eval(jar, sf[k].D, sf[k].mu, f, W);
+  }
 #pragma unroll
   for (int k = 0; k < NSL; k++) if (sl[k].valid) { float f[3], W[6]; cs += pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, W); }
   if (dr.fl > 0.f) {
@@ -110,12 +127,13 @@ __device__ __forceinline__ float lane_rows_cost(const Slot3* sl, const SlotF* sf
   return cs;
 }
 
-__device__ __forceinline__ void lane_rows_dir(const Slot3* sl, const SlotF* sf, const DofRows3& dr, bool eq_lane, float eD, float ejar, float ejp, float al, float* d1, float* d2) {
+__device__ __forceinline__ void lane_rows_dir(const Slot3* sl, const SlotF* sf, float sff, float spf, const DofRows3& dr, bool eq_lane, float eD, float ejar, float ejp, float al, float* d1, float* d2) {
   float g1 = 0.f, g2 = 0.f;
+  const float sal = fmaf(al, spf, sff);  // a13 + a14 at the trial point
 #pragma unroll
-  for (int k = 0; k < NFS; k++) if (sf[k].valid) {
-    const float* jp = sf[k].jp;
-    float jar[3] = {fmaf(al, jp[0], sf[k].jar[0]), fmaf(al, jp[1], sf[k].jar[1]), fmaf(al, jp[2], sf[k].jar[2])};
+  for (int k = 0; k < NFS; k++) if (sf[k].D > 0.f) {
+    const float jp[3] = {sf[k].Jf[0] * spf, sf[k].Jf[1] * spf, sf[k].Jf[2] * spf};
+    const float jar[3] = {fmaf(sf[k].Jf[0], sal, -sf[k].aref[0]), fmaf(sf[k].Jf[1], sal, -sf[k].aref[1]), fmaf(sf[k].Jf[2], sal, -sf[k].aref[2])};
     pyramid_dir(jar, jp, sf[k].D, sf[k].mu, &g1, &g2);
   }
 #pragma unroll
@@ -177,7 +195,7 @@ __device__ __forceinline__ void geom_pose3(const RS3& S, const float* gf, int bo
 }
 
 template <bool MATERIALIZE>
-__global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V3_WPE, JH_V3_WPE))) void k_fr3_v3(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
                                                     const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
                                                     const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                     const float* __restrict__ tp, int phase, int N, int n_offset, int H, int K,
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
   }
   int n_iters = 0, n_maxed = 0;
 #ifdef JH_V3_EXITSTATS
-  int n_x[4] = {0, 0, 0, 0};  // solver exits: gradient / not a descent direction / expected decrease / iteration cap
+  int n_x[5] = {0, 0, 0, 0, 0};  // solver exits: gradient / not a descent direction / expected decrease / iteration cap / gradient at its fp32 rounding floor
 #endif
   float acc = 0.f;
   __syncthreads();
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
     if (l == 0) { S.ncon = 0; S.nhit = 0; S.nff = 0; }
     __syncthreads();
     // ================================================================ kinematics: every lane walks the 7-hinge chain (uniform records -> scalar loads)
-    float ax[8][3], og[8][3], Rown[9], pown[3], axown[3], Rc[9];
+    float Rown[9], pown[3], axown[3], Rc[9];  // joint axes / anchors of the whole chain go to LDS (S.axw, S.xpos): the dynamics below reads them from there
     {
       float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
       qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
@@ -289,11 +307,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         float P2[3], R0[9];
         if (j == 0) { for (int k = 0; k < 3; k++) P2[k] = bf[BF_LPOS + k]; for (int k = 0; k < 9; k++) R0[k] = bf[BF_LR + k]; }
         else { mulMV(P2, R, bf + BF_LPOS); for (int k = 0; k < 3; k++) P2[k] += P[k]; mulMM(R0, R, bf + BF_LR); }
-        mulMV(ax[j], R0, bf + BF_AXIS);
-        for (int k = 0; k < 3; k++) { og[j][k] = P2[k]; P[k] = P2[k]; }
+        float axj[3]; mulMV(axj, R0, bf + BF_AXIS);
+        for (int k = 0; k < 3; k++) P[k] = P2[k];
         float Rq[9]; rodrigues(Rq, bf + BF_AXIS, S.sn[j], S.cs[j]);
         mulMM(R, R0, Rq);
-        if (j == ai) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = ax[j][k]; } for (int k = 0; k < 9; k++) Rown[k] = R[k]; }
+        if (j == ai) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = axj[k]; } for (int k = 0; k < 9; k++) Rown[k] = R[k]; }
       }
       {  // finger slide hanging off link 7 (lanes that are not a finger compute finger 7 and ignore it)
         const int fi = isfinger ? ai : NCHAIN;
@@ -301,10 +319,10 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         float P2[3], R0[9], lp[3] = {bf[BF_LPOS], bf[BF_LPOS + 1], bf[BF_LPOS + 2]}, lr[9], la[3] = {bf[BF_AXIS], bf[BF_AXIS + 1], bf[BF_AXIS + 2]};
         for (int k = 0; k < 9; k++) lr[k] = bf[BF_LR + k];
         mulMV(P2, R, lp); mulMM(R0, R, lr);
-        mulMV(ax[7], R0, la);
+        float ax7[3]; mulMV(ax7, R0, la);
         const float qf = S.q[fi];
-        for (int k = 0; k < 3; k++) { P2[k] += P[k] + ax[7][k] * qf; og[7][k] = P2[k]; }
-        if (isfinger) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = ax[7][k]; } for (int k = 0; k < 9; k++) Rown[k] = R0[k]; }
+        for (int k = 0; k < 3; k++) P2[k] += P[k] + ax7[k] * qf;
+        if (isfinger) { for (int k = 0; k < 3; k++) { pown[k] = P2[k]; axown[k] = ax7[k]; } for (int k = 0; k < 9; k++) Rown[k] = R0[k]; }
       }
       if (isarm) {
         for (int k = 0; k < 3; k++) { S.xpos[1 + ai][k] = pown[k]; S.axw[1 + ai][k] = axown[k]; }
@@ -366,17 +384,18 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         const float qdj = S.qd[j];
         if (j <= depth) {
           if (j > 0) {
-            float d[3] = {og[j][0] - og[j - 1][0], og[j][1] - og[j - 1][1], og[j][2] - og[j - 1][2]}, t1[3], t2[3], t3[3];
+            float d[3] = {S.xpos[1 + j][0] - S.xpos[j][0], S.xpos[1 + j][1] - S.xpos[j][1], S.xpos[1 + j][2] - S.xpos[j][2]}, t1[3], t2[3], t3[3];
             cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d);
             for (int k = 0; k < 3; k++) ao[k] += t3[k] + t2[k];
           }
-          float wxa[3]; cross3(wxa, wv, ax[j]);
-          for (int k = 0; k < 3; k++) { al[k] += wxa[k] * qdj; wv[k] += ax[j][k] * qdj; }
+          const float axj[3] = {S.axw[1 + j][0], S.axw[1 + j][1], S.axw[1 + j][2]};
+          float wxa[3]; cross3(wxa, wv, axj);
+          for (int k = 0; k < 3; k++) { al[k] += wxa[k] * qdj; wv[k] += axj[k] * qdj; }
         }
       }
       if (isfinger) {  // slide joint: the origin moves with the parent, plus the Coriolis term of the sliding rate
-        float d[3] = {og[7][0] - og[6][0], og[7][1] - og[6][1], og[7][2] - og[6][2]}, t1[3], t2[3], t3[3], wxa[3];
-        cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d); cross3(wxa, wv, ax[7]);
+        float d[3] = {pown[0] - S.xpos[NCHAIN][0], pown[1] - S.xpos[NCHAIN][1], pown[2] - S.xpos[NCHAIN][2]}, t1[3], t2[3], t3[3], wxa[3];
+        cross3(t1, wv, d); cross3(t2, wv, t1); cross3(t3, al, d); cross3(wxa, wv, axown);
         for (int k = 0; k < 3; k++) ao[k] += t3[k] + t2[k] + 2.f * wxa[k] * qd;
       }
       float t1[3], t2[3], t3[3], ac[3];
@@ -389,19 +408,21 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
 #pragma unroll
       for (int e = 0; e < NCHAIN; e++) {
         const bool val = e <= depth;
-        float ri[3] = {com[0] - og[e][0], com[1] - og[e][1], com[2] - og[e][2]}, rxF[3];
-        cross3(Jv[e], ax[e], ri); cross3(rxF, ri, Fk);
-        bias[e] = val ? ax[e][0] * (Nk[0] + rxF[0]) + ax[e][1] * (Nk[1] + rxF[1]) + ax[e][2] * (Nk[2] + rxF[2]) : 0.f;
+        const float axe[3] = {S.axw[1 + e][0], S.axw[1 + e][1], S.axw[1 + e][2]};
+        float ri[3] = {com[0] - S.xpos[1 + e][0], com[1] - S.xpos[1 + e][1], com[2] - S.xpos[1 + e][2]}, rxF[3];
+        cross3(Jv[e], axe, ri); cross3(rxF, ri, Fk);
+        bias[e] = val ? axe[0] * (Nk[0] + rxF[0]) + axe[1] * (Nk[1] + rxF[1]) + axe[2] * (Nk[2] + rxF[2]) : 0.f;
         if (!val) Jv[e][0] = Jv[e][1] = Jv[e][2] = 0.f;
       }
-      for (int k = 0; k < 3; k++) Jv[7][k] = isfinger ? ax[7][k] : 0.f;
-      bias[7] = isfinger ? dot3(ax[7], Fk) : 0.f;
+      for (int k = 0; k < 3; k++) Jv[7][k] = isfinger ? axown[k] : 0.f;
+      bias[7] = isfinger ? dot3(axown, Fk) : 0.f;
 #pragma unroll
       for (int a = 0; a < NCHAIN; a++) {
-        float tB[3]; inertia_mul(tB, Rk, di, ax[a]);
+        const float axa[3] = {S.axw[1 + a][0], S.axw[1 + a][1], S.axw[1 + a][2]};
+        float tB[3]; inertia_mul(tB, Rk, di, axa);
         const bool va = a <= depth;
 #pragma unroll
-        for (int b = 0; b <= a; b++) Mc[tri(a, b)] = va ? mass * dot3(Jv[a], Jv[b]) + dot3(tB, ax[b]) : 0.f;
+        for (int b = 0; b <= a; b++) Mc[tri(a, b)] = va ? mass * dot3(Jv[a], Jv[b]) + tB[0] * S.axw[1 + b][0] + tB[1] * S.axw[1 + b][1] + tB[2] * S.axw[1 + b][2] : 0.f;
       }
 #pragma unroll
       for (int b = 0; b < NCHAIN; b++) Mf[b] = mass * dot3(Jv[7], Jv[b]);  // slide row: translational coupling only
@@ -504,19 +525,18 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
 #pragma unroll
     for (int k = 0; k < NFS; k++) {  // finger-finger contacts go straight into registers of their owner lane
       const int c = l + 16 * k;
-      sf[k].valid = c < nff;
       sf[k].D = 0.f; sf[k].mu = 0.f;
-      for (int w = 0; w < 3; w++) sf[k].aref[w] = sf[k].jar[w] = sf[k].jp[w] = sf[k].J13[w] = sf[k].J14[w] = 0.f;
-      if (sf[k].valid) {
+      for (int w = 0; w < 3; w++) sf[k].aref[w] = sf[k].Jf[w] = 0.f;
+      if (c < nff) {
         const float* e = &S.J[0][0] + c * RAW_F;
         float fr[9]; fr[0] = e[3]; fr[1] = e[4]; fr[2] = e[5];
         make_frame(fr);
         const float dist = e[6]; const int p = __float_as_int(e[7]);
         const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
         const int bA = gI[m.oAGI + g1 * GEOM_I], bB = gI[m.oAGI + g2 * GEOM_I];
-        const float s13 = (bB == LF ? 1.f : 0.f) - (bA == LF ? 1.f : 0.f), s14 = (bB == RF ? 1.f : 0.f) - (bA == RF ? 1.f : 0.f);
-        const float a13[3] = {S.axw[LF][0], S.axw[LF][1], S.axw[LF][2]}, a14[3] = {S.axw[RF][0], S.axw[RF][1], S.axw[RF][2]};
-        for (int w = 0; w < 3; w++) { sf[k].J13[w] = s13 * dot3(fr + 3 * w, a13); sf[k].J14[w] = s14 * dot3(fr + 3 * w, a14); }
+        const float s13 = (bB == LF ? 1.f : 0.f) - (bA == LF ? 1.f : 0.f);
+        const float a13[3] = {S.axw[LF][0], S.axw[LF][1], S.axw[LF][2]};
+        for (int w = 0; w < 3; w++) sf[k].Jf[w] = s13 * dot3(fr + 3 * w, a13);  // = s14 * (frame . a14): the two slide axes are antiparallel
         const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
         const float* q1 = gF + m.oGPF + g1 * GP_F; const float* q2 = gF + m.oGPF + g2 * GP_F;
         const float mu = fmaxf(f1[GF_MU], f2[GF_MU]), tran = f1[GF_TRAN] + f2[GF_TRAN];
@@ -527,8 +547,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran * (1.f + mu * mu));
         const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
         sf[k].D = 1.f / Rpy; sf[k].mu = mu;
-        const float v13 = S.qd[LF - 1], v14 = S.qd[RF - 1];
-        for (int w = 0; w < 3; w++) { const float vel = sf[k].J13[w] * v13 + sf[k].J14[w] * v14; sf[k].aref[w] = -cB * vel - (w == 0 ? cK * imp * dist : 0.f); }
+        const float vff = S.qd[LF - 1] + S.qd[RF - 1];
+        for (int w = 0; w < 3; w++) { const float vel = sf[k].Jf[w] * vff; sf[k].aref[w] = -cB * vel - (w == 0 ? cK * imp * dist : 0.f); }
       }
     }
     __syncthreads();
@@ -613,7 +633,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
     }
     PH3(4)
     // ================================================================ Newton solver
-    float a_own;
+    float a_own, sff = 0.f;  // sff = a13 + a14 of the current iterate: all a finger-finger contact sees of it
     const float iMd = 1.f / Md_own;
     const float snorm = gsum(hasdof ? fs_own * fs_own * iMd : 0.f);
     int iters_this = 0;
@@ -625,34 +645,32 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
         float xc[6], jar_ws[NSL][3];
         for (int k = 0; k < 6; k++) xc[k] = S.vec[0][k];
         for (int k = 0; k < NSL; k++) if (sl[k].valid) { float jx[3]; contact_Jx(S, l + 16 * k, xc, S.vec[0] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
-        for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jar[w] = sf[k].J13[w] * S.vec[0][13] + sf[k].J14[w] * S.vec[0][14] - sf[k].aref[w];
+        const float sff_ws = S.vec[0][13] + S.vec[0][14], sff_0 = S.vec[1][13] + S.vec[1][14];
         dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
         ejar = has_eq ? quad_get(qws, 1) - e_a1 * quad_get(qws, 2) - earef : 0.f;
         float mdw = 0.f;
         if (isarm) { for (int a = 0; a < NA; a++) mdw += Mrow[a] * S.vec[2][6 + a]; } else if (iscube) mdw = Md_own * (qws - a0_own);
-        const float cost_ws = gsum(lane_rows_cost(sl, sf, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
+        const float cost_ws = gsum(lane_rows_cost(sl, sf, sff_ws, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
         for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) jar_ws[k][w] = sl[k].jar[w];
-        float jarf_ws[NFS][3];
-        for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) { jarf_ws[k][w] = sf[k].jar[w]; sf[k].jar[w] = sf[k].J13[w] * S.vec[1][13] + sf[k].J14[w] * S.vec[1][14] - sf[k].aref[w]; }
         const float jf_ws = dr.jf, jl_ws = dr.jl, ej_ws = ejar;
         for (int k = 0; k < 6; k++) xc[k] = S.vec[1][k];
         for (int k = 0; k < NSL; k++) if (sl[k].valid) { float jx[3]; contact_Jx(S, l + 16 * k, xc, S.vec[1] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
         dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
         ejar = has_eq ? quad_get(a0_own, 1) - e_a1 * quad_get(a0_own, 2) - earef : 0.f;
-        const float cost_0 = gsum(lane_rows_cost(sl, sf, dr, eq_lane, eD, ejar));
+        const float cost_0 = gsum(lane_rows_cost(sl, sf, sff_0, dr, eq_lane, eD, ejar));
         if (cost_ws < cost_0) {
           a_own = qws;
           for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] = jar_ws[k][w];
-          for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jar[w] = jarf_ws[k][w];
-          dr.jf = jf_ws; dr.jl = jl_ws; ejar = ej_ws;
-        } else a_own = a0_own;
+          dr.jf = jf_ws; dr.jl = jl_ws; ejar = ej_ws; sff = sff_ws;
+        } else { a_own = a0_own; sff = sff_0; }
         __syncthreads();
       }
       bool has_rows_l = dr.fl > 0.f || dr.lims != 0.f || has_eq;
       for (int k = 0; k < NSL; k++) has_rows_l |= sl[k].valid;
-      for (int k = 0; k < NFS; k++) has_rows_l |= sf[k].valid;
+      for (int k = 0; k < NFS; k++) has_rows_l |= sf[k].D > 0.f;
       bool act = gor((int)has_rows_l) != 0;
-      if (!act) a_own = a0_own;
+      if (!act) { a_own = a0_own; sff = 0.f; }
+      float hdiag = 0.f;  // own diagonal entry of the last assembled Hessian
       for (int it = 0; it < cap && __any(act); it++) {
         // ---- (1) gradient row: M (a - a0) + dof rows + equality - J' f
         const float da_own = a_own - a0_own;
@@ -676,27 +694,33 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
           const float* jc = S.J[c] + 3 * l; const float* fc = S.fW[c];
           g_own -= jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2];
         }
-        float ffg13 = 0.f, ffg14 = 0.f, ffh0 = 0.f, ffh1 = 0.f, ffh2 = 0.f;  // finger-finger contacts: -J'f and J'WJ on the two finger dofs
+        float ffg = 0.f, ffh = 0.f;  // finger-finger contacts: -Jf'f and Jf'W Jf, the same number on both finger dofs and on their coupling
 #pragma unroll
-        for (int k = 0; k < NFS; k++) if (sf[k].valid) {
-          float f[3], Wm[6]; pyramid_eval(sf[k].jar, sf[k].D, sf[k].mu, f, Wm);
-          const float* j13 = sf[k].J13; const float* j14 = sf[k].J14;
-          ffg13 -= j13[0] * f[0] + j13[1] * f[1] + j13[2] * f[2]; ffg14 -= j14[0] * f[0] + j14[1] * f[1] + j14[2] * f[2];
-          const float G0 = Wm[0] * j13[0] + Wm[1] * j13[1] + Wm[3] * j13[2], G1 = Wm[1] * j13[0] + Wm[2] * j13[1] + Wm[4] * j13[2], G2 = Wm[3] * j13[0] + Wm[4] * j13[1] + Wm[5] * j13[2];
-          const float K0 = Wm[0] * j14[0] + Wm[1] * j14[1] + Wm[3] * j14[2], K1 = Wm[1] * j14[0] + Wm[2] * j14[1] + Wm[4] * j14[2], K2 = Wm[3] * j14[0] + Wm[4] * j14[1] + Wm[5] * j14[2];
-          ffh0 += j13[0] * G0 + j13[1] * G1 + j13[2] * G2; ffh1 += j14[0] * G0 + j14[1] * G1 + j14[2] * G2; ffh2 += j14[0] * K0 + j14[1] * K1 + j14[2] * K2;
+        for (int k = 0; k < NFS; k++) if (sf[k].D > 0.f) {
+          const float* jf = sf[k].Jf;
+          const float jar[3] = {fmaf(jf[0], sff, -sf[k].aref[0]), fmaf(jf[1], sff, -sf[k].aref[1]), fmaf(jf[2], sff, -sf[k].aref[2])};
+          float f[3], Wm[6]; pyramid_eval(jar, sf[k].D, sf[k].mu, f, Wm);
+          ffg -= jf[0] * f[0] + jf[1] * f[1] + jf[2] * f[2];
+          const float G0 = Wm[0] * jf[0] + Wm[1] * jf[1] + Wm[3] * jf[2], G1 = Wm[1] * jf[0] + Wm[2] * jf[1] + Wm[4] * jf[2], G2 = Wm[3] * jf[0] + Wm[4] * jf[1] + Wm[5] * jf[2];
+          ffh += jf[0] * G0 + jf[1] * G1 + jf[2] * G2;
         }
         if (__any(nff > 0)) {
-          ffg13 = gsum(ffg13); ffg14 = gsum(ffg14); ffh0 = gsum(ffh0); ffh1 = gsum(ffh1); ffh2 = gsum(ffh2);
-          if (l == 13) g_own += ffg13;
-          if (l == 14) g_own += ffg14;
+          ffg = gsum(ffg); ffh = gsum(ffh);
+          if (l == 13 || l == 14) g_own += ffg;
         }
         // ---- (2) convergence on the scaled gradient; leave before any Hessian work once every rollout of the wave is done
-        const float gn = gsum(hasdof ? g_own * g_own * iMd : 0.f);
+        // fp32 floor of the gradient: one ulp of the iterate moves row l of the gradient by H_ll * eps * |a_l|.  Stiff rows (sum D J'J ~ 1e4..1e5 on a finger
+        // of 0.2 kg against an acceleration of a few hundred m/s^2: a closing gripper whose pad stacks meet at 1 m/s) put that far above tol * |smooth force|;
+        // the iterate then sits on the fp32 number nearest to the minimiser, the gradient test never passes and the solve would run to the iteration cap
+        // hopping in the soft directions on the rounding noise of the stiff ones.  H_ll is the diagonal of the last assembled Hessian (0 before the first).
+        // Row by row: only what a row's gradient exceeds its own floor by counts, so the soft rows still have to meet the tolerance themselves.
+        const float gfl = JH_V3_NOISE * hdiag * a_own;
+        const float gn = gsum(hasdof ? fmaxf(g_own * g_own - gfl * gfl, 0.f) * iMd : 0.f);
+        const float gtol = tol * tol * fmaxf(snorm, 1e-12f);
 #ifdef JH_V3_EXITSTATS
-        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) n_x[0]++;
+        if (act && gn <= gtol) n_x[gsum(hasdof ? g_own * g_own * iMd : 0.f) <= gtol ? 0 : 4]++;
 #endif
-        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        if (act && gn <= gtol) act = false;
         if (!__any(act)) break;
         if (act) iters_this++;
         // ---- (3) Hessian row r (columns 0..r): M + dof rows + equality + sum_c J_c[:,r]' W_c J_c[:,0..r]; lane 15 holds -g
@@ -714,8 +738,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
           if (l == 13) Hrow[13] += eD;
           if (l == 14) { Hrow[14] += e_a1 * e_a1 * eD; Hrow[13] -= e_a1 * eD; }
         }
-        if (l == 13) Hrow[13] += ffh0;
-        if (l == 14) { Hrow[13] += ffh1; Hrow[14] += ffh2; }
+        if (l == 13) Hrow[13] += ffh;
+        if (l == 14) { Hrow[13] += ffh; Hrow[14] += ffh; }
         if (hasdof) for (int c = 0; c < ncon; c++) {
           const float* fc = S.fW[c];
           if (fc[3] == 0.f && fc[5] == 0.f && fc[8] == 0.f) continue;  // no active pyramid row
@@ -725,6 +749,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
 #pragma unroll
           for (int j = 0; j < NVT; j++) Hrow[j] += Jc[3 * j] * G0 + Jc[3 * j + 1] * G1 + Jc[3 * j + 2] * G2;
         }
+#pragma unroll
+        for (int j = 0; j < NVT; j++) if (j == l) hdiag = Hrow[j];
         __syncthreads();
         if (l == 15) {
 #pragma unroll
@@ -786,13 +812,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
           for (int j = 0; j < NVT; j++) { o0 = fmaf(Jc[3 * j], p[j], o0); o1 = fmaf(Jc[3 * j + 1], p[j], o1); o2 = fmaf(Jc[3 * j + 2], p[j], o2); }
           sl[k].jp[0] = o0; sl[k].jp[1] = o1; sl[k].jp[2] = o2;
         }
-        for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jp[w] = sf[k].J13[w] * p[13] + sf[k].J14[w] * p[14];
+        const float spf = p[13] + p[14];
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         ejp = has_eq ? p[13] - e_a1 * p[14] : 0.f;
         float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
-        for (int ls = 0; ls < 12 && __any(lsact); ls++) {
+        for (int ls = 0; ls < JH_V3_LSCAP && __any(lsact); ls++) {
           float d1, d2;
-          lane_rows_dir(sl, sf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
+          lane_rows_dir(sl, sf, sff, spf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
@@ -806,10 +832,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
           }
         }
         // ---- (7) step
+#ifdef JH_V3_TRACE
+        if (lane == 0 && it >= 6 && it < 22) printf("step %d it %d gn %.3e gtol %.3e gp %.3e alpha %.5g sff %.6f spf %.3e lo %.4g hi %.4g\n", hh, it, gn, gtol, gp, alpha, sff, spf, lo, hi);
+#endif
         if (act) {
           a_own += alpha * p_own;
           for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] += alpha * sl[k].jp[w];
-          for (int k = 0; k < NFS; k++) for (int w = 0; w < 3; w++) sf[k].jar[w] += alpha * sf[k].jp[w];
+          sff = fmaf(alpha, spf, sff);
           dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl; ejar += alpha * ejp;
 #ifdef JH_V3_EXITSTATS
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) n_x[2]++;
@@ -820,7 +849,10 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
       }
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
 #ifdef JH_V3_EXITSTATS
-      if (act) n_x[3]++;
+      if (act) {
+        n_x[3]++;
+        if (stats && l == 0 && atomicCAS(stats + 39, 0, 1) == 0) { stats[40] = n_offset + n; stats[41] = hh; }  // the first solve that ran into the iteration cap: which rollout, which step
+      }
 #endif
     }
     PH3(5)
@@ -890,7 +922,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_fr3_v3(const float* __restrict__ gF
   }
   if (!MATERIALIZE && live && l == 0) costs[n] = acc;
 #ifdef JH_V3_EXITSTATS
-  if (stats && live && l == 0) for (int k = 0; k < 4; k++) atomicAdd(stats + 24 + k, n_x[k]);
+  if (stats && live && l == 0) for (int k = 0; k < 5; k++) atomicAdd(stats + 24 + k, n_x[k]);
 #ifdef JH_V3_PHASES
   PH3(6)
   if (stats && lane == 0) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)ph_acc[k]);
@@ -921,6 +953,14 @@ bool jh_model_is_fr3(const jh_model* m) {
     const int* pi = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + 2 * p;
     const int b1 = m->h_i[gi + 8 + pi[0] * jh_eng::GEOM_I], b2 = m->h_i[gi + 8 + pi[1] * jh_eng::GEOM_I];
     if (b1 >= 1 && b2 >= 1 && !((b1 == LF && b2 == RF) || (b1 == RF && b2 == LF))) return false;
+  }
+  {  // the two finger slides must be antiparallel in the frame of their common parent: the finger-finger slots rely on it (struct SlotF)
+    float w[2][3];
+    for (int f = 0; f < 2; f++) {
+      const float* bf = m->h_f.data() + jh_eng::HEADER_F + (LF + f) * jh_eng::BODY_F;
+      for (int i = 0; i < 3; i++) w[f][i] = bf[jh_eng::BF_LR + 3 * i] * bf[jh_eng::BF_AXIS] + bf[jh_eng::BF_LR + 3 * i + 1] * bf[jh_eng::BF_AXIS + 1] + bf[jh_eng::BF_LR + 3 * i + 2] * bf[jh_eng::BF_AXIS + 2];
+    }
+    for (int i = 0; i < 3; i++) if (fabsf(w[0][i] + w[1][i]) > 1e-6f) return false;
   }
   if (neq == 1) { const int* ei = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2; if (ei[0] != 13 || ei[1] != 14) return false; }
   for (int u = 0; u < NU; u++) if (m->h_i[jh_eng::HEADER_I + NMB * jh_eng::BODY_I + m->h_i[1] * jh_eng::BLOCK_I + u * jh_eng::ACT_I] != 6 + u) return false;

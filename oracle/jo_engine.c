@@ -559,6 +559,37 @@ static int collide_plane_box(const double* pp, const double* Rp, const double* p
   return cnt;
 }
 
+/* One geom pair -> raw contacts (normal from geom 1 to geom 2 after `flip` is applied by the caller).  Returns the number of contacts; -1 = no routine for
+ * this pair of types (the shipped models never pair them). */
+static int collide_geoms(int t1, const double* s1, const double* p1, const double* R1, int t2, const double* s2, const double* p2, const double* R2, double margin, rawcon* rc, int* flip) {
+  int n = -1; *flip = 0;
+  for (int i = 0; i < 8; i++) rc[i].has_t = 0;
+  if (t1 == JO_GEOM_PLANE || t2 == JO_GEOM_PLANE) {
+    int first = t1 == JO_GEOM_PLANE;
+    const double *pp = first ? p1 : p2, *Rp = first ? R1 : R2, *po = first ? p2 : p1, *Ro = first ? R2 : R1, *so = first ? s2 : s1;
+    int to = first ? t2 : t1;
+    *flip = !first;
+    if (to == JO_GEOM_SPHERE) n = collide_plane_sphere(pp, Rp, po, so[0], margin, rc);
+    else if (to == JO_GEOM_CAPSULE) n = collide_plane_capsule(pp, Rp, po, Ro, so, margin, rc);
+    else if (to == JO_GEOM_BOX) n = collide_plane_box(pp, Rp, po, Ro, so, margin, rc);
+  } else
+  if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_BOX) n = collide_box_box(p1, R1, s1, p2, R2, s2, margin, rc);
+  else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_SPHERE) n = collide_box_sphere(p1, R1, s1, p2, s2[0], margin, rc);
+  else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(p2, R2, s2, p1, s1[0], margin, rc); *flip = 1; }
+  else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_SPHERE) n = collide_sphere_sphere(p1, s1[0], p2, s2[0], margin, rc);
+  else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) n = collide_cyl_cyl_parallel(p1, R1, s1, p2, R2, s2, margin, rc);
+  return n;
+}
+
+/* test hook (tests/test_oracle_independent.py): one pair of free-standing shapes -> contacts as rows (dist, pos[3], normal[3] from shape 1 to shape 2) */
+int jo_collide_shapes(int t1, const double* s1, const double* p1, const double* q1, int t2, const double* s2, const double* p2, const double* q2, double margin, double* out /* 8*7 */) {
+  double R1[9], R2[9]; quat2mat(R1, q1); quat2mat(R2, q2);
+  rawcon rc[8]; int flip = 0;
+  int n = collide_geoms(t1, s1, p1, R1, t2, s2, p2, R2, margin, rc, &flip);
+  for (int i = 0; i < n; i++) { out[7 * i] = rc[i].dist; copy3(out + 7 * i + 1, rc[i].pos); for (int k = 0; k < 3; k++) out[7 * i + 4 + k] = flip ? -rc[i].n[k] : rc[i].n[k]; }
+  return n;
+}
+
 static void collision(const jo_model* m, jo_data* d) {
   d->ncon = 0;
   if (!m->contact_enabled) return;
@@ -568,21 +599,9 @@ static void collision(const jo_model* m, jo_data* d) {
     double dc[3] = {d->geom_xpos[g2][0] - d->geom_xpos[g1][0], d->geom_xpos[g2][1] - d->geom_xpos[g1][1], d->geom_xpos[g2][2] - d->geom_xpos[g1][2]};
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     if (t1 != JO_GEOM_PLANE && t2 != JO_GEOM_PLANE && norm3(dc) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue; /* bounding-sphere filter */
-    rawcon rc[8]; int n = 0, flip = 0;
-    for (int i = 0; i < 8; i++) rc[i].has_t = 0;
-    if (t1 == JO_GEOM_PLANE || t2 == JO_GEOM_PLANE) {
-      int gp = t1 == JO_GEOM_PLANE ? g1 : g2, go = t1 == JO_GEOM_PLANE ? g2 : g1, to = m->geom_type[go];
-      flip = (gp != g1);
-      if (to == JO_GEOM_SPHERE) n = collide_plane_sphere(d->geom_xpos[gp], d->geom_xmat[gp], d->geom_xpos[go], m->geom_size[go][0], margin, rc);
-      else if (to == JO_GEOM_CAPSULE) n = collide_plane_capsule(d->geom_xpos[gp], d->geom_xmat[gp], d->geom_xpos[go], d->geom_xmat[go], m->geom_size[go], margin, rc);
-      else if (to == JO_GEOM_BOX) n = collide_plane_box(d->geom_xpos[gp], d->geom_xmat[gp], d->geom_xpos[go], d->geom_xmat[go], m->geom_size[go], margin, rc);
-    } else
-    if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_BOX) n = collide_box_box(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
-    else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_SPHERE) n = collide_box_sphere(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], m->geom_size[g2][0], margin, rc);
-    else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], d->geom_xpos[g1], m->geom_size[g1][0], margin, rc); flip = 1; }
-    else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_SPHERE) n = collide_sphere_sphere(d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2], m->geom_size[g2][0], margin, rc);
-    else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) n = collide_cyl_cyl_parallel(d->geom_xpos[g1], d->geom_xmat[g1], m->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2], m->geom_size[g2], margin, rc);
-    for (int i = 0; i < n; i++) {
+    rawcon rc[8]; int flip = 0;
+    int n = collide_geoms(t1, m->geom_size[g1], d->geom_xpos[g1], d->geom_xmat[g1], t2, m->geom_size[g2], d->geom_xpos[g2], d->geom_xmat[g2], margin, rc, &flip);
+    for (int i = 0; i < n; i++) {  /* n = -1 (no routine for the pair): nothing */
       if (d->ncon >= JO_MAXCON) { d->con_overflow++; break; }
       jo_contact* c = &d->con[d->ncon++];
       c->dist = rc[i].dist; copy3(c->pos, rc[i].pos);
@@ -973,6 +992,22 @@ void jo_forward(const jo_model* m, jo_data* d) {
   solve_constraints(m, d);
 }
 
+/* mj_integratePos: qpos advanced by qvel over h (free joints: linear velocity in the world frame, angular velocity in the body frame) */
+static void integrate_pos(const jo_model* m, jo_data* d, double h) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == JO_JNT_FREE) {
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k];
+      double w[3] = {d->qvel[da + 3], d->qvel[da + 4], d->qvel[da + 5]}, ang = norm3(w) * h;
+      if (ang > 0) {
+        double ax[3] = {w[0] / norm3(w), w[1] / norm3(w), w[2] / norm3(w)}, dq[4], qn[4];
+        axisangle2quat(dq, ax, ang); quat_mul(qn, d->qpos + qa + 3, dq); memcpy(d->qpos + qa + 3, qn, sizeof(qn));
+      }
+      quat_normalize(d->qpos + qa + 3);
+    } else d->qpos[qa] += h * d->qvel[da];
+  }
+}
+
 static void integrate(const jo_model* m, jo_data* d) {
   int nv = m->nv; double h = m->dt;
   double extra[JO_MAXDOF]; int any = 0;
@@ -991,18 +1026,7 @@ static void integrate(const jo_model* m, jo_data* d) {
     cholesky(nv, A, LA); chol_solve(nv, LA, qacc);
   } else memcpy(qacc, d->qacc, sizeof(double) * nv);
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
-  for (int j = 0; j < m->njnt; j++) { /* mj_integratePos with the updated velocity */
-    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
-    if (m->jnt_type[j] == JO_JNT_FREE) {
-      for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k];
-      double w[3] = {d->qvel[da + 3], d->qvel[da + 4], d->qvel[da + 5]}, ang = norm3(w) * h;
-      if (ang > 0) {
-        double ax[3] = {w[0] / norm3(w), w[1] / norm3(w), w[2] / norm3(w)}, dq[4], qn[4];
-        axisangle2quat(dq, ax, ang); quat_mul(qn, d->qpos + qa + 3, dq); memcpy(d->qpos + qa + 3, qn, sizeof(qn));
-      }
-      quat_normalize(d->qpos + qa + 3);
-    } else d->qpos[qa] += h * d->qvel[da];
-  }
+  integrate_pos(m, d, h); /* mj_integratePos with the updated velocity */
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
   for (int i = 0; i < nv; i++) d->qacc_con_prev[i] = d->qacc[i] - d->qacc_smooth[i];
 }
@@ -1039,6 +1063,49 @@ int jo_forward_probe(const jo_model* m, const double* qpos, const double* qvel, 
   int n = d->ncon;
   jo_data_free(d);
   return n;
+}
+
+/* test hooks: kinematics only.  World pose of a body at qpos; mj_integratePos of qpos by dq (nv) over a unit time. */
+void jo_body_pose(const jo_model* m, const double* qpos, int body, double* pos, double* mat) {
+  jo_data* d = jo_data_new();
+  memcpy(d->qpos, qpos, sizeof(double) * m->nq);
+  kinematics(m, d);
+  copy3(pos, d->xpos[body]); memcpy(mat, d->xmat[body], 9 * sizeof(double));
+  jo_data_free(d);
+}
+void jo_integrate_pos(const jo_model* m, const double* qpos, const double* dq, double* out) {
+  jo_data* d = jo_data_new();
+  memcpy(d->qpos, qpos, sizeof(double) * m->nq); memcpy(d->qvel, dq, sizeof(double) * m->nv);
+  integrate_pos(m, d, 1.0);
+  memcpy(out, d->qpos, sizeof(double) * m->nq);
+  jo_data_free(d);
+}
+
+/* The assembled constraint problem of one forward pass, for checks that do not share a line with solve_constraints (tests/test_oracle_independent.py builds
+ * MuJoCo's documented primal objective from these arrays in numpy and minimises it with a generic solver): M (nv*nv), qacc_smooth (nv), then per row the
+ * Jacobian (nefc*nv), aref, R, frictionloss, type, contact id; per contact the first row, dim, regularised mu and the friction coefficients (5).  dims = {nefc, ncon,
+ * cone}.  Returns nefc, or -1 when a buffer is too small. */
+int jo_export_problem(const jo_model* m, const double* qpos, const double* qvel, const double* ctrl, const double* qacc_warmstart, int max_efc, int max_con,
+                      double* M_out, double* qacc_smooth, double* J, double* aref, double* R, double* frictionloss, int* type, int* id,
+                      int* con_adr, int* con_dim, double* con_mu, double* con_friction, double* qacc, int* dims) {
+  jo_data* d = jo_data_new();
+  memcpy(d->qpos, qpos, sizeof(double) * m->nq); memcpy(d->qvel, qvel, sizeof(double) * m->nv); if (m->nact) memcpy(d->ctrl, ctrl, sizeof(double) * m->nact);
+  if (qacc_warmstart) memcpy(d->qacc_warmstart, qacc_warmstart, sizeof(double) * m->nv);
+  jo_forward(m, d);
+  int nv = m->nv, ne = d->nefc, rc = ne;
+  dims[0] = ne; dims[1] = d->ncon; dims[2] = m->cone;
+  if (ne > max_efc || d->ncon > max_con) rc = -1;
+  else {
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) M_out[i * nv + j] = d->M[i][j];
+    memcpy(qacc_smooth, d->qacc_smooth, sizeof(double) * nv); memcpy(qacc, d->qacc, sizeof(double) * nv);
+    for (int r = 0; r < ne; r++) {
+      memcpy(J + (size_t)r * nv, d->efc_J[r], sizeof(double) * nv);
+      aref[r] = d->efc_aref[r]; R[r] = d->efc_R[r]; frictionloss[r] = d->efc_frictionloss[r]; type[r] = d->efc_type[r]; id[r] = d->efc_id[r];
+    }
+    for (int c = 0; c < d->ncon; c++) { con_adr[c] = d->con[c].efc_adr; con_dim[c] = d->con[c].dim; con_mu[c] = d->con[c].mu; memcpy(con_friction + 5 * c, d->con[c].friction, 5 * sizeof(double)); }
+  }
+  jo_data_free(d);
+  return rc;
 }
 
 /* ------------------------------------------------------------------ finalize: qpos0, dof tree, inverse weights at qpos0 (mjModel "set0") */

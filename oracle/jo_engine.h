@@ -45,8 +45,8 @@ extern "C" {
 #define JO_MAXSENSORDATA 48
 #define JO_MAXPAIR 2048
 #define JO_MAXEQ 4
-#define JO_MAXCON 96
-#define JO_MAXEFC 400
+#define JO_MAXCON 160
+#define JO_MAXEFC 720
 
 enum { JO_JNT_FREE = 0, JO_JNT_SLIDE = 2, JO_JNT_HINGE = 3 };
 enum { JO_GEOM_PLANE = 0, JO_GEOM_SPHERE = 2, JO_GEOM_CAPSULE = 3, JO_GEOM_CYLINDER = 5, JO_GEOM_BOX = 6 };
@@ -159,6 +159,16 @@ double jo_energy(const jo_model* m, jo_data* d, double* kinetic, double* potenti
 int jo_forward_probe(const jo_model* m, const double* qpos, const double* qvel, const double* ctrl, double* qacc, double* qacc_smooth,
                      double* qfrc_bias, double* qfrc_constraint, double* sensordata, int* ncon_nefc_iter, double* contacts /* ncon*16 */,
                      double* stats /* cost, gradnorm, trace(M) */);
+
+/* test hooks for checks that use the kinematics / one narrow-phase routine in isolation (tests/test_oracle_independent.py) */
+void jo_body_pose(const jo_model* m, const double* qpos, int body, double* pos, double* mat);
+void jo_integrate_pos(const jo_model* m, const double* qpos, const double* dq, double* out);
+int jo_collide_shapes(int t1, const double* s1, const double* p1, const double* q1, int t2, const double* s2, const double* p2, const double* q2, double margin, double* out /* 8 rows of 7 */);
+
+/* the assembled constraint problem of one forward pass (independent-solver checks in tests/): see jo_engine.c */
+int jo_export_problem(const jo_model* m, const double* qpos, const double* qvel, const double* ctrl, const double* qacc_warmstart, int max_efc, int max_con,
+                      double* M_out, double* qacc_smooth, double* J, double* aref, double* R, double* frictionloss, int* type, int* id,
+                      int* con_adr, int* con_dim, double* con_mu, double* con_friction, double* qacc, int* dims);
 
 /* rollout: x0 (nq+nv), controls (H,nu) -> states (H,nq+nv) after each step, sensors (H,ns) as held by the step
  * that produced the state (computed by the forward pass at the START of that step: MuJoCo semantics,

@@ -71,6 +71,12 @@ def lib() -> C.CDLL:
         L.jo_energy.restype = C.c_double
         L.jo_energy.argtypes = [C.c_void_p, C.c_void_p, dp, dp]
         L.jo_forward_probe.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp]
+        L.jo_body_pose.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
+        L.jo_integrate_pos.argtypes = [C.c_void_p, dp, dp, dp]
+        L.jo_collide_shapes.argtypes = [C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, C.c_double, dp]
+        L.jo_collide_shapes.restype = C.c_int
+        L.jo_export_problem.argtypes = [C.c_void_p, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip, dp, dp, dp, ip]
+        L.jo_export_problem.restype = C.c_int
         L.jo_rollout_batch.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, C.c_int, dp, dp, C.c_int]
         L.jo_spline_weights.argtypes = [C.c_int, C.c_int, dp, C.c_int, dp, dp]
         L.jo_spline_eval.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
@@ -238,13 +244,51 @@ class Model:
         out = {k: np.zeros(self.nv) for k in ("qacc", "qacc_smooth", "qfrc_bias", "qfrc_constraint")}
         sens = np.zeros(max(self.ns, 1))
         info = (C.c_int * 4)()
-        cons = np.zeros((96, 16))
+        cons = np.zeros((160, 16))  # JO_MAXCON rows
         stats = np.zeros(3)
         ctrl = np.zeros(max(self.nu, 1)) if self.nu == 0 else np.ascontiguousarray(ctrl, dtype=np.float64)
         n = L.jo_forward_probe(self.ptr, _d(qpos), _d(qvel), _d(ctrl), _d(out["qacc"]), _d(out["qacc_smooth"]), _d(out["qfrc_bias"]),
                                _d(out["qfrc_constraint"]), _d(sens), info, _d(cons), _d(stats))
         out.update(sensordata=sens[: self.ns], ncon=info[0], nefc=info[1], solver_iter=info[2], con_overflow=info[3], contacts=cons[:n], solver_cost=stats[0], solver_gradnorm=stats[1], trace_M=stats[2])
         return out
+
+    # ---- kinematics in isolation (tests/test_oracle_independent.py)
+    def body_pose(self, qpos, body: int) -> tuple[np.ndarray, np.ndarray]:
+        pos, mat = np.zeros(3), np.zeros(9)
+        lib().jo_body_pose(C.c_void_p(self.ptr), _d(np.ascontiguousarray(qpos, dtype=np.float64)), int(body), _d(pos), _d(mat))
+        return pos, mat.reshape(3, 3)
+
+    def point_world(self, qpos, body: int, local) -> np.ndarray:
+        pos, mat = self.body_pose(qpos, body)
+        return pos + mat @ np.asarray(local, dtype=np.float64)
+
+    def body_local(self, qpos, body: int, world_point) -> np.ndarray:
+        pos, mat = self.body_pose(qpos, body)
+        return mat.T @ (np.asarray(world_point, dtype=np.float64) - pos)
+
+    def integrate_pos(self, qpos, dq) -> np.ndarray:
+        out = np.zeros(self.nq)
+        lib().jo_integrate_pos(C.c_void_p(self.ptr), _d(np.ascontiguousarray(qpos, dtype=np.float64)), _d(np.ascontiguousarray(dq, dtype=np.float64)), _d(out))
+        return out
+
+    def problem(self, qpos, qvel, ctrl, qacc_warmstart=None) -> dict:
+        """The assembled constraint problem of one forward pass (`jo_export_problem`) and the oracle's own solution `qacc`."""
+        L = lib()
+        nv, me, mc = self.nv, 1024, 256
+        M, a0, qacc = np.zeros((nv, nv)), np.zeros(nv), np.zeros(nv)
+        J, aref, R, fl = np.zeros((me, nv)), np.zeros(me), np.zeros(me), np.zeros(me)
+        tp, rid = np.zeros(me, dtype=np.int32), np.zeros(me, dtype=np.int32)
+        cadr, cdim, cmu, cfr = np.zeros(mc, dtype=np.int32), np.zeros(mc, dtype=np.int32), np.zeros(mc), np.zeros((mc, 5))
+        dims = (C.c_int * 3)()
+        ipt = lambda a: a.ctypes.data_as(ip)
+        ctrl = np.zeros(max(self.nu, 1)) if self.nu == 0 else np.ascontiguousarray(ctrl, dtype=np.float64)
+        ws = None if qacc_warmstart is None else _d(np.ascontiguousarray(qacc_warmstart, dtype=np.float64))
+        ne = L.jo_export_problem(C.c_void_p(self.ptr), _d(np.ascontiguousarray(qpos, dtype=np.float64)), _d(np.ascontiguousarray(qvel, dtype=np.float64)), _d(ctrl), ws, me, mc,
+                                 _d(M), _d(a0), _d(J), _d(aref), _d(R), _d(fl), ipt(tp), ipt(rid), ipt(cadr), ipt(cdim), _d(cmu), _d(cfr), _d(qacc), C.cast(dims, ip))
+        assert ne >= 0, "jo_export_problem: buffers too small"
+        nc = dims[1]
+        return dict(M=M, qacc_smooth=a0, J=J[:ne].copy(), aref=aref[:ne].copy(), R=R[:ne].copy(), frictionloss=fl[:ne].copy(), type=tp[:ne].copy(), id=rid[:ne].copy(),
+                    con_adr=cadr[:nc].copy(), con_dim=cdim[:nc].copy(), con_mu=cmu[:nc].copy(), con_friction=cfr[:nc].copy(), qacc=qacc, cone=int(dims[2]), ncon=nc)
 
     def rollout(self, x0: np.ndarray, controls: np.ndarray, nthread: int | None = None) -> tuple[np.ndarray, np.ndarray]:
         """controls (N,H,nu), x0 (nx,) or (N,nx) -> states (N,H,nx), sensors (N,H,ns)  [RolloutBackend.rollout semantics]."""
@@ -257,6 +301,22 @@ class Model:
         sensors = np.zeros((N, H, self.ns))
         lib().jo_rollout_batch(self.ptr, _d(x0), batched, _d(controls), N, H, _d(states), _d(sensors), nthread or os.cpu_count() or 1)
         return states, sensors
+
+
+# ---------------------------------------------------------------- one narrow-phase routine in isolation
+def supports_pair(kind_a: str, kind_b: str) -> bool:
+    z3, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    far = np.array([10.0, 0, 0])
+    return lib().jo_collide_shapes(GEOM[kind_a], _d(np.ones(3)), _d(z3), _d(q), GEOM[kind_b], _d(np.ones(3)), _d(far), _d(q), 0.0, _d(np.zeros(56))) >= 0
+
+
+def collide_pair(kind_a, size_a, pos_a, quat_a, kind_b, size_b, pos_b, quat_b, margin: float = 0.0):
+    """Contacts of two free-standing shapes as [(dist, pos, normal a->b)]."""
+    out = np.zeros(56)
+    sa, sb = (list(np.atleast_1d(size_a)) + [0, 0, 0])[:3], (list(np.atleast_1d(size_b)) + [0, 0, 0])[:3]
+    n = lib().jo_collide_shapes(GEOM[kind_a], _d(sa), _d(pos_a), _d(quat_a), GEOM[kind_b], _d(sb), _d(pos_b), _d(quat_b), float(margin), _d(out))
+    assert n >= 0, f"no collision routine for {kind_a}-{kind_b}"
+    return [(out[7 * i], out[7 * i + 1 : 7 * i + 4].copy(), out[7 * i + 4 : 7 * i + 7].copy()) for i in range(n)]
 
 
 # ---------------------------------------------------------------- plan-path primitives (numpy in / numpy out)

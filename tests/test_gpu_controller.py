@@ -297,3 +297,6 @@ def test_full_size_configs_properties(gpu, task_name, opt_name, N, H):
     if task_name == "fr3_pick":
         st = ctrl.solver_stats()
         assert st["steps"] >= N * H and st["newton_cap_hits"] < 1e-3 * st["steps"]
+        # the product's own threshold for "approximate" (Controller.solver_stats): the first plan step from reset closes many empty grippers -- round 2
+        # dropped 5.8 contacts per rollout-step here
+        assert st["contact_overflow"] < 1e-4 * st["steps"], st

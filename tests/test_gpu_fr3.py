@@ -61,9 +61,71 @@ def test_fr3_rollout_backend_matches_oracle(gpu, x0_kind):
     es = np.abs(gsens - rsens)
     assert np.median(es) < 1e-6 and np.percentile(es, 99) < 5e-4
     st = be.model.stats()
-    # closing the empty gripper slams the two pad stacks together: for 1-2 steps the oracle itself sees up to 72 contacts (36 box
-    # pairs), above the kernel capacity (48 finger-finger + 32 other contacts); the dropped points are redundant pad-pad contacts (parity above is unaffected)
-    assert st["contact_overflow"] < 4 * st["steps"]
+    # closing the empty gripper slams the two pad stacks together: for 1-2 steps the oracle sees up to 72 contacts (36 box pairs); the kernel holds 96
+    # finger-finger + 32 other contacts per rollout since round 3, so nothing is dropped any more
+    assert st["contact_overflow"] == 0
+
+
+def test_fr3_closed_empty_gripper_keeps_every_pad_contact(gpu):
+    """a gripper closed on nothing puts up to 92 pad-against-pad contacts between the two fingers (the reference's pad boxes,
+    fr3_components/fr3.xml:84-116 + params_and_default.xml:43-55; 36 box pairs).  Single steps from jammed finger states (the oracle counts the contacts and
+    the test insists that the case is really reached) and the closing motion itself (command 0 on the gripper: the stacks slam together around step 17-18):
+    nothing may be dropped and the step must agree with the oracle as tightly as everywhere else."""
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.tasks import FR3Pick
+    from oracle import oracle as O
+
+    om, task = O.Model("fr3_pick"), FR3Pick()
+    rng = np.random.default_rng(0)
+    N = 192
+    x0 = np.tile(task.default_state(), (N, 1))
+    x0[:, 14:16] = rng.uniform(-0.003, 0.0005, (N, 2))         # both slides past the closed position: the pad stacks interpenetrate
+    x0[:, 16 + 13 : 16 + 15] = rng.uniform(-0.3, 0.1, (N, 2))  # still closing / bouncing back
+    U = np.tile(task.reset_command, (N, 1, 1))
+    ncon = np.array([om.forward(x[:16], x[16:], task.reset_command)["ncon"] for x in x0])
+    assert ncon.max() >= 88 and (ncon > 48).sum() >= N // 4, (ncon.max(), (ncon > 48).sum())  # round 2 kept 48 of them
+    rs, _ = om.rollout(x0, U)
+    be = GpuRolloutBackend("fr3_pick", N)
+    gs, _, _ = be.rollout(x0, U)
+    st = be.model.stats()
+    assert st["contact_overflow"] == 0 and st["newton_cap_hits"] == 0
+    # the finger velocities after the step are what up to 90 stiff rows decide: compare them relative to the step's own velocity change.
+    # Reachable states first: total interpenetration below the pad thickness of 4 mm (a gripper closing at its fastest gains 1.2 mm per step).
+    deep = x0[:, 14] + x0[:, 15] < -0.0039
+    assert deep.sum() >= 10 and (~deep & (ncon > 48)).sum() >= 20
+    dv = np.abs(rs[:, 0, 16 + 13 : 16 + 15] - x0[:, 16 + 13 : 16 + 15]).max(axis=1) + 1e-3
+    ev = np.abs(gs[:, 0, 16 + 13 : 16 + 15] - rs[:, 0, 16 + 13 : 16 + 15]).max(axis=1) / dv
+    # observed: median 4e-6 .. 2.4e-5 by contact count, max 9e-5 (the solve ends on the fp32 resolution of the finger accelerations, DESIGN.md section 5)
+    assert np.median(ev[~deep]) < 5e-5 and ev[~deep].max() < 5e-4, (np.median(ev[~deep]), ev[~deep].max())
+    np.testing.assert_allclose(gs[~deep, 0, :16], rs[~deep, 0, :16], atol=1e-6)
+    # Beyond 4 mm the pad boxes have been pushed THROUGH one another: contacts with opposite normals fight each other, the constraint cost at the optimum is
+    # ~6e7 (5e2 just below 4 mm) and the finger accelerations of ~50 m/s^2 are the difference of row forces ~1e6.  The problem itself is ill-conditioned there:
+    # the fp64 oracle's own answer moves by 1-4 m/s^2 when its inputs are merely rounded to fp32 (measured below), so that is the yardstick, not 1e-5.
+    # (An independent solver confirms the oracle's minimiser to 1e-8 on these states, tests/test_oracle_independent.py.)  Nothing is dropped there either.
+    spread = 0.0
+    for i in np.nonzero(deep)[0][:6]:
+        s32, _ = om.rollout(x0[i].astype(np.float32).astype(np.float64), U[:1])
+        spread = max(spread, np.abs(s32[0, 0, 16 + 13 : 16 + 15] - rs[i, 0, 16 + 13 : 16 + 15]).max())
+    assert spread > 1e-3   # m/s after one 4 ms step: the oracle against itself
+    assert np.abs(gs[deep, 0, 16 + 13 : 16 + 15] - rs[deep, 0, 16 + 13 : 16 + 15]).max() < max(4 * spread, 0.02)
+    # the closing motion from the home pose, gripper commanded shut: the servo drives the fingers together at up to 0.95 m/s = 3.8 mm per step and finger, so the
+    # fastest ones tunnel into the regime above in the step of the impact; parity is asked for up to the step in which a rollout gets there
+    H, M = 40, 32
+    u = task.reset_command.copy(); u[7] = 0.0
+    U2 = np.tile(u, (M, H, 1))
+    U2[:, :, 7] = rng.uniform(-0.02, 0.01, (M, 1))  # shut, each rollout a little differently
+    rs2, _ = om.rollout(task.default_state(), U2)
+    be2 = GpuRolloutBackend("fr3_pick", M)
+    gs2, _, _ = be2.rollout(task.default_state(), U2)
+    st2 = be2.model.stats()
+    assert st2["contact_overflow"] == 0 and np.isfinite(gs2).all()
+    pen = rs2[:, :, 14] + rs2[:, :, 15]
+    assert (pen.min(axis=1) < -5e-4).sum() >= M // 2   # the stacks did slam together
+    first_deep = np.where((pen < -0.0039).any(axis=1), (pen < -0.0039).argmax(axis=1), H)  # the state AFTER that step is deep: that step and all before it are well-posed
+    ok = np.arange(H)[None, :] <= first_deep[:, None]
+    assert ok.sum() > 0.5 * M * H and (first_deep < H).sum() >= 4
+    e = np.abs(gs2 - rs2)
+    assert np.median(e[ok]) < 2e-7 and e[:, :, 14:16][ok].max() < 2e-5 and np.percentile(e[:, :, 16 + 13 :][ok], 99) < 5e-3, (np.median(e[ok]), e[:, :, 14:16][ok].max(), np.percentile(e[:, :, 16 + 13 :][ok], 99))
 
 
 @pytest.mark.parametrize("phase", [0, 1, 2, 3])

@@ -1,0 +1,236 @@
+"""The physics oracle checked by code that was not derived from it ("what's weak" 1 / "do this" 2).
+
+`oracle/jo_engine.c` is parity-unpinned at the MuJoCo boundary (no `mujoco` wheel on disk).  Until one exists, these tests at least take the SOLVER,
+the cone functions, the contact Jacobians and the narrow phase out of the "one reading agreeing with itself" category:
+
+(a) for random contact states of every model family the oracle's `qacc` must be a stationary point of MuJoCo's documented primal objective as restated in
+    numpy (`tests/independent.py::primal_objective`): KKT residual <= 1e-9 in MuJoCo's own scaling -- and scipy's trust-region Newton, started from the
+    unconstrained acceleration and run on a finite-difference Hessian, must not find a lower objective;
+(b) every contact row of the exported Jacobian must equal the finite-difference derivative of the contact point's relative position with respect to the
+    generalised coordinates, computed from the oracle's KINEMATICS only (positions of two body-fixed points), not from its Jacobian code;
+(c) the narrow phase (SAT + face clipping) against support-function geometry: the reported deepest penetration and its normal against the sampled
+    minimum translation of the two convex shapes, and every reported contact point inside both shapes.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import independent as I
+
+
+# ------------------------------------------------------------------------------------------------ state generators (contact-rich, per family)
+def _leap_states(n, seed, task="leap_cube"):
+    from judo_amd.tasks import CALTECH_LEAP_QPOS_HOME, LEAP_QPOS_HOME
+
+    home = CALTECH_LEAP_QPOS_HOME if task == "caltech_leap_cube" else LEAP_QPOS_HOME
+    om = O.Model(task)
+    rng = np.random.default_rng(seed)
+    r = np.array([a["ctrlrange"] for a in om.desc["actuators"]])
+    q = home[7:] + 0.5 * (r[:, 0] + (r[:, 1] - r[:, 0]) * rng.uniform(0, 1, (n, 16)) - home[7:])  # fingers cross each other and dig into the palm
+    xs = np.zeros((n, 45))
+    xs[:, :3] = home[:3] + rng.uniform(-0.02, 0.02, (n, 3))  # the cube jammed into the hand
+    quat = rng.standard_normal((n, 4)); xs[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    xs[:, 7:23] = q
+    xs[:, 23:] = rng.standard_normal((n, 22)) * np.concatenate([[0.2] * 3, [2.0] * 3, [0.5] * 16])
+    return om, xs, q
+
+
+def _fr3_states(n, seed):
+    from judo_amd.tasks import FR3Pick
+
+    om, t = O.Model("fr3_pick"), FR3Pick()
+    rng = np.random.default_rng(seed)
+    xs = np.tile(t.default_state(), (n, 1))
+    grasp = np.array([0.0, 0.55, 0.0, -2.05, 0.0, 2.6, 0.785])
+    k = n // 2
+    xs[:k, 7:14] = grasp + 0.03 * rng.standard_normal((k, 7))      # fingers around / on / in the cube, pads against the table
+    xs[:k, 14:16] = rng.uniform(0.015, 0.04, (k, 2))
+    xs[:k, 0:3] += rng.uniform(-0.01, 0.01, (k, 3))
+    xs[k:, 14:16] = rng.uniform(-0.0019, 0.0005, (n - k, 2))        # empty gripper closed: up to ~70 pad-against-pad contacts
+    xs[:, 16:] = 0.3 * rng.standard_normal((n, 15))
+    u = np.tile(t.reset_command, (n, 1)) + 0.1 * rng.standard_normal((n, 8))
+    return om, xs, u
+
+
+def _cylinder_states(n, seed):
+    om = O.Model("cylinder_push")
+    rng = np.random.default_rng(seed)
+    xs = np.zeros((n, 8))
+    xs[:, 0:2] = rng.uniform(-1, 1, (n, 2))
+    ang, dist = rng.uniform(0, 2 * np.pi, n), rng.uniform(0.42, 0.52, n)  # overlapping or just apart (radii sum 0.5)
+    xs[:, 2:4] = xs[:, 0:2] + dist[:, None] * np.stack([np.cos(ang), np.sin(ang)], 1)
+    xs[:, 4:] = rng.standard_normal((n, 4))
+    return om, xs, rng.uniform(-2, 2, (n, 2))
+
+
+def _spot_states(n, seed):
+    from oracle.policy import spot_model, spot_reset_state
+
+    om = spot_model()
+    rng = np.random.default_rng(seed)
+    xs = np.tile(spot_reset_state(), (n, 1))
+    xs[:, 2] = rng.uniform(0.25, 0.55, n)  # dropped onto / pressed into the ground
+    quat = np.array([1.0, 0, 0, 0]) + 0.15 * rng.standard_normal((n, 4)); xs[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    xs[:, 7:26] += 0.2 * rng.standard_normal((n, 19))
+    xs[:, 26:] = rng.standard_normal((n, 25)) * 0.5
+    u = xs[:, 7:26] + 0.1 * rng.standard_normal((n, 19))
+    return om, xs, u
+
+
+FAMILIES = {
+    "leap_cube": lambda n, s: _leap_states(n, s),            # elliptic cones, impratio 100, hand self-contacts + cube
+    "caltech_leap_cube": lambda n, s: _leap_states(n, s, "caltech_leap_cube"),
+    "fr3_pick": _fr3_states,                                 # pyramidal cones, impratio 10, joint equality, friction loss, limits
+    "cylinder_push": _cylinder_states,                       # one frictionless-by-clamp pyramidal contact
+    "spot": _spot_states,                                    # pyramidal, plane contacts, 25 dofs, limits and friction loss on every joint
+}
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+def test_oracle_qacc_is_the_minimiser_of_the_documented_objective(family):
+    n_kkt, n_generic = 200, 12
+    om, xs, us = FAMILIES[family](n_kkt, 11)
+    nq = om.nq
+    res, ncon, worse = [], [], 0
+    for i in range(n_kkt):
+        P = om.problem(xs[i, :nq], xs[i, nq:], us[i])
+        res.append(I.kkt_excess(P, P["qacc"])); ncon.append(P["ncon"])
+        if i < n_generic * 4 and i % 4 == 0:  # the generic solver on a subset (0.1 .. 1 s each)
+            c_or = I.primal_objective(P, P["qacc"])[0]
+            a, c_gen = I.generic_minimise(P)
+            assert c_or <= c_gen + 1e-9 * max(1.0, abs(c_gen)), (family, i, c_or, c_gen)
+            # and where the generic solver got close, it landed on the same accelerations
+            if I.kkt_residual(P, a) < 1e-6:
+                np.testing.assert_allclose(a, P["qacc"], rtol=1e-5, atol=1e-5 * max(1.0, np.abs(P["qacc"]).max()))
+    res, ncon = np.array(res), np.array(ncon)
+    assert (ncon > 0).mean() > 0.5, f"{family}: the generator must produce contacts ({(ncon > 0).mean():.2f})"
+    # MuJoCo's Newton tolerance is 1e-8 in this scaling; the oracle runs to 1e-10 or to the fp64 floor of a stiff problem (`kkt_excess` discounts that floor:
+    # cylinder_push's clamped friction, D = 7e10, sits on it at 1e-5 .. 1e-4, and so does scipy's solver)
+    assert np.percentile(res, 99) < 1e-9 and res.max() < 1e-8, (family, np.percentile(res, [50, 99, 100]))
+
+
+def _point_world(om, qpos, body, local):
+    """World position of a body-fixed point from the oracle's kinematics alone (forward pass, site-free: via xpos / xmat of a probe)."""
+    pos, mat = om.body_pose(qpos, body)
+    return pos + mat @ local
+
+
+@pytest.mark.parametrize("family", ["leap_cube", "fr3_pick", "spot"])
+def test_contact_jacobian_rows_match_finite_differences_of_the_kinematics(family):
+    om, xs, us = FAMILIES[family](40, 5)
+    nq, nv = om.nq, om.nv
+    body_of = [g["body"] for g in om.desc["geoms"]]
+    checked = 0
+    for i in range(40):
+        qpos, qvel = xs[i, :nq], xs[i, nq:]
+        f = om.forward(qpos, qvel, us[i])
+        P = om.problem(qpos, qvel, us[i])
+        if P["ncon"] == 0:
+            continue
+        for c in range(min(P["ncon"], 6)):
+            row = f["contacts"][c]
+            pos, frame, g1, g2 = row[1:4], row[4:13].reshape(3, 3), int(row[13]), int(row[14])
+            b1, b2 = body_of[g1], body_of[g2]
+            # the contact point as a body-fixed point of each side
+            l1 = om.body_local(qpos, b1, pos); l2 = om.body_local(qpos, b2, pos)
+            Jfd = np.zeros((3, nv))
+            for k in range(nv):
+                h = 1e-6
+                dq = np.zeros(nv); dq[k] = h
+                qp, qm = om.integrate_pos(qpos, dq), om.integrate_pos(qpos, -dq)
+                rel = lambda q: om.point_world(q, b2, l2) - om.point_world(q, b1, l1)
+                Jfd[:, k] = frame @ (rel(qp) - rel(qm)) / (2 * h)
+            r0 = P["con_adr"][c]
+            if P["cone"] == 1 or P["con_dim"][c] == 1:
+                J = P["J"][r0 : r0 + min(3, P["con_dim"][c])]
+                np.testing.assert_allclose(J, Jfd[: len(J)], atol=2e-6)
+            else:  # pyramidal rows: normal +- mu * tangent
+                mu = P["con_friction"][c][0]
+                np.testing.assert_allclose(P["J"][r0], Jfd[0] + mu * Jfd[1], atol=2e-6)
+                np.testing.assert_allclose(P["J"][r0 + 1], Jfd[0] - mu * Jfd[1], atol=2e-6)
+                np.testing.assert_allclose(P["J"][r0 + 2], Jfd[0] + mu * Jfd[2], atol=2e-6)
+            checked += 1
+    assert checked >= 30
+
+
+# ------------------------------------------------------------------------------------------------ (c) narrow phase against support functions
+def _rand_rot(rng):
+    q = rng.standard_normal(4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]), q
+
+
+def _quat_of(R):
+    from scipy.spatial.transform import Rotation
+
+    x, y, z, w = Rotation.from_matrix(R).as_quat()
+    return np.array([w, x, y, z])
+
+
+@pytest.mark.parametrize("kinds", [("box", "box"), ("box", "sphere"), ("sphere", "sphere"), ("box", "capsule"), ("capsule", "plane"), ("box", "cylinder"), ("sphere", "cylinder")])
+def test_narrow_phase_agrees_with_support_function_geometry(kinds):
+    """Deepest penetration and normal of the oracle's collision routine against the signed distance of the two shapes computed from support functions
+    (`tests/independent.py::signed_distance`), and every contact point inside both shapes (to the penetration)."""
+    ka, kb = kinds
+    if not O.supports_pair(ka, kb):
+        pytest.skip(f"the oracle has no {ka}-{kb} routine (not needed by any shipped model)")
+    rng = np.random.default_rng(hash(kinds) % 2**32)
+    done = 0
+    for trial in range(220):
+        def mk(kind):
+            R, q = _rand_rot(rng)
+            if kind == "box":
+                size = rng.uniform(0.01, 0.05, 3)
+            elif kind == "sphere":
+                size = np.array([rng.uniform(0.01, 0.04)])
+            elif kind == "plane":
+                size = np.zeros(3)
+            else:
+                size = np.array([rng.uniform(0.008, 0.02), rng.uniform(0.01, 0.05)])
+            return kind, size, R, q
+        A, B = mk(ka), mk(kb)
+        pa = np.zeros(3)
+        pb = rng.standard_normal(3); pb *= rng.uniform(0.0, 0.09) / np.linalg.norm(pb)
+        out = O.collide_pair(A[0], A[1], pa, A[3], B[0], B[1], pb, B[3])  # list of (dist, pos, normal A->B)
+        if B[0] == "plane":
+            continue_plane = True
+        SA = I.Shape(A[0], A[1], pa, A[2]) if A[0] != "plane" else None
+        SB = I.Shape(B[0], B[1], pb, B[2]) if B[0] != "plane" else None
+        if SB is None:  # shape against the half space z_local <= 0 of the plane: exact depth = lowest support point
+            n = B[2][:, 2]
+            depth = n @ (SA.support(-n) - pb)
+            if depth >= 0:
+                assert len(out) == 0
+                continue
+            assert len(out) >= 1
+            assert abs(min(o[0] for o in out) - depth) < 1e-9
+            for dist, pos, nrm in out:
+                assert np.allclose(np.abs(nrm @ n), 1.0, atol=1e-9)
+            done += 1
+            continue
+        sd, dirn = I.signed_distance(SA, SB, n_dirs=500, seed=trial, extra_dirs=[o[2] for o in out] if out else None)
+        if sd > 1e-6:
+            assert len(out) == 0, (kinds, trial, sd, out)
+            continue
+        if sd > -2e-4:
+            continue  # grazing: either answer is fine
+        assert len(out) >= 1, (kinds, trial, sd)
+        deepest = min(o[0] for o in out)
+        # the routine's penetration can only UNDER-estimate the true minimum translation when it restricts itself to a subset of the separating
+        # directions (SAT over 15 axes is exact for boxes); it must never report a deeper overlap than exists
+        # (box-box prefers a face axis over an edge-edge axis unless the edge pair separates 5 % better -- MuJoCo's own box-box routine carries the same kind of
+        # fudge factor -- so its face answer may be up to 5 % deeper than the minimum translation, which an edge direction attains)
+        slack = 0.05 * abs(sd) if kinds == ("box", "box") else 0.0
+        assert deepest >= sd - slack - 1e-6, (kinds, trial, deepest, sd)
+        if set(kinds) <= {"box", "sphere"}:
+            assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd) + slack, (kinds, trial, deepest, sd)   # exact routines (sampling error of the reference only)
+        for dist, pos, nrm in out:
+            assert abs(np.linalg.norm(nrm) - 1) < 1e-9
+            # the contact point sits mid-way between the two surfaces: inside both shapes grown by half the local penetration
+            assert SA.contains(pos, tol=0.5 * abs(dist) + 1e-6) and SB.contains(pos, tol=0.5 * abs(dist) + 1e-6), (kinds, trial, dist, pos)
+            # and its normal is a direction along which the shapes really overlap by at least that much
+            assert I.separation_along(SA, SB, nrm) <= dist + 1e-6 + 1e-3 * abs(dist), (kinds, trial, dist, I.separation_along(SA, SB, nrm))
+        done += 1
+    assert done >= 40, (kinds, done)

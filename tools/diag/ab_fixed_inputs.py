@@ -41,6 +41,11 @@ else:
             per_step = dn.reshape(dn.shape[0], -1).max(axis=1)
             print(f"  returned nominal vs {os.environ['REF']}: median {np.median(dn):.2e} rad, 99th percentile {np.percentile(dn, 99):.2e}, max {dn.max():.2e}; plan steps (of {len(per_step)}) whose nominal "
                   f"moved by more than 2e-3 rad anywhere: {int((per_step > 2e-3).sum())} (MPPI at temperature 0.0025 is close to an argmin: such a step picked another winner)")
+        if os.environ.get("HIST"):
+            import ctypes as C
+            from judo_amd import _lib
+            L = _lib.lib(); L.jh_model_hist.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; hh = (C.c_int * 40)(); L.jh_model_hist(c.model.handle, hh)
+            print("  solver exits (EXITSTATS builds) gradient / not-descent / expected-decrease / cap / rounding-floor:", list(hh)[:5])
         st = c.model.stats()
         print(f"  contacts dropped above the pool {st['contact_overflow']} ({st['contact_overflow'] / max(st['steps'], 1):.2e} per step), Newton cap hits {st['newton_cap_hits']}")
         print(f"{os.environ.get('JUDO_AMD_LIB', 'default')} lstol={EM.SOLVER_LS_TOL:g} tol={EM.SOLVER_TOL:g}: kernel mean {k.mean():.2f} ms  (first 10: {k[:10].mean():.2f}, last 10: {k[-10:].mean():.2f})  iters/step {st['newton_iters'] / (NR * HS * S):.3f}")
