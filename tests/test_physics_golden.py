@@ -10,7 +10,7 @@ import pytest
 from tests.conftest import GOLDEN
 
 
-@pytest.mark.parametrize("task", ["cartpole", "cylinder_push", "leap_cube", "fr3_pick"])
+@pytest.mark.parametrize("task", ["cartpole", "cylinder_push", "leap_cube", "leap_cube_down", "caltech_leap_cube", "fr3_pick"])
 def test_oracle_engine_matches_mujoco_trajectories(task):
     path = os.path.join(GOLDEN, f"physics_{task}.npz")
     if not os.path.exists(path):

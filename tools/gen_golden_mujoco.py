@@ -8,8 +8,11 @@ Per task: `mj_step` trajectories from the reference's `MJRolloutBackend` call pa
 reset pose and from perturbed states: x0, controls, states (N, H, nq+nv), sensordata (N, H, ns), plus one-step probes that isolate the three MuJoCo
 facts the oracle could only take from the documentation: the sensor lag (sensordata[h] describes the state before step h), the
 pyramidal friction regularisation with mu clamped to its minimum (cylinder_push: contact force along the line of centres), and the soft joint limit.
-cartpole / cylinder_push need no meshes and are generated here; leap_cube / fr3_pick reference mesh assets that are not in the repository
-(`.MISSING_LARGE_BLOBS`), so their fixtures can only come from a checkout that has them -- add the task to CASES there.
+Models: the reference's own MJCF where it needs no mesh assets (cartpole, cylinder_push), and for every task the build's model description written back out
+as mesh-free MJCF by tools/export_mjcf.py -- the reference's bodies, joints, actuators and sensors with the documented primitive stand-ins for the collision
+meshes, i.e. exactly the model the kernels and the oracle simulate (leap / fr3 / Spot reference mesh assets that are not in the repository,
+`.MISSING_LARGE_BLOBS`, so the reference files themselves cannot be loaded anywhere without them).  Fixtures from exported models are named
+physics_<task>.npz as well; `model_source` inside says which file produced them.
 """
 
 from __future__ import annotations
@@ -24,11 +27,25 @@ sys.path.insert(0, ROOT)
 from oracle import mujoco_probe as MP  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-CASES = {
-    # task: (x0, control scale, N, H)
-    "cartpole": (np.array([1.0, np.pi, 0.0, 0.0]), 1.5, 16, 64),
-    "cylinder_push": (np.array([0.0, 0.0, 0.45, 0.1, 0.5, 0, 0, 0]), 1.0, 16, 64),  # starts in contact
-}
+
+
+def _cases() -> dict:
+    """task: (x0, control centre, control scale, N, H)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from judo_amd.tasks import CALTECH_LEAP_QPOS_HOME, LEAP_QPOS_HOME, FR3Pick, LeapCubeDown
+
+    fr3 = FR3Pick()
+    grasp = fr3.default_state().copy()
+    grasp[7:14] = [0.0, 0.55, 0.0, -2.05, 0.0, 2.6, 0.785]; grasp[14:16] = [0.03, 0.025]  # fingers around the cube: table / pad / cube contacts, the finger equality
+    down = LeapCubeDown()
+    return {
+        "cartpole": (np.array([1.0, np.pi, 0.0, 0.0]), np.zeros(1), 1.5, 16, 64),
+        "cylinder_push": (np.array([0.0, 0.0, 0.45, 0.1, 0.5, 0, 0, 0]), np.zeros(2), 1.0, 16, 64),  # starts in contact
+        "leap_cube": (np.concatenate([LEAP_QPOS_HOME, np.zeros(22)]), LEAP_QPOS_HOME[7:], 0.3, 16, 64),
+        "leap_cube_down": (down.default_state(), down.reset_command, 0.3, 16, 48),
+        "caltech_leap_cube": (np.concatenate([CALTECH_LEAP_QPOS_HOME, np.zeros(22)]), CALTECH_LEAP_QPOS_HOME[7:], 0.3, 16, 64),
+        "fr3_pick": (grasp, fr3.reset_command, 0.1, 16, 40),
+    }
 
 
 def main() -> int:
@@ -38,18 +55,24 @@ def main() -> int:
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(2024)
     wrote = 0
-    for task, (x0, scale, N, H) in CASES.items():
-        if MP.reference_xml(task) is None:
-            print(f"{task}: MJCF not reachable (set JUDO_REFERENCE_ROOT), skipped")
-            continue
-        nu = {"cartpole": 1, "cylinder_push": 2}[task]
-        U = np.repeat(rng.standard_normal((N, H // 4, nu)) * scale, 4, axis=1)
-        states, sensors = MP.rollout(task, x0, U, nthread=1)
-        xb = x0[None] + 0.05 * rng.standard_normal((N, x0.size))
-        states_b, sensors_b = MP.rollout(task, xb, U, nthread=1)
+    from tools import export_mjcf
+
+    mjcf_dir = os.path.join(ROOT, "build", "mjcf")
+    for task, (x0, centre, scale, N, H) in _cases().items():
+        xml, source = MP.reference_xml(task) if task in MP.MESH_FREE_TASKS else None, "reference"
+        if xml is None:  # the build's model description as MJCF (the reference file needs mesh assets, or is not reachable)
+            xml, source = export_mjcf.write(task, mjcf_dir), "judo_amd/models/%s.json via tools/export_mjcf.py" % task
+        nu = centre.size
+        U = centre[None, None] + np.repeat(rng.standard_normal((N, H // 4, nu)) * scale, 4, axis=1)
+        states, sensors = MP.rollout(task, x0, U, nthread=1, xml_path=xml)
+        from judo_amd.models import layout, load_description
+
+        nv = layout(load_description(task)).nv
+        xb = np.tile(x0, (N, 1)); xb[:, -nv:] += 0.05 * rng.standard_normal((N, nv))  # perturbed velocities (positions stay valid quaternions / joint ranges)
+        states_b, sensors_b = MP.rollout(task, xb, U, nthread=1, xml_path=xml)
         np.savez_compressed(os.path.join(OUT, f"physics_{task}.npz"), x0=x0, controls=U, states=states, sensors=sensors, x0_batched=xb,
-                            states_batched=states_b, sensors_batched=sensors_b, mujoco_version=np.array(MP.find_mujoco().__version__))
-        print(f"{task}: wrote tests/golden/physics_{task}.npz ({N} x {H} steps)")
+                            states_batched=states_b, sensors_batched=sensors_b, mujoco_version=np.array(MP.find_mujoco().__version__), model_source=np.array(source))
+        print(f"{task}: wrote tests/golden/physics_{task}.npz ({N} x {H} steps, model: {source})")
         wrote += 1
     return 0 if wrote else 1
 
