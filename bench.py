@@ -40,7 +40,7 @@ WORKLOADS = {
     "spot_navigate": ("mppi", 65536, 100),
 }
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = "r02_traffic.json"
+TRAFFIC_FILE = "r03_traffic.json"
 
 
 def usable_cpus() -> int:
@@ -223,6 +223,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
     ap.add_argument("--settle", type=float, default=0.4, help="seconds of untimed plan steps on a throw-away plan before the W warm-up steps (runtime one-offs)")
+    ap.add_argument("--no-with-traces", action="store_true", help="skip the extra plan steps that read Controller.traces (run after the timed region)")
     ap.add_argument("--no-cube-only", action="store_true", help="leap_cube: skip the extra cube-contacts-only steps run after the timed region")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
@@ -309,6 +310,7 @@ def main() -> None:
         ctrl.update_action()
         t_plan += 1.0 / ctrl.controller_cfg.control_freq
     ctrl.kernel_events.clear()
+    ctrl.exchange_events.clear()
     ctrl.solver_warnings = False
     if not is_policy:
         ctrl.solver_stats()  # zero the kernels' counters: the line reports the timed steps alone
@@ -330,6 +332,15 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])) if ctrl.kernel_events else float("nan")
+    exch_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.exchange_events])) if ctrl.exchange_events else 0.0
+    # where a plan step goes on this rank: the rollout kernel, the exchange (update records: block partials, all-gather over the ranks, merge kernel) and the rest
+    # (host: time shift, packing, launches, the one wait for the new nominal).  With several GPUs every rank reports its own split.
+    split = {"rank": rank, "rollouts": int(ctrl.last_shard.count), "kernel_ms": kern_ms, "exchange_ms": exch_ms, "plan_step_ms": float(np.mean(per_step) * 1e3),
+             "host_and_launch_ms": float(np.mean(per_step) * 1e3 - kern_ms - exch_ms)}
+    per_rank = [split]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, split)
     solver = None
     if not is_policy and ctrl.model is not None and args.task not in ("cartpole", "cylinder_push"):
         st = ctrl.solver_stats()
@@ -339,6 +350,23 @@ def main() -> None:
             if st.get("wave_steps"):
                 solver["wave_newton_iters_per_step"] = st["wave_newton_iters"] / st["wave_steps"]
                 solver["lock_step_inflation"] = solver["wave_newton_iters_per_step"] / max(solver["newton_iters_per_step"], 1e-9)
+    # the reference's plan time includes update_traces (judo/controller/controller.py:299); here the elites' trace polylines are staged on the device inside the
+    # plan step and re-rolled only when `Controller.traces` is read, so `value` does not pay for them: the same steps again, reading the traces every time
+    with_traces = None
+    if not is_policy and ctrl.trace_sensors and not args.no_with_traces:
+        n_extra, tq = min(args.steps, 10), t_plan
+        torch.cuda.synchronize()
+        barrier()
+        tw = time.perf_counter()
+        for _ in range(n_extra):
+            ctrl.time = tq
+            ctrl.update_action()
+            _ = ctrl.traces
+            tq += 1.0 / ctrl.controller_cfg.control_freq
+        torch.cuda.synchronize()
+        barrier()
+        with_traces = {"ms_per_step": (time.perf_counter() - tw) / n_extra * 1e3, "steps": n_extra, "max_num_traces": int(ctrl.max_num_traces),
+                       "note": "update_action + Controller.traces (elite re-rollout in materialise mode + polyline packing), continuing from the timed steps' plan"}
     # leap_cube: the same measurement restarted with the hand's own contacts switched off (the model round 1 measured), outside the timed region
     cube_only = None
     if args.task == "leap_cube" and world == 1 and ctrl.model is not None and ctrl.model.self_collision and not args.no_cube_only:
@@ -399,7 +427,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
                        "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters,
-                       "hand_self_collision": self_on if args.task.startswith("leap") else None},
+                       "hand_self_collision": self_on if args.task.startswith("leap") else None,
+                       "traces": "staged on the device inside the plan step, fetched (elite re-rollout) when Controller.traces is read: not in `value`, see plan_step_ms_with_traces"},
             "plan_step_ms": {"mean": float(ms.mean()), "std": float(ms.std()), "median": float(np.median(ms)), "iqr": float(np.percentile(ms, 75) - np.percentile(ms, 25)),
                              "min": float(ms.min()), "max": float(ms.max())},
             "physics_steps_per_s": N * H * substeps * args.steps / elapsed,
@@ -409,6 +438,9 @@ def main() -> None:
                          "traffic_source": traffic_src,
                          "note": "latency/VALU-issue-bound by construction (H serial physics steps, ~1e5 flop per step against a few hundred algorithmic bytes per rollout); see DESIGN.md section 6"},
         }
+        line["per_rank"] = per_rank
+        if with_traces:
+            line["plan_step_ms_with_traces"] = with_traces
         if solver:
             line["solver"] = solver
         if cube_only:

@@ -121,6 +121,12 @@ int jh_rollout_materialize(const jh_model* m, const float* x0, int x0_batched, c
 int jh_task_reward(const jh_model* m, const float* states, const float* sensors, const float* controls, const float* task_params,
                    int phase, int N, int H, float* rewards, void* stream);
 
+/* The optimizers' noise, `np.random.randn(num_rollouts - 1, num_nodes, nu)` of judo/optimizers/{mppi.py:52,ps.py:43,cem.py:67}, drawn on the device in the
+ * kernels' layout: out[row * ldn + n] for row < rows (= K * nu) and local rollout n < n_local is the standard normal that belongs to GLOBAL rollout
+ * n_offset + n of draw number `draw` under `seed` (Philox4x32-10, counter-based: a pure function of seed, draw, row and the global rollout index, two
+ * Box-Muller pairs per block of four rollouts).  A rank generates exactly its shard's columns; the plan does not depend on the number of GPUs. */
+int jh_noise_normal(unsigned long long seed, unsigned int draw, int rows, int n_offset, int n_local, float* out, int ldn, void* stream);
+
 /* Optimizer.sample_control_knots for callers that want the (N,K,nu) row-major array itself
  * (row n = nominal + sigma * noise[:, :, n], row 0 of global index 0 = nominal), optionally clipped. */
 int jh_sample_knots(const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi /* NULL = no clip */,

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "jh_rollout_cost": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_rollout_materialize": (C.c_int, [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_task_reward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
+    "jh_noise_normal": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p]),
     "jh_sample_knots": (C.c_int, [f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
     "jh_spline_controls": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
     "jh_knot_moments": (C.c_int, [f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),

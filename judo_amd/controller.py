@@ -111,6 +111,7 @@ class Controller:
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
         self._prefetch_args = None
         self.keep_candidates = False
+        self.exchange_events: list = []  # (start, end) HIP event pairs around the record all-gather + merge of every iteration while `record_kernel_events` is on
         self.force_materialize = False  # True: always take the materialise path (rollout arrays + Task.reward), e.g. to inspect trajectories
         self.last_rollout = None  # (states, sensors, controls) device tensors of the last materialised iteration
         self.record_kernel_events = False  # bench.py: HIP events around the rollout kernel on the launch stream
@@ -282,17 +283,16 @@ class Controller:
         return self._noise_bufs[self._noise_cur]
 
     def _draw_noise(self, n_local: int, n_offset: int) -> torch.Tensor:
-        """The optimizer's noise for this shard, drawn into a persistent (K, nu, N) buffer when it comes from the device generator -- or taken from the
-        draw `_prefetch_noise` enqueued behind the last iteration's download (same generator, same order of draws: the same numbers, earlier)."""
+        """The optimizer's noise for this shard, generated into a persistent (K, nu, n_local) buffer when it comes from the device noise stream -- or taken from
+        the draw `_prefetch_noise` enqueued behind the last iteration's download (same stream, same draw number: the same numbers, earlier)."""
         opt = self.optimizer
         if opt.injected_noise is None:
             K, nu = opt.num_nodes, self.nu
-            total = max(int(opt.num_rollouts), n_offset + n_local)
             ahead, self._noise_ahead = self._noise_ahead, None
-            if ahead is not None and ahead[0] == (K, nu, total, n_local, n_offset) and ahead[1] is opt._generator and ahead[1] is not None:
+            if ahead is not None and ahead[0] == (K, nu, n_local, n_offset) and ahead[1] is opt._generator and ahead[1] is not None:
                 opt.last_noise = ahead[2]
                 return ahead[2]
-            return opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, total)))
+            return opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
         self._noise_ahead = None
         return opt.draw_noise(n_local, n_offset, self.device)
 
@@ -303,11 +303,10 @@ class Controller:
         if not self.prefetch_noise or opt.injected_noise is not None or type(opt).draw_noise is not Optimizer.draw_noise or opt._generator is None:
             return
         K, nu = opt.num_nodes, self.nu
-        total = max(int(opt.num_rollouts), n_offset + n_local)
         keep = opt.last_noise
-        noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, total)))
+        noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
         opt.last_noise = keep
-        self._noise_ahead = ((K, nu, total, n_local, n_offset), opt._generator, noise)
+        self._noise_ahead = ((K, nu, n_local, n_offset), opt._generator, noise)
 
     # ---- the plan step -------------------------------------------------------------------------------------------
     @property
@@ -464,8 +463,14 @@ class Controller:
             ev1.record()
             self.kernel_events.append((ev0, ev1))
         opt.device_partial(costs, None, b.nominal, noise_p, b.sigma, b.lohi, shard.count, shard.offset, b.scratch, b.rec, ldn=ldn, stream=stream)
+        if self.record_kernel_events:  # the exchange of the per-rank records and the merge (bench.py attributes the plan step: kernel / exchange / host)
+            ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ex0.record()
         recs = all_gather_records(b.rec, self.group)
         opt.device_merge(recs, world, b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, clip_sigma=False, stream=stream)
+        if self.record_kernel_events:
+            ex1.record()
+            self.exchange_events.append((ex0, ex1))
         state.update(costs=costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
         is_cem = hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray)
         res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))

@@ -250,6 +250,55 @@ extern "C" size_t jh_update_scratch_floats(int N, int K, int nu) {
   return nb * (per > tk ? per : tk) + 16;
 }
 
+// ------------------------------------------------------------------------------------------------ optimizer noise: counter-based normals
+// np.random.randn(N - 1, K, nu) of the reference's optimizers (judo/optimizers/mppi.py:52) in the kernels' (K*nu, N) layout.  Element (row, n) of draw number
+// `draw` under `seed` is a pure function of those four numbers -- Philox4x32-10 keyed by the seed, counter = (block of 4 global rollout indices, row, draw) --
+// so a rank that owns rollouts [n_offset, n_offset + n_local) generates exactly its columns and the plan does not depend on how the rollouts are sharded.
+// One thread: one Philox block = 4 consecutive rollouts of one row (two Box-Muller pairs), 16 contiguous bytes.
+namespace {
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(kUB) void k_noise_normal(uint32_t seed_lo, uint32_t seed_hi, uint32_t draw, int rows, int n_offset, int n_local, float* __restrict__ out, int ldn) {
+  const int blocks_per_row = (n_offset + n_local + 3) / 4 - n_offset / 4;  // Philox blocks that touch this shard's columns
+  const size_t t = (size_t)blockIdx.x * kUB + threadIdx.x;
+  if (t >= (size_t)rows * blocks_per_row) return;
+  const int row = (int)(t / blocks_per_row), blk = n_offset / 4 + (int)(t % blocks_per_row);
+  uint32_t x[4];
+  philox4x32_10((uint32_t)blk, (uint32_t)row, draw, 0u, seed_lo, seed_hi, x);
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {  // Box-Muller on (u1, u2) in (0, 1): u = (x + 0.5) * 2^-32
+    const float u1 = ((float)(x[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f, u2 = ((float)(x[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // 24 bits each
+    const float rad = sqrtf(-2.f * logf(u1));
+    float sn, cs; sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+  }
+  const int n0 = 4 * blk - n_offset;  // local index of the block's first rollout (may be negative / run past the shard at the edges)
+  float* o = out + (size_t)row * ldn + n0;
+  if (n0 >= 0 && n0 + 3 < n_local && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) *reinterpret_cast<float4*>(o) = make_float4(z[0], z[1], z[2], z[3]);
+  else
+    for (int k = 0; k < 4; k++) if (n0 + k >= 0 && n0 + k < n_local) o[k] = z[k];
+}
+}  // namespace
+
+extern "C" int jh_noise_normal(unsigned long long seed, unsigned int draw, int rows, int n_offset, int n_local, float* out, int ldn, void* stream) {
+  JH_REQUIRE(out != nullptr, "noise_normal: null pointer");
+  JH_REQUIRE(rows > 0 && n_local > 0 && n_offset >= 0 && ldn >= n_local, "noise_normal: rows, n_local must be positive, n_offset >= 0, ldn >= n_local (rows=%d n_local=%d n_offset=%d ldn=%d)", rows, n_local, n_offset, ldn);
+  const size_t blocks_per_row = (size_t)((n_offset + n_local + 3) / 4 - n_offset / 4), total = (size_t)rows * blocks_per_row;
+  hipLaunchKernelGGL(k_noise_normal, dim3((unsigned)((total + kUB - 1) / kUB)), dim3(kUB), 0, (hipStream_t)stream, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw, rows, n_offset,
+                     n_local, out, ldn);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
 extern "C" int jh_sample_knots(const float* nominal, const float* noise, int ldn, const float* sigma, const float* lohi, int N, int n_offset, int K,
                                int nu, float* knots_nku, void* stream) {
   if (int e = check_dims(N, K, nu)) return e;

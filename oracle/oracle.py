@@ -319,6 +319,33 @@ def collide_pair(kind_a, size_a, pos_a, quat_a, kind_b, size_b, pos_b, quat_b, m
     return [(out[7 * i], out[7 * i + 1 : 7 * i + 4].copy(), out[7 * i + 4 : 7 * i + 7].copy()) for i in range(n)]
 
 
+# ---------------------------------------------------------------- the optimizers' device noise stream, restated (jh_noise_normal)
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123) on uint32 arrays: the counter-based generator behind `jh_noise_normal`."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M0, M1, W0, W1, LO = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & LO, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & LO
+        k0, k1 = (k0 + W0) & LO, (k1 + W1) & LO
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def noise_normal(seed: int, draw: int, rows: int, n_total: int) -> np.ndarray:
+    """(rows, n_total) standard normals of draw number `draw`: block b of four rollouts of row r = Philox(counter (b, r, draw, 0), key = seed), two Box-Muller
+    pairs on the top 24 bits of each word -- the definition `jh_noise_normal` implements (fp64 here: the kernel's fp32 transcendentals differ in the last bits)."""
+    nb = (n_total + 3) // 4
+    b, r = np.meshgrid(np.arange(nb, dtype=np.uint64), np.arange(rows, dtype=np.uint64))
+    x = philox4x32_10(b, r, np.full_like(b, draw), np.zeros_like(b), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = [((xi >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24 for xi in x]
+    z = np.empty((rows, nb, 4))
+    for h in range(2):
+        rad, th = np.sqrt(-2.0 * np.log(u[2 * h])), 2.0 * np.pi * u[2 * h + 1]
+        z[:, :, 2 * h], z[:, :, 2 * h + 1] = rad * np.cos(th), rad * np.sin(th)
+    return z.reshape(rows, 4 * nb)[:, :n_total]
+
+
 # ---------------------------------------------------------------- plan-path primitives (numpy in / numpy out)
 def spline_weights(kind: str | int, knot_times, query_times) -> np.ndarray:
     k = {"zero": 0, "linear": 1, "cubic": 3}.get(kind, kind)

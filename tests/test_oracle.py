@@ -310,3 +310,19 @@ def test_spot_walks_under_the_extracted_policy():
             np.testing.assert_allclose(got, vel, atol=tol)
         else:
             assert abs(got[2] - vel[2]) < tol and np.abs(st[-1, :2]).max() < 0.3
+
+
+def test_philox_known_answers_and_normal_moments():
+    """The optimizers' device noise stream (jh_noise_normal) is Philox4x32-10 + Box-Muller: the oracle's restatement against the Random123 known-answer
+    vectors (kat_vectors: zeros, all ones, digits of pi) and the moments of what comes out."""
+    from scipy import stats
+
+    assert [int(v[0]) for v in O.philox4x32_10([0], [0], [0], [0], 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(v[0]) for v in O.philox4x32_10([0xFFFFFFFF], [0xFFFFFFFF], [0xFFFFFFFF], [0xFFFFFFFF], 0xFFFFFFFF, 0xFFFFFFFF)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert [int(v[0]) for v in O.philox4x32_10([0x243F6A88], [0x85A308D3], [0x13198A2E], [0x03707344], 0xA4093822, 0x299F31D0)] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    z = O.noise_normal(1234, 3, 64, 16384)
+    assert abs(z.mean()) < 4e-3 and abs(z.std() - 1) < 4e-3 and abs(stats.kurtosis(z.ravel())) < 2e-2 and abs(stats.skew(z.ravel())) < 1e-2
+    assert stats.kstest(z.ravel()[:100000], "norm").pvalue > 1e-3
+    # rows and draws are independent streams
+    z2 = O.noise_normal(1234, 4, 64, 16384)
+    assert abs(np.corrcoef(z.ravel(), z2.ravel())[0, 1]) < 5e-3 and abs(np.corrcoef(z[0], z[1])[0, 1]) < 3e-2
