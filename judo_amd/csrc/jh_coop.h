@@ -261,6 +261,21 @@ __device__ __forceinline__ void collide_box_sphere(Sink& sk, const float* pb, co
 }
 
 
+// box against capsule (radius r, half length L along the local z of Rc): the two end spheres, and the point of the axis closest to the box when that lies strictly
+// inside the segment (a capsule across an edge of the box); normal from the box to the capsule.  The fr3 links' stand-ins.
+template <class Sink>
+__device__ __forceinline__ void collide_box_capsule(Sink& sk, const float* pb, const float* Rb, const float* hb, const float* pc, const float* Rc, float r, float L) {
+  float axis[3]; col3(axis, Rc, 2);
+  const float tm = capsule_box_closest(pb, Rb, hb, pc, axis, L);
+#pragma unroll 1
+  for (int e = 0; e < 3; e++) {  // + end, - end, interior point (one copy of the box-sphere code)
+    const float t = e == 0 ? L : (e == 1 ? -L : tm);
+    if (e == 2 && tm > L) break;
+    const float c[3] = {fmaf(t, axis[0], pc[0]), fmaf(t, axis[1], pc[1]), fmaf(t, axis[2], pc[2])};
+    collide_box_sphere(sk, pb, Rb, hb, c, r);
+  }
+}
+
 // signed box-box distance = largest separation over the 15 SAT axes (exact when a face or an edge pair is closest; see the oracle)
 __device__ __forceinline__ float box_box_distance(const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
   float A[3][3], B[3][3], dv[3], best = -1e30f;

@@ -332,6 +332,17 @@ __device__ void collision(const EngineModel& m, Work<C>& w) {
       geom_pose(m, w, g1, p1, R1, true);
       w.cur_bodyA = b1;
       collide_box_sphere(w, p1, R1, f1 + GF_SIZE, p2, f2[GF_SIZE], b2, mu, tran);
+    } else if (t1 == GBOX && t2 == GCAPSULE) {  // the capsule's two end spheres and, when it lies inside the segment, the point of its axis closest to the box
+      geom_pose(m, w, g1, p1, R1, true); geom_pose(m, w, g2, p2, R2, true);
+      w.cur_bodyA = b1;
+      float axis[3]; col3(axis, R2, 2);
+      const float L = f2[GF_SIZE + 1], tm = capsule_box_closest(p1, R1, f1 + GF_SIZE, p2, axis, L);
+      for (int e = 0; e < 3; e++) {
+        const float t = e == 0 ? L : (e == 1 ? -L : tm);
+        if (e == 2 && tm > L) break;
+        const float c[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
+        collide_box_sphere(w, p1, R1, f1 + GF_SIZE, c, f2[GF_SIZE], b2, mu, tran);
+      }
     } else if (t1 == GSPHERE && t2 == GBOX) {  // normal must point from geom 1 (sphere) to geom 2 (box): swap the sides of the box-sphere routine
       geom_pose(m, w, g2, p2, R2, true);
       int before = w.ncon;

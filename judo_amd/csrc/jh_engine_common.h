@@ -7,7 +7,7 @@
 namespace jh_eng {
 
 constexpr int JFREE = 0, JSLIDE = 2, JHINGE = 3;
-constexpr int GBOX = 6, GSPHERE = 2;
+constexpr int GBOX = 6, GSPHERE = 2, GCAPSULE = 3;
 constexpr int HEADER_I = 24, HEADER_F = 24;
 constexpr int BODY_I = 6, GEOM_I = 2, ACT_I = 2, BLOCK_I = 4, SENS_I = 3;
 constexpr int BODY_F = 32, DOF_F = 20, ACT_F = 8, GEOM_F = 20, SITE_F = 3;
@@ -97,6 +97,25 @@ __device__ __forceinline__ float impedance(const float* si, float dist) {
   else if (x <= s3) y = powf(x, s4) / powf(s3, s4 - 1.f);
   else y = 1.f - powf(1.f - x, s4) / powf(1.f - s3, s4 - 1.f);
   return s0 + y * (s1 - s0);
+}
+
+// Capsule (centre pc, unit axis, half length L) against a box: parameter t in (-L, L) of the point of the capsule's axis that is closest to the box, or a value
+// >= L when the minimum sits at an end of the segment (the end spheres, which the callers test anyway, then have it).  The squared distance
+// d(t)^2 = sum_k max(|c_k + t a_k| - h_k, 0)^2 (box frame) is convex in t and its derivative monotone: 24 bisection steps resolve t to L * 1e-7.
+__device__ __forceinline__ float capsule_box_closest(const float* pb, const float* Rb, const float* hb, const float* pc, const float* axis, float L) {
+  const float d0[3] = {pc[0] - pb[0], pc[1] - pb[1], pc[2] - pb[2]};
+  float c[3], a[3]; mulMTV(c, Rb, d0); mulMTV(a, Rb, axis);
+  auto slope = [&](float t) __attribute__((always_inline)) {
+    float g = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float sk = fmaf(t, a[k], c[k]); g = fmaf(sk > hb[k] ? sk - hb[k] : (sk < -hb[k] ? sk + hb[k] : 0.f), a[k], g); }
+    return g;
+  };
+  float lo = -L, hi = L;
+  if (slope(lo) >= 0.f || slope(hi) <= 0.f) return 2.f * L + 1.f;
+  for (int it = 0; it < 24; it++) { const float t = 0.5f * (lo + hi); if (slope(t) < 0.f) lo = t; else hi = t; }
+  const float t = 0.5f * (lo + hi);
+  return fabsf(t) >= L * (1.f - 1e-6f) ? 2.f * L + 1.f : t;
 }
 
 // contact frame from the normal, tangents as MuJoCo's mju_makeFrame picks them

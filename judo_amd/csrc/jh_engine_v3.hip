@@ -512,7 +512,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V3_WPE,
           geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, R1, true); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, R2, true);
           const int sbA = gI[m.oAGI + g1 * GEOM_I], sbB = gI[m.oAGI + g2 * GEOM_I];
           Sink3 sk{&S, stats, p, sbA >= 1 && sbB >= 1};
-          collide_box_box(sk, p1, R1, h1, p2, R2, h2);
+          if (gI[m.oAGI + g2 * GEOM_I + 1] == GCAPSULE) collide_box_capsule(sk, p1, R1, h1, p2, R2, h2[0], h2[1]);  // (a pair's capsule is its second geom: jh_model_is_fr3)
+          else collide_box_box(sk, p1, R1, h1, p2, R2, h2);
         }
       }
     }
@@ -948,11 +949,14 @@ bool jh_model_is_fr3(const jh_model* m) {
   if (neq > 1 || ngs > G || m->h_i[gi + 4] > 8) return false;
   for (int s = 0; s < ngs; s++) if (m->h_i[gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3] + m->h_i[gi + 4] * 4 + s * 4] == 2) return false;  // no jointpos sensors
   { int nt = 0; const int* di = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3]; for (int s = 0; s < m->h_i[gi + 4]; s++) nt += di[4 * s + 1] * di[4 * s + 3]; if (nt > MAXDT) return false; }
-  for (int g = 0; g < nag; g++) if (m->h_i[gi + 8 + g * jh_eng::GEOM_I + 1] != jh_eng::GBOX) return false;
+  for (int g = 0; g < nag; g++) { const int tp = m->h_i[gi + 8 + g * jh_eng::GEOM_I + 1]; if (tp != jh_eng::GBOX && tp != jh_eng::GCAPSULE) return false; }  // boxes; capsules = arm-link stand-ins
   for (int p = 0; p < npair; p++) {  // pairs between two articulated bodies are kept as finger-finger contacts: nothing else qualifies
     const int* pi = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + 2 * p;
     const int b1 = m->h_i[gi + 8 + pi[0] * jh_eng::GEOM_I], b2 = m->h_i[gi + 8 + pi[1] * jh_eng::GEOM_I];
     if (b1 >= 1 && b2 >= 1 && !((b1 == LF && b2 == RF) || (b1 == RF && b2 == LF))) return false;
+    // a capsule is always the second geom of its pair and meets a box of the static geometry or of the free body only
+    if (m->h_i[gi + 8 + pi[0] * jh_eng::GEOM_I + 1] != jh_eng::GBOX) return false;
+    if (m->h_i[gi + 8 + pi[1] * jh_eng::GEOM_I + 1] == jh_eng::GCAPSULE && b1 >= 1) return false;
   }
   {  // the two finger slides must be antiparallel in the frame of their common parent: the finger-finger slots rely on it (struct SlotF)
     float w[2][3];

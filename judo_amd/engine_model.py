@@ -30,7 +30,7 @@ from judo_amd.models import (
 )
 
 JFREE, JSLIDE, JHINGE = 0, 2, 3
-GBOX, GSPHERE = 6, 2
+GBOX, GSPHERE, GCAPSULE = 6, 2, 3
 MAX_MOVING, MAX_DOF, MAX_BLOCKS, MAX_BLOCK_DOF, MAX_GEOM, MAX_SITE = 20, 24, 4, 9, 80, 8
 
 # ints per record
@@ -247,10 +247,12 @@ def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = No
         for b in range(a + 1, len(geoms)):
             ga, gb = geoms[a], geoms[b]
             ta, tb = ga["type"], gb["type"]
-            if not ((ta == "box" and tb in ("box", "sphere")) or (ta == "sphere" and tb == "box") or (ta == "sphere" and tb == "sphere" and cube_only is False)):
+            if not ((ta == "box" and tb in ("box", "sphere", "capsule")) or (ta == "sphere" and tb == "box") or (ta == "sphere" and tb == "sphere" and cube_only is False)):
                 continue  # (sphere-sphere: the fingertips of two fingers; only jh_engine_v5.hip collides the hand with itself)
             ba, bb = ga["orig_body"], gb["orig_body"]
             wa, wb = weld(ba), weld(bb)
+            if tb == "capsule" and not (wa == 0 or ga["body"] == free_fused):
+                continue  # the arm links' stand-ins meet static geometry and the free body only (oracle/oracle.py::collision_pairs has the reason)
             if wa == wb or tuple(sorted((ba, bb))) in excl:
                 continue
             if (weld_parent(ba) == wb and wb != 0) or (weld_parent(bb) == wa and wa != 0):
@@ -504,7 +506,7 @@ def pack_engine_model(desc: dict) -> bytes:
             F += [*ctr, float(np.linalg.norm(half)), *half, 0.0]
     # ---- generic sections (reference kernel): every collision geom incl. the cube, explicit candidate pairs, joint
     # equalities, sensor frames with orientation, geom-distance sensors
-    allg = [g for g in desc["geoms"] if g["type"] in ("box", "sphere")]
+    allg = [g for g in desc["geoms"] if g["type"] in ("box", "sphere", "capsule")]
     gidx = {id(g): i for i, g in enumerate(allg)}
     pairs_all = generic_pairs(orig, dict(desc, geoms=allg), st)
     frames = []
@@ -529,8 +531,8 @@ def pack_engine_model(desc: dict) -> bytes:
         else:
             pos, R, mb = np.array(g["pos"]), quat_to_mat(g["quat"]), midx[b]
         size = (list(g["size"]) + [0, 0, 0])[:3]
-        rb = size[0] if g["type"] == "sphere" else float(np.linalg.norm(size))
-        I += [mb, GBOX if g["type"] == "box" else GSPHERE]
+        rb = size[0] if g["type"] == "sphere" else (size[0] + size[1] if g["type"] == "capsule" else float(np.linalg.norm(size)))
+        I += [mb, {"box": GBOX, "sphere": GSPHERE, "capsule": GCAPSULE}[g["type"]]]
         F += [*size, *pos, *R.reshape(-1), rb, max(MINMU, g["friction"][0]), bodyw_geom(g), 0, 0]
     for g in allg:  # per-geom solver parameters, mixed per contact (solref/solimp averaged, friction max)
         F += [*g["solref"], *clamp_solimp(g["solimp"]), 0.0]

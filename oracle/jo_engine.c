@@ -521,6 +521,43 @@ static double box_box_distance(const double* p1, const double* R1, const double*
   return best;
 }
 
+/* Box against capsule (radius size[0], half length size[1] along its local z).  The fr3 links' collision meshes are not in the reference repository, so no
+ * routine of MuJoCo's could be restated for them anyway (its mjc_CapsuleBox has no closed form either); this is the build's own definition, checked against
+ * support-function geometry in tests/test_oracle_independent.py.  The capsule is its axis segment swept by a sphere:
+ *   1. both end spheres are tested like box-sphere (a capsule lying flat on a face rests on its two ends);
+ *   2. the point of the segment closest to the box -- d(t)^2 = sum_k max(|c_k + t a_k| - h_k, 0)^2 is convex in t, its derivative monotone: bisection -- is
+ *      tested the same way when it lies strictly inside the segment (a capsule across an edge of the box touches with its cylinder, not its ends).
+ * Up to three contacts, normal from the box to the capsule. */
+static int collide_box_capsule(const double* pb, const double* Rb, const double* hb, const double* pc, const double* Rc, const double* size, double margin, rawcon* out) {
+  double axis[3]; col(axis, Rc, 2);
+  const double r = size[0], L = size[1];
+  int n = 0;
+  for (int sgn = 1; sgn >= -1; sgn -= 2) {
+    double c[3] = {pc[0] + sgn * L * axis[0], pc[1] + sgn * L * axis[1], pc[2] + sgn * L * axis[2]};
+    n += collide_box_sphere(pb, Rb, hb, c, r, margin, out + n);
+  }
+  /* closest point of the segment, in the box frame */
+  double d0[3] = {pc[0] - pb[0], pc[1] - pb[1], pc[2] - pb[2]}, c[3], a[3];
+  for (int k = 0; k < 3; k++) { c[k] = Rb[k] * d0[0] + Rb[3 + k] * d0[1] + Rb[6 + k] * d0[2]; a[k] = Rb[k] * axis[0] + Rb[3 + k] * axis[1] + Rb[6 + k] * axis[2]; }
+  double lo = -L, hi = L, glo = 0, ghi = 0;
+  for (int k = 0; k < 3; k++) {
+    double sl = c[k] + lo * a[k], sh = c[k] + hi * a[k];
+    glo += (sl > hb[k] ? sl - hb[k] : (sl < -hb[k] ? sl + hb[k] : 0)) * a[k];
+    ghi += (sh > hb[k] ? sh - hb[k] : (sh < -hb[k] ? sh + hb[k] : 0)) * a[k];
+  }
+  if (glo >= 0 || ghi <= 0) return n; /* the minimum sits at an end (or the whole segment is equally far / inside): the end spheres have it */
+  for (int it = 0; it < 60; it++) {
+    double t = 0.5 * (lo + hi), g = 0;
+    for (int k = 0; k < 3; k++) { double sk = c[k] + t * a[k]; g += (sk > hb[k] ? sk - hb[k] : (sk < -hb[k] ? sk + hb[k] : 0)) * a[k]; }
+    if (g < 0) lo = t; else hi = t;
+  }
+  double t = 0.5 * (lo + hi);
+  if (fabs(t) >= L * (1 - 1e-9)) return n;
+  double cm[3] = {pc[0] + t * axis[0], pc[1] + t * axis[1], pc[2] + t * axis[2]};
+  n += collide_box_sphere(pb, Rb, hb, cm, r, margin, out + n);
+  return n;
+}
+
 /* Plane (geom 1) against sphere / capsule / box (engine_collision_primitive.c: mjc_PlaneSphere, mjc_PlaneCapsule, mjc_PlaneBox).
  * The plane's normal is its local z axis; contact normal = plane normal (from geom 1 to geom 2), position midway between the surfaces. */
 static int collide_plane_sphere(const double* pp, const double* Rp, const double* c, double r, double margin, rawcon* out) {
@@ -578,6 +615,8 @@ static int collide_geoms(int t1, const double* s1, const double* p1, const doubl
   else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(p2, R2, s2, p1, s1[0], margin, rc); *flip = 1; }
   else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_SPHERE) n = collide_sphere_sphere(p1, s1[0], p2, s2[0], margin, rc);
   else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) n = collide_cyl_cyl_parallel(p1, R1, s1, p2, R2, s2, margin, rc);
+  else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_CAPSULE) n = collide_box_capsule(p1, R1, s1, p2, R2, s2, margin, rc);
+  else if (t1 == JO_GEOM_CAPSULE && t2 == JO_GEOM_BOX) { n = collide_box_capsule(p2, R2, s2, p1, R1, s1, margin, rc); *flip = 1; }
   return n;
 }
 

@@ -122,7 +122,7 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
         return weld(bodies[w]["parent"]) if w > 0 else 0
 
     excl = {tuple(sorted(e)) for e in desc["excludes"]}
-    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("sphere", "sphere"), ("cylinder", "cylinder"),
+    supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("sphere", "sphere"), ("cylinder", "cylinder"), ("box", "capsule"), ("capsule", "box"),
                  ("plane", "sphere"), ("plane", "capsule"), ("plane", "box"), ("sphere", "plane"), ("capsule", "plane"), ("box", "plane")}
     pairs = []
     for g1 in range(len(geoms)):
@@ -138,6 +138,14 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
                 continue
             if (geoms[g1]["type"], geoms[g2]["type"]) not in supported:
                 continue
+            if {geoms[g1]["type"], geoms[g2]["type"]} == {"capsule", "box"}:
+                # fr3_pick: the capsules stand in for the arm links' collision meshes (absent from the reference repository).  They collide with static geometry
+                # (table) and with the free body (cube); link-against-link and link-against-gripper pairs are left out -- hulls fitted by eye overlap their
+                # neighbours and would inject contact forces the reference does not have
+                ob = b2 if geoms[g1]["type"] == "capsule" else b1
+                free = any(j["body"] == ob and j["type"] == "free" for j in desc["joints"])
+                if not (weld(ob) == 0 or free):
+                    continue
             if desc.get("family", desc["task"]) == "leap_cube" and scope in ("cube", "task"):
                 cube = next(i for i, g in enumerate(geoms) if g["name"] == "cube")
                 if cube not in (g1, g2):
