@@ -137,12 +137,12 @@ def test_fused_fixed_bodies_preserve_the_dynamics():
         np.testing.assert_allclose(M1, M2, rtol=1e-12, atol=1e-14)
     st = engine_structure(f)
     assert len(st["moving"]) == 10 and [len(b) for b in st["blocks"]] == [9]
-    allg = [g for g in f["geoms"] if g["type"] in ("box", "sphere")]
+    allg = [g for g in f["geoms"] if g["type"] in ("box", "sphere", "capsule")]
     pairs = generic_pairs(d, dict(f, geoms=allg), st)
     names = {tuple(sorted((allg[a]["name"], allg[b]["name"]))) for a, b in pairs}
     om = O.Model("fr3_pick")
     onames = {tuple(sorted((om.desc["geoms"][a]["name"], om.desc["geoms"][b]["name"]))) for a, b in om.pairs}
-    assert names == onames and len(names) == 63
+    assert names == onames and len(names) == 78  # 63 box pairs + the arm links' capsules against table (7) and cube (8), round 3
 
 
 def test_c_abi_library_exports_every_declared_symbol():
