@@ -64,8 +64,8 @@ int jh_model_dims(const jh_model* m, int* dims /* HOST */);
  * summed over wavefronts; out[6], out[7] reserved (0).  The counters are 32-bit and wrap: reset them at least every ~10^9 rollout-steps.  HOST pointer. */
 int jh_model_stats(jh_model* m, int* out /* HOST, 8 ints */, int reset);
 
-/* Articulated-body engine kernel generation for this model: 3 (default for leap_cube) = cooperative kernel on a register diet, two waves per SIMD,
- * hand self-collision; 2 (default for fr3_pick) = cooperative kernel, 16 lanes per rollout, one wave per SIMD;
+/* Articulated-body engine kernel generation for this model: 3 (default) = cooperative kernel on a register diet, two waves per SIMD (leap_cube: hand
+ * self-collision; fr3_pick: matrix-free contact Jacobian, jh_engine_v6.hip); 2 = cooperative kernel, 16 lanes per rollout, one wave per SIMD;
  * 1 = one lane per rollout (kept as an independent second implementation for the parity tests).  "leap_cube" is the model family: leap_cube, leap_cube_down
  * and caltech_leap_cube (the last one only on generation 3: its sensor layout and static-geometry groups exist there alone). */
 int jh_model_set_kernel(jh_model* m, int generation);

@@ -30,7 +30,7 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE) ? 3 : 2; m->self_collision = 1;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
@@ -184,6 +184,7 @@ extern "C" int jh_rollout_cost(const jh_model* m, const float* x0, const float* 
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH)
     return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen >= 2) return jh_engine3_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
   return jh_engine_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
@@ -197,6 +198,7 @@ extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) return jh_simple_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen >= 2) return jh_engine3_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   return jh_engine_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);

@@ -24,7 +24,7 @@ struct jh_model {
   size_t nf, ni;
   float* d_f;  // device copy of the float section
   int* d_i;    // device copy of the int section
-  int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, several waves per SIMD (leap_cube: v5; fr3_pick: as 2), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
+  int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
   int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
   std::vector<float> h_f;
@@ -99,6 +99,12 @@ bool jh_model_is_fr3(const jh_model* m);
 int jh_engine3_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
                             const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st);
 int jh_engine3_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                           hipStream_t st);
+
+// jh_engine_v6.hip: fr3_pick, matrix-free contact Jacobian (kernel generation 3 of the fr3 model)
+int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                            const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st);
+int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st);
 
 // ---- device helpers ------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -48,12 +49,15 @@ class GpuModel:
         st = _lib.lib().jh_model_create(buf, len(blob), self.device.index or 0, C.byref(handle))
         _lib.check(st, "jh_model_create")
         self.handle = handle
-        self.kernel_generation = 3 if self.desc.get("family", self.task) == "leap_cube" else 2  # library defaults (jh_model_create)
+        self.kernel_generation = 3 if self.desc.get("family", self.task) in ("leap_cube", "fr3_pick") else 2  # library defaults (jh_model_create)
         self._self_collision_requested = True
+        gen = os.environ.get("JUDO_AMD_FR3_KERNEL")  # diagnostic: run the fr3_pick tests / benches on another kernel generation of the library
+        if gen and self.task == "fr3_pick":
+            self.set_kernel(int(gen))
         self.self_collision = self.desc.get("family", self.task) == "leap_cube"  # library default: on where the kernel models it
 
     def set_kernel(self, generation: int) -> None:
-        """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: leap_cube default; 2 = cooperative: fr3_pick default; 1 = one lane per rollout)."""
+        """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: the default; 2 = cooperative, one wave per SIMD; 1 = one lane per rollout)."""
         _lib.check(_lib.lib().jh_model_set_kernel(self.handle, int(generation)), "jh_model_set_kernel")
         self.kernel_generation = int(generation)
         # only generation 3 of the leap family models the hand's own contacts: what bench.py / tests report must follow the kernel actually selected

@@ -194,6 +194,14 @@ def test_fr3_two_kernel_generations_agree(gpu):
     np.testing.assert_allclose(y2[:, :3], y1[:, :3], atol=2e-4)
     e = np.abs(s2 - s1)
     assert np.median(e) < 2e-6 and np.percentile(e[:, -1, :3], 90) < 5e-3
+    # generation 2 (jh_engine_v3.hip: contact Jacobian in LDS, row-per-lane assembly, one wave per SIMD) against the default generation 3
+    # (jh_engine_v6.hip: matrix-free columns, Hessian by float atomics, two waves per SIMD): the same step up to summation order
+    b3 = GpuRolloutBackend("fr3_pick", N)
+    b3.model.set_kernel(2)
+    s3, y3, _ = b3.rollout(x0, U)
+    np.testing.assert_allclose(s3[:, :3], s2[:, :3], atol=2e-5)
+    e = np.abs(s3 - s2)
+    assert np.median(e) < 5e-7 and np.percentile(e[:, -1, :3], 90) < 2e-3, (np.median(e), np.percentile(e[:, -1, :3], 90))
 
 
 def test_fr3_arm_links_collide_with_table_and_cube(gpu):
