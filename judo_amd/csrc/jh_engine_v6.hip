@@ -475,7 +475,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     }
     PH6(1)
     // ================================================================ arm dynamics: 9x9 inertia and bias from per-link contributions
-    float Mrow[NA], a0_own, fs_own, Md_own, fsc[6], a0c[6];
+    float a0_own, fs_own, Md_own, fsc[6], a0c[6];  // (the own row of the arm inertia is read from S.M where it is used: nine registers less to carry)
     {
       // own link (lanes that own no arm dof contribute a massless link 1)
       const float* bo = gF + m.oBodyF + (1 + ai) * BODY_F;
@@ -569,14 +569,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       __syncthreads();
       float x9[NA];
 #pragma unroll
-      for (int a = 0; a < NA; a++) { x9[a] = S.vec[0][a]; Mrow[a] = S.M[ai][a]; }
+      for (int a = 0; a < NA; a++) x9[a] = S.vec[0][a];
       chol_solve<NA>(Lm, x9);
       a0_own = 0.f;
 #pragma unroll
       for (int a = 0; a < NA; a++) if (a == ai) a0_own = x9[a];
-      Md_own = Mrow[0];
-#pragma unroll
-      for (int a = 1; a < NA; a++) if (a == ai) Md_own = Mrow[a];
+      Md_own = S.M[ai][ai];
       // free body: M = diag(m, m, m, I)
       float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
       for (int k = 0; k < 3; k++) { fsc[k] = cmass * grav[k]; a0c[k] = grav[k]; fsc[3 + k] = -gc[k]; a0c[3 + k] = -gc[k] / cI[k]; }
@@ -602,6 +600,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, nullptr, false); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, nullptr, false);
           float dc[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, rs = f1[GF_RBOUND] + f2[GF_RBOUND];
           hit = dot3(dc, dc) <= rs * rs;
+          if (hit) {  // second level: the bounding sphere of geom 2 against the BOX geom 1 itself (the table's bounding sphere alone contains the whole scene: without
+                      // this its twenty pairs reach the narrow phase in every step).  Conservative, so the contacts do not change.
+            float R1[9], dl[3];
+            const int b1 = gI[m.oAGI + g1 * GEOM_I];
+            if (b1 < 0) { for (int k = 0; k < 9; k++) R1[k] = f1[GF_R + k]; } else mulMM(R1, S.xR[b1], f1 + GF_R);
+            mulMTV(dl, R1, dc);
+            const float ex = fmaxf(fabsf(dl[0]) - f1[GF_SIZE], 0.f), ey = fmaxf(fabsf(dl[1]) - f1[GF_SIZE + 1], 0.f), ez = fmaxf(fabsf(dl[2]) - f1[GF_SIZE + 2], 0.f);
+            hit = ex * ex + ey * ey + ez * ez <= f2[GF_RBOUND] * f2[GF_RBOUND];
+          }
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nh + __popc(m16 & ((1u << l) - 1u));
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
         ejar = has_eq ? quad_get(qws, 1) - e_a1 * quad_get(qws, 2) - earef : 0.f;
         float mdw = 0.f;
-        if (isarm) { for (int a = 0; a < NA; a++) mdw += Mrow[a] * S.vec[2][6 + a]; } else if (iscube) mdw = Md_own * (qws - a0_own);
+        if (isarm) { for (int a = 0; a < NA; a++) mdw += S.M[ai][a] * S.vec[2][6 + a]; } else if (iscube) mdw = Md_own * (qws - a0_own);
         const float cost_ws = gsum(lane_rows_cost(sl, sf, sff_ws, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
         for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) jar_ws[k][w] = sl[k].jar[w];
         const float jf_ws = dr.jf, jl_ws = dr.jl, ej_ws = ejar;
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         if (hasdof) S.vec[0][l] = da_own;
         __syncthreads();
         float g_own = 0.f, hd = 0.f;
-        if (isarm) { for (int a = 0; a < NA; a++) g_own += Mrow[a] * S.vec[0][6 + a]; } else if (iscube) g_own = Md_own * da_own;
+        if (isarm) { for (int a = 0; a < NA; a++) g_own += S.M[ai][a] * S.vec[0][6 + a]; } else if (iscube) g_own = Md_own * da_own;
         if (dr.fl > 0.f) {
           float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
           if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += dr.fD * x; hd += dr.fD; }
@@ -828,7 +835,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         for (int j = 0; j < 16; j++) Hrow[j] = 0.f;
         if (isarm) {
 #pragma unroll
-          for (int a = 0; a < NA; a++) Hrow[6 + a] = Mrow[a];
+          for (int a = 0; a < NA; a++) Hrow[6 + a] = S.M[ai][a];
         }
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) Hrow[j] = (iscube ? Md_own : Hrow[j]) + hd;
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         float Mp_own = 0.f;
         if (isarm) {
 #pragma unroll
-          for (int a = 0; a < NA; a++) Mp_own += Mrow[a] * p[6 + a];
+          for (int a = 0; a < NA; a++) Mp_own += S.M[ai][a] * p[6 + a];
         } else if (iscube) Mp_own = Md_own * p_own;
         const float pMp = gsum(p_own * Mp_own), pMd = gsum(Mp_own * da_own), gp = gsum(g_own * p_own);
 #ifdef JH_V6_EXITSTATS
@@ -964,7 +971,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       if (hasdof) S.vec[0][l] = da_own;
       __syncthreads();
       float rhs_own = fs_own;
-      if (isarm) { for (int a = 0; a < NA; a++) rhs_own += Mrow[a] * S.vec[0][6 + a]; } else if (iscube) rhs_own += Md_own * da_own;
+      if (isarm) { for (int a = 0; a < NA; a++) rhs_own += S.M[ai][a] * S.vec[0][6 + a]; } else if (iscube) rhs_own += Md_own * da_own;
       if (hasdof) S.vec[1][l] = rhs_own;
       __syncthreads();
       float Lm[45], x9[NA];
