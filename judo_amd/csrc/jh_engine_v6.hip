@@ -54,6 +54,7 @@ struct __attribute__((aligned(16))) RS6 {  // per-rollout shared state
   };
   float ffraw[NFF][FF_F];                       // finger-finger contacts between narrow phase and slots: normal3, dist, pair
   float g[16];                                  // gradient (own rows + contact forces by float atomics)
+  float cq[8], cv[8];                           // the free body's position / quaternion and velocity: ONE copy per rollout here instead of one per lane in registers
   float y[16];                                  // sensordata of the forward pass
   float kn[NU][8];                              // spline knots per actuator (kept out of the register file: they are read once per step)
   unsigned short hits[MAXHIT];
@@ -352,11 +353,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
   float e_si[5]; for (int k = 0; k < 5; k++) e_si[k] = ef[EF_SOLIMP + k];
   const bool eq_lane = has_eq && l == 13;  // the lane that accounts for the row's cost / line-search terms
   // ---- state: replicated free body + own joint
-  float q = 0.f, qd = 0.f, qws = 0.f, qc[7], vc[6];
+  float q = 0.f, qd = 0.f, qws = 0.f;
   {
     const float* xi = x0 + ((MATERIALIZE && x0_batched) ? (size_t)nc * NX : 0);
-    for (int k = 0; k < 7; k++) qc[k] = xi[k];
-    for (int k = 0; k < 6; k++) vc[k] = xi[NQ + k];
+    if (l < 7) S.cq[l] = xi[l];
+    if (l < 6) S.cv[l] = xi[NQ + l];
     if (isarm) { q = xi[7 + ai]; qd = xi[NQ + 6 + ai]; }
   }
   // ---- own actuator's spline knots (fused mode)
@@ -401,8 +402,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     if (l == 0) { S.ncon = 0; S.nhit = 0; S.nff = 0; }
     __syncthreads();
     // ================================================================ kinematics: every lane walks the 7-hinge chain (uniform records -> scalar loads)
-    float Rown[9], pown[3], axown[3], Rc[9];  // joint axes / anchors of the whole chain go to LDS (S.axw, S.xpos): the dynamics below reads them from there
+    float Rown[9], pown[3], axown[3];  // joint axes / anchors of the whole chain go to LDS (S.axw, S.xpos): the dynamics below reads them from there
     {
+      float qc[7], Rc[9];
+      for (int k = 0; k < 7; k++) qc[k] = S.cq[k];
       float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
       qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
       quat2mat(Rc, qc + 3);
@@ -576,7 +579,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       for (int a = 0; a < NA; a++) if (a == ai) a0_own = x9[a];
       Md_own = S.M[ai][ai];
       // free body: M = diag(m, m, m, I)
-      float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
+      const float wc[3] = {S.cv[3], S.cv[4], S.cv[5]};
+      float Icw[3] = {cI[0] * wc[0], cI[1] * wc[1], cI[2] * wc[2]}, gc[3]; cross3(gc, wc, Icw);
       for (int k = 0; k < 3; k++) { fsc[k] = cmass * grav[k]; a0c[k] = grav[k]; fsc[3 + k] = -gc[k]; a0c[3 + k] = -gc[k] / cI[k]; }
       if (iscube) {
 #pragma unroll
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran * (1.f + mu * mu));
         const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
         sl[k].D = 1.f / Rpy; sl[k].mu = mu;
-        float vel[3]; slot_Jx(sl[k], S, vc, S.qd, vel);
+        float vel[3]; slot_Jx(sl[k], S, S.cv, S.qd, vel);
         sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
       }
     }
@@ -965,8 +969,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     }
     PH6(5)
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
+    float qc[7], vc[6];  // the free body's state after the step (registers from here to the end of the step only)
     {
       __syncthreads();
+      // (the own joint's position / velocity and the free body's state come back from LDS: registers held them only up to the kinematics)
+      if (isarm) { q = S.q[ai]; qd = S.qd[ai]; }
       const float da_own = a_own - a0_own;
       if (hasdof) S.vec[0][l] = da_own;
       __syncthreads();
@@ -988,7 +995,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       for (int a = 0; a < NA; a++) if (a == ai) qacc = x9[a];
       if (isarm) { qd = fmaf(h, qacc, qd); q = fmaf(h, qd, q); }
       qws = a_own;
-      for (int k = 0; k < 3; k++) {  // free body: every lane integrates the replicated state from the published right-hand side
+      for (int k = 0; k < 7; k++) qc[k] = S.cq[k];
+      for (int k = 0; k < 6; k++) vc[k] = S.cv[k];
+      for (int k = 0; k < 3; k++) {  // free body: every lane integrates the rollout's copy of the state from the published right-hand side
         const float al = S.vec[1][k] / cmass, aw = S.vec[1][3 + k] / cI[k];
         vc[k] = fmaf(h, al, vc[k]); vc[3 + k] = fmaf(h, aw, vc[3 + k]);
       }
@@ -1005,15 +1014,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
       const float nn = rsqrtf(qc[3] * qc[3] + qc[4] * qc[4] + qc[5] * qc[5] + qc[6] * qc[6]);
       qc[3] *= nn; qc[4] *= nn; qc[5] *= nn; qc[6] *= nn;
+      __syncthreads();  // (every lane has read the old copy)
+      if (l < 7) { float v = qc[0]; for (int k = 1; k < 7; k++) if (k == l) v = qc[k]; S.cq[l] = v; }
+      if (l < 6) { float v = vc[0]; for (int k = 1; k < 6; k++) if (k == l) v = vc[k]; S.cv[l] = v; }
     }
     if (MATERIALIZE) {
       if (states && live) {
         float* o = states + ((size_t)nc * H + hh) * NX;
         if (isarm) { o[7 + ai] = q; o[NQ + 6 + ai] = qd; }
-        if (l < 7) o[l] = qc[l];
-        if (l < 6) o[NQ + l] = vc[l];
       }
       __syncthreads();
+      if (states && live) {
+        float* o = states + ((size_t)nc * H + hh) * NX;
+        if (l < 7) o[l] = S.cq[l];
+        if (l < 6) o[NQ + l] = S.cv[l];
+      }
     } else {
       // running cost: the state after the step with the sensors of the forward pass that produced it (judo/tasks/fr3_pick.py:225-311)
       __syncthreads();
