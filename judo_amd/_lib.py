@@ -25,6 +25,7 @@ _SIGNATURES = {
     "jh_model_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "jh_model_set_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_model_limits": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "jh_register_xcheck": (C.c_int, [C.c_void_p]),
     "jh_model_max_fused_knots": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_model_set_self_collision": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

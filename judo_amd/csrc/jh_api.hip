@@ -81,8 +81,22 @@ extern "C" int jh_model_hist(jh_model* m, int* out /* 24 ints: Newton-iteration 
   return JH_OK;
 }
 
+static jh_xcheck_launchers g_xcheck = {nullptr, nullptr, nullptr};
+
+extern "C" int jh_register_xcheck(const jh_xcheck_launchers* launchers) {
+  JH_REQUIRE(launchers && launchers->rollout_cost && launchers->rollout_materialize && launchers->max_knots, "register_xcheck: incomplete launcher table");
+  g_xcheck = *launchers;
+  return JH_OK;
+}
+
+static bool articulated(const jh_model* m) { return m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK; }
+
 extern "C" int jh_model_set_kernel(jh_model* m, int generation) {
   JH_REQUIRE(m && generation >= 1 && generation <= 3, "model_set_kernel: generation must be 1, 2 or 3");
+  if (generation != 3 && articulated(m) && !g_xcheck.rollout_cost) {
+    jh_set_error("model_set_kernel: generations 1 and 2 are cross-check kernels of the test build (libjudo_amd_xcheck.so), not part of this library");
+    return JH_ERR_UNSUPPORTED;
+  }
   m->kernel_gen = generation;
   return JH_OK;
 }
@@ -98,7 +112,7 @@ static int max_fused_knots(const jh_model* m, int H) {
   int k = JH_MAX_KNOT_DIM / (m->nu > 0 ? m->nu : 1);
   if (coop) return k < 8 ? k : 8;
   // the one-lane kernels stage W (H x K) and 64 lanes' knots in LDS: the launcher's 64 KiB budget bounds K as well
-  const int lds_k = (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) ? jh_simple_max_knots(m, H) : jh_engine_max_knots(m, H);
+  const int lds_k = (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) ? jh_simple_max_knots(m, H) : (g_xcheck.max_knots ? g_xcheck.max_knots(m, H) : 0);
   return k < lds_k ? k : lds_k;
 }
 
@@ -185,9 +199,8 @@ extern "C" int jh_rollout_cost(const jh_model* m, const float* x0, const float* 
     return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
   if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
-  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen >= 2) return jh_engine3_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
-  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
-  return jh_engine_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
+  if (!g_xcheck.rollout_cost) { jh_set_error("rollout_cost: no kernel for this model / generation in this library"); return JH_ERR_UNSUPPORTED; }
+  return g_xcheck.rollout_cost(m, m->kernel_gen, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, stream);
 }
 
 extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
@@ -199,9 +212,8 @@ extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) return jh_simple_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
-  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen >= 2) return jh_engine3_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
-  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 2) return jh_engine2_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
-  return jh_engine_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (!g_xcheck.rollout_materialize) { jh_set_error("rollout_materialize: no kernel for this model / generation in this library"); return JH_ERR_UNSUPPORTED; }
+  return g_xcheck.rollout_materialize(m, m->kernel_gen, x0, x0_batched, controls, N, H, states, sensors, stream);
 }
 
 extern "C" int jh_task_reward(const jh_model* m, const float* states, const float* sensors, const float* controls, const float* tp, int phase, int N,

@@ -934,43 +934,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V3_WPE,
 
 }  // namespace
 
-bool jh_model_is_fr3(const jh_model* m) {
-  if (!(m->kind == JH_TASK_FR3_PICK && m->nq == NQ && m->nv == NVT && m->nu == NU && m->ns == NS && m->h_i.size() > 24 && m->h_i[0] == NMB && m->h_i[9] == 0)) return false;
-  const int gi = m->h_i[13];
-  // 7 hinges in a chain welded to the world, two slides on the last link; boxes only; at most one joint equality on the fingers
-  for (int b = 1; b <= 9; b++) {
-    const int* bi = m->h_i.data() + jh_eng::HEADER_I + b * jh_eng::BODY_I;
-    const int par = bi[0], jt = bi[1], dof = bi[2];
-    if (dof != 5 + b) return false;
-    if (b <= 7) { if (jt != jh_eng::JHINGE || par != (b == 1 ? -1 : b - 1)) return false; }
-    else if (jt != jh_eng::JSLIDE || par != 7) return false;
-  }
-  const int nag = m->h_i[gi], npair = m->h_i[gi + 1], neq = m->h_i[gi + 2], ngs = m->h_i[gi + 5];
-  if (neq > 1 || ngs > G || m->h_i[gi + 4] > 8) return false;
-  for (int s = 0; s < ngs; s++) if (m->h_i[gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3] + m->h_i[gi + 4] * 4 + s * 4] == 2) return false;  // no jointpos sensors
-  { int nt = 0; const int* di = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3]; for (int s = 0; s < m->h_i[gi + 4]; s++) nt += di[4 * s + 1] * di[4 * s + 3]; if (nt > MAXDT) return false; }
-  for (int g = 0; g < nag; g++) { const int tp = m->h_i[gi + 8 + g * jh_eng::GEOM_I + 1]; if (tp != jh_eng::GBOX && tp != jh_eng::GCAPSULE) return false; }  // boxes; capsules = arm-link stand-ins
-  for (int p = 0; p < npair; p++) {  // pairs between two articulated bodies are kept as finger-finger contacts: nothing else qualifies
-    const int* pi = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + 2 * p;
-    const int b1 = m->h_i[gi + 8 + pi[0] * jh_eng::GEOM_I], b2 = m->h_i[gi + 8 + pi[1] * jh_eng::GEOM_I];
-    if (b1 >= 1 && b2 >= 1 && !((b1 == LF && b2 == RF) || (b1 == RF && b2 == LF))) return false;
-    // a capsule is always the second geom of its pair and meets a box of the static geometry or of the free body only
-    if (m->h_i[gi + 8 + pi[0] * jh_eng::GEOM_I + 1] != jh_eng::GBOX) return false;
-    if (m->h_i[gi + 8 + pi[1] * jh_eng::GEOM_I + 1] == jh_eng::GCAPSULE && b1 >= 1) return false;
-  }
-  {  // the two finger slides must be antiparallel in the frame of their common parent: the finger-finger slots rely on it (struct SlotF)
-    float w[2][3];
-    for (int f = 0; f < 2; f++) {
-      const float* bf = m->h_f.data() + jh_eng::HEADER_F + (LF + f) * jh_eng::BODY_F;
-      for (int i = 0; i < 3; i++) w[f][i] = bf[jh_eng::BF_LR + 3 * i] * bf[jh_eng::BF_AXIS] + bf[jh_eng::BF_LR + 3 * i + 1] * bf[jh_eng::BF_AXIS + 1] + bf[jh_eng::BF_LR + 3 * i + 2] * bf[jh_eng::BF_AXIS + 2];
-    }
-    for (int i = 0; i < 3; i++) if (fabsf(w[0][i] + w[1][i]) > 1e-6f) return false;
-  }
-  if (neq == 1) { const int* ei = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2; if (ei[0] != 13 || ei[1] != 14) return false; }
-  for (int u = 0; u < NU; u++) if (m->h_i[jh_eng::HEADER_I + NMB * jh_eng::BODY_I + m->h_i[1] * jh_eng::BLOCK_I + u * jh_eng::ACT_I] != 6 + u) return false;
-  return true;
-}
-
 int jh_engine3_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
                             const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
   if (!jh_model_is_fr3(m)) { jh_set_error("rollout_cost: the cooperative arm kernel is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }

@@ -26,4 +26,7 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     torch.cuda.set_device(0)
+    from tests import xcheck
+
+    xcheck.load()  # the cross-check kernel generations (test build): `GpuModel.set_kernel(1 | 2)` works from here on
     return torch.device("cuda", 0)

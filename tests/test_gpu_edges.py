@@ -2,6 +2,8 @@
 multiple of the 4 rollouts a wave holds), a one-step horizon, the maximum knot count the kernels keep in registers / LDS (K = 8), and the
 argument errors the C ABI reports.  Oracle = the fp64 engine on the same candidates."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -130,3 +132,40 @@ def test_device_noise_is_a_function_of_the_global_rollout_index(gpu):
     assert abs(float(torch.corrcoef(torch.stack([full.flatten(), other.flatten()]))[0, 1])) < 1e-2
     with pytest.raises(ValueError):
         _lib.check(L.jh_noise_normal(seed, draw, rows, 0, 8, full.data_ptr(), 4, current_stream_ptr()), "jh_noise_normal")
+
+
+def test_product_library_ships_one_kernel_generation(gpu):
+    """The product library alone (a fresh process that never loads tests/libjudo_amd_xcheck.so) knows generation 3 only: selecting a cross-check generation is an
+    error that says where those kernels live, and the default path runs."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np\n"
+        "from judo_amd.device import GpuModel\n"
+        "from judo_amd import _lib\n"
+        "from judo_amd.rollout_backend import GpuRolloutBackend\n"
+        "for task in ('leap_cube', 'fr3_pick'):\n"
+        "    m = GpuModel(task)\n"
+        "    for gen in (1, 2):\n"
+        "        try:\n"
+        "            m.set_kernel(gen)\n"
+        "            raise SystemExit(f'{task}: generation {gen} accepted without the test build')\n"
+        "        except _lib.JudoAmdError as e:\n"
+        "            assert 'libjudo_amd_xcheck' in str(e), e\n"
+        "    m.set_kernel(3)\n"
+        "    be = GpuRolloutBackend(task, 4)\n"
+        "    from judo_amd.tasks import get_registered_tasks\n"
+        "    t = get_registered_tasks()[task][0]()\n"
+        "    s, y, _ = be.rollout(t.default_state(), np.tile(t.optimizer_warm_start(), (4, 3, 1)))\n"
+        "    assert np.isfinite(s).all()\n"
+        "print('ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+    # and nothing of the product imports the test build
+    for dirpath, _, files in os.walk(os.path.join(root, "judo_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "xcheck" not in open(os.path.join(dirpath, f)).read().replace("jh_register_xcheck", ""), f

@@ -4,6 +4,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from judo_amd.controller import make_controller
+from tests import xcheck; xcheck.load()  # kernel generations 1 / 2 live in the test build
 from judo_amd import engine_model as EM
 if os.environ.get("LSTOL"): EM.SOLVER_LS_TOL = float(os.environ["LSTOL"])
 if os.environ.get("TOL"): EM.SOLVER_TOL = float(os.environ["TOL"])

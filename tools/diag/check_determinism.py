@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd.rollout_backend import GpuRolloutBackend
+from tests import xcheck; xcheck.load()  # kernel generations 1 / 2 live in the test build
 from judo_amd.tasks import get_registered_tasks
 for task, N, H in (("leap_cube", 512, 64), ("fr3_pick", 512, 40), ("cartpole", 512, 64)):
     t = get_registered_tasks()[task][0]()

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from judo_amd.controller import make_controller
+from tests import xcheck; xcheck.load()  # kernel generations 1 / 2 live in the test build
 from oracle import oracle as O
 from tests.harness import oracle_plan_step
 np.set_printoptions(precision=5, suppress=True, linewidth=200)

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from tests.test_gpu_fr3 import _controls
 from judo_amd.rollout_backend import GpuRolloutBackend
+from tests import xcheck; xcheck.load()  # kernel generations 1 / 2 live in the test build
 from judo_amd import engine_model
 if os.environ.get('TOL'): engine_model.SOLVER_TOL = float(os.environ['TOL'])
 if os.environ.get('LSTOL'): engine_model.SOLVER_LS_TOL = float(os.environ['LSTOL'])

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from judo_amd.rollout_backend import GpuRolloutBackend
+from tests import xcheck; xcheck.load()  # kernel generations 1 / 2 live in the test build
 from judo_amd.tasks import LeapCubeDown
 from oracle import oracle as O
 t = LeapCubeDown(); om = O.Model("leap_cube_down", scope="cube")
