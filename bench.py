@@ -220,6 +220,7 @@ def main() -> None:
     ap.add_argument("--optimizer", default=None)
     ap.add_argument("--rollouts", type=int, default=None)
     ap.add_argument("--horizon-steps", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the optimizer's device noise stream (the same on every rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
     ap.add_argument("--settle", type=float, default=0.4, help="seconds of untimed plan steps on a throw-away plan before the W warm-up steps (runtime one-offs)")
@@ -272,7 +273,7 @@ def main() -> None:
     ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if args.task == "leap_cube" else {}
     if args.no_self_collision and ctrl.model is not None:
         ctrl.model.set_self_collision(False)
-    ctrl.optimizer.seed(1234)  # the same seed on every rank: each rank slices its shard out of the same noise, the plan does not depend on --gpus
+    ctrl.optimizer.seed(args.seed)  # the same seed on every rank: each rank slices its shard out of the same noise, the plan does not depend on --gpus
     is_policy = ctrl.task.uses_locomotion_policy
     if is_policy:
         ctrl.rollout_cutoff_time = None  # throughput run: no 125 ms deadline
@@ -303,7 +304,7 @@ def main() -> None:
         torch.cuda.synchronize()
     ctrl.reset()
     ctrl.current_state = ctrl.task.default_state()
-    ctrl.optimizer.seed(1234)
+    ctrl.optimizer.seed(args.seed)
     t_plan = 0.0
     for _ in range(args.warmup):
         ctrl.time = t_plan
@@ -376,7 +377,7 @@ def main() -> None:
         ctrl.model.set_self_collision(False)
         ctrl.reset()
         ctrl.current_state = ctrl.task.default_state()
-        ctrl.optimizer.seed(1234)
+        ctrl.optimizer.seed(args.seed)
         n_extra, tq = min(args.steps, 10), 0.0
         for i in range(args.warmup + n_extra):
             if i == args.warmup:
