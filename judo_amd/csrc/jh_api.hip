@@ -110,6 +110,7 @@ extern "C" int jh_model_set_self_collision(jh_model* m, int on) {
 static int max_fused_knots(const jh_model* m, int H) {
   const bool coop = m->kernel_gen >= 2 && (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK);
   int k = JH_MAX_KNOT_DIM / (m->nu > 0 ? m->nu : 1);
+  if (coop && m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen >= 3) return k;  // generation 3 reads its knots from memory every step: no on-chip staging, no limit of its own
   if (coop) return k < 8 ? k : 8;
   // the one-lane kernels stage W (H x K) and 64 lanes' knots in LDS: the launcher's 64 KiB budget bounds K as well
   const int lds_k = (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) ? jh_simple_max_knots(m, H) : (g_xcheck.max_knots ? g_xcheck.max_knots(m, H) : 0);
@@ -121,7 +122,7 @@ extern "C" int jh_model_limits(const jh_model* m, int* out) {
   out[0] = max_fused_knots(m, 1);  // upper bound over all horizons; jh_model_max_fused_knots(m, H) is the figure for a given H
   out[1] = JH_MAX_KNOT_DIM;
   out[2] = JH_MAX_ELITES;
-  out[3] = (m->kind == JH_TASK_LEAP_CUBE || m->kind == JH_TASK_FR3_PICK) ? 32 : 0;
+  out[3] = m->kind == JH_TASK_LEAP_CUBE ? (m->kernel_gen >= 3 ? 48 : 32) : (m->kind == JH_TASK_FR3_PICK ? 32 : 0);  // (fr3 generation 3: + 96 pad-against-pad slots)
   return JH_OK;
 }
 

@@ -66,8 +66,15 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_NSLOT
 #define JH_V5_NSLOT 2
 #endif
-constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane: the pool holds 16 * NSLOT contacts per rollout
-constexpr int NCP = 16 * NSLOT;  // contact pool per rollout
+#ifndef JH_V5_BIGPROB
+#define JH_V5_BIGPROB 0.999999  // how sure the compiler may be that a wave-step stays on the NSLOT copy (block frequencies steer the placement of register spills)
+#endif
+#ifndef JH_V5_NSBIG
+#define JH_V5_NSBIG 3
+#endif
+constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane of the common case: steps with at most 16 * NSLOT contacts in every rollout of the wave
+constexpr int NSBIG = JH_V5_NSBIG;  // ... of the rare case (6e-4 of the rollout-steps of the headline workload): the wave runs a second copy of the solver with this many slots
+constexpr int NCP = 16 * NSBIG;  // contact pool per rollout
 #ifndef JH_V5_MAXHIT
 #define JH_V5_MAXHIT 64
 #endif
@@ -83,11 +90,22 @@ constexpr int NDH = 22 * 23 / 2;  // dense Hessian (packed lower) of a rollout w
 constexpr int NV = 22, NQ = 23, NU = 16, NS = 31, NS_CALTECH = 23, NX = 45, NMB = 17;
 constexpr int NBC = 20;  // hand bodies of the self-collision tables: 0 = static geometry, 1..16 = finger links, 17..19 = further groups of static geometry (engine_model.py)
 __device__ __forceinline__ bool static_code(int b) { return b == 0 || b >= NMB; }
-constexpr int MAXK = 8;
+#ifndef JH_V5_KNOTS_LDS
+#define JH_V5_KNOTS_LDS 0  // 1: the round-1..3 layout (the lane's knots staged in LDS; at most JH_V5_MAXK of them)
+#endif
+#ifndef JH_V5_MAXK
+#define JH_V5_MAXK 8
+#endif
+constexpr int MAXK = JH_V5_MAXK;
 
 // per-lane model constants staged in LDS (index = lane & 15)
 enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_N = JH_V5_LCN };  // (row stride of the LDS table: odd, so that the 16 lanes' rows start in 16 different banks)
 
+#ifdef JH_V5_X_DIET  // occupancy experiments on the cube-only instantiations: the arrays only the hand's own contacts use shrink to stubs
+constexpr int RS_NBC = 1, RS_NBPL = 4, RS_NHX = 1, RS_NDH = 4;
+#else
+constexpr int RS_NBC = NBC, RS_NBPL = MAXBPL, RS_NHX = 6, RS_NDH = NDH;
+#endif
 struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float pa[NMB][JH_V5_PAS];   // body origin (0..2) and joint axis in the world (4..6); odd row stride: lanes reading 16 different bodies hit 16 different banks
   float xR[NMB][9];
@@ -97,10 +115,10 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float rhs6[6];
   union {
     struct {
-      float bs[NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
+      float bs[RS_NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
                           // bounding box's too; its half sizes and axes come from the model image and the body rotation)
       unsigned short hits[MAXHIT];
-      unsigned char bpl[MAXBPL];
+      unsigned char bpl[RS_NBPL];
     };
     // the collision arrays are dead from the constraint rows on: the step-level state the Newton loop does not touch is parked here instead of being held in
     // registers (or spilled to scratch memory by the compiler) across the loop.  The joint velocity and the cube's velocity are in qv already.
@@ -108,9 +126,9 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   };
   union {  // the contact pool is dead once every lane has loaded its slots; the Newton Hessian then reuses its storage
     float pool[NCP][POOL_F];
-    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[6][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[pidx(a,b)][ib*4+ia]: block (chain b, chain a)
+    struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[RS_NHX][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[pidx(a,b)][ib*4+ia]: block (chain b, chain a)
                                                                          // of a contact-coupled pair of chains a < b (hand self-collision)
-    struct { float Hd[NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
+    struct { float Hd[RS_NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
   };
   int ncon, nhit;
 #if JH_V5_RSPAD > 0
@@ -232,10 +250,11 @@ __device__ __forceinline__ float dof_rows_cost(const DofRows& dr) {
 }
 
 // slope and curvature of the lane's rows along the search direction at step al (line search)
+template <int NS>
 __device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr, float al, float* d1, float* d2) {
   float g1 = 0.f, g2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < NSLOT; k++) {
+  for (int k = 0; k < NS; k++) {
     if (sl[k].la < 0) continue;
     const float* jp = sl[k].jp;
     const float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
@@ -322,13 +341,23 @@ __device__ __forceinline__ bool chain_elim_order(int cmask, int c, int& level, i
 
 // ------------------------------------------------------------------------------------------------ the kernel
 template <bool MATERIALIZE, int WPB, bool SELF>
-__global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
+#ifdef JH_V5_NUM_VGPR  // (occupancy experiments: a register budget independent of what the LDS footprint allows)
+#define JH_V5_REGATTR __attribute__((amdgpu_num_vgpr(JH_V5_NUM_VGPR)))
+#else
+#define JH_V5_REGATTR
+#endif
+__global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void k_leap_v5(const float* __restrict__ gF, const int* __restrict__ gI, const float* __restrict__ x0, int x0_batched,
                                                    const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
                                                    const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                    const float* __restrict__ tp, int N, int n_offset, int H, int K, float* __restrict__ costs,
                                                    float* __restrict__ knots_out, const float* __restrict__ controls, float* __restrict__ states,
                                                    float* __restrict__ sensors, int* __restrict__ stats) {
+#ifdef JH_V5_X_DYNRS  // (occupancy experiments: the compiler does not see the per-rollout LDS, so the register budget follows JH_V5_WAVES_PER_EU alone)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dynRS[];
+  RS* sRS = reinterpret_cast<RS*>(dynRS);
+#else
   __shared__ RS sRS[RPW * WPB];
+#endif
   __shared__ float sBody[16 * JH_V5_BFS];
   __shared__ float sTp[16];
   __shared__ float sGeomF[MAXG * GEOM_F];
@@ -338,11 +367,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
   __shared__ int sBP[SELF ? 2 * MAXBP : 4];    // hand body pairs (side A, side B): every geom of A is a candidate against every geom of B
   __shared__ int sBG[SELF ? 2 * NBC : 4];    // per hand body: first collision geom, number of geoms (contiguous in the geom table)
   __shared__ float sBB[SELF ? NBC * 8 : 4];  // per hand body: bounding-box centre (body frame; static geometry: world), bounding radius, half sizes
+#if JH_V5_KNOTS_LDS
   __shared__ float sKnAll[MAXK * WAVE * WPB];
+#endif
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane >> 4;
   int l = lane & 15, c = l >> 2, s = l & 3;  // (not const: see the top of the step loop)
   RS& S = sRS[wv * RPW + r];
+#if JH_V5_KNOTS_LDS
   float* sKn = sKnAll + wv * (MAXK * WAVE);
+#endif
   const int nmI = gI[0], nblkI = gI[1], nuI = gI[4], ngI = gI[5], nsiteI = gI[6], nsI = gI[7], oRef = gI[18];
   const int oBodyF = HEADER_F, oDofF = oBodyF + nmI * BODY_F, oActF = oDofF + gI[2] * DOF_F, oGeomF = oActF + nuI * ACT_F, oSiteF = oGeomF + ngI * GEOM_F;
   const int oGeomI = HEADER_I + nmI * BODY_I + nblkI * BLOCK_I + nuI * ACT_I, oSiteI = oGeomI + ngI * GEOM_I;
@@ -387,18 +420,19 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     q = xi[7 + l]; qd = xi[NQ + 6 + l];
   }
   // ---- own actuator's spline knots (fused mode): clip(nominal + sigma*noise) -> LDS; global sample 0 keeps the nominal
+  // The knots are NOT kept on chip: 8 knots x 16 actuators are 512 B of LDS per rollout (a sixth of its state), and the step loop needs them once per step -- K
+  // L2-resident loads of the noise matrix and of the nominal, issued ahead of the kinematics (`knot_at` below); the LDS goes to the contact pool instead.
+  auto knot_at = [&](int k, int ll, int ncc) -> float {  // clip(nominal + sigma * noise) of actuator ll, knot k, rollout ncc (global sample 0 keeps the nominal)
+    const int i = k * NU + ll;
+    float v = nominal[i];
+    if (n_offset + ncc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + ncc], v);
+    return jh_clampf(v, lohi[ll], lohi[NU + ll]);
+  };
   if (!MATERIALIZE) {
-    for (int k = 0; k < MAXK; k++) {
-      float v = 0.f;
-      if (k < K) {
-        int i = k * NU + l;
-        v = nominal[i];
-        if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
-        v = jh_clampf(v, lohi[l], lohi[NU + l]);
-        if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
-      }
-      sKn[k * WAVE + lane] = v;
-    }
+#if JH_V5_KNOTS_LDS
+    for (int k = 0; k < MAXK; k++) sKn[k * WAVE + lane] = k < K ? knot_at(k, l, nc) : 0.f;
+#endif
+    if (knots_out && live) for (int k = 0; k < K; k++) knots_out[(size_t)(k * NU + l) * ldn + n] = knot_at(k, l, nc);
   }
   S.ws[6 + l] = 0.f; if (l < 6) S.ws[l] = 0.f;
   int n_iters = 0, n_maxed = 0, n_wave_iters = 0;  // (the last: iterations this wave ran -- per step the maximum over its four rollouts)
@@ -425,7 +459,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     // ================================================================ controls
     float u;
     if (MATERIALIZE) u = controls[((size_t)nc * H + hh) * NU + l];
-    else { u = 0.f; for (int k = 0; k < K && k < MAXK; k++) u = fmaf(W[hh * K + k], sKn[k * WAVE + lane], u); }
+    else {
+      u = 0.f;
+#if JH_V5_KNOTS_LDS
+      for (int k = 0; k < K && k < MAXK; k++) u = fmaf(W[hh * K + k], sKn[k * WAVE + lane], u);
+#else
+      {  // (the rollout index is recomputed from an opaque copy of the lane id: held across the step loop it would cost a register the loop does not have)
+        int lo_ = lane; OPAQUE(lo_);
+        const int n_ = (blockIdx.x * WPB + wv) * RPW + (lo_ >> 4), nc_ = n_ < N ? n_ : N - 1;
+        for (int k = 0; k < K; k++) u = fmaf(W[hh * K + k], knot_at(k, l, nc_), u);
+      }
+#endif
+    }
     // ================================================================ kinematics (each lane walks its chain up to its own link)
     float Mrow[NLK], fs_own, a0_own;
     {
@@ -720,12 +765,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     WSYNC();
     V5_TICK(2)
     // ================================================================ constraint rows: <= 2 contacts per lane + the own dof's friction-loss / limit rows
+    // The constraint rows and the Newton solver exist once per slot count: a wave in which some rollout has more than 16 * NSLOT contacts this step (jammed cube:
+    // several 4-point box-box manifolds at once) runs the copy with NSBIG slots per lane, all others the copy with NSLOT -- the third slot's 27 registers would
+    // otherwise be spilled and reloaded inside every iteration of every rollout (measured: +17 % on the headline workload for 6e-4 of its rollout-steps).
+    float a_own, ac_own; int iters_this = 0;
+    auto solve_step = [&](auto NS_) __attribute__((always_inline)) {
+    constexpr int NS = decltype(NS_)::value;
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
-    Slot sl[NSLOT];
+    Slot sl[NS];
     {
       float wv3[3]; mulMV(wv3, S.xR[0], vc + 3);  // world angular velocity of the cube
 #pragma unroll
-      for (int k = 0; k < NSLOT; k++) {
+      for (int k = 0; k < NS; k++) {
         int idx = l + 16 * k;
         sl[k].la = -1; sl[k].lb = 0;
         for (int i = 0; i < 9; i++) sl[k].fr[i] = 0.f;
@@ -762,7 +813,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     // blocks take the Schur update and which factorises at a later stage `lvl`); then the cube.  A graph with a cycle takes the dense direction.
     bool anyslot = false; int cmask = 0;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
+    for (int k = 0; k < NS; k++) {
       anyslot |= sl[k].la >= 0;
       if (SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2)) cmask |= 1 << (4 * ((sl[k].la - 1) >> 2) + ((sl[k].lb - 1) >> 2));
     }
@@ -783,21 +834,20 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
     if (l == 0) { S.pk_cq[0] = qc[3]; S.pk_cq[1] = qc[4]; S.pk_cq[2] = qc[5]; S.pk_cq[3] = qc[6]; S.pk_acc = acc; }
 #endif
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
-    float a_own, ac_own;
     const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
     const float fsc_own = mck * a0c_own;
     const float snorm = gsum(fs_own * fs_own * iMd + fsc_own * fsc_own * imck);
     const bool has_rows = gor((int)(anyslot || dr.fl > 0.f || dr.lims != 0.f)) != 0;
-    int iters_this = 0;
+    iters_this = 0;
     if (!has_rows) { a_own = a0_own; ac_own = a0c_own; }
     else {
       // ---- warm start: the better of last step's acceleration (S.ws) and the unconstrained one
       {
         const float qws = S.ws[6 + l], wsc_own = l < 6 ? S.ws[l] : 0.f;
         float xl[3] = {S.ws[0], S.ws[1], S.ws[2]}, xr[3] = {S.ws[3], S.ws[4], S.ws[5]}, wa[3]; mulMV(wa, S.xR[0], xr);
-        float cs = 0.f, jx[3], jar_ws[NSLOT][3];
+        float cs = 0.f, jx[3], jar_ws[NS][3];
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
+        for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
           slot_Jx<SELF>(sl[k], S, qc, xl, wa, S.ws, jx);
           for (int rw = 0; rw < 3; rw++) { sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; jar_ws[k][rw] = sl[k].jar[rw]; }
           cs += cone_cost(sl[k]);
@@ -816,7 +866,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float xl0[3] = {S.p[0], S.p[1], S.p[2]}, xr0[3] = {S.p[3], S.p[4], S.p[5]}; mulMV(wa, S.xR[0], xr0);
         cs = 0.f;
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
+        for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
           slot_Jx<SELF>(sl[k], S, qc, xl0, wa, S.p, jx);
           for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw];
           cs += cone_cost(sl[k]);
@@ -827,7 +877,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (cost_ws < cost_0) {
           a_own = qws; ac_own = wsc_own;
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar_ws[k][rw];
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jar_ws[k][rw];
           dr.jf = jf_ws; dr.jl = jl_ws;
         } else { a_own = a0_own; ac_own = a0c_own; }
         WSYNC();
@@ -840,7 +890,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       auto forget_slots = [&]() __attribute__((always_inline)) {
         if constexpr (OPQ > 0) {
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) {
+          for (int k = 0; k < NS; k++) {
             OPAQUE(sl[k].la); OPAQUE(sl[k].lb);
             if constexpr (OPQ > 1) { OPAQUE(sl[k].rc[0]); OPAQUE(sl[k].rc[1]); OPAQUE(sl[k].rc[2]); }
             if constexpr (OPQ > 2) { for (int q9 = 0; q9 < 9; q9++) OPAQUE(sl[k].fr[q9]); }
@@ -866,7 +916,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
         if (act) {
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) {
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
             const Slot& t = sl[k];
             float f[3], Wt[6];
             const float D[3] = {t.D0, t.D1, t.D1};
@@ -909,7 +959,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         }
         WSYNC();
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) {
+        for (int k = 0; k < NS; k++) {
           const Slot& t = sl[k];
           float Wk[6] = {0, 0, 0, 0, 0, 0};
           bool on = aact && t.la >= 0;
@@ -1116,7 +1166,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
           }
           WSYNC();
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) {
+          for (int k = 0; k < NS; k++) {
             const Slot& t = sl[k];
             if (!(dact && t.la >= 0)) continue;
             float f[3], Wk[6];
@@ -1237,13 +1287,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         {
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) slot_Jx<SELF>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<SELF>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
         for (int ls = 0; ls < JH_V5_LSMAX && __any(lsact); ls++) {
           float d1, d2;
-          lane_rows_dir(sl, dr, alpha, &d1, &d2);
+          lane_rows_dir<NS>(sl, dr, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
@@ -1260,7 +1310,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
         if (act) {
           a_own += alpha * p_own; ac_own += alpha * xcl;
 #pragma unroll
-          for (int k = 0; k < NSLOT; k++) if (sl[k].la >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] += alpha * sl[k].jp[rw];
           dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl;
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         }
@@ -1270,6 +1320,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) void k_leap_v5(cons
       if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
+    };
+    if (__builtin_expect_with_probability(NSBIG > NSLOT && __any(S.ncon > 16 * NSLOT), 0, JH_V5_BIGPROB)) solve_step(std::integral_constant<int, NSBIG>{}); else solve_step(std::integral_constant<int, NSLOT>{});
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
       S.ws[6 + l] = a_own; if (l < 6) { S.ws[l] = ac_own; S.acn[l] = ac_own; }
@@ -1339,16 +1391,23 @@ bool model_is_leap(const jh_model* m) {
 
 }  // namespace
 
+#ifdef JH_V5_X_DYNRS
+#define JH_V5_DYNBYTES (sizeof(RS) * RPW * JH_V5_WPB)
+#else
+#define JH_V5_DYNBYTES 0
+#endif
 int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
                             const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
   if (!model_is_leap(m)) { jh_set_error("rollout_cost: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
+#if JH_V5_KNOTS_LDS
   JH_REQUIRE(K <= MAXK, "rollout_cost: the cooperative leap kernel keeps at most 8 knots per actuator (K=%d)", K);
+#endif
   int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
   if (m->self_collision && m->h_i[17] > 0)
-    hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
+    hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
                        knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
   else
-    hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
+    hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
                        knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
   JH_HIP(hipGetLastError());
   return JH_OK;
@@ -1359,11 +1418,11 @@ int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, c
   if (!model_is_leap(m)) { jh_set_error("rollout_materialize: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
   int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
   if (m->self_collision && m->h_i[17] > 0)
-    hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+    hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
                        controls, states, sensors, m->d_stats);
   else
-    hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
+    hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
                        controls, states, sensors, m->d_stats);
   JH_HIP(hipGetLastError());

@@ -180,9 +180,11 @@ def test_fused_path_several_iterations_match_oracle_harness(gpu, task_name, opt_
         np.testing.assert_allclose(ctrl.traces, exp, rtol=0, atol=5e-3)
 
 
-def test_knot_count_above_the_fused_kernels_registers_takes_the_materialise_path(gpu):
-    """A live `num_nodes` edit to 10 on leap_cube (the cooperative kernel holds 8 knots per actuator in registers) must not kill the control
-    loop: the plan step goes through spline -> rollout arrays -> reward kernels instead and still matches the oracle."""
+@pytest.mark.parametrize("task,opt,fused,cap", [("leap_cube", "mppi", True, 32), ("fr3_pick", "mppi", False, 8)])
+def test_knot_count_of_ten_fused_where_the_kernel_allows_it_materialised_where_not(gpu, task, opt, fused, cap):
+    """A live `num_nodes` edit to 10 must not kill the control loop.  The leap kernel (generation 3) reads its knots from memory and takes any K up to
+    JH_MAX_KNOT_DIM / nu in the fused path; the fr3 kernel keeps 8 knots per actuator on chip: there the plan step goes through spline -> rollout arrays ->
+    reward kernels instead.  Either way it matches the oracle."""
     import torch
 
     from judo_amd.controller import make_controller
@@ -190,17 +192,18 @@ def test_knot_count_above_the_fused_kernels_registers_takes_the_materialise_path
     from tests.harness import oracle_plan_step
 
     rng = np.random.default_rng(8)
-    ctrl = make_controller("leap_cube", "mppi")
+    ctrl = make_controller(task, opt)
     ctrl.optimizer.config.num_rollouts = 48
     ctrl.controller_cfg.horizon = 0.2
     ctrl.reset()
     ctrl.current_state = ctrl.task.default_state()
-    ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])}
+    ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
     ctrl.update_action()
     assert ctrl.uses_fused_cost
+    nu = ctrl.task.nu
     ctrl.optimizer.config.num_nodes = 10
-    assert not ctrl.uses_fused_cost and ctrl.model.max_fused_knots == 8
-    noise = rng.standard_normal((47, 10, 16)).astype(np.float32)
+    assert ctrl.uses_fused_cost == fused and ctrl.model.max_fused_knots == cap
+    noise = rng.standard_normal((47, 10, nu)).astype(np.float32)
     ctrl.optimizer.injected_noise = noise
     ctrl.keep_candidates = True
     ctrl.time = 0.05
@@ -209,13 +212,13 @@ def test_knot_count_above_the_fused_kernels_registers_takes_the_materialise_path
     shifted = evaluate(ctrl.spline_order, ctrl.times, ctrl.nominal_knots, ctrl.time + ctrl.spline_timesteps)
     ctrl.update_action()
     torch.cuda.synchronize()
-    ref = oracle_plan_step(O.Model("leap_cube"), ctrl, shifted, noise, "mppi")
+    ref = oracle_plan_step(O.Model(task), ctrl, shifted, noise, opt)
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
     np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
     d = np.abs(ctrl.rewards - ref["rewards"])
     assert np.median(d) < 1e-5 and np.percentile(d, 95) < 2e-3
-    assert ctrl.nominal_knots.shape == (10, 16) and np.isfinite(ctrl.nominal_knots).all()
-    ctrl.optimizer.config.num_nodes = 40  # 640 knot values: above JH_MAX_KNOT_DIM, refused before anything is launched
+    assert ctrl.nominal_knots.shape == (10, nu) and np.isfinite(ctrl.nominal_knots).all()
+    ctrl.optimizer.config.num_nodes = 520 // nu + 1  # above JH_MAX_KNOT_DIM (K * nu <= 512): refused before anything is launched
     with pytest.raises(ValueError):
         ctrl.update_action()
 

@@ -56,14 +56,15 @@ def test_small_and_ragged_plan_steps_match_oracle(gpu, task, opt, N, H, K):
 
 
 def test_engine_kernels_reject_more_knots_than_they_hold(gpu):
-    """The C entry point refuses K > 8 on the cooperative kernels (a lane's knots live in 8 registers); the controller routes such a plan step through
-    the materialise path instead (tests/test_gpu_controller.py), so a live num_nodes edit never raises in the control loop."""
+    """The C entry point refuses K > 8 on the cooperative fr3 kernel (a lane's knots are staged on chip, 8 of them); the controller routes such a plan step
+    through the materialise path instead (tests/test_gpu_controller.py), so a live num_nodes edit never raises in the control loop.  The leap kernel reads its
+    knots from memory: 9 knots are a fused plan step there."""
     import torch
 
     from judo_amd import _lib
     from judo_amd.controller import make_controller
 
-    for task in ("leap_cube", "fr3_pick"):
+    for task, fused in (("leap_cube", True), ("fr3_pick", False)):
         ctrl = make_controller(task, "mppi")
         ctrl.optimizer.config.num_rollouts = 8
         ctrl.optimizer.config.num_nodes = 9
@@ -71,15 +72,18 @@ def test_engine_kernels_reject_more_knots_than_they_hold(gpu):
         ctrl.reset()
         ctrl.current_state = ctrl.task.default_state()
         ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
-        assert not ctrl.uses_fused_cost
+        assert ctrl.uses_fused_cost == fused
         ctrl.update_action()
         assert np.isfinite(ctrl.nominal_knots).all() and ctrl.nominal_knots.shape == (9, ctrl.nu)
         K, nu, N, H = 9, ctrl.nu, 8, 8
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device="cuda")  # noqa: E731
         st = _lib.lib().jh_rollout_cost(ctrl.model.handle, _lib.ptr(z(ctrl.task.nq + ctrl.task.nv)), _lib.ptr(z(K * nu)), _lib.ptr(z(K * nu * N)), N, _lib.ptr(z(K * nu)),
                                         _lib.ptr(z(H * K)), _lib.ptr(z(2 * nu)), _lib.ptr(z(32)), 0, N, 0, H, K, _lib.ptr(z(N)), None, 0)
-        with pytest.raises(ValueError, match="at most 8 knots"):
+        if fused:
             _lib.check(st, "jh_rollout_cost")
+        else:
+            with pytest.raises(ValueError, match="at most 8 knots"):
+                _lib.check(st, "jh_rollout_cost")
 
 
 @pytest.mark.parametrize("task,N,H", [("leap_cube", 130, 48), ("fr3_pick", 130, 40), ("cylinder_push", 200, 64)])

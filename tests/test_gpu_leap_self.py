@@ -29,6 +29,9 @@ def _tangled_states(N, seed, frac=0.6, task="leap_cube"):
     return om, xs, q
 
 
+POOL = 48  # contacts per rollout the leap kernel (generation 3) holds: jh_model_limits out[3]
+
+
 def _contact_kinds(om, x, u):
     """(cube contacts, hand contacts within one finger chain or against the palm, contacts between two finger chains) in the oracle's forward pass."""
     f = om.forward(x[:23], x[23:], u)
@@ -82,10 +85,10 @@ def test_self_collision_single_steps_match_oracle(gpu):
     # coupling graphs with a cycle (the thumb and two fingers all touching each other) are rare even here: pick them out of a larger draw
     _, xs2, q2 = _tangled_states(12000, seed=6, frac=0.7)
     kinds2 = np.array([_contact_kinds(om, xs2[i], q2[i]) for i in range(len(xs2))])
-    cyc = (kinds2[:, 3] == 2) & (kinds2[:, :3].sum(1) <= 32)
+    cyc = (kinds2[:, 3] == 2) & (kinds2[:, :3].sum(1) <= POOL)
     xs, q, kinds = np.concatenate([xs, xs2[cyc]]), np.concatenate([q, q2[cyc]]), np.concatenate([kinds, kinds2[cyc]])
     us = q[:, None, :]
-    ok = kinds[:, :3].sum(1) <= 32  # within the kernel's contact capacity per rollout
+    ok = kinds[:, :3].sum(1) <= POOL  # within the kernel's contact capacity per rollout
     within, across = ok & (kinds[:, 1] > 0) & (kinds[:, 2] == 0), ok & (kinds[:, 2] > 0)
     paired, forest, tangled = across & (kinds[:, 3] == 0), across & (kinds[:, 3] == 1), across & (kinds[:, 3] == 2)
     assert within.sum() > 10 and paired.sum() > 50 and forest.sum() > 20 and tangled.sum() > 20, (within.sum(), paired.sum(), forest.sum(), tangled.sum())
@@ -157,7 +160,7 @@ def test_caltech_self_collision_single_steps_match_oracle(gpu):
     ok = np.ones(len(xs), dtype=bool)
     for i in range(len(xs)):
         f = om.forward(xs[i, :23], xs[i, 23:], q[i])
-        ok[i] = f["ncon"] <= 32
+        ok[i] = f["ncon"] <= POOL
         for row in f["contacts"]:
             ba, bb = body[int(row[13])], body[int(row[14])]
             n_static += (ba in static) != (bb in static)
@@ -187,8 +190,10 @@ def test_random_states_with_the_cube_jammed_into_the_hand(gpu):
     xs[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
     xs[:, 23:29] = rng.standard_normal((N, 6)) * np.array([0.2, 0.2, 0.2, 2, 2, 2])
     kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(N)])
-    ok = kinds[:, :3].sum(1) <= 32  # within the kernel's contact pool
-    assert ok.sum() > 800 and (ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)).sum() > 80
+    ncon = kinds[:, :3].sum(1)
+    ok = ncon <= POOL  # within the kernel's contact pool
+    big = ok & (ncon > 32)  # ... through the solver copy with three slots per lane (a wave takes it when one of its rollouts has more than 32 contacts)
+    assert ok.mean() > 0.9 and big.sum() > 100 and (ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)).sum() > 80, (ok.mean(), big.sum())
     U = q[:, None, :]
     ref, _ = om.rollout(xs, U)
     be = GpuRolloutBackend("leap_cube", N)
@@ -196,6 +201,7 @@ def test_random_states_with_the_cube_jammed_into_the_hand(gpu):
     assert np.isfinite(g).all()
     scale = np.maximum(1.0, np.abs(ref[:, 0, 23:]).max(axis=1, keepdims=True))
     ev = (np.abs(g[:, 0] - ref[:, 0])[:, 23:] / scale).max(1)
-    for name, sel in (("cube only", ok & (kinds[:, 0] > 0) & (kinds[:, 1] + kinds[:, 2] == 0)), ("cube and coupled chains", ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)), ("all", ok)):
+    for name, sel in (("cube only", ok & (kinds[:, 0] > 0) & (kinds[:, 1] + kinds[:, 2] == 0)), ("cube and coupled chains", ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)),
+                      ("33 to 48 contacts", big), ("all", ok)):
         assert np.median(ev[sel]) < 5e-6 and np.percentile(ev[sel], 95) < 1e-4 and ev[sel].max() < 5e-2, (name, np.median(ev[sel]), np.percentile(ev[sel], 95), ev[sel].max())
     assert be.model.stats()["newton_cap_hits"] == 0
