@@ -87,6 +87,10 @@ int jh_register_xcheck(const jh_xcheck_launchers* launchers);
  * with on = 0, the cube's contacts alone (what generations 1 and 2 model). */
 int jh_model_set_self_collision(jh_model* m, int on);
 
+/* Small launches (latency mode): when N rollouts would leave SIMDs idle, the cooperative kernels (leap_cube, fr3_pick: four rows of 16 lanes per wave; Spot tree: two
+ * rows of 32) let 4 or 2 rows of a wave compute the same rollout -- identical arithmetic, the first row writes -- so that a wave does not wait for the slowest of
+ * its different rollouts' Newton solves in every step.  Results are bit-identical to the full mapping.  Chosen per launch from N and the CU count; the environment
+ * variable JUDO_AMD_LATENCY_SHIFT=0 switches it off (1 / 2: force two / four copies). */
 /* Limits of this model's kernels: out[0] = largest knot count K the fused kernel (jh_rollout_cost) accepts -- the cooperative fr3_pick kernel
  * keeps a lane's knots on chip (8 of them); the leap_cube kernel of generation 3 reads them from memory every step and is bounded by
  * JH_MAX_KNOT_DIM / nu alone.  A larger K goes through jh_spline_controls + jh_rollout_materialize + jh_task_reward, which have no such limit;

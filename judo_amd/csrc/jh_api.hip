@@ -1,4 +1,5 @@
 // jh_api.hip -- C-ABI entry points of libjudo_amd.so (argument checks, model handles, dispatch).
+#include <cstdlib>
 #include <cstring>
 
 #include "jh_internal.h"
@@ -105,6 +106,17 @@ extern "C" int jh_model_set_self_collision(jh_model* m, int on) {
   JH_REQUIRE(m != nullptr, "model_set_self_collision: null pointer");
   m->self_collision = on ? 1 : 0;
   return JH_OK;
+}
+
+int jh_latency_shift(int N, int rpw) {
+  static int cus = 0;
+  if (cus == 0) { int dev = 0, v = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+  int most = 0; while ((2 << most) <= rpw) most++;
+  const char* e = getenv("JUDO_AMD_LATENCY_SHIFT");  // diagnostic override: 0 = every row its own rollout, always
+  if (e && e[0] >= '0' && e[0] <= '2') return (e[0] - '0') < most ? (e[0] - '0') : most;
+  const long alone = (long)cus * 4;  // waves that each have a SIMD to themselves: a second wave on a SIMD takes from the first what the copies would gain
+  for (int sh = most; sh > 0; sh--) if (((long)N << sh) <= alone * rpw) return sh;
+  return 0;
 }
 
 static int max_fused_knots(const jh_model* m, int H) {

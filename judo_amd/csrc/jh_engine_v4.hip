@@ -315,7 +315,7 @@ __device__ __forceinline__ float dot_row(const float* Mrow, const float* v) {
 
 __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI, const float* state_in, int ld_in,
                                                     const float* __restrict__ ctrl, float* __restrict__ warm, int N, int substeps, float* state_out, int ld_out,
-                                                    float* __restrict__ sensors_out, int ld_sens, int* __restrict__ stats) {
+                                                    float* __restrict__ sensors_out, int ld_sens, int* __restrict__ stats, int dshift) {
   __shared__ RS4 sRS[RPW];
   __shared__ __attribute__((aligned(16))) float sF[SF_MAX];  // the model image, shared by the rollouts of the wave
   __shared__ int sI[SI_MAX];
@@ -324,9 +324,10 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
   for (int i = lane; i < nF && i < SF_MAX; i += WAVE) sF[i] = gF[i];  // (the sensor records at the end of the image are read from global memory, once per launch)
   for (int i = lane; i < nI && i < SI_MAX; i += WAVE) sI[i] = gI[i];
   __syncthreads();
-  const int n = blockIdx.x * RPW + r;
-  const bool live = n < N;
-  const int nc = live ? n : N - 1;
+  // (latency mode, jh_internal.h: with dshift = 1 both rows of the wave compute the same rollout and the first writes -- the shipped 24-rollout plans)
+  const int n = (blockIdx.x << (1 - dshift)) + (r >> dshift);
+  const bool live = n < N && (r & ((1 << dshift) - 1)) == 0;
+  const int nc = n < N ? n : N - 1;
   const int nj = NJ, ng = sI[1];
   const bool isbase = l < 6, isjoint = l >= 6 && l < 6 + nj, hasdof = isbase || isjoint, isbody = l == 0 || isjoint;
   const int k = isjoint ? l - 6 : 0;                   // own joint
@@ -885,8 +886,9 @@ extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const f
                                 void* stream) {
   JH_REQUIRE(t && state_in && ctrl && state_out, "tree_substeps: null pointer");
   JH_REQUIRE(N > 0 && substeps > 0, "tree_substeps: need at least one rollout and one step");
-  hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
-                     sensors_out, t->ns, t->d_stats);
+  const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
+  hipLaunchKernelGGL(k_tree_v4, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
+                     sensors_out, t->ns, t->d_stats, dshift);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -927,8 +929,9 @@ extern "C" int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0
     const int rc = jh_policy_step_strided(p, xin, ld, NQ, 0, 0, 7, 6, commands + (size_t)i * 25, T * 25, policy_out, control, scratch, N, st);
     if (rc != JH_OK) return rc;
     if (reset_warmstart) JH_HIP(hipMemsetAsync(warmstart, 0, (size_t)N * NVT * sizeof(float), st));
-    hipLaunchKernelGGL(k_tree_v4, dim3((N + RPW - 1) / RPW), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
-                       sensors ? sensors + (size_t)i * t->ns : nullptr, T * t->ns, t->d_stats);
+    const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
+    hipLaunchKernelGGL(k_tree_v4, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
+                       sensors ? sensors + (size_t)i * t->ns : nullptr, T * t->ns, t->d_stats, dshift);
     if (deadline) JH_HIP(hipEventRecord(t->events[i + 1], st));
   }
   JH_HIP(hipGetLastError());

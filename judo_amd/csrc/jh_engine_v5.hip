@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                                                    const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                    const float* __restrict__ tp, int N, int n_offset, int H, int K, float* __restrict__ costs,
                                                    float* __restrict__ knots_out, const float* __restrict__ controls, float* __restrict__ states,
-                                                   float* __restrict__ sensors, int* __restrict__ stats) {
+                                                   float* __restrict__ sensors, int* __restrict__ stats, int dshift) {
 #ifdef JH_V5_X_DYNRS  // (occupancy experiments: the compiler does not see the per-rollout LDS, so the register budget follows JH_V5_WAVES_PER_EU alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char dynRS[];
   RS* sRS = reinterpret_cast<RS*>(dynRS);
@@ -400,9 +400,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     lc[LC_KP] = af[AF_KP]; lc[LC_KV] = af[AF_KV]; lc[LC_CLIM] = af[AF_CLIM]; lc[LC_CLO] = af[AF_CLO]; lc[LC_CHI] = af[AF_CHI];
   }
   const float* lc = sLane + l * LC_N;
-  const int n = (blockIdx.x * WPB + wv) * RPW + r;  // rollout handled by this row of 16 lanes
-  const bool live = n < N;
-  const int nc = live ? n : N - 1;
+  // Rollout handled by this row of 16 lanes.  A launch too small to fill the GPU (`dshift` > 0, chosen by the launcher) gives a wave 4 >> dshift rollouts instead of four and
+  // lets 1 << dshift rows compute the same one: the copies run the same arithmetic (a rollout's result does not depend on its wave-mates), only the first writes, and the
+  // wave no longer waits for the slowest of four different Newton solves in every step -- the latency mode of small shards and of the reference's 32-rollout configurations.
+  const int n = ((blockIdx.x * WPB + wv) << (2 - dshift)) + (r >> dshift);
+  const bool live = n < N && (r & ((1 << dshift) - 1)) == 0;
+  const int nc = n < N ? n : N - 1;
   const float h = gF[HF_DT], impratio = gF[HF_IMPRATIO], tol = gF[HF_TOL], lstol = gF[HF_LSTOL]; const int cap = (int)gF[HF_MAXITER];
   const float grav[3] = {gF[HF_GRAV], gF[HF_GRAV + 1], gF[HF_GRAV + 2]};
   const float cmass = gF[HF_CMASS], cI[3] = {gF[HF_CINERTIA], gF[HF_CINERTIA + 1], gF[HF_CINERTIA + 2]};
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #else
       {  // (the rollout index is recomputed from an opaque copy of the lane id: held across the step loop it would cost a register the loop does not have)
         int lo_ = lane; OPAQUE(lo_);
-        const int n_ = (blockIdx.x * WPB + wv) * RPW + (lo_ >> 4), nc_ = n_ < N ? n_ : N - 1;
+        const int n_ = ((blockIdx.x * WPB + wv) << (2 - dshift)) + ((lo_ >> 4) >> dshift), nc_ = n_ < N ? n_ : N - 1;
         for (int k = 0; k < K; k++) u = fmaf(W[hh * K + k], knot_at(k, l, nc_), u);
       }
 #endif
@@ -1402,13 +1405,14 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
 #if JH_V5_KNOTS_LDS
   JH_REQUIRE(K <= MAXK, "rollout_cost: the cooperative leap kernel keeps at most 8 knots per actuator (K=%d)", K);
 #endif
-  int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
+  const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;
+  int grid = (N + per_block - 1) / per_block;
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift);
   else
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -1416,15 +1420,16 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
 int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st) {
   if (!model_is_leap(m)) { jh_set_error("rollout_materialize: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
-  int grid = (N + RPW * JH_V5_WPB - 1) / (RPW * JH_V5_WPB);
+  const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;
+  int grid = (N + per_block - 1) / per_block;
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
-                       controls, states, sensors, m->d_stats);
+                       controls, states, sensors, m->d_stats, dshift);
   else
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
-                       controls, states, sensors, m->d_stats);
+                       controls, states, sensors, m->d_stats, dshift);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
                                                     const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                     const float* __restrict__ tp, int phase, int N, int n_offset, int H, int K,
                                                     float* __restrict__ costs, float* __restrict__ knots_out, const float* __restrict__ controls,
-                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats) {
+                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats, int dshift) {
   __shared__ RS6 sRS[RPW];
   __shared__ int sDT[MAXDT][3];  // distance-sensor tasks: sensordata address, geom a, geom b
   __shared__ int sNDT, sDadr[8];
@@ -322,9 +322,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
   const bool isarm = l >= 6 && l < 15, iscube = l < 6, hasdof = l < 15;
   const int ai = isarm ? l - 6 : 0;        // arm dof index 0..8 (7, 8 = finger slides)
   const bool isfinger = isarm && ai >= NCHAIN;
-  const int n = blockIdx.x * RPW + r;
-  const bool live = n < N;
-  const int nc = live ? n : N - 1;
+  // (latency mode, jh_internal.h: 1 << dshift rows of the wave compute the same rollout, the first of them writes)
+  const int n = (blockIdx.x << (2 - dshift)) + (r >> dshift);
+  const bool live = n < N && (r & ((1 << dshift) - 1)) == 0;
+  const int nc = n < N ? n : N - 1;
   if (lane == 0) {  // flatten the distance sensors into (address, geom, geom) tasks
     int nt = 0;
     for (int s = 0; s < m.NGS; s++) {
@@ -1097,9 +1098,10 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
                             const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
   if (!jh_model_is_fr3(m)) { jh_set_error("rollout_cost: the cooperative arm kernel (matrix-free generation) is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }
   JH_REQUIRE(K <= 8, "rollout_cost: the cooperative arm kernel keeps at most 8 knots per actuator in registers (K=%d)", K);
-  int grid = (N + RPW - 1) / RPW;
+  const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
+  int grid = (N + per_wave - 1) / per_wave;
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
-                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats);
+                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -1107,10 +1109,11 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
 int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st) {
   if (!jh_model_is_fr3(m)) { jh_set_error("rollout_materialize: the cooperative arm kernel is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }
-  int grid = (N + RPW - 1) / RPW;
+  const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
+  int grid = (N + per_wave - 1) / per_wave;
   hipLaunchKernelGGL(k_fr3_v6<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
-                     (float*)nullptr, controls, states, sensors, m->d_stats);
+                     (float*)nullptr, controls, states, sensors, m->d_stats, dshift);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

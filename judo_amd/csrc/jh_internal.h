@@ -68,6 +68,10 @@ enum {
 int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                            const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
                            float* knots_out, hipStream_t st);
+// Latency mode of the cooperative kernels (rows of `lanes` lanes, `rpw` rows per wave): a launch too small to give every SIMD a wave lets 1 << shift rows of a wave
+// compute the same rollout -- the copies run the same arithmetic, only the first writes -- so that a wave no longer waits for the slowest of `rpw` different Newton
+// solves in every step.  Returns the largest shift (<= log2 rpw) that still leaves every wave of the launch a SIMD of its own; JUDO_AMD_LATENCY_SHIFT=0..2 overrides.
+int jh_latency_shift(int N, int rpw);
 int jh_simple_max_knots(const jh_model* m, int H);  // largest fused K at horizon H (LDS staging budget of the launcher)
 int jh_engine_max_knots(const jh_model* m, int H);
 int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
