@@ -108,6 +108,34 @@ def test_rollouts_are_bit_reproducible_and_independent_of_their_wave_position(gp
         assert torch.equal(s2[sh:], s0[:-sh]) and torch.equal(y2[sh:], y0[:-sh])
 
 
+@pytest.mark.parametrize("task,N,H", [("leap_cube", 37, 48), ("fr3_pick", 37, 40)])
+def test_latency_mode_of_small_launches_changes_no_bit(gpu, task, N, H, monkeypatch):
+    """A launch that would leave SIMDs idle lets four (or two) rows of a wave compute the same rollout so that the wave does not wait for the slowest of four different
+    Newton solves (include/judo_amd.h, jh_latency_shift): same arithmetic, the first row writes -- the results are the bits of the one-rollout-per-row mapping."""
+    import torch
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.tasks import get_registered_tasks
+
+    t = get_registered_tasks()[task][0]()
+    x0 = torch.as_tensor(np.asarray(t.default_state(), dtype=np.float32)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    U = (0.3 * torch.randn((N, H, t.nu), device="cuda", generator=g) + torch.as_tensor(np.asarray(t.optimizer_warm_start(), dtype=np.float32)).cuda()).contiguous()
+    be = GpuRolloutBackend(task, N)
+    out = {}
+    for mode in ("0", "1", "2", None):  # one rollout per row; two copies; four copies; the launcher's own choice (four at this size)
+        if mode is None:
+            monkeypatch.delenv("JUDO_AMD_LATENCY_SHIFT", raising=False)
+        else:
+            monkeypatch.setenv("JUDO_AMD_LATENCY_SHIFT", mode)
+        be.model.stats()
+        s, y = be.rollout_device(x0, U)
+        out[mode] = (s.clone(), y.clone(), be.model.stats())
+    for mode in ("1", "2", None):
+        assert torch.equal(out[mode][0], out["0"][0]) and torch.equal(out[mode][1], out["0"][1])
+        # the copies are not counted: the solver statistics describe N rollouts, not N x copies
+        assert out[mode][2]["steps"] == out["0"][2]["steps"] == N * H and out[mode][2]["newton_iters"] == out["0"][2]["newton_iters"]
+
+
 def test_device_noise_is_a_function_of_the_global_rollout_index(gpu):
     """jh_noise_normal (the optimizers' noise: Philox4x32-10 + Box-Muller, include/judo_amd.h): against the oracle's restatement, and shard by shard -- any
     column range, aligned to the generator's blocks of four or not, into a buffer with any row stride, is bit-identical to those columns of the full draw.

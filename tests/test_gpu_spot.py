@@ -149,6 +149,23 @@ def test_policy_rollout_is_reproducible_and_batch_independent(spot):
     c, _, _ = be.rollout(X[perm], cmds[perm], np.zeros((N, 12)))
     assert np.array_equal(c, a[perm])
     assert torch.cuda.is_available()
+    # latency mode (both rows of a wave on the same rollout at small N): the same bits as one rollout per row
+    import os
+    n = 24
+    be2 = PolicyRolloutBackend(n)
+    prev = os.environ.get("JUDO_AMD_LATENCY_SHIFT")
+    try:
+        os.environ["JUDO_AMD_LATENCY_SHIFT"] = "0"
+        d0, _, _ = be2.rollout(X[:n], cmds[:n], np.zeros((n, 12)))
+        os.environ.pop("JUDO_AMD_LATENCY_SHIFT")
+        be2.update(n)
+        d1, _, _ = be2.rollout(X[:n], cmds[:n], np.zeros((n, 12)))
+    finally:
+        if prev is not None:
+            os.environ["JUDO_AMD_LATENCY_SHIFT"] = prev
+        else:
+            os.environ.pop("JUDO_AMD_LATENCY_SHIFT", None)
+    assert np.array_equal(d0, d1) and np.array_equal(d0, a[:n])
 
 
 def test_spot_navigate_controller_plans_through_the_policy_rollout(spot):
