@@ -404,13 +404,14 @@ def main() -> None:
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
     # measurement of this exact launch (profiles/, separate --pmc passes) is reported when the workload matches.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, issue = None, None, None
     tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     self_on = bool(ctrl.model is not None and ctrl.model.self_collision)
     if world == 1 and (N, H) == WORKLOADS[args.task][1:] and os.path.exists(tfile):
         t = json.load(open(tfile)).get(args.task if self_on or args.task != "leap_cube" else "leap_cube_cube_only")
         if t:
             traffic, traffic_src = t["hbm_bytes_per_launch"], f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            issue = t.get("issue")  # the bound that does apply: VALU issue slots of the same profiled launches (SQ_INSTS_VALU against SQ_BUSY_CYCLES)
 
     if rank == 0:
         ms = np.array(per_step) * 1e3
@@ -442,6 +443,8 @@ def main() -> None:
                          "traffic_source": traffic_src,
                          "note": "latency/VALU-issue-bound by construction (H serial physics steps, ~1e5 flop per step against a few hundred algorithmic bytes per rollout); see DESIGN.md section 6"},
         }
+        if issue:
+            line["roofline"]["issue"] = dict(issue, source=f"profiles/{TRAFFIC_FILE}: the committed profile of this workload, not this run")
         line["per_rank"] = per_rank
         if with_traces:
             line["plan_step_ms_with_traces"] = with_traces

@@ -596,6 +596,200 @@ static int collide_plane_box(const double* pp, const double* Rp, const double* p
   return cnt;
 }
 
+/* ---- general convex pair (MuJoCo's mjc_Convex: every pair without a primitive routine -- box-cylinder, cylinder-cylinder, capsule-cylinder -- goes through its
+ * convex collider, since 3.2 the native GJK + EPA pair, `engine_collision_convex.c` / `engine_collision_gjk.c` of the pinned 3.5.0; neither file is in the reference
+ * repository).  Restated from the published algorithms: GJK on the Minkowski difference A - B decides overlap and leaves a tetrahedron around the origin, EPA expands it
+ * until the face closest to the origin is a supporting plane of A - B within `CCD_TOL` -- that face's normal is the direction of least penetration, its distance the depth.
+ * One contact (multiccd is off in every shipped model): normal from A to B, position midway between the two witness points.  Separated shapes give no contact (the
+ * shipped geoms carry margin 0).  Support mappings: box, sphere, capsule, cylinder (size = radius, half length along local z). */
+#define CCD_TOL 1e-10
+#define CCD_MAXV 96
+#define CCD_MAXF 192
+typedef struct { int type; const double *size, *pos, *R; } cshape;
+typedef struct { double w[3], a[3], b[3]; } cvert; /* w = a - b */
+static void shape_support(const cshape* s, const double* d, double* out) {
+  copy3(out, s->pos);
+  double ax[3];
+  switch (s->type) {
+    case JO_GEOM_SPHERE: { double l = norm3(d); if (l > 0) addscl3(out, d, s->size[0] / l); } break;
+    case JO_GEOM_BOX: for (int k = 0; k < 3; k++) { col(ax, s->R, k); addscl3(out, ax, dot3(d, ax) >= 0 ? s->size[k] : -s->size[k]); } break;
+    case JO_GEOM_CAPSULE: { col(ax, s->R, 2); addscl3(out, ax, dot3(d, ax) >= 0 ? s->size[1] : -s->size[1]); double l = norm3(d); if (l > 0) addscl3(out, d, s->size[0] / l); } break;
+    case JO_GEOM_CYLINDER: {
+      col(ax, s->R, 2); double da = dot3(d, ax);
+      addscl3(out, ax, da >= 0 ? s->size[1] : -s->size[1]);
+      double r[3] = {d[0] - da * ax[0], d[1] - da * ax[1], d[2] - da * ax[2]}; double l = norm3(r);
+      if (l > 1e-14 * (fabs(da) + l)) addscl3(out, r, s->size[0] / l);
+    } break;
+    default: break;
+  }
+}
+static void ccd_support(const cshape* A, const cshape* B, const double* d, cvert* v) {
+  double nd[3] = {-d[0], -d[1], -d[2]};
+  shape_support(A, d, v->a); shape_support(B, nd, v->b);
+  for (int k = 0; k < 3; k++) v->w[k] = v->a[k] - v->b[k];
+}
+/* GJK, overlap only: returns 1 with four vertices around the origin in sx[0..3], 0 when a separating direction was found */
+static int ccd_gjk(const cshape* A, const cshape* B, cvert* sx) {
+  double d[3] = {B->pos[0] - A->pos[0], B->pos[1] - A->pos[1], B->pos[2] - A->pos[2]};
+  if (norm3(d) < 1e-12) { d[0] = 1; d[1] = 0; d[2] = 0; }
+  int n = 0;
+  ccd_support(A, B, d, &sx[n++]);
+  d[0] = -sx[0].w[0]; d[1] = -sx[0].w[1]; d[2] = -sx[0].w[2];
+  for (int it = 0; it < 128; it++) {
+    if (norm3(d) < 1e-14) { /* the origin lies on the current simplex: touching or degenerate -- take any direction that grows the simplex */
+      double e[3] = {1, 0, 0}; if (n >= 2) { double ab[3] = {sx[1].w[0] - sx[0].w[0], sx[1].w[1] - sx[0].w[1], sx[1].w[2] - sx[0].w[2]}; double t[3] = {0, 1, 0}; cross3(e, ab, t); if (norm3(e) < 1e-12) { t[0] = 0; t[1] = 0; t[2] = 1; cross3(e, ab, t); } }
+      copy3(d, e);
+    }
+    cvert nv; ccd_support(A, B, d, &nv);
+    if (dot3(nv.w, d) < 0) return 0; /* the new support point did not pass the origin: separated */
+    /* newest vertex first */
+    for (int i = n; i > 0; i--) sx[i] = sx[i - 1];
+    sx[0] = nv; n++;
+    const double *a = sx[0].w, *b = sx[1].w;
+    double ao[3] = {-a[0], -a[1], -a[2]}, ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    if (n == 2) {
+      if (dot3(ab, ao) > 0) { double t[3]; cross3(t, ab, ao); cross3(d, t, ab); } else { n = 1; copy3(d, ao); }
+    } else if (n == 3) {
+      const double* c = sx[2].w; double ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, abc[3], t[3];
+      cross3(abc, ab, ac);
+      cross3(t, abc, ac);
+      if (dot3(t, ao) > 0) {
+        if (dot3(ac, ao) > 0) { sx[1] = sx[2]; n = 2; double u[3]; cross3(u, ac, ao); cross3(d, u, ac); }
+        else if (dot3(ab, ao) > 0) { n = 2; double u[3]; cross3(u, ab, ao); cross3(d, u, ab); }
+        else { n = 1; copy3(d, ao); }
+      } else {
+        cross3(t, ab, abc);
+        if (dot3(t, ao) > 0) {
+          if (dot3(ab, ao) > 0) { n = 2; double u[3]; cross3(u, ab, ao); cross3(d, u, ab); } else { n = 1; copy3(d, ao); }
+        } else if (dot3(abc, ao) > 0) copy3(d, abc);
+        else { cvert tmp = sx[1]; sx[1] = sx[2]; sx[2] = tmp; d[0] = -abc[0]; d[1] = -abc[1]; d[2] = -abc[2]; }
+      }
+    } else { /* tetrahedron a (new), b, c, dd: which face, if any, sees the origin */
+      const double *c = sx[2].w, *dd = sx[3].w;
+      double ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, ad[3] = {dd[0] - a[0], dd[1] - a[1], dd[2] - a[2]}, abc[3], acd[3], adb[3];
+      cross3(abc, ab, ac); cross3(acd, ac, ad); cross3(adb, ad, ab);
+      /* orient the three faces through `a` away from the opposite vertex */
+      if (dot3(abc, ad) > 0) { abc[0] = -abc[0]; abc[1] = -abc[1]; abc[2] = -abc[2]; }
+      if (dot3(acd, ab) > 0) { acd[0] = -acd[0]; acd[1] = -acd[1]; acd[2] = -acd[2]; }
+      if (dot3(adb, ac) > 0) { adb[0] = -adb[0]; adb[1] = -adb[1]; adb[2] = -adb[2]; }
+      if (dot3(abc, ao) > 0) { n = 3; copy3(d, abc); }                                   /* keep a, b, c */
+      else if (dot3(acd, ao) > 0) { sx[1] = sx[2]; sx[2] = sx[3]; n = 3; copy3(d, acd); } /* keep a, c, d */
+      else if (dot3(adb, ao) > 0) { sx[2] = sx[1]; sx[1] = sx[3]; n = 3; copy3(d, adb); } /* keep a, d, b */
+      else return 1;
+      /* (the face case continues with a plain direction: the triangle's own region tests run on the next vertex) */
+    }
+  }
+  return 0;
+}
+typedef struct { int v[3]; double n[3], dist; int alive; } cface;
+static int ccd_make_face(const cvert* V, int i, int j, int k, cface* f) {
+  double e1[3], e2[3];
+  for (int c = 0; c < 3; c++) { e1[c] = V[j].w[c] - V[i].w[c]; e2[c] = V[k].w[c] - V[i].w[c]; }
+  cross3(f->n, e1, e2);
+  double l = norm3(f->n);
+  if (l < 1e-30) return 0;
+  for (int c = 0; c < 3; c++) f->n[c] /= l;
+  f->dist = dot3(f->n, V[i].w);
+  f->v[0] = i; f->v[1] = j; f->v[2] = k; f->alive = 1;
+  if (f->dist < 0) { f->dist = -f->dist; for (int c = 0; c < 3; c++) f->n[c] = -f->n[c]; f->v[1] = k; f->v[2] = j; }
+  return 1;
+}
+static int collide_convex(int t1, const double* s1, const double* p1, const double* R1, int t2, const double* s2, const double* p2, const double* R2, double margin, rawcon* out) {
+  (void)margin;
+  cshape A = {t1, s1, p1, R1}, B = {t2, s2, p2, R2};
+  cvert V[CCD_MAXV]; cface F[CCD_MAXF]; int nv = 0, nf = 0;
+  if (!ccd_gjk(&A, &B, V)) return 0;
+  nv = 4;
+  { /* outward-oriented tetrahedron */
+    static const int idx[4][3] = {{0, 1, 2}, {0, 2, 3}, {0, 3, 1}, {1, 3, 2}};
+    for (int f = 0; f < 4; f++) {
+      if (!ccd_make_face(V, idx[f][0], idx[f][1], idx[f][2], &F[nf])) return 0; /* flat simplex: the shapes touch without volume */
+      /* the opposite vertex must lie behind the face */
+      int opp = 6 - idx[f][0] - idx[f][1] - idx[f][2];
+      if (dot3(F[nf].n, V[opp].w) - F[nf].dist > 1e-12) { for (int c = 0; c < 3; c++) F[nf].n[c] = -F[nf].n[c]; F[nf].dist = -F[nf].dist; int t = F[nf].v[1]; F[nf].v[1] = F[nf].v[2]; F[nf].v[2] = t; }
+      nf++;
+    }
+  }
+  int best = -1;
+  for (int it = 0; it < 4 * CCD_MAXV; it++) {
+    best = -1;
+    for (int f = 0; f < nf; f++) if (F[f].alive && (best < 0 || F[f].dist < F[best].dist)) best = f;
+    if (best < 0) return 0;
+    cvert nw; ccd_support(&A, &B, F[best].n, &nw);
+    double grow = dot3(nw.w, F[best].n) - F[best].dist;
+    if (grow < CCD_TOL || nv >= CCD_MAXV || nf + 2 * 32 >= CCD_MAXF) break;
+    /* remove the faces the new point sees, collect the horizon */
+    int edges[256][2], ne = 0;
+    for (int f = 0; f < nf; f++) {
+      if (!F[f].alive || dot3(F[f].n, nw.w) - F[f].dist <= 1e-14) continue;
+      F[f].alive = 0;
+      for (int e = 0; e < 3; e++) {
+        int a = F[f].v[e], b = F[f].v[(e + 1) % 3], found = -1;
+        for (int q = 0; q < ne; q++) if (edges[q][0] == b && edges[q][1] == a) { found = q; break; }
+        if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; ne--; }
+        else if (ne < 256) { edges[ne][0] = a; edges[ne][1] = b; ne++; }
+      }
+    }
+    if (ne == 0) break; /* numerically on the surface already */
+    V[nv] = nw;
+    /* compact the face list */
+    int k = 0; for (int f = 0; f < nf; f++) if (F[f].alive) F[k++] = F[f]; nf = k;
+    for (int e = 0; e < ne && nf < CCD_MAXF; e++) {
+      cface nfc;
+      if (!ccd_make_face(V, edges[e][0], edges[e][1], nv, &nfc)) continue;
+      /* keep the winding of the horizon edge: the normal must point away from the interior (origin side) */
+      F[nf++] = nfc;
+    }
+    nv++;
+  }
+  if (best < 0) return 0;
+  { /* witness points: barycentric coordinates of the origin's projection onto the closest face */
+    const cface* f = &F[best];
+    const cvert *a = &V[f->v[0]], *b = &V[f->v[1]], *c = &V[f->v[2]];
+    double pr[3] = {f->n[0] * f->dist, f->n[1] * f->dist, f->n[2] * f->dist};
+    double v0[3], v1[3], v2[3];
+    for (int k = 0; k < 3; k++) { v0[k] = b->w[k] - a->w[k]; v1[k] = c->w[k] - a->w[k]; v2[k] = pr[k] - a->w[k]; }
+    double d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1), den = d00 * d11 - d01 * d01;
+    double bv = den > 1e-300 ? (d11 * d20 - d01 * d21) / den : 0, bw = den > 1e-300 ? (d00 * d21 - d01 * d20) / den : 0, bu = 1 - bv - bw;
+    double wa[3], wb[3];
+    for (int k = 0; k < 3; k++) { wa[k] = bu * a->a[k] + bv * b->a[k] + bw * c->a[k]; wb[k] = bu * a->b[k] + bv * b->b[k] + bw * c->b[k]; }
+    /* A - B reaches `dist` along n: B has to move by dist along n to separate, i.e. the normal from A to B is n */
+    out->dist = -f->dist;
+    for (int k = 0; k < 3; k++) { out->n[k] = f->n[k]; out->pos[k] = 0.5 * (wa[k] + wb[k]); }
+    out->has_t = 0;
+  }
+  return 1;
+}
+
+/* sphere against cylinder (MuJoCo's primitive mjc_SphereCylinder, `engine_collision_primitive.c`: side, cap or rim, whichever the sphere's centre is nearest to):
+ * the closest point of the solid cylinder to the centre, the normal from the cylinder to the sphere along that line, position midway through the overlap.  A centre
+ * inside the cylinder leaves through the nearer of side and cap. */
+static int collide_cylinder_sphere(const double* pc, const double* Rc, const double* sc, const double* ps, double rs, double margin, rawcon* out) {
+  double ax[3]; col(ax, Rc, 2);
+  double v[3] = {ps[0] - pc[0], ps[1] - pc[1], ps[2] - pc[2]};
+  double x = dot3(v, ax), rad[3] = {v[0] - x * ax[0], v[1] - x * ax[1], v[2] - x * ax[2]}, rl = norm3(rad);
+  double er[3] = {0, 0, 0};
+  if (rl > 1e-14) { for (int k = 0; k < 3; k++) er[k] = rad[k] / rl; } else { double t[3] = {1, 0, 0}; if (fabs(ax[0]) > 0.9) { t[0] = 0; t[1] = 1; } cross3(er, ax, t); double l = norm3(er); for (int k = 0; k < 3; k++) er[k] /= l; }
+  double r = sc[0], L = sc[1], sx = x >= 0 ? 1.0 : -1.0;
+  double n[3], dist, cp[3]; /* closest point on the cylinder */
+  if (fabs(x) <= L && rl <= r) { /* centre inside */
+    double dside = r - rl, dcap = L - fabs(x);
+    if (dside <= dcap) { copy3(n, er); dist = -dside - rs; for (int k = 0; k < 3; k++) cp[k] = pc[k] + x * ax[k] + r * er[k]; }
+    else { for (int k = 0; k < 3; k++) { n[k] = sx * ax[k]; cp[k] = pc[k] + sx * L * ax[k] + rl * er[k]; } dist = -dcap - rs; }
+  } else {
+    double cx = fabs(x) > L ? sx * L : x, cr = rl > r ? r : rl;
+    for (int k = 0; k < 3; k++) cp[k] = pc[k] + cx * ax[k] + cr * er[k];
+    double dv[3] = {ps[0] - cp[0], ps[1] - cp[1], ps[2] - cp[2]}; double l = norm3(dv);
+    if (l < 1e-14) return 0;
+    for (int k = 0; k < 3; k++) n[k] = dv[k] / l;
+    dist = l - rs;
+  }
+  if (dist >= margin) return 0;
+  out->dist = dist; copy3(out->n, n); out->has_t = 0;
+  for (int k = 0; k < 3; k++) out->pos[k] = cp[k] + n[k] * (0.5 * dist);
+  return 1;
+}
+
 /* One geom pair -> raw contacts (normal from geom 1 to geom 2 after `flip` is applied by the caller).  Returns the number of contacts; -1 = no routine for
  * this pair of types (the shipped models never pair them). */
 static int collide_geoms(int t1, const double* s1, const double* p1, const double* R1, int t2, const double* s2, const double* p2, const double* R2, double margin, rawcon* rc, int* flip) {
@@ -614,7 +808,15 @@ static int collide_geoms(int t1, const double* s1, const double* p1, const doubl
   else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_SPHERE) n = collide_box_sphere(p1, R1, s1, p2, s2[0], margin, rc);
   else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_BOX) { n = collide_box_sphere(p2, R2, s2, p1, s1[0], margin, rc); *flip = 1; }
   else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_SPHERE) n = collide_sphere_sphere(p1, s1[0], p2, s2[0], margin, rc);
-  else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) n = collide_cyl_cyl_parallel(p1, R1, s1, p2, R2, s2, margin, rc);
+  else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_CYLINDER) {
+    double a1[3], a2[3]; col(a1, R1, 2); col(a2, R2, 2);
+    /* parallel axes (cylinder_push, where the planar joints keep them parallel for ever): the closed form; anything else: the general convex routine */
+    n = fabs(dot3(a1, a2)) >= 1 - 1e-9 ? collide_cyl_cyl_parallel(p1, R1, s1, p2, R2, s2, margin, rc) : collide_convex(t1, s1, p1, R1, t2, s2, p2, R2, margin, rc);
+  }
+  else if (t1 == JO_GEOM_CYLINDER && t2 == JO_GEOM_SPHERE) n = collide_cylinder_sphere(p1, R1, s1, p2, s2[0], margin, rc);
+  else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_CYLINDER) { n = collide_cylinder_sphere(p2, R2, s2, p1, s1[0], margin, rc); *flip = 1; }
+  else if ((t1 == JO_GEOM_CYLINDER && (t2 == JO_GEOM_BOX || t2 == JO_GEOM_CAPSULE)) || (t2 == JO_GEOM_CYLINDER && (t1 == JO_GEOM_BOX || t1 == JO_GEOM_CAPSULE)))
+    n = collide_convex(t1, s1, p1, R1, t2, s2, p2, R2, margin, rc);
   else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_CAPSULE) n = collide_box_capsule(p1, R1, s1, p2, R2, s2, margin, rc);
   else if (t1 == JO_GEOM_CAPSULE && t2 == JO_GEOM_BOX) { n = collide_box_capsule(p2, R2, s2, p1, R1, s1, margin, rc); *flip = 1; }
   return n;

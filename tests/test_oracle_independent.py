@@ -169,7 +169,7 @@ def _quat_of(R):
     return np.array([w, x, y, z])
 
 
-@pytest.mark.parametrize("kinds", [("box", "box"), ("box", "sphere"), ("sphere", "sphere"), ("box", "capsule"), ("capsule", "plane"), ("box", "cylinder"), ("sphere", "cylinder")])
+@pytest.mark.parametrize("kinds", [("box", "box"), ("box", "sphere"), ("sphere", "sphere"), ("box", "capsule"), ("capsule", "plane"), ("box", "cylinder"), ("sphere", "cylinder"), ("cylinder", "cylinder"), ("capsule", "cylinder")])
 def test_narrow_phase_agrees_with_support_function_geometry(kinds):
     """Deepest penetration and normal of the oracle's collision routine against the signed distance of the two shapes computed from support functions
     (`tests/independent.py::signed_distance`), and every contact point inside both shapes (to the penetration)."""
@@ -224,6 +224,9 @@ def test_narrow_phase_agrees_with_support_function_geometry(kinds):
         # fudge factor -- so its face answer may be up to 5 % deeper than the minimum translation, which an edge direction attains)
         slack = 0.05 * abs(sd) if kinds == ("box", "box") else 0.0
         assert deepest >= sd - slack - 1e-6, (kinds, trial, deepest, sd)
+        if "cylinder" in kinds:
+            # sphere-cylinder is a closed form, the others go through GJK + EPA to 1e-10: exact minimum translation (up to the sampling error of this check)
+            assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd), (kinds, trial, deepest, sd)
         if set(kinds) <= {"box", "sphere"}:
             assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd) + slack, (kinds, trial, deepest, sd)   # exact routines (sampling error of the reference only)
         if kinds == ("box", "capsule") and sd > -0.98 * B[1][0]:

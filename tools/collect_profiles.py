@@ -31,11 +31,26 @@ for name in sorted(os.listdir(src)):
             m = re.search(r"^(" + prefix + r".*?)\s+" + cn + r"\s+(\d+)\s+([\d.]+)\s", txt, re.M)
             if m:
                 vals[cn], kern = float(m.group(3)), m.group(1)
+        issue = {}
+        for cn in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_LDS_IDX_ACTIVE"):  # the issue side of the same launches (per launch, summed over the GPU)
+            m = re.search(r"^" + prefix + r".*?\s+" + cn + r"\s+(\d+)\s+([\d.]+)\s", txt, re.M)
+            if m:
+                issue[cn] = float(m.group(2))
         ms = re.findall(r"mean of the last 20: ([\d.]+) us", txt)
         if vals:
             traffic[case] = {"kernel": re.sub(r"\(float const\*.*", "", kern).strip(), "kernel_ms_default_bench_last20": float(ms[-1]) / 1e3 if ms else None,
                              "FETCH_SIZE_KB_per_launch": vals.get("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": vals.get("WRITE_SIZE"),
                              "hbm_bytes_per_launch": int(1024 * (vals.get("FETCH_SIZE", 0) + vals.get("WRITE_SIZE", 0)))}
+            if "SQ_INSTS_VALU" in issue and "SQ_BUSY_CYCLES" in issue:
+                # SQ_BUSY_CYCLES is per shader engine (32 of them), in clock cycles: the kernel's own duration; 1 024 SIMDs; one wave64 VALU instruction per 2.74 cycles is
+                # the best rate tools/ubench/valu_rate.hip measures on this part (profiles/r03_valu_rate.txt), 2 cycles the nominal one
+                cyc = issue["SQ_BUSY_CYCLES"] / 32.0
+                traffic[case]["issue"] = {"valu_wave_instructions_per_launch": issue["SQ_INSTS_VALU"], "kernel_cycles": cyc,
+                                          "cycles_per_valu_instruction_per_simd": cyc * 1024 / issue["SQ_INSTS_VALU"], "measured_best_cycles_per_valu_instruction": 2.74,
+                                          "frac_of_measured_valu_issue_rate": 2.74 * issue["SQ_INSTS_VALU"] / (cyc * 1024),
+                                          "frac_of_nominal_valu_issue_rate": 2.0 * issue["SQ_INSTS_VALU"] / (cyc * 1024),
+                                          "active_inst_any_over_simd_cycles": (4.0 * issue["SQ_ACTIVE_INST_ANY"] / (cyc * 1024)) if "SQ_ACTIVE_INST_ANY" in issue else None,
+                                          "lds_array_busy_frac": (issue["SQ_LDS_IDX_ACTIVE"] / (cyc * 256)) if "SQ_LDS_IDX_ACTIVE" in issue else None}
     elif name.endswith("_bench_under_rocprof.json") or ((name.startswith("bench_") or name.startswith("materialize_")) and name.endswith(".json")):
         lines = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]
         if lines:
