@@ -224,7 +224,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
     ap.add_argument("--settle", type=float, default=0.4, help="seconds of untimed plan steps on a throw-away plan before the W warm-up steps (runtime one-offs)")
-    ap.add_argument("--no-with-traces", action="store_true", help="skip the extra plan steps that read Controller.traces (run after the timed region)")
+    ap.add_argument("--no-with-traces", action="store_true", help="skip the extra plan steps that measure what reading Controller.traces costs (run after the timed region)")
+    ap.add_argument("--traces-outside-step", action="store_true", help="do not read Controller.traces inside the timed plan steps (rounds 1-2 timed it that way)")
     ap.add_argument("--no-cube-only", action="store_true", help="leap_cube: skip the extra cube-contacts-only steps run after the timed region")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
@@ -315,6 +316,7 @@ def main() -> None:
     ctrl.solver_warnings = False
     if not is_policy:
         ctrl.solver_stats()  # zero the kernels' counters: the line reports the timed steps alone
+    traces_in_step = bool(not is_policy and ctrl.trace_sensors and not args.traces_outside_step)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -323,6 +325,8 @@ def main() -> None:
         ts = time.perf_counter()
         ctrl.time = t_plan
         ctrl.update_action()
+        if traces_in_step:
+            _ = ctrl.traces  # the reference's update_action ends with update_traces (judo/controller/controller.py:299): the timed step does too
         t_plan += 1.0 / ctrl.controller_cfg.control_freq
         per_step.append(time.perf_counter() - ts)
     torch.cuda.synchronize()
@@ -351,8 +355,8 @@ def main() -> None:
             if st.get("wave_steps"):
                 solver["wave_newton_iters_per_step"] = st["wave_newton_iters"] / st["wave_steps"]
                 solver["lock_step_inflation"] = solver["wave_newton_iters_per_step"] / max(solver["newton_iters_per_step"], 1e-9)
-    # the reference's plan time includes update_traces (judo/controller/controller.py:299); here the elites' trace polylines are staged on the device inside the
-    # plan step and re-rolled only when `Controller.traces` is read, so `value` does not pay for them: the same steps again, reading the traces every time
+    # the reference's plan time includes update_traces (judo/controller/controller.py:299).  Since round 3 the fused kernels write every rollout's trace sensors and the
+    # elites' rows are gathered on the device, so reading `Controller.traces` is part of the timed steps above; what it costs on its own is measured here, on further steps
     with_traces = None
     if not is_policy and ctrl.trace_sensors and not args.no_with_traces:
         # (the plan keeps moving, and with it the cost of a plan step: the extra steps are not compared with the timed ones as wholes -- what is measured is the
@@ -368,9 +372,11 @@ def main() -> None:
             torch.cuda.synchronize()
             t_tr += time.perf_counter() - tw
             tq += 1.0 / ctrl.controller_cfg.control_freq
-        with_traces = {"ms_per_step": elapsed / args.steps * 1e3 + t_tr / n_extra * 1e3, "traces_ms": t_tr / n_extra * 1e3, "steps": n_extra, "max_num_traces": int(ctrl.max_num_traces),
-                       "note": "ms_per_step of the timed steps + the mean time of reading Controller.traces after a plan step (elite re-rollout in materialise mode + "
-                               "polyline packing), measured on further plan steps"}
+        base = elapsed / args.steps * 1e3
+        with_traces = {"ms_per_step": base if traces_in_step else base + t_tr / n_extra * 1e3, "traces_ms": t_tr / n_extra * 1e3, "steps": n_extra, "max_num_traces": int(ctrl.max_num_traces),
+                       "in_value": traces_in_step,
+                       "note": "traces_ms = mean time of reading Controller.traces after a plan step (fetch of the elites' trace rows + polyline packing), measured on further plan "
+                               "steps; in_value: the timed steps read the traces themselves, as the reference's update_action does"}
     # leap_cube: the same measurement restarted with the hand's own contacts switched off (the model round 1 measured), outside the timed region
     cube_only = None
     if args.task == "leap_cube" and world == 1 and ctrl.model is not None and ctrl.model.self_collision and not args.no_cube_only:
@@ -433,7 +439,8 @@ def main() -> None:
             "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
                        "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters,
                        "hand_self_collision": self_on if args.task.startswith("leap") else None,
-                       "traces": "staged on the device inside the plan step, fetched (elite re-rollout) when Controller.traces is read: not in `value`, see plan_step_ms_with_traces"},
+                       "traces": ("read inside every timed plan step (update_traces is part of the reference's update_action): the fused kernel writes every rollout's trace sensors, "
+                                  "the elites' rows are gathered on the device" if traces_in_step else "not read inside the timed steps; see plan_step_ms_with_traces")},
             "plan_step_ms": {"mean": float(ms.mean()), "std": float(ms.std()), "median": float(np.median(ms)), "iqr": float(np.percentile(ms, 75) - np.percentile(ms, 25)),
                              "min": float(ms.min()), "max": float(ms.max())},
             "physics_steps_per_s": N * H * substeps * args.steps / elapsed,

@@ -59,6 +59,8 @@ class _PlanBuffers:
         self.out_host = torch.empty(2 * K * nu, dtype=torch.float32).pin_memory()
         self.out_np = self.out_host.numpy()
         self.out_host_ptr = self.out_host.data_ptr()
+        self.trace_buf = None   # (n_local * H * trace floats) when the fused kernel writes the trace sensors
+        self.trace_rows = None  # elites' records [cost, index, trace row]
         self.trace_recs = [torch.full((max(trace_k, 1) * (2 + K * nu),), float("inf"), dtype=torch.float32, device=dev) for _ in range(2)]  # alternated per plan step
         self.trace_flip = 0
         self.knots_out: torch.Tensor | None = None
@@ -97,6 +99,7 @@ class Controller:
         self.costs_device: torch.Tensor | None = None
         self._last_fused: dict | None = None
         self.trace_sensors = [s for s in task.desc["sensors"] if s["type"] == "framepos" and "trace" in s["name"]]  # visualizers/utils.py:169-178
+        self.fused_traces = True  # let the fused kernel write every rollout's trace sensors (include/judo_amd.h, jh_model_set_trace_buffer); False: re-roll the elites
         self._traces: np.ndarray | None = None
         self._trace_stage: dict | None = None
         self._w_cache: dict[tuple, torch.Tensor] = {}
@@ -446,12 +449,24 @@ class Controller:
         if self.record_kernel_events:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        state["trace_buf"] = None
         if self.uses_fused_cost:
-            st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(b.x0), _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(W),
-                                     _lib.ptr(b.lohi), _lib.ptr(b.tp), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs),
-                                     _lib.ptr(knots_out), stream)
+            nfl = self._fused_trace_floats()
+            if nfl:  # the kernel also writes the trace sensors of every rollout: `traces` becomes a gather of the elites' rows instead of a second rollout
+                if b.trace_buf is None or b.trace_buf.numel() != shard.count * H * nfl:
+                    b.trace_buf = torch.empty(shard.count * H * nfl, dtype=torch.float32, device=self.device)
+                self.model.set_trace_buffer(b.trace_buf.data_ptr())
+            try:
+                st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(b.x0), _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(W),
+                                         _lib.ptr(b.lohi), _lib.ptr(b.tp), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs),
+                                         _lib.ptr(knots_out), stream)
+            finally:
+                if nfl:
+                    self.model.set_trace_buffer(None)
             _lib.check(st, "jh_rollout_cost")
             costs = b.costs
+            if nfl:
+                state["trace_buf"] = (b.trace_buf, H * nfl)
         else:
             costs = self._materialised_costs(b.x0, b.nominal, noise_p, ldn, b.sigma, b.lohi, None, W, shard, H, K, stream)
             if knots_out is not None:  # the materialise path never wrote the candidates: sample them into the (K, nu, N) layout the fused kernel uses
@@ -601,6 +616,17 @@ class Controller:
         return st
 
     # ---- traces --------------------------------------------------------------------------------------------------
+    def _fused_trace_floats(self) -> int:
+        """Floats per rollout-step the fused kernel writes into a trace buffer, when they are exactly this task's trace sensors in order; else 0."""
+        if not (self.fused_traces and self.model is not None and self.trace_sensors and self._num_trace_elites(1 << 30) > 0):
+            return 0
+        key = (self.model.kernel_generation, id(self.model))
+        if getattr(self, "_trace_layout_key", None) != key:
+            adr, nfl, cm = self.model.trace_layout()
+            ok = nfl > 0 and [s["adr"] for s in self.trace_sensors] == [adr + 3 * k for k in range(nfl // 3)]
+            self._trace_layout_key, self._trace_layout_nfl, self._trace_colmajor = key, (nfl if ok else 0), cm
+        return self._trace_layout_nfl
+
     def _num_trace_elites(self, N: int) -> int:
         E = min(int(self.max_num_traces), N)  # controller.py:333-334
         if E > _lib.MAX_ELITES:
@@ -640,6 +666,20 @@ class Controller:
             st = lib.jh_topk_partial(_lib.ptr(costs), _lib.ptr(state["knots_nku"]), _lib.ptr(b.nominal), state["noise_p"], state["ldn"], _lib.ptr(b.sigma), _lib.ptr(b.lohi),
                                      shard.count, shard.offset, K, nu, kl, 1, _lib.ptr(b.scratch), _lib.ptr(trace_rec), stream)
             _lib.check(st, "jh_topk_partial")
+            tb = state.get("trace_buf")
+            if tb is not None:  # the elites' rows of the trace buffer travel instead of their knots: nothing is re-rolled when the traces are read
+                row = tb[1]
+                if b.trace_rows is None or b.trace_rows.numel() != 2 * E * (2 + row):
+                    b.trace_rows = torch.empty(2 * E * (2 + row), dtype=torch.float32, device=self.device)
+                out = b.trace_rows[b.trace_flip * E * (2 + row) : (b.trace_flip + 1) * E * (2 + row)]
+                if kl < E:
+                    out.fill_(float("inf"))  # (records beyond this shard's rollouts: an infinite cost marks them empty)
+                st = lib.jh_trace_gather(_lib.ptr(trace_rec), kl, stride, shard.offset, shard.count, _lib.ptr(tb[0]), row, int(self._trace_colmajor), _lib.ptr(out), stream)
+                _lib.check(st, "jh_trace_gather")
+                kind, stride = "sensors", 2 + row
+                recs = all_gather_records(out, self.group)
+                self._trace_stage = dict(kind=kind, recs=recs, stride=stride, E=E, x0=x0, times=np.array(new_times), order=self.spline_order, H=H, K=K, nu=nu, index_is_bits=True)
+                return
             kind = "knots"
             recs = all_gather_records(trace_rec, self.group)
         self._trace_stage = dict(kind=kind, recs=recs, stride=stride, E=E, x0=x0, times=np.array(new_times), order=self.spline_order, H=H, K=K, nu=nu,

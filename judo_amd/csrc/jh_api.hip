@@ -31,7 +31,7 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->d_trace = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
@@ -99,6 +99,29 @@ extern "C" int jh_model_set_kernel(jh_model* m, int generation) {
     return JH_ERR_UNSUPPORTED;
   }
   m->kernel_gen = generation;
+  return JH_OK;
+}
+
+// trace sensors the fused kernel can write per rollout and step: first sensor address, number of floats (0: none -- the elites are re-rolled in materialise mode instead)
+static void trace_layout(const jh_model* m, int* adr, int* nfl, int* colmajor) {
+  *adr = 0; *nfl = 0; *colmajor = 0;
+  if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) { *nfl = 6; *colmajor = 1; return; }  // both models' six sensors are their two trace sites; one lane per rollout: column-major
+  if (m->kernel_gen != 3) return;
+  if (m->kind == JH_TASK_LEAP_CUBE && m->ns == 31) { *adr = 16; *nfl = 15; }   // trace_cube, trace_{if,mf,rf,th}_tip (leap_cube.xml: the five framepos sensors)
+  else if (m->kind == JH_TASK_FR3_PICK) { *adr = 8; *nfl = 6; }               // trace_object, trace_grasp_site
+}
+
+extern "C" int jh_model_trace_layout(const jh_model* m, int* out) {
+  JH_REQUIRE(m && out, "model_trace_layout: null pointer");
+  trace_layout(m, out, out + 1, out + 2);
+  return JH_OK;
+}
+
+extern "C" int jh_model_set_trace_buffer(jh_model* m, float* buf) {
+  JH_REQUIRE(m != nullptr, "model_set_trace_buffer: null pointer");
+  int adr, nfl, cm; trace_layout(m, &adr, &nfl, &cm);
+  JH_REQUIRE(buf == nullptr || nfl > 0, "model_set_trace_buffer: this model's fused kernel writes no trace sensors (jh_model_trace_layout)");
+  m->d_trace = buf;
   return JH_OK;
 }
 

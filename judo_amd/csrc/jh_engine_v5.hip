@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                                                    const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                    const float* __restrict__ tp, int N, int n_offset, int H, int K, float* __restrict__ costs,
                                                    float* __restrict__ knots_out, const float* __restrict__ controls, float* __restrict__ states,
-                                                   float* __restrict__ sensors, int* __restrict__ stats, int dshift) {
+                                                   float* __restrict__ sensors, int* __restrict__ stats, int dshift, float* __restrict__ trace) {
 #ifdef JH_V5_X_DYNRS  // (occupancy experiments: the compiler does not see the per-rollout LDS, so the register budget follows JH_V5_WAVES_PER_EU alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char dynRS[];
   RS* sRS = reinterpret_cast<RS*>(dynRS);
@@ -503,6 +503,16 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         if (l == 0) { for (int k = 0; k < 3; k++) S.pa[0][k] = qc[k]; for (int k = 0; k < 9; k++) S.xR[0][k] = Rc[k]; S.ncon = 0; S.nhit = 0; }
         S.qv[6 + l] = qd;
         if (l < 6) S.qv[l] = vc[l];
+      }
+      // fused mode with a trace buffer (jh_model_set_trace_buffer): the five trace sites of this forward pass -- what the materialise mode writes as sensors 16..30 --
+      // for EVERY rollout: 60 B per rollout-step, 250 MB per plan step of the headline workload, and `Controller.traces` becomes a gather instead of a re-rollout
+      if (!MATERIALIZE && trace && nsI == NS) {
+        WSYNC();
+        if (live && l < nsiteI && l < 5) {
+          int b = gI[oSiteI + l]; float p3[3]; mulMV(p3, S.xR[b], gF + oSiteF + l * SITE_F);
+          float* tr = trace + ((size_t)n * H + hh) * 15 + 3 * l;
+          for (int k = 0; k < 3; k++) tr[k] = p3[k] + S.pa[b][k];
+        }
       }
       // sensors of this forward pass (materialise mode): 16 joint positions, then 5 site positions
       if (MATERIALIZE && sensors) {
@@ -1409,10 +1419,10 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
   int grid = (N + per_block - 1) / per_block;
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift);
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, m->d_trace);
   else
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift);
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, m->d_trace);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -1425,11 +1435,11 @@ int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, c
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
-                       controls, states, sensors, m->d_stats, dshift);
+                       controls, states, sensors, m->d_stats, dshift, (float*)nullptr);
   else
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
-                       controls, states, sensors, m->d_stats, dshift);
+                       controls, states, sensors, m->d_stats, dshift, (float*)nullptr);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
                                                     const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                     const float* __restrict__ tp, int phase, int N, int n_offset, int H, int K,
                                                     float* __restrict__ costs, float* __restrict__ knots_out, const float* __restrict__ controls,
-                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats, int dshift) {
+                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats, int dshift, float* __restrict__ trace) {
   __shared__ RS6 sRS[RPW];
   __shared__ int sDT[MAXDT][3];  // distance-sensor tasks: sensordata address, geom a, geom b
   __shared__ int sNDT, sDadr[8];
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
       __syncthreads();
       if (MATERIALIZE && sensors && live && l < NS) sensors[((size_t)nc * H + hh) * NS + l] = S.y[l];
+      if (!MATERIALIZE && trace && live && l < 6) trace[((size_t)n * H + hh) * 6 + l] = S.y[8 + l];  // trace_object, trace_grasp_site of every rollout (jh_model_set_trace_buffer)
     }
     PH6(1)
     // ================================================================ arm dynamics: 9x9 inertia and bias from per-link contributions
@@ -1101,7 +1102,7 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
   const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
   int grid = (N + per_wave - 1) / per_wave;
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
-                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift);
+                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, m->d_trace);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -1113,7 +1114,7 @@ int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, c
   int grid = (N + per_wave - 1) / per_wave;
   hipLaunchKernelGGL(k_fr3_v6<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
-                     (float*)nullptr, controls, states, sensors, m->d_stats, dshift);
+                     (float*)nullptr, controls, states, sensors, m->d_stats, dshift, (float*)nullptr);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

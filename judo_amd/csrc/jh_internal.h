@@ -26,6 +26,7 @@ struct jh_model {
   int* d_i;    // device copy of the int section
   int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
+  float* d_trace;  // optional (jh_model_set_trace_buffer): the fused kernels of leap_cube / fr3_pick write the trace sensors of every rollout and step here
   int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
   std::vector<float> h_f;
   std::vector<int> h_i;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
                                                          const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
                                                          const float* __restrict__ sigma, const float* __restrict__ W,
                                                          const float* __restrict__ lohi, const float* __restrict__ tp, int N, int n_offset,
-                                                         int H, int K, float* __restrict__ costs, float* __restrict__ knots_out) {
+                                                         int H, int K, float* __restrict__ costs, float* __restrict__ knots_out, float* __restrict__ trace) {
   extern __shared__ float lds[];
   const int KU = K * T::NU;
   float* sW = lds;                 // H*K
@@ -197,6 +197,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
   for (int h = 0; h < H; h++) {
     float u[T::NU];
     spline_controls<T::NU>(sp, h, lane, u);
+    if (trace) {  // jh_model_set_trace_buffer: the sensors of this forward pass (all of them are trace sensors in these two models), column-major: element (n, i) at [i * N + n]
+      float y[T::NS]; s.sensors(sP, y);
+      if (live) for (int k = 0; k < T::NS; k++) trace[(size_t)(h * T::NS + k) * N + n] = y[k];
+    }
     s.step(sP, u);
     acc += s.cost(sTp, u);
   }
@@ -314,7 +318,7 @@ int launch_cost(const jh_model* m, const float* x0, const float* nominal, const 
   JH_REQUIRE(lds <= 64 * 1024, "rollout_cost: H*K too large for the LDS staging (%zu bytes)", lds);
   int grid = (N + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(k_rollout_cost<T>, dim3(grid), dim3(kBlock), lds, st, m->d_f, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K,
-                     costs, knots_out);
+                     costs, knots_out, m->d_trace);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

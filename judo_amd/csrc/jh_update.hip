@@ -379,6 +379,26 @@ extern "C" int jh_topk_partial(const float* costs, const float* knots_nku, const
   return JH_OK;
 }
 
+// rows of the trace buffer for the elites of a jh_topk_partial record set: rec_out[e] = [cost, global index (bits), trace row]
+__global__ void k_trace_gather(const float* __restrict__ rec_in, int k, int stride_in, int n_offset, int n_local, const float* __restrict__ trace, int row, int colmajor,
+                               float* __restrict__ rec_out) {
+  const int e = blockIdx.x;
+  const float cost = rec_in[(size_t)e * stride_in]; const int gi = __float_as_int(rec_in[(size_t)e * stride_in + 1]);
+  float* o = rec_out + (size_t)e * (2 + row);
+  const int li = gi - n_offset;
+  const bool ok = gi >= 0 && li >= 0 && li < n_local && cost < 3.0e38f;
+  if (threadIdx.x == 0) { o[0] = ok ? cost : __int_as_float(0x7f800000); o[1] = __int_as_float(ok ? gi : -1); }
+  for (int i = threadIdx.x; i < row; i += blockDim.x) o[2 + i] = ok ? (colmajor ? trace[(size_t)i * n_local + li] : trace[(size_t)li * row + i]) : 0.f;
+}
+
+extern "C" int jh_trace_gather(const float* rec_in, int k, int stride_in, int n_offset, int n_local, const float* trace, int row_floats, int colmajor, float* rec_out,
+                               void* stream) {
+  JH_REQUIRE(rec_in && trace && rec_out && k >= 1 && k <= JH_MAX_ELITES && stride_in >= 2 && row_floats >= 1 && n_local >= 1, "trace_gather: bad arguments");
+  hipLaunchKernelGGL(k_trace_gather, dim3(k), dim3(256), 0, (hipStream_t)stream, rec_in, k, stride_in, n_offset, n_local, trace, row_floats, colmajor, rec_out);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
 extern "C" int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float smin, float smax, float* nominal_out, float* sigma_out,
                               void* stream) {
   if (int e = check_dims(1, K, nu)) return e;

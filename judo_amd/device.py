@@ -69,6 +69,16 @@ class GpuModel:
         self._self_collision_requested = bool(on)
         self.self_collision = bool(on) and self.kernel_generation == 3 and self.desc.get("family", self.task) == "leap_cube"
 
+    def trace_layout(self) -> tuple[int, int, bool]:
+        """(first sensor address, number of floats, buffer is column-major) of the trace sensors the fused kernel can write for every rollout
+        (`jh_model_trace_layout`); 0 floats: none."""
+        out = (C.c_int * 3)()
+        _lib.check(_lib.lib().jh_model_trace_layout(self.handle, out), "jh_model_trace_layout")
+        return int(out[0]), int(out[1]), bool(out[2])
+
+    def set_trace_buffer(self, ptr: int | None) -> None:
+        _lib.check(_lib.lib().jh_model_set_trace_buffer(self.handle, ptr), "jh_model_set_trace_buffer")
+
     @property
     def max_fused_knots(self) -> int:
         """Largest knot count the fused rollout kernel of this model accepts (`jh_model_limits`)."""

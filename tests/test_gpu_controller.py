@@ -223,6 +223,37 @@ def test_knot_count_of_ten_fused_where_the_kernel_allows_it_materialised_where_n
         ctrl.update_action()
 
 
+@pytest.mark.parametrize("task,opt", [("leap_cube", "mppi"), ("fr3_pick", "cem"), ("cartpole", "ps"), ("cylinder_push", "mppi")])
+def test_traces_from_the_fused_kernel_equal_the_re_rolled_elites(gpu, task, opt):
+    """`Controller.traces` (judo/controller/controller.py:323-363): with a trace buffer the fused kernel writes the trace sensors of every rollout and the elites' rows are
+    gathered; without (fused_traces = False, the rounds 1-2 path) the elites are re-rolled in materialise mode when the traces are read.  Same elites, same segments."""
+    from judo_amd.controller import make_controller
+
+    out = {}
+    for fused in (True, False):
+        ctrl = make_controller(task, opt)
+        ctrl.fused_traces = fused
+        ctrl.optimizer.config.num_rollouts = 300
+        ctrl.controller_cfg.max_num_traces = 4
+        ctrl.reset()
+        ctrl.current_state = ctrl.task.default_state()
+        ctrl.system_metadata = {"goal_quat": np.array([0.0, 1.0, 0.0, 0.0])} if task == "leap_cube" else {}
+        ctrl.optimizer.seed(77)
+        segs = []
+        for step in range(3):
+            ctrl.time = 0.05 * step
+            ctrl.update_action()
+            assert ctrl.uses_fused_cost
+            assert (ctrl._trace_stage["kind"] == "sensors") == fused
+            segs.append(ctrl.traces.copy())
+        out[fused] = (segs, ctrl.nominal_knots.copy())
+    S = len(ctrl.trace_sensors)
+    for a, b in zip(out[True][0], out[False][0]):
+        assert a.shape == b.shape == (4 * S * (ctrl.num_timesteps - 1), 2, 3)
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)  # the fused and the materialise instantiation of the kernel round differently in the last bits
+    np.testing.assert_array_equal(out[True][1], out[False][1])  # the plan itself does not depend on how the traces are produced
+
+
 def test_reset_restarts_the_policy_state(gpu):
     """judo/controller/controller.py:318-321: reset() zeroes the last policy output of a locomotion-policy task; the plant solver's warm start goes with it."""
     import torch
