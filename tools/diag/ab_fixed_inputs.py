@@ -24,6 +24,7 @@ else:
     d = np.load(path)
     c.record_kernel_events = True
     if os.environ.get("KERNEL_GEN"): c.model.set_kernel(int(os.environ["KERNEL_GEN"]))
+    if os.environ.get("FUSED_TRACES") is not None: c.fused_traces = os.environ["FUSED_TRACES"] == "1"
     if os.environ.get("SELF") is not None: c.model.set_self_collision(os.environ["SELF"] == "1")
     noms = []
     for rep in range(int(os.environ.get("REPS", "1"))):
