@@ -89,15 +89,14 @@ int jh_model_set_self_collision(jh_model* m, int on);
 
 /* Traces without a second rollout (judo/controller/controller.py:323-363, `update_traces`: line segments of the best rollouts' `trace*` framepos sensors).  The
  * reference reads them out of the sensor array its rollout materialises for every sample; the fused path has no such array, so round 1-2 re-rolled the elites in
- * materialise mode when the traces were read (8 ms on the headline workload: one lone wave for 64 serial steps).  With a trace buffer set, jh_rollout_cost on
- * leap_cube / fr3_pick (kernel generation 3) also writes the trace sensors of EVERY rollout and step: row n (rollout index within the launch) holds
+ * materialise mode when the traces were read (8 ms on the headline workload: one lone wave for 64 serial steps).  jh_rollout_cost_traced (jh_rollout_cost with one more argument) on
+ * leap_cube / fr3_pick (kernel generation 3), cartpole and cylinder_push also writes the trace sensors of EVERY rollout and step into `trace`: row n (rollout index within the launch) holds
  * H x out[1] floats, the sensors out[0] .. out[0] + out[1] - 1 of jh_model_trace_layout (leap_cube: 16, 15 = five site positions; fr3_pick: 8, 6; cartpole,
  * cylinder_push: 0, 6; out[1] = 0: the model's kernel writes none).  out[2] = 1: the buffer is column-major -- element i of rollout n at [i * N + n] (the one-lane-
  * per-rollout kernels of cartpole / cylinder_push: coalesced) -- else row-major, [n * H * out[1] + i].  60 B per rollout-step, a few hundred MB per plan step that
  * nobody reads back except the elites' rows: jh_trace_gather copies, for each record [cost, global index (bits), ...] of a jh_topk_partial result, the row of that
  * rollout behind cost and index -- the payload the ranks exchange. */
 int jh_model_trace_layout(const jh_model* m, int* out /* HOST, 3 ints */);
-int jh_model_set_trace_buffer(jh_model* m, float* buf /* DEVICE, N x H x out[1] floats; NULL switches it off */);
 int jh_trace_gather(const float* rec_in /* DEVICE, k x stride_in */, int k, int stride_in, int n_offset, int n_local, const float* trace /* DEVICE */, int row_floats,
                     int colmajor, float* rec_out /* DEVICE, k x (2 + row_floats) */, void* stream);
 
@@ -140,6 +139,9 @@ int jh_download_end(void);
 int jh_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                     const float* W, const float* ctrl_lo_hi, const float* task_params, int phase, int N, int n_offset, int H, int K,
                     float* costs, float* knots_out, void* stream);
+int jh_rollout_cost_traced(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                    const float* W, const float* ctrl_lo_hi, const float* task_params, int phase, int N, int n_offset, int H, int K,
+                    float* costs, float* knots_out, float* trace /* DEVICE, N x H x jh_model_trace_layout out[1] floats, or NULL */, void* stream);
 
 /* Drop-in RolloutBackend.rollout(x0, controls) -> (states, sensors)   judo/utils/rollout_backend.py:20-39.
  * controls (N,H,nu), states (N,H,nq+nv), sensors (N,H,nsensordata), all row-major; x0 is (nq+nv) or, when

@@ -29,13 +29,13 @@ _SIGNATURES = {
     "jh_model_max_fused_knots": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_model_set_self_collision": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_model_trace_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
-    "jh_model_set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jh_trace_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "jh_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jh_download_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jh_download_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jh_download_end": (C.c_int, []),
     "jh_rollout_cost": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
+    "jh_rollout_cost_traced": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_void_p]),
     "jh_rollout_materialize": (C.c_int, [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_task_reward": (C.c_int, [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
     "jh_noise_normal": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p]),

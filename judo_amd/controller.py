@@ -99,7 +99,7 @@ class Controller:
         self.costs_device: torch.Tensor | None = None
         self._last_fused: dict | None = None
         self.trace_sensors = [s for s in task.desc["sensors"] if s["type"] == "framepos" and "trace" in s["name"]]  # visualizers/utils.py:169-178
-        self.fused_traces = True  # let the fused kernel write every rollout's trace sensors (include/judo_amd.h, jh_model_set_trace_buffer); False: re-roll the elites
+        self.fused_traces = True  # let the fused kernel write every rollout's trace sensors (include/judo_amd.h, jh_rollout_cost_traced); False: re-roll the elites
         self._traces: np.ndarray | None = None
         self._trace_stage: dict | None = None
         self._w_cache: dict[tuple, torch.Tensor] = {}
@@ -455,14 +455,9 @@ class Controller:
             if nfl:  # the kernel also writes the trace sensors of every rollout: `traces` becomes a gather of the elites' rows instead of a second rollout
                 if b.trace_buf is None or b.trace_buf.numel() != shard.count * H * nfl:
                     b.trace_buf = torch.empty(shard.count * H * nfl, dtype=torch.float32, device=self.device)
-                self.model.set_trace_buffer(b.trace_buf.data_ptr())
-            try:
-                st = lib.jh_rollout_cost(self.model.handle, _lib.ptr(b.x0), _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(W),
-                                         _lib.ptr(b.lohi), _lib.ptr(b.tp), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs),
-                                         _lib.ptr(knots_out), stream)
-            finally:
-                if nfl:
-                    self.model.set_trace_buffer(None)
+            st = lib.jh_rollout_cost_traced(self.model.handle, _lib.ptr(b.x0), _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(W),
+                                            _lib.ptr(b.lohi), _lib.ptr(b.tp), int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs),
+                                            _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, stream)
             _lib.check(st, "jh_rollout_cost")
             costs = b.costs
             if nfl:

@@ -31,7 +31,7 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->d_trace = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
@@ -114,14 +114,6 @@ static void trace_layout(const jh_model* m, int* adr, int* nfl, int* colmajor) {
 extern "C" int jh_model_trace_layout(const jh_model* m, int* out) {
   JH_REQUIRE(m && out, "model_trace_layout: null pointer");
   trace_layout(m, out, out + 1, out + 2);
-  return JH_OK;
-}
-
-extern "C" int jh_model_set_trace_buffer(jh_model* m, float* buf) {
-  JH_REQUIRE(m != nullptr, "model_set_trace_buffer: null pointer");
-  int adr, nfl, cm; trace_layout(m, &adr, &nfl, &cm);
-  JH_REQUIRE(buf == nullptr || nfl > 0, "model_set_trace_buffer: this model's fused kernel writes no trace sensors (jh_model_trace_layout)");
-  m->d_trace = buf;
   return JH_OK;
 }
 
@@ -225,16 +217,24 @@ extern "C" int jh_model_profile(jh_model* m, long long* out /* 8 phase cycle tot
 extern "C" int jh_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                                const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
                                float* knots_out, void* stream) {
+  return jh_rollout_cost_traced(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, nullptr, stream);
+}
+
+extern "C" int jh_rollout_cost_traced(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
+                                      const float* W, const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs,
+                                      float* knots_out, float* trace, void* stream) {
   JH_REQUIRE(m && x0 && nominal && noise && sigma && W && lohi && tp && costs, "rollout_cost: null pointer");
+  if (trace) { int adr, nfl, cm; trace_layout(m, &adr, &nfl, &cm); JH_REQUIRE(nfl > 0, "rollout_cost_traced: this model's fused kernel writes no trace sensors (jh_model_trace_layout)"); }
   JH_REQUIRE(N > 0 && H > 0 && K >= 1, "rollout_cost: N, H, K must be positive (N=%d H=%d K=%d)", N, H, K);
   JH_REQUIRE(ldn >= N, "rollout_cost: ldn (%d) < N (%d)", ldn, N);
   JH_REQUIRE(K * m->nu <= JH_MAX_KNOT_DIM, "rollout_cost: K*nu = %d exceeds %d", K * m->nu, JH_MAX_KNOT_DIM);
   JH_REQUIRE(n_offset >= 0, "rollout_cost: negative n_offset");
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH)
-    return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
-  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
-  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, st);
+    return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
+  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
+  if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, trace, st);
+  JH_REQUIRE(trace == nullptr, "rollout_cost_traced: only the product kernels (generation 3, cartpole, cylinder_push) write trace sensors");
   if (!g_xcheck.rollout_cost) { jh_set_error("rollout_cost: no kernel for this model / generation in this library"); return JH_ERR_UNSUPPORTED; }
   return g_xcheck.rollout_cost(m, m->kernel_gen, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, stream);
 }

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         S.qv[6 + l] = qd;
         if (l < 6) S.qv[l] = vc[l];
       }
-      // fused mode with a trace buffer (jh_model_set_trace_buffer): the five trace sites of this forward pass -- what the materialise mode writes as sensors 16..30 --
+      // fused mode with a trace buffer (jh_rollout_cost_traced): the five trace sites of this forward pass -- what the materialise mode writes as sensors 16..30 --
       // for EVERY rollout: 60 B per rollout-step, 250 MB per plan step of the headline workload, and `Controller.traces` becomes a gather instead of a re-rollout
       if (!MATERIALIZE && trace && nsI == NS) {
         WSYNC();
@@ -1410,7 +1410,7 @@ bool model_is_leap(const jh_model* m) {
 #define JH_V5_DYNBYTES 0
 #endif
 int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
-                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st) {
   if (!model_is_leap(m)) { jh_set_error("rollout_cost: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
 #if JH_V5_KNOTS_LDS
   JH_REQUIRE(K <= MAXK, "rollout_cost: the cooperative leap kernel keeps at most 8 knots per actuator (K=%d)", K);
@@ -1419,10 +1419,10 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
   int grid = (N + per_block - 1) / per_block;
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, m->d_trace);
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace);
   else
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
-                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, m->d_trace);
+                       knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
       __syncthreads();
       if (MATERIALIZE && sensors && live && l < NS) sensors[((size_t)nc * H + hh) * NS + l] = S.y[l];
-      if (!MATERIALIZE && trace && live && l < 6) trace[((size_t)n * H + hh) * 6 + l] = S.y[8 + l];  // trace_object, trace_grasp_site of every rollout (jh_model_set_trace_buffer)
+      if (!MATERIALIZE && trace && live && l < 6) trace[((size_t)n * H + hh) * 6 + l] = S.y[8 + l];  // trace_object, trace_grasp_site of every rollout (jh_rollout_cost_traced)
     }
     PH6(1)
     // ================================================================ arm dynamics: 9x9 inertia and bias from per-link contributions
@@ -1096,13 +1096,13 @@ bool jh_model_is_fr3(const jh_model* m) {
 }
 
 int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
-                            const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+                            const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st) {
   if (!jh_model_is_fr3(m)) { jh_set_error("rollout_cost: the cooperative arm kernel (matrix-free generation) is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }
   JH_REQUIRE(K <= 8, "rollout_cost: the cooperative arm kernel keeps at most 8 knots per actuator in registers (K=%d)", K);
   const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
   int grid = (N + per_wave - 1) / per_wave;
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
-                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, m->d_trace);
+                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -26,7 +26,6 @@ struct jh_model {
   int* d_i;    // device copy of the int section
   int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
-  float* d_trace;  // optional (jh_model_set_trace_buffer): the fused kernels of leap_cube / fr3_pick write the trace sensors of every rollout and step here
   int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
   std::vector<float> h_f;
   std::vector<int> h_i;
@@ -68,7 +67,7 @@ enum {
 // ---- launchers implemented per translation unit ------------------------------------------------------------
 int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                            const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
-                           float* knots_out, hipStream_t st);
+                           float* knots_out, float* trace, hipStream_t st);
 // Latency mode of the cooperative kernels (rows of `lanes` lanes, `rpw` rows per wave): a launch too small to give every SIMD a wave lets 1 << shift rows of a wave
 // compute the same rollout -- the copies run the same arithmetic, only the first writes -- so that a wave no longer waits for the slowest of `rpw` different Newton
 // solves in every step.  Returns the largest shift (<= log2 rpw) that still leaves every wave of the launch a SIMD of its own; JUDO_AMD_LATENCY_SHIFT=0..2 overrides.
@@ -95,7 +94,7 @@ int jh_engine2_materialize(const jh_model* m, const float* x0, int x0_batched, c
 
 // jh_engine_v5.hip: the leap_cube cooperative kernel on a register diet (several waves per SIMD)
 int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
-                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st);
+                            const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st);
 int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st);
 
@@ -108,7 +107,7 @@ int jh_engine3_materialize(const jh_model* m, const float* x0, int x0_batched, c
 
 // jh_engine_v6.hip: fr3_pick, matrix-free contact Jacobian (kernel generation 3 of the fr3 model)
 int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
-                            const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st);
+                            const float* lohi, const float* tp, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st);
 int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st);
 

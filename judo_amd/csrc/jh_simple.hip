@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
   for (int h = 0; h < H; h++) {
     float u[T::NU];
     spline_controls<T::NU>(sp, h, lane, u);
-    if (trace) {  // jh_model_set_trace_buffer: the sensors of this forward pass (all of them are trace sensors in these two models), column-major: element (n, i) at [i * N + n]
+    if (trace) {  // jh_rollout_cost_traced: the sensors of this forward pass (all of them are trace sensors in these two models), column-major: element (n, i) at [i * N + n]
       float y[T::NS]; s.sensors(sP, y);
       if (live) for (int k = 0; k < T::NS; k++) trace[(size_t)(h * T::NS + k) * N + n] = y[k];
     }
@@ -313,12 +313,12 @@ __global__ __launch_bounds__(kBlock) void k_reward(const float* __restrict__ sta
 
 template <class T>
 int launch_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
-                const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, hipStream_t st) {
+                const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st) {
   size_t lds = sizeof(float) * ((size_t)H * K + (size_t)K * T::NU * kBlock + T::NP + T::NTP + T::NX);
   JH_REQUIRE(lds <= 64 * 1024, "rollout_cost: H*K too large for the LDS staging (%zu bytes)", lds);
   int grid = (N + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(k_rollout_cost<T>, dim3(grid), dim3(kBlock), lds, st, m->d_f, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K,
-                     costs, knots_out, m->d_trace);
+                     costs, knots_out, trace);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -332,9 +332,9 @@ int jh_simple_max_knots(const jh_model* m, int H) { return m->kind == JH_TASK_CA
 
 int jh_simple_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma,
                            const float* W, const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs,
-                           float* knots_out, hipStream_t st) {
-  if (m->kind == JH_TASK_CARTPOLE) return launch_cost<Cartpole>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
-  return launch_cost<CylinderPush>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, st);
+                           float* knots_out, float* trace, hipStream_t st) {
+  if (m->kind == JH_TASK_CARTPOLE) return launch_cost<Cartpole>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
+  return launch_cost<CylinderPush>(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
 }
 
 int jh_simple_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,

@@ -76,9 +76,6 @@ class GpuModel:
         _lib.check(_lib.lib().jh_model_trace_layout(self.handle, out), "jh_model_trace_layout")
         return int(out[0]), int(out[1]), bool(out[2])
 
-    def set_trace_buffer(self, ptr: int | None) -> None:
-        _lib.check(_lib.lib().jh_model_set_trace_buffer(self.handle, ptr), "jh_model_set_trace_buffer")
-
     @property
     def max_fused_knots(self) -> int:
         """Largest knot count the fused rollout kernel of this model accepts (`jh_model_limits`)."""
