@@ -38,7 +38,8 @@ def _plan(task, opt, N, noise, group=None):
     sig = np.asarray(ctrl.optimizer.sigma, dtype=np.float64) if opt == "cem" else np.zeros(1)
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
     assert cand.shape[0] == ctrl.last_shard.count
-    return ctrl.nominal_knots.copy(), sig, ctrl.last_shard, -ctrl.rewards_local, cand
+    tr = ctrl.traces  # the elites of ALL shards: their trace rows travel with the per-rank records (jh_trace_gather + all-gather)
+    return ctrl.nominal_knots.copy(), sig, ctrl.last_shard, -ctrl.rewards_local, cand, (np.zeros((0, 2, 3)) if tr is None else tr.copy())
 
 
 def _worker(rank, world, port, cases, out_dir):
@@ -51,9 +52,9 @@ def _worker(rank, world, port, cases, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
         noise = None if seed < 0 else np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
-        nom, sig, shard, costs, cand = _plan(task, opt, N, noise, group=dist.group.WORLD)
+        nom, sig, shard, costs, cand, tr = _plan(task, opt, N, noise, group=dist.group.WORLD)
         assert (shard.world, shard.rank) == (world, rank) and shard.count in (N // world, N // world + 1)
-        np.savez(os.path.join(out_dir, f"case{i}_rank{rank}.npz"), nom=nom, sig=sig, costs=costs, cand=cand)
+        np.savez(os.path.join(out_dir, f"case{i}_rank{rank}.npz"), nom=nom, sig=sig, costs=costs, cand=cand, tr=tr)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,7 +69,7 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
     mp.spawn(_worker, args=(world, port, cases, str(tmp_path)), nprocs=world, join=True)
     for i, (task, opt, N, nu, seed) in enumerate(cases):
         noise = None if seed < 0 else np.random.default_rng(seed).standard_normal((N - 1, _knots(task), nu)).astype(np.float32)
-        nom1, sig1, _, costs1, cand1 = _plan(task, opt, N, noise)
+        nom1, sig1, _, costs1, cand1, tr1 = _plan(task, opt, N, noise)
         r0, r1 = np.load(tmp_path / f"case{i}_rank0.npz"), np.load(tmp_path / f"case{i}_rank1.npz")
         np.testing.assert_array_equal(r0["nom"], r1["nom"])  # identical on every rank without a broadcast
         np.testing.assert_array_equal(r0["sig"], r1["sig"])
@@ -80,6 +81,10 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
         # the kept candidates of the two shards are the single process's, rank-major (a sharded device draw is a column view of the full draw:
         # the kernel's row stride is the full width, the buffer must have it too -- ADVICE round 2)
         np.testing.assert_array_equal(np.concatenate([r0["cand"], r1["cand"]]), cand1)
+        # traces: the same elites (chosen among both shards' rollouts) and the same trace rows on every rank and in the single-process run
+        np.testing.assert_array_equal(r0["tr"], r1["tr"])
+        np.testing.assert_array_equal(r0["tr"], tr1)
+        assert tr1.shape[0] > 0 or task.startswith("caltech")
         # vs one process only the reduction is regrouped (two block records instead of one): fp32 summation order in the MPPI average
         np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=5e-6 if opt == "mppi" else 0)
         np.testing.assert_allclose(r0["sig"], sig1, rtol=1e-6, atol=1e-7)
