@@ -14,4 +14,5 @@ for i in (0, 10, 20, 39):
     c.update_action(); torch.cuda.synchronize()
     out = (C.c_int * 40)(); L.jh_model_hist(c.model.handle, out)
     dense, its, l2, bp, ws, hh = out[0], out[1], out[2], out[3], out[4], out[5]
-    print(f"plan step {i}: wave-iterations {its}, dense {dense} ({dense / max(its, 1):.3%}); per rollout-step: body pairs hit {bp / (65536 * 64):.2f}, hand geom pairs hit {hh / (65536 * 64):.3f}; level-2 passes per wave-step {l2 / max(ws, 1):.1f}")
+    print(f"plan step {i}: wave-iterations {its}, dense {dense} ({dense / max(its, 1):.3%}); per rollout-step: body pairs hit {bp / (65536 * 64):.2f}, hand geom pairs hit {hh / (65536 * 64):.3f}; level-2 passes per wave-step {l2 / max(ws, 1):.1f}; "
+          f"coupling classes per rollout-step [none, pairs, a chain with two neighbours, cycle] {[round(out[6 + k] / (65536 * 64), 4) for k in range(4)]}")
