@@ -17,7 +17,7 @@ quat = rng.standard_normal((N, 4)); xs[:, 3:7] = quat / np.linalg.norm(quat, axi
 xs[:, 23:29] = rng.standard_normal((N, 6)) * np.array([0.2, 0.2, 0.2, 2, 2, 2])
 kinds = np.array([T._contact_kinds(om, xs[i], q[i]) for i in range(N)])
 ncon = kinds[:, :3].sum(1)
-ok = ncon <= 32
+ok = ncon <= 48  # the leap kernel's contact pool (jh_model_limits out[3])
 for H in (1, 3):
     U = np.repeat(q[:, None, :], H, axis=1)
     ref, _ = om.rollout(xs, U)
@@ -25,7 +25,7 @@ for H in (1, 3):
     assert np.isfinite(g).all()
     scale = np.maximum(1.0, np.abs(ref[:, -1, 23:]).max(axis=1, keepdims=True))
     e = np.abs(g[:, -1] - ref[:, -1]); ev = (e[:, 23:] / scale).max(1); ep = e[:, :23].max(1)
-    print(f"{task} H={H}: {N} states, {int(ok.sum())} within the 32-contact pool; contacts per state mean {ncon.mean():.1f} max {ncon.max()}")
+    print(f"{task} H={H}: {N} states, {int(ok.sum())} within the 48-contact pool; contacts per state mean {ncon.mean():.1f} max {ncon.max()}")
     for name, sel in (("no contact", ok & (ncon == 0)), ("cube only", ok & (kinds[:, 0] > 0) & (kinds[:, 1] + kinds[:, 2] == 0)), ("hand only", ok & (kinds[:, 0] == 0) & (kinds[:, 1] + kinds[:, 2] > 0)),
                       ("cube + hand, arrow", ok & (kinds[:, 0] > 0) & (kinds[:, 1] > 0) & (kinds[:, 2] == 0)), ("cube + coupled chains (staged)", ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0) & (kinds[:, 3] < 2)),
                       ("cycle (dense)", ok & (kinds[:, 3] == 2)), ("pool overflow", ~ok)):
