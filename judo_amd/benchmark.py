@@ -32,6 +32,7 @@ def plan_times(task: str, optimizer: str, num_samples: int, warmup: int, rollout
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ctrl.update_action()  # ends with the device -> host copy of the new nominal: the plan is usable when it returns
+        _ = ctrl.traces       # the reference's update_action ends with update_traces (controller.py:299): part of its plan time, so part of this one
         dt = time.perf_counter() - t0
         if i >= warmup:
             out.append(dt)
