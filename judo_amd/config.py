@@ -20,34 +20,62 @@ from typing import Any, Literal
 
 import numpy as np
 
-_OVERRIDES: dict[type, dict[str, dict[str, Any]]] = {}
+# class -> override key -> field name -> value.  (`_OVERRIDE_REGISTRY` is the reference's name, judo/config.py:9; its tests reach into it.)
+_OVERRIDE_REGISTRY: dict[type, dict[str, dict[str, Any]]] = {}
+_OVERRIDES = _OVERRIDE_REGISTRY
 
 
 def set_config_overrides(override_key: str, cls: type, field_override_values: dict[str, Any]) -> None:
-    """Register per-key field values for a config class (unknown field names are rejected)."""
+    """Register (or update) per-key field values for a config class (judo/config.py:66-96).  A class that is not a dataclass is a TypeError; a name that
+    is not a field of the class is skipped with a UserWarning, the other names of the same call still register; an empty dict registers the key."""
+    import warnings
+
     if not dataclasses.is_dataclass(cls):
-        raise TypeError(f"{cls.__name__} is not a dataclass")
-    names = {f.name for f in dataclasses.fields(cls)}
-    unknown = set(field_override_values) - names
-    if unknown:
-        raise KeyError(f"{cls.__name__} has no field(s) {sorted(unknown)}")
-    _OVERRIDES.setdefault(cls, {}).setdefault(override_key, {}).update(field_override_values)
+        raise TypeError(f"Provided class {cls.__name__} is not a dataclass.")
+    per_key = _OVERRIDE_REGISTRY.setdefault(cls, {}).setdefault(override_key, {})
+    known = {f.name for f in dataclasses.fields(cls)}
+    for name, value in field_override_values.items():
+        if name not in known:
+            warnings.warn(f"Field '{name}' not found in class '{cls.__name__}'. No override value added for this field under key '{override_key}'.", UserWarning, stacklevel=2)
+            continue
+        per_key[name] = value
+
+
+def _same(a: Any, b: Any) -> bool:
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and np.array_equal(a, b)
+    return bool(a == b)
 
 
 @dataclass
 class OverridableConfig:
-    """A config whose fields can be switched to a registered per-key (per-task) set of values."""
+    """A config whose fields can be switched to a registered per-key (per-task) set of values (judo/config.py:12-63)."""
+
+    def __post_init__(self) -> None:
+        _OVERRIDE_REGISTRY.setdefault(type(self), {})  # an existing entry (overrides registered before the first instance) is left alone
 
     def set_override(self, key: str, reset_to_defaults: bool = True) -> None:
-        chosen = _OVERRIDES.get(type(self), {}).get(key, {})
+        """Fields with a (non-None) value registered under `key` take it (the registered object itself, not a copy).  With `reset_to_defaults` every other field
+        goes back to its default -- a fresh `default_factory()` result for factory fields -- and a field that has neither is left as it is with a UserWarning;
+        without it the other fields keep their current values, silently.  An unknown key behaves like a key without values."""
+        import warnings
+
+        chosen = _OVERRIDE_REGISTRY.get(type(self), {}).get(key, {})
         for f in dataclasses.fields(self):
-            if chosen.get(f.name) is not None:
-                setattr(self, f.name, chosen[f.name])
+            value = chosen.get(f.name)
+            if value is not None:
+                if not _same(getattr(self, f.name, dataclasses.MISSING), value):
+                    setattr(self, f.name, value)
             elif reset_to_defaults:
                 if f.default is not dataclasses.MISSING:
-                    setattr(self, f.name, f.default)
+                    default = f.default
                 elif f.default_factory is not dataclasses.MISSING:  # type: ignore[misc]
-                    setattr(self, f.name, f.default_factory())  # type: ignore[misc]
+                    default = f.default_factory()  # type: ignore[misc]
+                else:
+                    warnings.warn(f"Field '{f.name}' has no default value to reset to and no override for key '{key}'. Its current value remains unchanged.", UserWarning, stacklevel=2)
+                    continue
+                if not _same(getattr(self, f.name, dataclasses.MISSING), default):
+                    setattr(self, f.name, default)
 
 
 @dataclass
