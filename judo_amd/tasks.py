@@ -91,6 +91,39 @@ class Task(ABC, Generic[ConfigT]):
             self._ctrlrange.setflags(write=False)
         return self._ctrlrange
 
+    # ---- indices into the `states` / `sensors` arrays by name (judo/tasks/base.py:180-204: what a plugin's `reward` uses to find its columns) ----
+    def _joint_addresses(self) -> dict[str, tuple[int, int]]:
+        if getattr(self, "_jadr", None) is None:
+            nq_of, nv_of = {"free": 7, "ball": 4, "slide": 1, "hinge": 1}, {"free": 6, "ball": 3, "slide": 1, "hinge": 1}
+            out, q, v = {}, 0, 0
+            for j in self.desc["joints"]:  # MuJoCo lays qpos / qvel out joint by joint in declaration (= body tree) order
+                out[j["name"]] = (q, v)
+                q += nq_of[j["type"]]
+                v += nv_of[j["type"]]
+            self._jadr = out
+        return self._jadr
+
+    def get_sensor_start_index(self, sensor_name: str) -> int:
+        """First column of the named sensor in the `sensors` array (`model.sensor(name).adr[0]`)."""
+        for sn in self.desc["sensors"]:
+            if sn["name"] == sensor_name:
+                return int(sn["adr"])
+        raise KeyError(f"Invalid name '{sensor_name}'. Valid names: {[sn['name'] for sn in self.desc['sensors']]}")
+
+    def get_joint_position_start_index(self, joint_name: str) -> int:
+        """First column of the named joint's position in the `states` array (`model.jnt_qposadr`)."""
+        try:
+            return self._joint_addresses()[joint_name][0]
+        except KeyError:
+            raise KeyError(f"Invalid name '{joint_name}'. Valid names: {list(self._joint_addresses())}") from None
+
+    def get_joint_velocity_start_index(self, joint_name: str) -> int:
+        """First column of the named joint's velocity in the `states` array: AFTER the nq position columns (`nq + model.jnt_dofadr`)."""
+        try:
+            return self.nq + self._joint_addresses()[joint_name][1]
+        except KeyError:
+            raise KeyError(f"Invalid name '{joint_name}'. Valid names: {list(self._joint_addresses())}") from None
+
     @property
     def uses_locomotion_policy(self) -> bool:
         return False

@@ -539,3 +539,28 @@ def test_exported_mjcf_round_trips(tmp_path):
             assert diff(got, ref) == [], (task, diff(got, ref)[:3])
     finally:
         CM.REF_XML = old
+
+
+def test_task_index_getters_by_name():
+    """judo/tasks/base.py:180-204 (the reference's tests/test_tasks/test_indexing.py: three slide joints -> positions 0, 1, 2, velocities nq + 0, 1, 2, a sensor's address):
+    on the shipped models, where free joints (7 / 6 columns) come before hinges."""
+    from judo_amd.tasks import get_registered_tasks
+
+    cyl = get_registered_tasks()["cylinder_push"][0]()
+    names = [j["name"] for j in cyl.desc["joints"]]
+    assert [cyl.get_joint_position_start_index(n) for n in names] == [0, 1, 2, 3]
+    assert [cyl.get_joint_velocity_start_index(n) for n in names] == [4, 5, 6, 7]
+    assert cyl.get_sensor_start_index("trace_pusher") == 0 and cyl.get_sensor_start_index("trace_cart") == 3
+    leap = get_registered_tasks()["leap_cube"][0]()
+    jn = [j["name"] for j in leap.desc["joints"]]
+    free = next(j["name"] for j in leap.desc["joints"] if j["type"] == "free")
+    assert leap.get_joint_position_start_index(free) == 0 and leap.get_joint_velocity_start_index(free) == leap.nq
+    first_hinge = next(j["name"] for j in leap.desc["joints"] if j["type"] == "hinge")
+    assert leap.get_joint_position_start_index(first_hinge) == 7 and leap.get_joint_velocity_start_index(first_hinge) == leap.nq + 6
+    last = jn[-1]
+    assert leap.get_joint_position_start_index(last) == leap.nq - 1 and leap.get_joint_velocity_start_index(last) == leap.nq + leap.nv - 1
+    assert leap.get_sensor_start_index("trace_cube") == 16
+    with pytest.raises(KeyError):
+        leap.get_sensor_start_index("no_such_sensor")
+    with pytest.raises(KeyError):
+        leap.get_joint_position_start_index("no_such_joint")
