@@ -125,8 +125,20 @@ class Task(ABC, Generic[ConfigT]):
             raise KeyError(f"Invalid name '{joint_name}'. Valid names: {list(self._joint_addresses())}") from None
 
     @property
+    def locomotion_policy_path(self) -> str | None:
+        """judo/tasks/base.py:83-90: path of the ONNX locomotion policy of a policy task (the Spot tasks override it), None otherwise."""
+        return None
+
+    @property
     def uses_locomotion_policy(self) -> bool:
         return False
+
+    def pre_sim_step(self) -> None:
+        """judo/tasks/base.py:140-144: hooks of the SIMULATION node around its own `mj_step`; the plan step never calls them (kept so that a plugin task written
+        against the reference's base class subclasses this one unchanged)."""
+
+    def post_sim_step(self) -> None:
+        pass
 
     def gpu_model(self, device=None):
         from judo_amd.device import GpuModel
