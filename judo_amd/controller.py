@@ -138,6 +138,30 @@ class Controller:
     def optimizer_cfg(self) -> OptimizerConfig:
         return self.optimizer.config
 
+    @optimizer_cfg.setter
+    def optimizer_cfg(self, cfg: OptimizerConfig) -> None:  # controller.py:164-167 (the GUI swaps whole config objects in)
+        self.optimizer.config = cfg
+
+    @property
+    def optimizer_cls(self) -> type:  # controller.py:169-177
+        return type(self.optimizer)
+
+    @property
+    def optimizer_config_cls(self) -> type:
+        return type(self.optimizer.config)
+
+    @property
+    def task_config(self):  # controller.py:179-187
+        return self.task.config
+
+    @task_config.setter
+    def task_config(self, cfg) -> None:
+        self.task.config = cfg
+
+    @property
+    def action_normalizer_type(self) -> str:  # controller.py:139-142
+        return self.controller_cfg.action_normalizer
+
     @property
     def horizon(self) -> float:
         return self.controller_cfg.horizon

@@ -564,3 +564,18 @@ def test_task_index_getters_by_name():
         leap.get_sensor_start_index("no_such_sensor")
     with pytest.raises(KeyError):
         leap.get_joint_position_start_index("no_such_joint")
+
+
+def test_controller_helper_properties_of_the_reference_exist():
+    """judo/controller/controller.py:109-207: the accessors the app layer uses on a Controller (config swaps from the GUI, class lookups)."""
+    import inspect
+
+    from judo_amd.controller import Controller
+
+    for name in ("horizon", "nu", "max_num_traces", "max_opt_iters", "spline_order", "spline_data", "action_normalizer_type", "num_timesteps", "rollout_times",
+                 "spline_timesteps", "optimizer_cfg", "optimizer_cls", "optimizer_config_cls", "task_config", "time", "controller_cfg"):
+        assert isinstance(inspect.getattr_static(Controller, name), property), name
+    for name in ("optimizer_cfg", "task_config", "time", "controller_cfg"):
+        assert inspect.getattr_static(Controller, name).fset is not None, name
+    for name in ("update_action", "action", "update_spline", "reset", "update_traces", "update_states"):
+        assert callable(getattr(Controller, name)), name
