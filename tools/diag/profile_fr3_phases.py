@@ -1,4 +1,4 @@
-"""Per-phase shader-cycle split of the fr3 kernel (needs a -DJH_V3_PHASES -DJH_V3_EXITSTATS build, JUDO_AMD_LIB=build/libjudo_amd_v3ph.so)."""
+"""Per-phase shader-cycle split of the fr3 kernel (needs a -DJH_V6_PHASES -DJH_V6_EXITSTATS build of jh_engine_v6.hip, JUDO_AMD_LIB=build/libjudo_amd_v6ph.so)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
