@@ -8,6 +8,8 @@
 //   finger slide: +-axis_f
 // and J'WJ = col_x' (Fr' W Fr) col_y goes into a dof-space Hessian in LDS with float atomics, whose rows the lanes then factorise as before.
 // Same lane roles as jh_engine_v3.hip (lane l < 6: free-body dof l; 6..14: arm dof l - 6; 15: right-hand side), same solver, same results to summation order.
+#include <type_traits>
+
 #include "jh_coop.h"
 
 using namespace jh_eng;
@@ -17,7 +19,16 @@ namespace {
 
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, NMB = 10;
-constexpr int NCP = 32, NSL = NCP / G, MAXHIT = 64, RAW_F = 8, JW = NVT * 3;  // MAXHIT: broad-phase survivors (candidate pairs) per rollout and step, 16 bits each
+#ifndef JH_V6_NSBIG
+#define JH_V6_NSBIG 4
+#endif
+#ifndef JH_V6_BIGPROB
+#define JH_V6_BIGPROB 0.999999  // how sure the compiler may be that a wave-step stays on the two-slot copy of the solver (block frequencies steer the placement of register spills)
+#endif
+// General contacts: NCP in the LDS pool (two slots per lane, the common case); a rollout with more -- a gripper pressed flat onto the table stacks 4-point manifolds of ten pad
+// boxes: 40-60 contacts, the reference's SHIPPED 1 s horizon visits such states all the time -- writes the rest to a row of global memory, and its wave runs a second copy
+// of the constraint rows + Newton solver with NSBIG slots per lane (the leap kernel's recipe, jh_engine_v5.hip `solve_step`).
+constexpr int NCP = 32, NSL = NCP / G, NSBIG = JH_V6_NSBIG, NOVF = (NSBIG - NSL) * G, MAXHIT = 64, RAW_F = 8, JW = NVT * 3;  // MAXHIT: broad-phase survivors (candidate pairs) per rollout and step, 16 bits each
 constexpr int MAXDT = 32;  // box pairs behind the distance sensors
 #ifndef JH_V6_NFS
 #define JH_V6_NFS 6
@@ -62,7 +73,7 @@ struct __attribute__((aligned(16))) RS6 {  // per-rollout shared state
 };
 
 struct Sink6 {  // contact sink of the narrow phase
-  RS6* S; int* overflow; int pair; bool ff;
+  RS6* S; int* overflow; int pair; bool ff; float* ovf;  // ovf: this rollout's row of the global overflow pool (NOVF x RAW_F floats), or null
   __device__ __forceinline__ void push(const float* pos, const float* n, float dist) {
     float* e;
     if (ff) {  // finger against finger: the point itself is not needed (both sides slide along one line: no lever arm enters)
@@ -73,8 +84,9 @@ struct Sink6 {  // contact sink of the narrow phase
       return;
     } else {
       int i = atomicAdd(&S->ncon, 1);
-      if (i >= NCP) { if (overflow) atomicAdd(overflow, 1); return; }
-      e = S->raw[i];
+      if (i < NCP) e = S->raw[i];
+      else if (ovf && i < NCP + NOVF) e = ovf + (i - NCP) * RAW_F;
+      else { if (overflow) atomicAdd(overflow, 1); return; }
     }
     e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = n[0]; e[4] = n[1]; e[5] = n[2]; e[6] = dist; e[7] = __int_as_float(pair);
   }
@@ -220,6 +232,7 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
   }
 }
 
+template <int NS>
 __device__ __forceinline__ float lane_rows_cost(const Slot6* sl, const SlotF* sf, float sff, const DofRows6& dr, bool eq_lane, float eD, float ejar) {
   float cs = 0.f;
 #pragma unroll
@@ -228,7 +241,7 @@ __device__ __forceinline__ float lane_rows_cost(const Slot6* sl, const SlotF* sf
     float f[3], W[6]; cs += pyramid_eval(jar, sf[k].D, sf[k].mu, f, W);
   }
 #pragma unroll
-  for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) { float f[3], W[6]; cs += pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, W); }
+  for (int k = 0; k < NS; k++) if (sl[k].sa > -2) { float f[3], W[6]; cs += pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, W); }
   if (dr.fl > 0.f) {
     float x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
     if (x <= -lim) cs += -0.5f * dr.fR * fl * fl - fl * x; else if (x >= lim) cs += -0.5f * dr.fR * fl * fl + fl * x; else cs += 0.5f * dr.fD * x * x;
@@ -238,6 +251,7 @@ __device__ __forceinline__ float lane_rows_cost(const Slot6* sl, const SlotF* sf
   return cs;
 }
 
+template <int NS>
 __device__ __forceinline__ void lane_rows_dir(const Slot6* sl, const SlotF* sf, float sff, float spf, const DofRows6& dr, bool eq_lane, float eD, float ejar, float ejp, float al, float* d1, float* d2) {
   float g1 = 0.f, g2 = 0.f;
   const float sal = fmaf(al, spf, sff);  // a13 + a14 at the trial point
@@ -248,7 +262,7 @@ __device__ __forceinline__ void lane_rows_dir(const Slot6* sl, const SlotF* sf, 
     pyramid_dir(jar, jp, sf[k].D, sf[k].mu, &g1, &g2);
   }
 #pragma unroll
-  for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) {
+  for (int k = 0; k < NS; k++) if (sl[k].sa > -2) {
     const float* jp = sl[k].jp;
     float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
     pyramid_dir(jar, jp, sl[k].D, sl[k].mu, &g1, &g2);
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
                                                     const float* __restrict__ sigma, const float* __restrict__ W, const float* __restrict__ lohi,
                                                     const float* __restrict__ tp, int phase, int N, int n_offset, int H, int K,
                                                     float* __restrict__ costs, float* __restrict__ knots_out, const float* __restrict__ controls,
-                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats, int dshift, float* __restrict__ trace) {
+                                                    float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats, int dshift, float* __restrict__ trace, float* __restrict__ ovf_all) {
   __shared__ RS6 sRS[RPW];
   __shared__ int sDT[MAXDT][3];  // distance-sensor tasks: sensordata address, geom a, geom b
   __shared__ int sNDT, sDadr[8];
@@ -632,7 +646,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           float p1[3], R1[9], p2[3], R2[9], h1[3] = {f1[GF_SIZE], f1[GF_SIZE + 1], f1[GF_SIZE + 2]}, h2[3] = {f2[GF_SIZE], f2[GF_SIZE + 1], f2[GF_SIZE + 2]};
           geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, R1, true); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, R2, true);
           const int sbA = gI[m.oAGI + g1 * GEOM_I], sbB = gI[m.oAGI + g2 * GEOM_I];
-          Sink6 sk{&S, stats, p, sbA >= 1 && sbB >= 1};
+          Sink6 sk{&S, stats, p, sbA >= 1 && sbB >= 1, ovf_all ? ovf_all + (size_t)nc * (NOVF * RAW_F) : nullptr};  // (copies of a rollout in latency mode write the same values to the same row)
           if (gI[m.oAGI + g2 * GEOM_I + 1] == GCAPSULE) collide_box_capsule(sk, p1, R1, h1, p2, R2, h2[0], h2[1]);  // (a pair's capsule is its second geom: jh_model_is_fr3)
           else collide_box_box(sk, p1, R1, h1, p2, R2, h2);
         }
@@ -641,7 +655,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     __syncthreads();
     PH6(3)
     // ================================================================ constraint rows
-    const int ncon = S.ncon < NCP ? S.ncon : NCP;
     const int nff = S.nff < NFF ? S.nff : NFF;
     SlotF sf[NFS];
 #pragma unroll
@@ -674,15 +687,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
     }
     __syncthreads();
-    Slot6 sl[NSL];
+    // The constraint rows and the Newton solver exist once per slot count (jh_engine_v5.hip does the same): a wave in which some rollout has more general contacts than the
+    // LDS pool holds runs the copy with NSBIG slots per lane, whose upper slots come from the rollout's row of the global overflow pool; every other wave the copy with NSL.
+    float a_own; int iters_this = 0;
+    auto solve_step = [&](auto NS_) __attribute__((always_inline)) {
+    constexpr int NS = decltype(NS_)::value;
+    const int ncon = S.ncon < 16 * NS ? S.ncon : 16 * NS;
+    Slot6 sl[NS];
 #pragma unroll
-    for (int k = 0; k < NSL; k++) {  // owner lanes: frame, point, sides, per-pair solver parameters, reference acceleration
+    for (int k = 0; k < NS; k++) {  // owner lanes: frame, point, sides, per-pair solver parameters, reference acceleration
       const int c = l + 16 * k;
       sl[k].sa = -2; sl[k].sb = -2; sl[k].D = 0.f; sl[k].mu = 0.f;
       for (int w = 0; w < 9; w++) sl[k].fr[w] = 0.f;
       for (int w = 0; w < 3; w++) sl[k].pos[w] = sl[k].aref[w] = sl[k].jar[w] = sl[k].jp[w] = 0.f;
       if (c < ncon) {
-        const float* e = S.raw[c];
+        const float* e = c < NCP ? S.raw[c] : ovf_all + (size_t)nc * (NOVF * RAW_F) + (c - NCP) * RAW_F;
         sl[k].pos[0] = e[0]; sl[k].pos[1] = e[1]; sl[k].pos[2] = e[2];
         sl[k].fr[0] = e[3]; sl[k].fr[1] = e[4]; sl[k].fr[2] = e[5];
         make_frame(sl[k].fr);
@@ -724,40 +743,40 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     }
     PH6(4)
     // ================================================================ Newton solver
-    float a_own, sff = 0.f;  // sff = a13 + a14 of the current iterate: all a finger-finger contact sees of it
+    float sff = 0.f;  // sff = a13 + a14 of the current iterate: all a finger-finger contact sees of it
     const float iMd = 1.f / Md_own;
     const float snorm = gsum(hasdof ? fs_own * fs_own * iMd : 0.f);
-    int iters_this = 0;
+    iters_this = 0;
     {
       // ---- warm start: the better of last step's acceleration and the unconstrained one
       {
         if (hasdof) { S.vec[0][l] = qws; S.vec[1][l] = a0_own; S.vec[2][l] = qws - a0_own; }
         __syncthreads();
-        float xc[6], jar_ws[NSL][3];
+        float xc[6], jar_ws[NS][3];
         for (int k = 0; k < 6; k++) xc[k] = S.vec[0][k];
-        for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) { float jx[3]; slot_Jx(sl[k], S, xc, S.vec[0] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
+        for (int k = 0; k < NS; k++) if (sl[k].sa > -2) { float jx[3]; slot_Jx(sl[k], S, xc, S.vec[0] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
         const float sff_ws = S.vec[0][13] + S.vec[0][14], sff_0 = S.vec[1][13] + S.vec[1][14];
         dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
         ejar = has_eq ? quad_get(qws, 1) - e_a1 * quad_get(qws, 2) - earef : 0.f;
         float mdw = 0.f;
         if (isarm) { for (int a = 0; a < NA; a++) mdw += S.M[ai][a] * S.vec[2][6 + a]; } else if (iscube) mdw = Md_own * (qws - a0_own);
-        const float cost_ws = gsum(lane_rows_cost(sl, sf, sff_ws, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
-        for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) jar_ws[k][w] = sl[k].jar[w];
+        const float cost_ws = gsum(lane_rows_cost<NS>(sl, sf, sff_ws, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
+        for (int k = 0; k < NS; k++) for (int w = 0; w < 3; w++) jar_ws[k][w] = sl[k].jar[w];
         const float jf_ws = dr.jf, jl_ws = dr.jl, ej_ws = ejar;
         for (int k = 0; k < 6; k++) xc[k] = S.vec[1][k];
-        for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) { float jx[3]; slot_Jx(sl[k], S, xc, S.vec[1] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
+        for (int k = 0; k < NS; k++) if (sl[k].sa > -2) { float jx[3]; slot_Jx(sl[k], S, xc, S.vec[1] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
         dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
         ejar = has_eq ? quad_get(a0_own, 1) - e_a1 * quad_get(a0_own, 2) - earef : 0.f;
-        const float cost_0 = gsum(lane_rows_cost(sl, sf, sff_0, dr, eq_lane, eD, ejar));
+        const float cost_0 = gsum(lane_rows_cost<NS>(sl, sf, sff_0, dr, eq_lane, eD, ejar));
         if (cost_ws < cost_0) {
           a_own = qws;
-          for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] = jar_ws[k][w];
+          for (int k = 0; k < NS; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] = jar_ws[k][w];
           dr.jf = jf_ws; dr.jl = jl_ws; ejar = ej_ws; sff = sff_ws;
         } else { a_own = a0_own; sff = sff_0; }
         __syncthreads();
       }
       bool has_rows_l = dr.fl > 0.f || dr.lims != 0.f || has_eq;
-      for (int k = 0; k < NSL; k++) has_rows_l |= sl[k].sa > -2;
+      for (int k = 0; k < NS; k++) has_rows_l |= sl[k].sa > -2;
       for (int k = 0; k < NFS; k++) has_rows_l |= sf[k].D > 0.f;
       bool act = gor((int)has_rows_l) != 0;
       if (!act) { a_own = a0_own; sff = 0.f; }
@@ -768,7 +787,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         // slots made opaque it recomputes from the 25 / 8 numbers of a slot instead (jh_engine_v5.hip found the same)
 #if JH_V6_OPAQUE
 #pragma unroll
-        for (int k = 0; k < NSL; k++) {
+        for (int k = 0; k < NS; k++) {
           OPAQUE6(sl[k].sa); OPAQUE6(sl[k].sb);
           for (int w = 0; w < 3; w++) OPAQUE6(sl[k].pos[w]);
           for (int w = 0; w < 9; w++) OPAQUE6(sl[k].fr[w]);
@@ -808,7 +827,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         __syncthreads();
         if (act) {
 #pragma unroll
-          for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) {
+          for (int k = 0; k < NS; k++) if (sl[k].sa > -2) {
             const Slot6& t = sl[k];
             float f[3], Wm[6]; pyramid_eval(t.jar, t.D, t.mu, f, Wm);
             if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
@@ -859,7 +878,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         __syncthreads();
         if (act) {
 #pragma unroll
-          for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) {
+          for (int k = 0; k < NS; k++) if (sl[k].sa > -2) {
             float f[3], Wm[6]; pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, Wm);
             if (Wm[0] == 0.f && Wm[2] == 0.f && Wm[5] == 0.f) continue;  // no active pyramid row
             slot_assemble(S, sl[k], Wm);
@@ -925,14 +944,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #endif
         if (act && !(gp < 0.f)) act = false;
 #pragma unroll
-        for (int k = 0; k < NSL; k++) if (sl[k].sa > -2) slot_Jx(sl[k], S, p, p + 6, sl[k].jp);
+        for (int k = 0; k < NS; k++) if (sl[k].sa > -2) slot_Jx(sl[k], S, p, p + 6, sl[k].jp);
         const float spf = p[13] + p[14];
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         ejp = has_eq ? p[13] - e_a1 * p[14] : 0.f;
         float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
         for (int ls = 0; ls < JH_V6_LSCAP && __any(lsact); ls++) {
           float d1, d2;
-          lane_rows_dir(sl, sf, sff, spf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
+          lane_rows_dir<NS>(sl, sf, sff, spf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
@@ -951,7 +970,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #endif
         if (act) {
           a_own += alpha * p_own;
-          for (int k = 0; k < NSL; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] += alpha * sl[k].jp[w];
+          for (int k = 0; k < NS; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] += alpha * sl[k].jp[w];
           sff = fmaf(alpha, spf, sff);
           dr.jf += alpha * dr.pf; dr.jl += alpha * dr.pl; ejar += alpha * ejp;
 #ifdef JH_V6_EXITSTATS
@@ -969,6 +988,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
 #endif
     }
+    };
+    if (__builtin_expect_with_probability(ovf_all != nullptr && __any(S.ncon > NCP), 0, JH_V6_BIGPROB)) {
+      __threadfence();  // the overflow rows were written with plain global stores by other lanes of this wave
+      solve_step(std::integral_constant<int, NSBIG>{});
+    } else solve_step(std::integral_constant<int, NSL>{});
     PH6(5)
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     float qc[7], vc[6];  // the free body's state after the step (registers from here to the end of the step only)
@@ -1101,9 +1125,14 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
   JH_REQUIRE(K <= 8, "rollout_cost: the cooperative arm kernel keeps at most 8 knots per actuator in registers (K=%d)", K);
   const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
   int grid = (N + per_wave - 1) / per_wave;
+  // one overflow row per rollout for the general contacts above the LDS pool: stream-ordered allocation (the pool hands the same block back launch after launch),
+  // no state on the model handle
+  float* ovf = nullptr;
+  JH_HIP(hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st));
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
-                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace);
+                     costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
   JH_HIP(hipGetLastError());
+  JH_HIP(hipFreeAsync(ovf, st));
   return JH_OK;
 }
 
@@ -1112,9 +1141,14 @@ int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, c
   if (!jh_model_is_fr3(m)) { jh_set_error("rollout_materialize: the cooperative arm kernel is instantiated for fr3_pick only"); return JH_ERR_UNSUPPORTED; }
   const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
   int grid = (N + per_wave - 1) / per_wave;
+  // one overflow row per rollout for the general contacts above the LDS pool: stream-ordered allocation (the pool hands the same block back launch after launch),
+  // no state on the model handle
+  float* ovf = nullptr;
+  JH_HIP(hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st));
   hipLaunchKernelGGL(k_fr3_v6<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
-                     (float*)nullptr, controls, states, sensors, m->d_stats, dshift, (float*)nullptr);
+                     (float*)nullptr, controls, states, sensors, m->d_stats, dshift, (float*)nullptr, ovf);
   JH_HIP(hipGetLastError());
+  JH_HIP(hipFreeAsync(ovf, st));
   return JH_OK;
 }

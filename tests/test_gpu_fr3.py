@@ -226,10 +226,11 @@ def test_fr3_arm_links_collide_with_table_and_cube(gpu):
     link_con = np.array([sum("link" in names[int(r[14])] for r in f["contacts"]) for f in fw])
     ncon = np.array([f["ncon"] for f in fw])
     assert (link_con > 0).sum() > N // 2 and link_con.max() >= 4
-    # (the hand box and the twelve finger boxes come down on the table with the links: a third of these states holds more than the kernel's 32 contacts outside
-    # the gripper; those are counted as dropped and left out of the comparison)
-    ok = (ncon <= 32) & (link_con > 0)
-    assert ok.sum() >= N // 4
+    # (the hand box and the twelve finger boxes come down on the table with the links; generation 1 holds 32 contacts outside the gripper, generation 3 up to 64 --
+    # `test_fr3_general_contacts_beyond_the_lds_pool` below is about those)
+    ok32 = (ncon <= 32) & (link_con > 0)
+    ok = (ncon <= 64) & (link_con > 0)
+    assert ok32.sum() >= N // 4
     rs, _ = om.rollout(x0, U)
     be = GpuRolloutBackend("fr3_pick", N)
     gs, _, _ = be.rollout(x0, U)
@@ -239,6 +240,7 @@ def test_fr3_arm_links_collide_with_table_and_cube(gpu):
     e1 = (np.abs(gs[:, 0, 16:] - rs[:, 0, 16:]) / sc).max(axis=1)
     assert np.median(e1[ok]) < 2e-5 and e1[ok].max() < 2e-3, (np.median(e1[ok]), e1[ok].max())
     np.testing.assert_allclose(gs[ok, 0, :16], rs[ok, 0, :16], atol=2e-5)
+    assert be.model.stats()["contact_overflow"] <= 64 * H * int((ncon > 60).sum() + 1)  # nothing is dropped below the capacity
     few = ok & (ncon <= 20)
     eH = np.abs(gs[few, -1, :16] - rs[few, -1, :16]).max(axis=1)
     assert few.sum() >= 10 and np.median(eH) < 1e-4 and np.percentile(eH, 75) < 5e-3, (few.sum(), np.median(eH), np.percentile(eH, 75))
@@ -247,4 +249,60 @@ def test_fr3_arm_links_collide_with_table_and_cube(gpu):
     b1.model.set_kernel(1)
     g1, _, _ = b1.rollout(x0, U[:, :2])
     e = (np.abs(g1[:, 0, 16:] - gs[:, 0, 16:]) / sc).max(axis=1)
-    assert np.median(e[ok]) < 2e-5 and e[ok].max() < 5e-3, (np.median(e[ok]), e[ok].max())
+    assert np.median(e[ok32]) < 2e-5 and e[ok32].max() < 5e-3, (np.median(e[ok32]), e[ok32].max())
+
+
+def test_fr3_general_contacts_beyond_the_lds_pool(gpu):
+    """The reference's SHIPPED fr3_pick configuration (64 rollouts, 1 s = 250 steps, judo/optimizers/overrides.py, judo/controller/overrides.py) presses the gripper onto
+    the table all the time: ten pad boxes with 4-point manifolds are 40-60 contacts outside the gripper, where the kernel's LDS pool holds 32 (0.3-0.4 contacts dropped per
+    rollout-step before round 3).  Generation 3 keeps up to 64: the rest lives in a row of global memory and the wave runs the four-slot copy of the solver.  States of that
+    very workload with 33..64 such contacts, single steps against the oracle; and the workload itself no longer drops anything."""
+    import torch
+
+    from judo_amd.controller import make_controller
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from oracle import oracle as O
+
+    ctrl = make_controller("fr3_pick", "cem")
+    ctrl.solver_warnings = False
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.optimizer.seed(3)
+    assert (ctrl.optimizer.num_rollouts, ctrl.num_timesteps) == (64, 250)
+    ctrl.solver_stats()
+    xs, t = [], 0.0
+    for step in range(100):
+        ctrl.force_materialize = step >= 30 and step % 5 == 0  # (the fused kernel otherwise: it is the one whose counters are asserted below)
+        ctrl.time = t
+        ctrl.update_action()
+        t += 0.05
+        if ctrl.force_materialize:
+            torch.cuda.synchronize()
+            st = ctrl.last_rollout[0].cpu().numpy().astype(np.float64)
+            xs.append(st[::4, ::5].reshape(-1, st.shape[-1]))
+    stats = ctrl.solver_stats()
+    assert stats["contact_overflow"] < 1e-4 * stats["steps"], stats  # (0.33 per step in round 2's kernel)
+    xs = np.concatenate(xs)
+    om = O.Model("fr3_pick")
+    gbody = [g["body"] for g in om.desc["geoms"]]
+    fing = {i for i, b in enumerate(om.desc["bodies"]) if "finger" in b["name"]}
+    gen, ff = np.zeros(len(xs), int), np.zeros(len(xs), int)
+    for i, x in enumerate(xs):
+        for r in om.forward(x[:16], x[16:], x[7:15])["contacts"]:
+            if gbody[int(r[13])] in fing and gbody[int(r[14])] in fing:
+                ff[i] += 1
+            else:
+                gen[i] += 1
+    sel = (gen > 32) & (gen <= 64) & (ff <= 96)
+    assert sel.sum() >= 10, (sel.sum(), np.bincount(np.minimum(gen // 8, 12)))
+    x = xs[sel]
+    U = x[:, None, 7:15]
+    ref, _ = om.rollout(x, U)
+    be = GpuRolloutBackend("fr3_pick", len(x))
+    be.model.stats()
+    g, _, _ = be.rollout(x, U)
+    assert be.model.stats()["contact_overflow"] == 0
+    sc = np.maximum(1.0, np.abs(ref[:, 0, 16:]).max(axis=1, keepdims=True))
+    e = (np.abs(g[:, 0, 16:] - ref[:, 0, 16:]) / sc).max(axis=1)
+    assert np.median(e) < 2e-5 and e.max() < 2e-3, (np.median(e), e.max())
+    np.testing.assert_allclose(g[:, 0, :16], ref[:, 0, :16], atol=2e-5)
