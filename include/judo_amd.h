@@ -87,6 +87,11 @@ int jh_register_xcheck(const jh_xcheck_launchers* launchers);
  * with on = 0, the cube's contacts alone (what generations 1 and 2 model). */
 int jh_model_set_self_collision(jh_model* m, int on);
 
+/* leap_cube family, kernel generation 3: contacts a rollout can hold.  48 (default: all in LDS) or 64 (a second build of the kernel, jh_engine_v5_cap64.hip: the 16 above the LDS
+ * pool in a per-rollout row of global memory; 2.8 % slower on every plan step).  The headline workload drops 2e-6 contacts per rollout-step at 48; the shipped leap_cube_down and
+ * caltech_leap_cube workloads 2e-4 .. 4e-4, which is why judo_amd selects 64 for those two models.  jh_model_limits out[3] reports the setting. */
+int jh_model_set_contact_capacity(jh_model* m, int contacts);
+
 /* Traces without a second rollout (judo/controller/controller.py:323-363, `update_traces`: line segments of the best rollouts' `trace*` framepos sensors).  The
  * reference reads them out of the sensor array its rollout materialises for every sample; the fused path has no such array, so round 1-2 re-rolled the elites in
  * materialise mode when the traces were read (8 ms on the headline workload: one lone wave for 64 serial steps).  jh_rollout_cost_traced (jh_rollout_cost with one more argument) on
@@ -107,7 +112,7 @@ int jh_trace_gather(const float* rec_in /* DEVICE, k x stride_in */, int k, int 
 /* Limits of this model's kernels: out[0] = largest knot count K the fused kernel (jh_rollout_cost) accepts -- the cooperative fr3_pick kernel
  * keeps a lane's knots on chip (8 of them); the leap_cube kernel of generation 3 reads them from memory every step and is bounded by
  * JH_MAX_KNOT_DIM / nu alone.  A larger K goes through jh_spline_controls + jh_rollout_materialize + jh_task_reward, which have no such limit;
- * out[1] = JH_MAX_KNOT_DIM; out[2] = JH_MAX_ELITES; out[3] = contact capacity per rollout of the general pool (leap_cube generation 3: 48;
+ * out[1] = JH_MAX_KNOT_DIM; out[2] = JH_MAX_ELITES; out[3] = contact capacity per rollout of the general pool (leap_cube generation 3: 48 or 64, jh_model_set_contact_capacity;
  * fr3_pick generation 3: 64 -- 32 on chip, 32 in a row of global memory -- next to its 96 pad-against-pad slots; 0 = the model has at most one contact).  HOST pointer. */
 int jh_model_limits(const jh_model* m, int* out /* HOST, 4 ints */);
 /* out[0] of jh_model_limits is an upper bound over all horizons.  The one-lane kernels (cartpole, cylinder_push, kernel generation 1) stage W (H x K) and

@@ -31,7 +31,7 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   JH_HIP(hipSetDevice(device));
   jh_model* m = new jh_model();
   m->device = device; m->kind = (int)h.kind; m->nq = h.nq; m->nv = h.nv; m->nu = h.nu; m->ns = h.ns; m->ntaskparam = h.ntaskparam;
-  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1;
+  m->nf = h.nfloat; m->ni = h.nint; m->d_f = nullptr; m->d_i = nullptr; m->d_stats = nullptr; m->kernel_gen = (h.kind == JH_TASK_LEAP_CUBE || h.kind == JH_TASK_FR3_PICK) ? 3 : 2; m->self_collision = 1; m->contact_capacity = 48;
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
@@ -117,6 +117,13 @@ extern "C" int jh_model_trace_layout(const jh_model* m, int* out) {
   return JH_OK;
 }
 
+extern "C" int jh_model_set_contact_capacity(jh_model* m, int contacts) {
+  JH_REQUIRE(m != nullptr, "model_set_contact_capacity: null pointer");
+  JH_REQUIRE(m->kind == JH_TASK_LEAP_CUBE && (contacts == 48 || contacts == 64), "model_set_contact_capacity: the leap_cube kernel is built for 48 and for 64 contacts per rollout (got %d)", contacts);
+  m->contact_capacity = contacts;
+  return JH_OK;
+}
+
 extern "C" int jh_model_set_self_collision(jh_model* m, int on) {
   JH_REQUIRE(m != nullptr, "model_set_self_collision: null pointer");
   m->self_collision = on ? 1 : 0;
@@ -149,7 +156,7 @@ extern "C" int jh_model_limits(const jh_model* m, int* out) {
   out[0] = max_fused_knots(m, 1);  // upper bound over all horizons; jh_model_max_fused_knots(m, H) is the figure for a given H
   out[1] = JH_MAX_KNOT_DIM;
   out[2] = JH_MAX_ELITES;
-  out[3] = m->kind == JH_TASK_LEAP_CUBE ? (m->kernel_gen >= 3 ? 48 : 32) : (m->kind == JH_TASK_FR3_PICK ? (m->kernel_gen >= 3 ? 64 : 32) : 0);  // (generation 3: leap 48, all in LDS; fr3 32 in LDS + 32 in a row of global memory, next to its 96 pad-against-pad slots)
+  out[3] = m->kind == JH_TASK_LEAP_CUBE ? (m->kernel_gen >= 3 ? m->contact_capacity : 32) : (m->kind == JH_TASK_FR3_PICK ? (m->kernel_gen >= 3 ? 64 : 32) : 0);  // (generation 3: leap 48, all in LDS, or 64 with 16 in a row of global memory: jh_model_set_contact_capacity; fr3 32 in LDS + 32 in such a row, next to its 96 pad-against-pad slots)
   return JH_OK;
 }
 
@@ -232,7 +239,9 @@ extern "C" int jh_rollout_cost_traced(const jh_model* m, const float* x0, const 
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH)
     return jh_simple_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
-  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
+  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3)
+    return m->contact_capacity > 48 ? jh_engine5_rollout_cost_cap64(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st)
+                                    : jh_engine5_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace, st);
   if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_rollout_cost(m, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, trace, st);
   JH_REQUIRE(trace == nullptr, "rollout_cost_traced: only the product kernels (generation 3, cartpole, cylinder_push) write trace sensors");
   if (!g_xcheck.rollout_cost) { jh_set_error("rollout_cost: no kernel for this model / generation in this library"); return JH_ERR_UNSUPPORTED; }
@@ -246,7 +255,8 @@ extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0
   JH_REQUIRE(N > 0 && H > 0, "rollout_materialize: N and H must be positive (N=%d H=%d)", N, H);
   hipStream_t st = (hipStream_t)stream;
   if (m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) return jh_simple_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
-  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3) return jh_engine5_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
+  if (m->kind == JH_TASK_LEAP_CUBE && m->kernel_gen == 3)
+    return m->contact_capacity > 48 ? jh_engine5_materialize_cap64(m, x0, x0_batched, controls, N, H, states, sensors, st) : jh_engine5_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (m->kind == JH_TASK_FR3_PICK && m->kernel_gen == 3) return jh_engine6_materialize(m, x0, x0_batched, controls, N, H, states, sensors, st);
   if (!g_xcheck.rollout_materialize) { jh_set_error("rollout_materialize: no kernel for this model / generation in this library"); return JH_ERR_UNSUPPORTED; }
   return g_xcheck.rollout_materialize(m, m->kernel_gen, x0, x0_batched, controls, N, H, states, sensors, stream);

@@ -1420,7 +1420,10 @@ bool model_is_leap(const jh_model* m) {
 #else
 #define JH_V5_DYNBYTES 0
 #endif
-int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+#ifndef JH_V5_NAME
+#define JH_V5_NAME(f) f
+#endif
+int JH_V5_NAME(jh_engine5_rollout_cost)(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
                             const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st) {
   if (!model_is_leap(m)) { jh_set_error("rollout_cost: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
 #if JH_V5_KNOTS_LDS
@@ -1441,7 +1444,7 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
   return JH_OK;
 }
 
-int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+int JH_V5_NAME(jh_engine5_materialize)(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st) {
   if (!model_is_leap(m)) { jh_set_error("rollout_materialize: the cooperative engine kernel is instantiated for leap_cube only"); return JH_ERR_UNSUPPORTED; }
   const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;

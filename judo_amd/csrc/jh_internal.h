@@ -25,6 +25,7 @@ struct jh_model {
   float* d_f;  // device copy of the float section
   int* d_i;    // device copy of the int section
   int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
+  int contact_capacity;  // leap_cube generation 3: 48 (all in LDS, jh_engine_v5.hip) or 64 (jh_engine_v5_cap64.hip); jh_model_set_contact_capacity
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
   int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
   std::vector<float> h_f;
@@ -97,6 +98,10 @@ int jh_engine5_rollout_cost(const jh_model* m, const float* x0, const float* nom
                             const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st);
 int jh_engine5_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
                            hipStream_t st);
+int jh_engine5_rollout_cost_cap64(const jh_model* m, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
+                                  const float* lohi, const float* tp, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, hipStream_t st);
+int jh_engine5_materialize_cap64(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
+                                 hipStream_t st);
 
 // jh_engine_v3.hip: cooperative kernel for fr3_pick (serial arm with a two-finger fork + free box, pyramidal cones)
 bool jh_model_is_fr3(const jh_model* m);

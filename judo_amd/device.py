@@ -55,6 +55,11 @@ class GpuModel:
         if gen and self.task == "fr3_pick":
             self.set_kernel(int(gen))
         self.self_collision = self.desc.get("family", self.task) == "leap_cube"  # library default: on where the kernel models it
+        # contacts a rollout can hold.  The leap kernel exists in two builds (48, all in LDS; 64 with 16 in global memory, 2.8 % slower): the headline model drops 2e-6
+        # contacts per rollout-step at 48, the SHIPPED workloads of the caged / primitive-hand variants 2e-4 .. 4e-4 (tools/diag/shipped_config_stats.py): those take 64
+        self.contact_capacity = 0
+        if self.desc.get("family", self.task) == "leap_cube":
+            self.set_contact_capacity(48 if self.task == "leap_cube" else 64)
 
     def set_kernel(self, generation: int) -> None:
         """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: the default; 2 = cooperative, one wave per SIMD; 1 = one lane per rollout)."""
@@ -62,6 +67,11 @@ class GpuModel:
         self.kernel_generation = int(generation)
         # only generation 3 of the leap family models the hand's own contacts: what bench.py / tests report must follow the kernel actually selected
         self.self_collision = self._self_collision_requested and self.kernel_generation == 3 and self.desc.get("family", self.task) == "leap_cube"
+
+    def set_contact_capacity(self, contacts: int) -> None:
+        """leap_cube family: 48 or 64 contacts per rollout (`jh_model_set_contact_capacity`)."""
+        _lib.check(_lib.lib().jh_model_set_contact_capacity(self.handle, int(contacts)), "jh_model_set_contact_capacity")
+        self.contact_capacity = int(contacts)
 
     def set_self_collision(self, on: bool) -> None:
         """leap_cube, kernel generation 3: model the hand's own contacts too (default) or the cube's alone."""
@@ -75,6 +85,12 @@ class GpuModel:
         out = (C.c_int * 3)()
         _lib.check(_lib.lib().jh_model_trace_layout(self.handle, out), "jh_model_trace_layout")
         return int(out[0]), int(out[1]), bool(out[2])
+
+    def limits(self) -> tuple[int, int, int, int]:
+        """`jh_model_limits`: (largest fused knot count, JH_MAX_KNOT_DIM, JH_MAX_ELITES, contact capacity per rollout)."""
+        out = (C.c_int * 4)()
+        _lib.check(_lib.lib().jh_model_limits(self.handle, out), "jh_model_limits")
+        return tuple(int(v) for v in out)
 
     @property
     def max_fused_knots(self) -> int:

@@ -160,7 +160,7 @@ def test_caltech_self_collision_single_steps_match_oracle(gpu):
     ok = np.ones(len(xs), dtype=bool)
     for i in range(len(xs)):
         f = om.forward(xs[i, :23], xs[i, 23:], q[i])
-        ok[i] = f["ncon"] <= POOL
+        ok[i] = f["ncon"] <= 64  # (this model runs the 64-contact build of the kernel: judo_amd/device.py)
         for row in f["contacts"]:
             ba, bb = body[int(row[13])], body[int(row[14])]
             n_static += (ba in static) != (bb in static)
@@ -175,7 +175,8 @@ def test_caltech_self_collision_single_steps_match_oracle(gpu):
     assert np.median(e) < 2e-5 and np.percentile(e, 95) < 2e-2, (np.median(e), np.percentile(e, 95))
 
 
-def test_random_states_with_the_cube_jammed_into_the_hand(gpu):
+@pytest.mark.parametrize("capacity", [48, 64])
+def test_random_states_with_the_cube_jammed_into_the_hand(gpu, capacity):
     """Random-state sweep (tools/diag/fuzz_leap.py, shortened): tangled hand configurations with the cube inside the hand at a random attitude -- cube contacts, the hand's own
     contacts and both at once, ~20 contacts per state, hard solves (the oracle needs up to 30 Newton iterations on some: the kernel's iteration cap is 50).  One physics step."""
     from judo_amd.rollout_backend import GpuRolloutBackend
@@ -191,17 +192,20 @@ def test_random_states_with_the_cube_jammed_into_the_hand(gpu):
     xs[:, 23:29] = rng.standard_normal((N, 6)) * np.array([0.2, 0.2, 0.2, 2, 2, 2])
     kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(N)])
     ncon = kinds[:, :3].sum(1)
-    ok = ncon <= POOL  # within the kernel's contact pool
-    big = ok & (ncon > 32)  # ... through the solver copy with three slots per lane (a wave takes it when one of its rollouts has more than 32 contacts)
-    assert ok.mean() > 0.9 and big.sum() > 100 and (ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)).sum() > 80, (ok.mean(), big.sum())
+    ok = ncon <= capacity  # within the kernel's contact capacity: 48 (the headline model's build, all in LDS) or 64 (the second build: 16 of them in global memory)
+    big = ok & (ncon > 32)  # ... through the solver copy with three / four slots per lane (a wave takes it when one of its rollouts has more than 32 contacts)
+    assert ok.mean() > (0.9 if capacity == 48 else 0.95) and big.sum() > 100 and (ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)).sum() > 80, (ok.mean(), big.sum())
     U = q[:, None, :]
     ref, _ = om.rollout(xs, U)
     be = GpuRolloutBackend("leap_cube", N)
+    assert be.model.contact_capacity == 48 and be.model.limits()[3] == 48
+    be.model.set_contact_capacity(capacity)
+    assert be.model.limits()[3] == capacity
     g, _, _ = be.rollout(xs, U)
     assert np.isfinite(g).all()
     scale = np.maximum(1.0, np.abs(ref[:, 0, 23:]).max(axis=1, keepdims=True))
     ev = (np.abs(g[:, 0] - ref[:, 0])[:, 23:] / scale).max(1)
     for name, sel in (("cube only", ok & (kinds[:, 0] > 0) & (kinds[:, 1] + kinds[:, 2] == 0)), ("cube and coupled chains", ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)),
-                      ("33 to 48 contacts", big), ("all", ok)):
+                      ("above 32 contacts", big), ("all", ok)):
         assert np.median(ev[sel]) < 5e-6 and np.percentile(ev[sel], 95) < 1e-4 and ev[sel].max() < 5e-2, (name, np.median(ev[sel]), np.percentile(ev[sel], 95), ev[sel].max())
     assert be.model.stats()["newton_cap_hits"] == 0
