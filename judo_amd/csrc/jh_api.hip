@@ -35,6 +35,14 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   const char* p = (const char*)blob + sizeof(h);
   m->h_f.assign((const float*)p, (const float*)p + h.nfloat);
   m->h_i.assign((const int*)(p + 4 * (size_t)h.nfloat), (const int*)(p + 4 * (size_t)h.nfloat) + h.nint);
+  {  // the cooperative kernels take a per-launch scratch block from the device's stream-ordered pool (contacts above the LDS pool): let the pool keep what it is
+     // handed back instead of returning it to the driver at every synchronisation (the default release threshold is 0: 0.2 ms per launch)
+    hipMemPool_t pool = nullptr; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+      unsigned long long keep = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+  }
   hipError_t e = hipMalloc(&m->d_f, 4 * (m->nf ? m->nf : 1));
   if (e == hipSuccess) e = hipMalloc(&m->d_i, 4 * (m->ni ? m->ni : 1));
   if (e == hipSuccess) e = hipMalloc(&m->d_stats, 64 * sizeof(int));
