@@ -4,7 +4,7 @@
 A "step" is one full plan step (`Controller.update_action`): sample -> clip -> spline -> rollout -> cost -> update,
 including the all-gather when several GPUs take part and the device->host copy of the new nominal knots.
 Default workload = BASELINE.json's metric configuration: leap_cube MPPI, 65 536 rollouts x H = 64 (K = 4, cubic,
-sigma = 0.2 ramp 4, lambda = 0.0025), synthetic standard-normal noise drawn on the device (seed 4, see --seed; every rank keeps its shard of the same draw), inputs
+sigma = 0.2 ramp 4, lambda = 0.0025), synthetic standard-normal noise drawn on the device (seed 1234, see --seed; every rank keeps its shard of the same draw), inputs
 resident in HBM; the plan time advances 0.05 s per step (control_freq 20 Hz).  With N GPUs the 65 536 rollouts are
 sharded (strong scaling: total work fixed) -- one process per GPU, one RCCL all-gather of a 66-float record per step.
 
@@ -220,10 +220,10 @@ def main() -> None:
     ap.add_argument("--optimizer", default=None)
     ap.add_argument("--rollouts", type=int, default=None)
     ap.add_argument("--horizon-steps", type=int, default=None)
-    # The bench closes the loop through the plan, so the noise stream decides which contact situations the plan visits and with them the cost of a plan step:
-    # 72.4-90.5 ms over eight seeds of the headline workload, mean 81.0 (profiles/r03_seed_sweep.txt).  The default is the seed closest to that mean (83.0 ms);
-    # rounds 1-3 up to that sweep used 1234 (88.7 ms, the second slowest of the eight).
-    ap.add_argument("--seed", type=int, default=4, help="seed of the optimizer's device noise stream (the same on every rank)")
+    # The bench closes the loop through the plan, so the noise stream decides which contact situations the plan visits and with them the cost of a plan step -- and the
+    # loop is chaotic in the last bits: the same eight seeds gave 72.4-90.5 ms (mean 81.0) on one build of round 3 and 74.0-87.8 (mean 81.9) on the next, with every
+    # seed's own number reshuffled (profiles/r03_seed_sweep.txt).  No seed stays representative across builds; the default is the one all rounds used.
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the optimizer's device noise stream (the same on every rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-collision", action="store_true", help="leap_cube: the cube's contacts only (round-1 model), not the hand's own")
     ap.add_argument("--settle", type=float, default=0.4, help="seconds of untimed plan steps on a throw-away plan before the W warm-up steps (runtime one-offs)")
@@ -442,8 +442,8 @@ def main() -> None:
             "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
                        "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters,
                        "noise_seed": args.seed,
-                       "closed_loop": "every plan step starts from the previous plan: ms_per_step depends on where the noise stream leads it (leap_cube, eight seeds: 72.4-90.5 ms, "
-                                      "mean 81.0; the default seed is the one closest to the mean; profiles/r03_seed_sweep.txt)",
+                       "closed_loop": "every plan step starts from the previous plan: ms_per_step depends on where the noise stream leads it, chaotically (leap_cube, eight seeds, final "
+                                      "round-3 build: 74.0-87.8 ms, mean 81.9 over 20 steps; 85.8-96.8, mean 89.4 over 100 steps; profiles/r03_seed_sweep.txt)",
                        "hand_self_collision": self_on if args.task.startswith("leap") else None,
                        "traces": ("read inside every timed plan step (update_traces is part of the reference's update_action): the fused kernel writes every rollout's trace sensors, "
                                   "the elites' rows are gathered on the device" if traces_in_step else "not read inside the timed steps; see plan_step_ms_with_traces")},
