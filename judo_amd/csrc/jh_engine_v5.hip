@@ -792,7 +792,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     float a_own, ac_own; int iters_this = 0;
     auto solve_step = [&](auto NS_) __attribute__((always_inline)) {
     constexpr int NS = decltype(NS_)::value;
-    const int ncon = S.ncon < 16 * NS ? S.ncon : 16 * NS;
+    const int ncap = (NOVF > 0 && ovf_all == nullptr && 16 * NS > NCP) ? NCP : 16 * NS;  // (no overflow rows: what the LDS pool holds)
+    const int ncon = S.ncon < ncap ? S.ncon : ncap;
     Slot sl[NS];
     {
       float wv3[3]; mulMV(wv3, S.xR[0], vc + 3);  // world angular velocity of the cube
@@ -1432,7 +1433,7 @@ int JH_V5_NAME(jh_engine5_rollout_cost)(const jh_model* m, const float* x0, cons
   const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;
   int grid = (N + per_block - 1) / per_block;
   float* ovf = nullptr;  // one row per rollout for the contacts above the LDS pool: stream-ordered allocation, no state on the model handle
-  if (NOVF > 0) JH_HIP(hipMallocAsync((void**)&ovf, (size_t)N * NOVF * POOL_F * sizeof(float), st));
+  if (NOVF > 0 && hipMallocAsync((void**)&ovf, (size_t)N * NOVF * POOL_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
                        knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
@@ -1450,7 +1451,7 @@ int JH_V5_NAME(jh_engine5_materialize)(const jh_model* m, const float* x0, int x
   const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;
   int grid = (N + per_block - 1) / per_block;
   float* ovf = nullptr;  // one row per rollout for the contacts above the LDS pool: stream-ordered allocation, no state on the model handle
-  if (NOVF > 0) JH_HIP(hipMallocAsync((void**)&ovf, (size_t)N * NOVF * POOL_F * sizeof(float), st));
+  if (NOVF > 0 && hipMallocAsync((void**)&ovf, (size_t)N * NOVF * POOL_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,

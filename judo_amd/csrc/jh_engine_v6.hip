@@ -1128,11 +1128,11 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
   // one overflow row per rollout for the general contacts above the LDS pool: stream-ordered allocation (the pool hands the same block back launch after launch),
   // no state on the model handle
   float* ovf = nullptr;
-  JH_HIP(hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st));
+  if (hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
                      costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
   JH_HIP(hipGetLastError());
-  JH_HIP(hipFreeAsync(ovf, st));
+  if (ovf) JH_HIP(hipFreeAsync(ovf, st));
   return JH_OK;
 }
 
@@ -1144,11 +1144,11 @@ int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, c
   // one overflow row per rollout for the general contacts above the LDS pool: stream-ordered allocation (the pool hands the same block back launch after launch),
   // no state on the model handle
   float* ovf = nullptr;
-  JH_HIP(hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st));
+  if (hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
   hipLaunchKernelGGL(k_fr3_v6<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
                      (float*)nullptr, controls, states, sensors, m->d_stats, dshift, (float*)nullptr, ovf);
   JH_HIP(hipGetLastError());
-  JH_HIP(hipFreeAsync(ovf, st));
+  if (ovf) JH_HIP(hipFreeAsync(ovf, st));
   return JH_OK;
 }

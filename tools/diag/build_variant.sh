@@ -7,7 +7,7 @@ name=$1; src=$2; shift 2
 base=$(basename "$src" .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Iinclude -Ijudo_amd/csrc $(cat "${src%.hip}.flags" 2>/dev/null) -c "$src" -o "build/${base}_${name}.o" "$@"
 objs=""
-for o in jh_api jh_simple jh_update jh_reward jh_engine_v5 jh_engine_v6 jh_engine_v4 jh_policy; do
+for o in jh_api jh_simple jh_update jh_reward jh_engine_v5 jh_engine_v5_cap64 jh_engine_v6 jh_engine_v4 jh_policy; do
   if [ "$o" == "$base" ]; then objs="$objs build/${base}_${name}.o"; else objs="$objs build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "build/libjudo_amd_${name}.so" $objs
