@@ -230,6 +230,7 @@ def main() -> None:
     ap.add_argument("--no-with-traces", action="store_true", help="skip the extra plan steps that measure what reading Controller.traces costs (run after the timed region)")
     ap.add_argument("--traces-outside-step", action="store_true", help="do not read Controller.traces inside the timed plan steps (rounds 1-2 timed it that way)")
     ap.add_argument("--no-cube-only", action="store_true", help="leap_cube: skip the extra cube-contacts-only steps run after the timed region")
+    ap.add_argument("--no-replay", action="store_true", help="skip the replay of the recorded plan inputs (the deterministic, round-to-round comparable figure) after the timed region")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
     args = ap.parse_args()
@@ -402,6 +403,35 @@ def main() -> None:
                      "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])),
                      "note": "hand self-collision off (the cube's contacts only): the model of round 1's 81.8 ms line, restarted from the same state and seed"}
         ctrl.model.set_self_collision(True)
+    # The timed steps above are a closed loop, chaotic in the last bits (+-9 % over seeds, reshuffled by every build).  The figure that IS comparable from build to build and
+    # from round to round: the plan inputs of 40 consecutive plan steps recorded once in round 2 (tools/diag/ab_fixed_inputs.py record), replayed with fixed per-step seeds.
+    replay = None
+    rfile = os.path.join(ROOT, "tools", "diag", {"leap_cube": "ab_inputs_leap.npz", "fr3_pick": "ab_inputs_fr3.npz"}.get(args.task, "-"))
+    if world == 1 and not is_policy and not args.no_replay and os.path.exists(rfile) and (N, H) == WORKLOADS[args.task][1:] and args.optimizer is None:
+        rec = np.load(rfile)
+        ctrl.reset()
+        ctrl.current_state = ctrl.task.default_state()
+        ctrl.kernel_events.clear()
+        tr0 = None
+        for i in range(rec["knots"].shape[0]):
+            if i == 2:
+                torch.cuda.synchronize()
+                tr0 = time.perf_counter()
+            ctrl.optimizer.seed(1000 + i)
+            ctrl.nominal_knots = rec["knots"][i].copy()
+            ctrl.times = rec["times"][i].copy()
+            ctrl.update_spline(ctrl.times, ctrl.nominal_knots)
+            ctrl.time = float(rec["t"][i])
+            if opt_name == "cem":
+                ctrl.optimizer.sigma = rec["sigma"][i].copy()
+            ctrl.update_action()
+        torch.cuda.synchronize()
+        nrep = rec["knots"].shape[0]
+        kk = np.array([a.elapsed_time(b) for a, b in ctrl.kernel_events])
+        replay = {"kernel_ms": float(kk.mean()), "kernel_ms_first10": float(kk[:10].mean()), "kernel_ms_last10": float(kk[-10:].mean()), "plan_step_ms": (time.perf_counter() - tr0) / (nrep - 2) * 1e3,
+                  "plan_steps": int(nrep), "inputs": os.path.relpath(rfile, ROOT),
+                  "note": "recorded plan inputs of 40 consecutive plan steps replayed with fixed seeds: deterministic workload, the figure to compare builds and rounds by "
+                          "(round 2's kernels: leap_cube 80.9 ms, fr3_pick 19.2 ms approximate / 21.1 ms exact)"}
     n_local = ctrl.last_shard.count
     substeps = ctrl.task.physics_substeps
     if is_policy:  # per control step the tree kernel reads state + control + warm start and writes state + warm start; H launches inside the timed region
@@ -465,6 +495,8 @@ def main() -> None:
             line["solver"] = solver
         if cube_only:
             line["cube_only"] = cube_only
+        if replay:
+            line["recorded_inputs"] = replay
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_policy(ctrl) if is_policy else cpu_baseline(args.task, ctrl)
         print(json.dumps(line))
