@@ -113,7 +113,7 @@ int jh_trace_gather(const float* rec_in /* DEVICE, k x stride_in */, int k, int 
  * keeps a lane's knots on chip (8 of them); the leap_cube kernel of generation 3 reads them from memory every step and is bounded by
  * JH_MAX_KNOT_DIM / nu alone.  A larger K goes through jh_spline_controls + jh_rollout_materialize + jh_task_reward, which have no such limit;
  * out[1] = JH_MAX_KNOT_DIM; out[2] = JH_MAX_ELITES; out[3] = contact capacity per rollout of the general pool (leap_cube generation 3: 48 or 64, jh_model_set_contact_capacity;
- * fr3_pick generation 3: 64 -- 32 on chip, 32 in a row of global memory -- next to its 96 pad-against-pad slots; 0 = the model has at most one contact).  HOST pointer. */
+ * fr3_pick generation 3: 96 -- 32 on chip, 64 in a row of global memory -- next to its 96 pad-against-pad slots; 0 = the model has at most one contact).  HOST pointer. */
 int jh_model_limits(const jh_model* m, int* out /* HOST, 4 ints */);
 /* out[0] of jh_model_limits is an upper bound over all horizons.  The one-lane kernels (cartpole, cylinder_push, kernel generation 1) stage W (H x K) and
  * their lanes' knots in LDS, so their largest fused K also depends on the horizon: this returns the K up to which jh_rollout_cost accepts a launch of H

@@ -164,7 +164,7 @@ extern "C" int jh_model_limits(const jh_model* m, int* out) {
   out[0] = max_fused_knots(m, 1);  // upper bound over all horizons; jh_model_max_fused_knots(m, H) is the figure for a given H
   out[1] = JH_MAX_KNOT_DIM;
   out[2] = JH_MAX_ELITES;
-  out[3] = m->kind == JH_TASK_LEAP_CUBE ? (m->kernel_gen >= 3 ? m->contact_capacity : 32) : (m->kind == JH_TASK_FR3_PICK ? (m->kernel_gen >= 3 ? 64 : 32) : 0);  // (generation 3: leap 48, all in LDS, or 64 with 16 in a row of global memory: jh_model_set_contact_capacity; fr3 32 in LDS + 32 in such a row, next to its 96 pad-against-pad slots)
+  out[3] = m->kind == JH_TASK_LEAP_CUBE ? (m->kernel_gen >= 3 ? m->contact_capacity : 32) : (m->kind == JH_TASK_FR3_PICK ? (m->kernel_gen >= 3 ? 96 : 32) : 0);  // (generation 3: leap 48, all in LDS, or 64 with 16 in a row of global memory: jh_model_set_contact_capacity; fr3 32 in LDS + 64 in such a row, next to its 96 pad-against-pad slots)
   return JH_OK;
 }
 

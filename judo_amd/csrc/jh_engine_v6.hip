@@ -20,7 +20,7 @@ namespace {
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, NMB = 10;
 #ifndef JH_V6_NSBIG
-#define JH_V6_NSBIG 4
+#define JH_V6_NSBIG 6  // 96 general contacts per rollout (32 in LDS, 64 in the global row); 4 and 6 cost the common path the same (nothing: 11.14 / 11.17 ms on recorded inputs)
 #endif
 #ifndef JH_V6_BIGPROB
 #define JH_V6_BIGPROB 0.999999  // how sure the compiler may be that a wave-step stays on the two-slot copy of the solver (block frequencies steer the placement of register spills)
