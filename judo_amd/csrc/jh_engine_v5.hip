@@ -1339,7 +1339,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         WSYNC();
       }
       };
-      if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
+      // (the rare slot-count copy instantiates the dense-capable loop only -- it serves rollouts without a dense row as well: three copies of the loop instead of four, and
+      // the common one came out 0.9 % faster for it)
+      if constexpr (SELF && NS > NSLOT) newton_loop(std::true_type{});
+      else if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
     };
