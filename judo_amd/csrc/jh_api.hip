@@ -45,8 +45,8 @@ extern "C" int jh_model_create(const void* blob, size_t nbytes, int device, jh_m
   }
   hipError_t e = hipMalloc(&m->d_f, 4 * (m->nf ? m->nf : 1));
   if (e == hipSuccess) e = hipMalloc(&m->d_i, 4 * (m->ni ? m->ni : 1));
-  if (e == hipSuccess) e = hipMalloc(&m->d_stats, 64 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(m->d_stats, 0, 64 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&m->d_stats, JH_NSTATS * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(m->d_stats, 0, JH_NSTATS * sizeof(int));
   if (e == hipSuccess && m->nf) e = hipMemcpy(m->d_f, m->h_f.data(), 4 * m->nf, hipMemcpyHostToDevice);
   if (e == hipSuccess && m->ni) e = hipMemcpy(m->d_i, m->h_i.data(), 4 * m->ni, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -80,13 +80,19 @@ extern "C" int jh_model_stats(jh_model* m, int* out, int reset) {
   JH_HIP(hipMemcpy(out, m->d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
   JH_HIP(hipMemcpy(out + 4, m->d_stats + 20, 2 * sizeof(int), hipMemcpyDeviceToHost));
   out[6] = out[7] = 0;
-  if (reset) JH_HIP(hipMemset(m->d_stats, 0, 64 * sizeof(int)));
+  if (reset) JH_HIP(hipMemset(m->d_stats, 0, JH_NSTATS * sizeof(int)));
   return JH_OK;
 }
 
 extern "C" int jh_model_hist(jh_model* m, int* out /* 24 ints: Newton-iteration histogram (profile builds only) */) {
   JH_REQUIRE(m && out, "model_hist: null pointer");
   JH_HIP(hipMemcpy(out, m->d_stats + 24, 40 * sizeof(int), hipMemcpyDeviceToHost));
+  return JH_OK;
+}
+
+extern "C" int jh_model_counters(jh_model* m, int* out, int first, int count) {  // diagnostic builds (JH_V5_CENSUS ...): a range of the raw counter block
+  JH_REQUIRE(m && out && first >= 0 && count >= 0 && first + count <= JH_NSTATS, "model_counters: bad range");
+  JH_HIP(hipMemcpy(out, m->d_stats + first, count * sizeof(int), hipMemcpyDeviceToHost));
   return JH_OK;
 }
 

@@ -73,6 +73,12 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_NSBIG 3  // 4: 64 contacts, the 16 above the LDS pool in a row of global memory (as jh_engine_v6.hip does): 0 instead of 1.7e-6 contacts dropped per rollout-step on the
                        // recorded headline inputs and 97 % instead of 91 % of the jammed-cube sweep inside the capacity, for +2.8 % on every plan step (81.0 against 78.8 ms): not the default
 #endif
+#ifndef JH_V5_NS1
+#define JH_V5_NS1 1  // a third copy of the constraint rows + Newton solver with ONE slot per lane for the wave-steps in which no rollout of the wave has more than 16 contacts
+#endif
+#ifndef JH_V5_NS1PROB
+#define JH_V5_NS1PROB 0.5
+#endif
 constexpr int NSLOT = JH_V5_NSLOT;  // contact slots per lane of the common case: steps with at most 16 * NSLOT contacts in every rollout of the wave
 constexpr int NSBIG = JH_V5_NSBIG;  // ... of the rare case (6e-4 of the rollout-steps of the headline workload): the wave runs a second copy of the solver with this many slots
 #ifndef JH_V5_NSLDS
@@ -744,7 +750,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       WSYNC();
       V5_TICK(1)
       // narrow phase: survivor i goes to lane i; side A is the cube or the first geom of a hand pair, side B a hand geom
-      PoolCtx pc{&S, stats, (NOVF > 0 && ovf_all) ? ovf_all + (size_t)nc * (NOVF * POOL_F) : nullptr};  // (copies of a rollout in latency mode write the same values to the same row)
+      // (copies of a rollout in latency mode write the same values to the same row; the padding rows of the last workgroup -- n >= N, they recompute rollout N - 1 out of
+      // lock step with the live row -- get no overflow row: their contacts above the LDS pool are dropped, and only live rows count what they drop)
+      PoolCtx pc{&S, live ? stats : nullptr, (NOVF > 0 && ovf_all && n < N) ? ovf_all + (size_t)nc * (NOVF * POOL_F) : nullptr};
       for (int base = 0; __any(base < nh); base += G) {
         int idx = base + l;
         if (idx < nh) {
@@ -790,9 +798,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     // several 4-point box-box manifolds at once) runs the copy with NSBIG slots per lane, all others the copy with NSLOT -- the third slot's 27 registers would
     // otherwise be spilled and reloaded inside every iteration of every rollout (measured: +17 % on the headline workload for 6e-4 of its rollout-steps).
     float a_own, ac_own; int iters_this = 0;
-    auto solve_step = [&](auto NS_) __attribute__((always_inline)) {
+#ifdef JH_V5_CENSUS  // diagnostic builds (tools/diag/census_v5.py): histograms in stats[64..]: contacts per rollout-step / the maximum over the wave's rollouts, Newton iterations per
+                     // rollout-step / per wave-step, line-search evaluations per Newton iteration of a rollout / of the wave, rollouts still active per Newton iteration of the wave
+    const int wave_it0 = n_wave_iters;
+    if (stats) {
+      int mx = S.ncon; mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+      if (l == 0 && live) atomicAdd(stats + 64 + min(S.ncon, 63), 1);
+      if (lane == 0) atomicAdd(stats + 128 + min(mx, 63), 1);
+    }
+#endif
+    auto solve_step = [&](auto NS_) __attribute__((always_inline)) -> bool {
     constexpr int NS = decltype(NS_)::value;
-    const int ncap = (NOVF > 0 && ovf_all == nullptr && 16 * NS > NCP) ? NCP : 16 * NS;  // (no overflow rows: what the LDS pool holds)
+    const int ncap = (NOVF > 0 && (ovf_all == nullptr || n >= N) && 16 * NS > NCP) ? NCP : 16 * NS;  // (no overflow row: what the LDS pool holds)
     const int ncon = S.ncon < ncap ? S.ncon : ncap;
     Slot sl[NS];
     {
@@ -851,6 +868,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       }
 #endif
     }
+    if constexpr (SELF && NS < NSLOT) { if (__any(dense_row)) return false; }  // (the one-slot copy has no dense direction: the wave takes the NSLOT copy; nothing was written yet)
 #if JH_V5_PARK
     S.pk_q[l] = q; S.pk_fs[l] = fs_own;
     if (l == 0) { S.pk_cq[0] = qc[3]; S.pk_cq[1] = qc[4]; S.pk_cq[2] = qc[5]; S.pk_cq[3] = qc[6]; S.pk_acc = acc; }
@@ -1313,8 +1331,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
+#ifdef JH_V5_CENSUS
+        int cen_ls = 0, cen_lsw = 0; const bool cen_act = act;
+        if (stats && lane == 0) atomicAdd(stats + 320 + __popcll(__ballot(act && l == 0)), 1);
+#endif
         for (int ls = 0; ls < JH_V5_LSMAX && __any(lsact); ls++) {
           float d1, d2;
+#ifdef JH_V5_CENSUS
+          cen_ls += lsact; cen_lsw++;
+#endif
           lane_rows_dir<NS>(sl, dr, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
@@ -1328,6 +1353,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             }
           }
         }
+#ifdef JH_V5_CENSUS
+        if (stats) { if (l == 0 && live && cen_act) atomicAdd(stats + 256 + min(cen_ls, 31), 1); if (lane == 0) atomicAdd(stats + 288 + min(cen_lsw, 31), 1); }
+#endif
         // ---- (6) step
         if (act) {
           a_own += alpha * p_own; ac_own += alpha * xcl;
@@ -1342,14 +1370,25 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       // (the rare slot-count copy instantiates the dense-capable loop only -- it serves rollouts without a dense row as well: three copies of the loop instead of four, and
       // the common one came out 0.9 % faster for it)
       if constexpr (SELF && NS > NSLOT) newton_loop(std::true_type{});
-      else if (SELF && __any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{});
+      else if constexpr (SELF && NS == NSLOT) { if (__any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{}); }
+      else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
+    return true;
     };
     if (__builtin_expect_with_probability(NSBIG > NSLOT && __any(S.ncon > 16 * NSLOT), 0, JH_V5_BIGPROB)) {
       if (NOVF > 0 && __any(S.ncon > NCP)) __threadfence();  // the overflow rows were written with plain global stores by other lanes of this wave
       solve_step(std::integral_constant<int, NSBIG>{});
-    } else solve_step(std::integral_constant<int, NSLOT>{});
+    } else {
+      bool done = false;
+      if constexpr (JH_V5_NS1 && NSLOT > 1) {
+        if (__builtin_expect_with_probability(!__any(S.ncon > 16), 1, JH_V5_NS1PROB)) done = solve_step(std::integral_constant<int, 1>{});
+      }
+      if (!done) solve_step(std::integral_constant<int, NSLOT>{});
+    }
+#ifdef JH_V5_CENSUS
+    if (stats) { if (l == 0 && live) atomicAdd(stats + 192 + min(iters_this, 31), 1); if (lane == 0) atomicAdd(stats + 224 + min(n_wave_iters - wave_it0, 31), 1); }
+#endif
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
       S.ws[6 + l] = a_own; if (l < 6) { S.ws[l] = ac_own; S.acn[l] = ac_own; }

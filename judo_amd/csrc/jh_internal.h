@@ -12,6 +12,7 @@
 
 #define JH_BLOB_MAGIC 0x314D484Au /* "JHM1" */
 #define JH_BLOB_VERSION 1u
+#define JH_NSTATS 512
 
 // Host-side blob header produced by judo_amd/models.py::pack_model (little-endian, 64 bytes):
 struct jh_blob_header {
@@ -27,7 +28,7 @@ struct jh_model {
   int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int contact_capacity;  // leap_cube generation 3: 48 (all in LDS, jh_engine_v5.hip) or 64 (jh_engine_v5_cap64.hip); jh_model_set_contact_capacity
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
-  int* d_stats;  // 4 diagnostic counters (contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps)
+  int* d_stats;  // JH_NSTATS diagnostic counters: [0..3] contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps; [20..21] wave-level iterations, steps; the rest: diagnostic builds
   std::vector<float> h_f;
   std::vector<int> h_i;
 };
