@@ -202,6 +202,15 @@ int jh_mppi_merge(const float* recs, int G, int K, int nu, float lambda, float* 
 int jh_topk_partial(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma,
                     const float* ctrl_lo_hi, int N, int n_offset, int K, int nu, int k, int tie_high, float* scratch, float* rec,
                     void* stream);
+/* The whole update of a ONE-GPU plan step in one launch (Controller.update_action's tail, judo/controller/controller.py:288-299): what jh_mppi_partial + jh_mppi_merge
+ * (mode 0) or jh_topk_partial + jh_elite_merge (mode 1: k elites, raw population std into sigma_out, which may be NULL) compute, plus -- when E > 0 -- the records
+ * [cost, global index (bits), trace row] of the E best rollouts (ties: higher index first) that jh_topk_partial + jh_trace_gather produce, into trace_out (E x (2 + row_floats)).
+ * Every workgroup writes its partial records to `scratch` and the last one to finish merges them: same arithmetic in the same order as the separate calls, bit-identical
+ * outputs.  `scratch`: jh_update_fused_scratch_floats(N, K, nu) floats, ZERO before its first use (it holds the ticket counter, which every launch leaves at zero). */
+size_t jh_update_fused_scratch_floats(int N, int K, int nu);
+int jh_update_fused(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi, int N,
+                    int n_offset, int K, int nu, int mode, float lambda, int k, int tie_high, int E, const float* trace, int row_floats, int colmajor, float* scratch,
+                    float* nominal_out, float* sigma_out, float* trace_out, void* stream);
 /* Merge G*k records -> global k elites -> mean and clipped population std (ddof 0).  sigma_out may be NULL (PS, k=1). */
 int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float sigma_min, float sigma_max, float* nominal_out,
                    float* sigma_out, void* stream);

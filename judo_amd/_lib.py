@@ -58,6 +58,9 @@ _SIGNATURES = {
     "jh_mppi_partial": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p, f32p, C.c_void_p]),
     "jh_mppi_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_float, f32p, C.c_void_p]),
     "jh_topk_partial": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
+    "jh_update_fused_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "jh_update_fused": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int,
+                                  f32p, f32p, f32p, f32p, C.c_void_p]),
     "jh_elite_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
 }
 

@@ -55,10 +55,9 @@ class _PlanBuffers:
         self.costs = torch.empty(n_local, dtype=torch.float32, device=dev)
         self.scratch = torch.empty(int(L.jh_update_scratch_floats(n_local, K, nu)), dtype=torch.float32, device=dev)
         self.rec = torch.empty(max(rec_floats, 1), dtype=torch.float32, device=dev)
-        self.out = torch.empty(2 * K * nu, dtype=torch.float32, device=dev)
-        self.out_host = torch.empty(2 * K * nu, dtype=torch.float32).pin_memory()
-        self.out_np = self.out_host.numpy()
-        self.out_host_ptr = self.out_host.data_ptr()
+        self.fused_scratch = torch.zeros(int(L.jh_update_fused_scratch_floats(n_local, K, nu)), dtype=torch.float32, device=dev)  # (zero: it holds jh_update_fused's ticket counter)
+        self.dev = dev
+        self.size_out(2 * K * nu)
         self.trace_buf = None   # (n_local * H * trace floats) when the fused kernel writes the trace sensors
         self.trace_rows = None  # elites' records [cost, index, trace row]
         self.trace_recs = [torch.full((max(trace_k, 1) * (2 + K * nu),), float("inf"), dtype=torch.float32, device=dev) for _ in range(2)]  # alternated per plan step
@@ -66,6 +65,16 @@ class _PlanBuffers:
         self.knots_out: torch.Tensor | None = None
         self.knots_nku: torch.Tensor | None = None
         self.mom: torch.Tensor | None = None
+
+
+    def size_out(self, n: int) -> None:
+        """The output block (nominal | sigma | trace elites' records) and its pinned host image hold at least n floats."""
+        if getattr(self, "out", None) is not None and self.out.numel() >= n:
+            return
+        self.out = torch.empty(n, dtype=torch.float32, device=self.dev)
+        self.out_host = torch.empty(n, dtype=torch.float32).pin_memory()
+        self.out_np = self.out_host.numpy()
+        self.out_host_ptr = self.out_host.data_ptr()
 
 
 class Controller:
@@ -112,6 +121,7 @@ class Controller:
         self._noise_cur = 0
         self._noise_ahead = None
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
+        self.fused_update = True  # one GPU: the whole update (block partials, merge, trace elites) in one launch and one download (jh_update_fused); False: the separate kernels
         self._prefetch_args = None
         self.keep_candidates = False
         self.exchange_events: list = []  # (start, end) HIP event pairs around the record all-gather + merge of every iteration while `record_kernel_events` is on
@@ -387,7 +397,7 @@ class Controller:
         tp0 = task.task_params(self.system_metadata)
         b = self._buffers(shard.count, K, nu, task.nq + task.nv, len(tp0), opt.record_floats() if fused_opt else 0, E)
         stream = self._stream = current_stream_ptr()
-        state: dict[str, Any] = {}
+        state: dict[str, Any] = dict(E=E, x0=x0, new_times=new_times)
         staged = False
 
         i = 0
@@ -496,18 +506,46 @@ class Controller:
         if self.record_kernel_events:
             ev1.record()
             self.kernel_events.append((ev0, ev1))
-        opt.device_partial(costs, None, b.nominal, noise_p, b.sigma, b.lohi, shard.count, shard.offset, b.scratch, b.rec, ldn=ldn, stream=stream)
-        if self.record_kernel_events:  # the exchange of the per-rank records and the merge (bench.py attributes the plan step: kernel / exchange / host)
-            ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ex0.record()
-        recs = all_gather_records(b.rec, self.group)
-        opt.device_merge(recs, world, b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, clip_sigma=False, stream=stream)
-        if self.record_kernel_events:
-            ex1.record()
-            self.exchange_events.append((ex0, ex1))
-        state.update(costs=costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
         is_cem = hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray)
-        res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))
+        state.update(costs=costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
+        tail = world == 1 and self.fused_update and hasattr(opt, "fused_update_args")
+        if tail:
+            # one GPU: block partials, merge and -- in the last iteration, when the rollout kernel wrote the trace buffer -- the trace elites' records in ONE launch,
+            # nominal | sigma | records in one output block, one download (controller.py:288-299 without the seven-launch chain)
+            tb, staging = state.get("trace_buf"), state.get("stage") is not None
+            E_t = min(int(state.get("E", 0)), _lib.MAX_ELITES) if (staging and tb is not None) else 0
+            row = tb[1] if E_t else 0
+            n_out = 2 * K * nu + E_t * (2 + row)
+            b.size_out(n_out)
+            mode, lam, k_el, tie = opt.fused_update_args()
+            if self.record_kernel_events:
+                ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ex0.record()
+            st = lib.jh_update_fused(_lib.ptr(costs), None, _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(b.lohi), shard.count, shard.offset, K, nu, mode, lam,
+                                     k_el, tie, E_t, _lib.ptr(tb[0]) if E_t else None, row, int(self._trace_colmajor) if E_t else 0, _lib.ptr(b.fused_scratch),
+                                     b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, (b.out.data_ptr() + 8 * K * nu) if E_t else None, stream)
+            _lib.check(st, "jh_update_fused")
+            if self.record_kernel_events:
+                ex1.record()
+                self.exchange_events.append((ex0, ex1))
+            if staging and E_t:
+                res = self._fetch(b, n_out)
+                self._traces = None
+                self._trace_stage = dict(kind="sensors", recs=b.out_np[2 * K * nu : n_out].copy(), stride=2 + row, E=int(state["E"]), x0=state["x0"], times=np.array(state["new_times"]),
+                                         order=self.spline_order, H=H, K=K, nu=nu, index_is_bits=True)
+            else:
+                res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))
+        else:
+            opt.device_partial(costs, None, b.nominal, noise_p, b.sigma, b.lohi, shard.count, shard.offset, b.scratch, b.rec, ldn=ldn, stream=stream)
+            if self.record_kernel_events:  # the exchange of the per-rank records and the merge (bench.py attributes the plan step: kernel / exchange / host)
+                ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ex0.record()
+            recs = all_gather_records(b.rec, self.group)
+            opt.device_merge(recs, world, b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, clip_sigma=False, stream=stream)
+            if self.record_kernel_events:
+                ex1.record()
+                self.exchange_events.append((ex0, ex1))
+            res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))
         nominal_n = (res[: K * nu].reshape(K, nu) - center[None, :]) / scale[None, :]  # the update acted on the normalised candidates
         if is_cem:  # CEM: refit in normalised units
             opt.sigma = np.clip(res[K * nu :].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
@@ -724,7 +762,8 @@ class Controller:
 
     def _finish_traces(self, st: dict) -> np.ndarray:
         S, H, E = len(self.trace_sensors), st["H"], st["E"]
-        recs = st["recs"].cpu().numpy().reshape(-1, st["stride"])
+        recs = st["recs"]
+        recs = (recs.cpu().numpy() if torch.is_tensor(recs) else np.asarray(recs)).reshape(-1, st["stride"])
         idx = recs[:, 1].view(np.int32).astype(np.int64) if st["index_is_bits"] else recs[:, 1].astype(np.int64)
         cost = recs[:, 0].astype(np.float64)
         ok = np.nonzero((idx >= 0) & np.isfinite(cost))[0]

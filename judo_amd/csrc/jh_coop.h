@@ -40,6 +40,10 @@ __device__ __forceinline__ int gor(int v) {
   v |= dppi<DPP_XOR1>(v); v |= dppi<DPP_XOR2>(v); v |= dppi<DPP_HALF_MIRROR>(v); v |= dppi<DPP_MIRROR>(v);
   return v;
 }
+__device__ __forceinline__ int gmini(int v) {  // min over the 16 lanes of a rollout (signed)
+  v = min(v, dppi<DPP_XOR1>(v)); v = min(v, dppi<DPP_XOR2>(v)); v = min(v, dppi<DPP_HALF_MIRROR>(v)); v = min(v, dppi<DPP_MIRROR>(v));
+  return v;
+}
 // value held by lane j of the caller's quad (j is a compile-time constant after unrolling)
 __device__ __forceinline__ float quad_get(float v, int j) {
   switch (j) { case 0: return dppf<0x00>(v); case 1: return dppf<0x55>(v); case 2: return dppf<0xAA>(v); default: return dppf<0xFF>(v); }

@@ -28,6 +28,15 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSMAX
 #define JH_V5_LSMAX 16
 #endif
+#ifndef JH_V5_LSKINK
+#define JH_V5_LSKINK 1  // line search: where the plain safeguarded Newton search is in trouble it tries the step lengths at which the slope jumps (below)
+#endif
+#ifndef JH_V5_LSSHRINK
+#define JH_V5_LSSHRINK 0.9f
+#endif
+#ifndef JH_V5_LSREV
+#define JH_V5_LSREV 0.03f
+#endif
 #ifndef JH_V5_WAVES_PER_EU
 #define JH_V5_WAVES_PER_EU 2
 #endif
@@ -74,7 +83,10 @@ constexpr int NCH = 4, NLK = 4;
                        // recorded headline inputs and 97 % instead of 91 % of the jammed-cube sweep inside the capacity, for +2.8 % on every plan step (81.0 against 78.8 ms): not the default
 #endif
 #ifndef JH_V5_NS1
-#define JH_V5_NS1 1  // a third copy of the constraint rows + Newton solver with ONE slot per lane for the wave-steps in which no rollout of the wave has more than 16 contacts
+#define JH_V5_NS1 0  // 1: a third copy of the constraint rows + Newton solver with ONE slot per lane for the wave-steps in which no rollout of the wave has more than 16 contacts.
+                     // Measured in round 4 (recorded inputs; profiles/r04_leap_experiments.txt): 93 % of the wave-steps qualify (5.2 contacts per rollout-step on average, the
+                     // wave's maximum 8.2), and the kernel is 1.1 % faster (79.7 against 80.6 ms) -- the second slot's code is skipped by wave-uniform branches already -- while the
+                     // bits of a rollout then depend on its wave-mates (the copies contract differently; test_leap_full_size_properties fails).  Off.
 #endif
 #ifndef JH_V5_NS1PROB
 #define JH_V5_NS1PROB 0.5
@@ -1330,6 +1342,25 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<SELF>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
+#if JH_V5_LSKINK
+        // Step lengths at which the slope of the 1-D cost (all but) JUMPS: the zero crossing of the own dof's friction-loss row, and for a contact the point where its
+        // tangential part passes closest to zero, if it gets there within JH_V5_LSREV of where it is at 0 or at 1 -- Coulomb friction reverses there, and with a cone as
+        // narrow as impratio = 100 makes it that is a jump.  A root of the slope AT such a jump is what the long searches of this workload were looking for (Newton from
+        // either side lands beyond the jump, inside the bracket, and the bracket shrinks by parts in a thousand per evaluation: 15 % of the wave's searches took 9 to 16
+        // evaluations, half of all its evaluations; CPU prototype: oracle/jo_engine.c::jo_set_ls_experiment, tools/proto/ls_experiment.py).  The search tries the candidate
+        // closest to the middle of the bracket whenever a Newton step leaves the bracket or an evaluation leaves more than JH_V5_LSSHRINK of it.
+        float kc[NS + 1];
+        kc[NS] = (dr.fl > 0.f && dr.pf != 0.f) ? -dr.jf * __frcp_rn(dr.pf) : -1.f;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+          kc[k] = -1.f;
+          if (sl[k].la >= 0) {
+            const float U1 = sl[k].jar[1], U2 = sl[k].jar[2], V1 = sl[k].jp[1], V2 = sl[k].jp[2];  // (both tangential rows carry the same friction coefficient: it drops out)
+            const float vv = V1 * V1 + V2 * V2, uv = U1 * V1 + U2 * V2, uu = U1 * U1 + U2 * U2;
+            if (vv > 0.f) { const float a = -uv * __frcp_rn(vv); if (uu + a * uv <= JH_V5_LSREV * JH_V5_LSREV * fmaxf(uu, uu + 2.f * uv + vv)) kc[k] = a; }
+          }
+        }
+#endif
         float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
 #ifdef JH_V5_CENSUS
         int cen_ls = 0, cen_lsw = 0; const bool cen_act = act;
@@ -1342,6 +1373,35 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #endif
           lane_rows_dir<NS>(sl, dr, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
+#if JH_V5_LSKINK
+          bool trouble = false; float nx = alpha;
+          if (lsact) {
+            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
+            else {
+              const float wprev = hi >= 0.f ? hi - lo : -1.f;
+              if (d1 < 0.f) lo = alpha; else hi = alpha;
+              nx = alpha - d1 * __frcp_rn(d2);
+              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
+              else {
+                const bool rejected = nx <= lo || nx >= hi;
+                trouble = rejected || (wprev > 0.f && hi - lo > JH_V5_LSSHRINK * wprev);
+                if (rejected) nx = 0.5f * (lo + hi);
+              }
+            }
+          }
+          if (__any(trouble)) {  // the candidate closest to the middle of the bracket, strictly inside it: |a - mid| with the side in the last mantissa bit, one row minimum
+            const float mid = 0.5f * (lo + hi), eps = 1e-6f * hi;
+            int key = 0x7f800000;
+#pragma unroll
+            for (int k = 0; k <= NS; k++) {
+              const float a = kc[k], dm = a - mid;
+              if (trouble && a > lo + eps && a < hi - eps) key = min(key, (__float_as_int(fabsf(dm)) & ~1) | (dm < 0.f ? 1 : 0));
+            }
+            key = gmini(trouble ? key : 0x7f800000);
+            if (trouble && key != 0x7f800000) { const float mag = __int_as_float(key & ~1); nx = (key & 1) ? mid - mag : mid + mag; }
+          }
+          if (lsact) alpha = nx;
+#else
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
@@ -1352,6 +1412,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
               alpha = nx;
             }
           }
+#endif
         }
 #ifdef JH_V5_CENSUS
         if (stats) { if (l == 0 && live && cen_act) atomicAdd(stats + 256 + min(cen_ls, 31), 1); if (lane == 0) atomicAdd(stats + 288 + min(cen_lsw, 31), 1); }

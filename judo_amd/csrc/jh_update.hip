@@ -81,10 +81,9 @@ __global__ __launch_bounds__(64) void k_knot_moments(KnotSrc src, const float* _
 }
 
 // ---------------------------------------------------------------- MPPI
-__global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ costs, KnotSrc src, int N, float inv_lambda,
-                                                   float* __restrict__ scratch) {
-  __shared__ float sred[4];
-  __shared__ float sV[4][JH_MAX_KNOT_DIM];
+// (the bodies of the update kernels are device functions: the one-launch tail k_update_tail below runs the same arithmetic in the same order -- bit-identical results)
+__device__ __forceinline__ void mppi_block_body(const float* __restrict__ costs, const KnotSrc& src, int N, float inv_lambda, float* __restrict__ scratch, float* sred,
+                                                float (*sV)[JH_MAX_KNOT_DIM]) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = blockIdx.x * kUB + tid;
   const bool live = n < N;
@@ -108,12 +107,14 @@ __global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ co
   if (tid == 0) { rec[0] = beta; rec[1] = sred[0] + sred[1] + sred[2] + sred[3]; }
   for (int idx = tid; idx < src.KU; idx += kUB) rec[2 + idx] = sV[0][idx] + sV[1][idx] + sV[2][idx] + sV[3][idx];
 }
+__global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ costs, KnotSrc src, int N, float inv_lambda, float* __restrict__ scratch) {
+  __shared__ float sred[4];
+  __shared__ float sV[4][JH_MAX_KNOT_DIM];
+  mppi_block_body(costs, src, N, inv_lambda, scratch, sred, sV);
+}
 
 // merge nrec records [beta, S, V...] -> one record, or (finalize) the nominal knots V/S
-__global__ __launch_bounds__(kUB) void k_mppi_merge(const float* __restrict__ recs, int nrec, int KU, float inv_lambda, int finalize,
-                                                   float* __restrict__ out) {
-  __shared__ float sred[4];
-  __shared__ float sS;
+__device__ __forceinline__ void mppi_merge_body(const float* __restrict__ recs, int nrec, int KU, float inv_lambda, int finalize, float* __restrict__ out, float* sred, float& sS) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int stride = 2 + KU;
   float m = INFINITY;
@@ -137,6 +138,11 @@ __global__ __launch_bounds__(kUB) void k_mppi_merge(const float* __restrict__ re
   }
   if (!finalize && tid == 0) { out[0] = beta; out[1] = sS; }
 }
+__global__ __launch_bounds__(kUB) void k_mppi_merge(const float* __restrict__ recs, int nrec, int KU, float inv_lambda, int finalize, float* __restrict__ out) {
+  __shared__ float sred[4];
+  __shared__ float sS;
+  mppi_merge_body(recs, nrec, KU, inv_lambda, finalize, out, sred, sS);
+}
 
 // ---------------------------------------------------------------- top-k (CEM elites, PS argmax)
 struct Cand { float c; int i; };
@@ -154,9 +160,7 @@ __device__ __forceinline__ Cand wave_best(Cand v, int tie_high) {
   return v;
 }
 
-__global__ __launch_bounds__(kUB) void k_topk_block(const float* __restrict__ costs, int N, int n_offset, int k, int tie_high,
-                                                   float* __restrict__ scratch) {
-  __shared__ Cand sred[4];
+__device__ __forceinline__ void topk_block_body(const float* __restrict__ costs, int N, int n_offset, int k, int tie_high, float* __restrict__ scratch, Cand* sred) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = blockIdx.x * kUB + tid;
   Cand mine{n < N ? costs[n] : INFINITY, n < N ? n_offset + n : -1};
@@ -172,12 +176,13 @@ __global__ __launch_bounds__(kUB) void k_topk_block(const float* __restrict__ co
     if (best.i == mine.i) { mine.c = INFINITY; mine.i = -1; }
   }
 }
+__global__ __launch_bounds__(kUB) void k_topk_block(const float* __restrict__ costs, int N, int n_offset, int k, int tie_high, float* __restrict__ scratch) {
+  __shared__ Cand sred[4];
+  topk_block_body(costs, N, n_offset, k, tie_high, scratch, sred);
+}
 
 // one workgroup: choose k best of ncand (cost, global index) pairs; emit records [cost, index, knots...]
-__global__ __launch_bounds__(kUB) void k_topk_select(const float* __restrict__ cand, int ncand, int k, int tie_high, KnotSrc src, int n_offset,
-                                                    float* __restrict__ rec) {
-  __shared__ Cand sred[4];
-  __shared__ Cand chosen[JH_MAX_ELITES];
+__device__ __forceinline__ void topk_choose(const float* __restrict__ cand, int ncand, int k, int tie_high, Cand* sred, Cand* chosen) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int e = 0; e < k; e++) {
     Cand mine{INFINITY, -1};
@@ -197,6 +202,9 @@ __global__ __launch_bounds__(kUB) void k_topk_select(const float* __restrict__ c
     }
     __syncthreads();
   }
+}
+__device__ __forceinline__ void topk_records(const Cand* chosen, int k, const KnotSrc& src, int n_offset, float* __restrict__ rec) {
+  const int tid = threadIdx.x;
   const int stride = 2 + src.KU;
   for (int e = 0; e < k; e++) {
     if (tid == 0) { rec[(size_t)e * stride] = chosen[e].c; rec[(size_t)e * stride + 1] = __int_as_float(chosen[e].i); }
@@ -204,11 +212,16 @@ __global__ __launch_bounds__(kUB) void k_topk_select(const float* __restrict__ c
     for (int idx = tid; idx < src.KU; idx += kUB) rec[(size_t)e * stride + 2 + idx] = chosen[e].i >= 0 ? src.get(nl, idx) : 0.f;
   }
 }
+__global__ __launch_bounds__(kUB) void k_topk_select(const float* __restrict__ cand, int ncand, int k, int tie_high, KnotSrc src, int n_offset, float* __restrict__ rec) {
+  __shared__ Cand sred[4];
+  __shared__ Cand chosen[JH_MAX_ELITES];
+  topk_choose(cand, ncand, k, tie_high, sred, chosen);
+  topk_records(chosen, k, src, n_offset, rec);
+}
 
 // one workgroup: G*k records -> k elites -> mean / clipped population std
-__global__ __launch_bounds__(kUB) void k_elite_merge(const float* __restrict__ recs, int nrec, int k, int KU, int tie_high, float smin, float smax,
-                                                    float* __restrict__ nominal_out, float* __restrict__ sigma_out) {
-  __shared__ int chosen[JH_MAX_ELITES];
+__device__ __forceinline__ void elite_merge_body(const float* __restrict__ recs, int nrec, int k, int KU, int tie_high, float smin, float smax, float* __restrict__ nominal_out,
+                                                 float* __restrict__ sigma_out, int* chosen) {
   const int tid = threadIdx.x, stride = 2 + KU;
   if (tid == 0) {
     for (int e = 0; e < k; e++) {
@@ -232,6 +245,72 @@ __global__ __launch_bounds__(kUB) void k_elite_merge(const float* __restrict__ r
     var /= (float)(cnt > 0 ? cnt : 1);
     nominal_out[idx] = mean;
     if (sigma_out) sigma_out[idx] = jh_clampf(sqrtf(var), smin, smax);
+  }
+}
+__global__ __launch_bounds__(kUB) void k_elite_merge(const float* __restrict__ recs, int nrec, int k, int KU, int tie_high, float smin, float smax,
+                                                    float* __restrict__ nominal_out, float* __restrict__ sigma_out) {
+  __shared__ int chosen[JH_MAX_ELITES];
+  elite_merge_body(recs, nrec, k, KU, tie_high, smin, smax, nominal_out, sigma_out, chosen);
+}
+
+// ---------------------------------------------------------------- the whole update of a one-GPU plan step in ONE launch
+// Controller.update_action's tail (judo/controller/controller.py:288-299: update_nominal_knots, then update_traces) used to be seven launches -- block partials, two
+// merges, block top-k, select, trace gather, plus two downloads -- around rollout kernels of 50 us (cartpole, cylinder_push): the plan step was bound by the launch
+// chain, not by any kernel.  Here every workgroup writes its partial records (MPPI weights / the update's elite candidates / the trace elites' candidates), takes a
+// ticket, and the workgroup that draws the last one merges them: nominal (and CEM sigma) plus the trace elites' records [cost, index, trace row] land in ONE
+// output block, one download.  Same device functions as the separate kernels above, same order of operations: bit-identical nominal, sigma and records.
+struct TailArgs {
+  const float* costs; KnotSrc src; int N, n_offset;
+  int mode;            // 0: MPPI, 1: elites (CEM, PS)
+  float inv_lambda;    // MPPI
+  int k, tie_high;     // the update's elites
+  int E;               // trace elites (0: none); ties: the higher global index first
+  const float* trace; int row, colmajor;  // trace buffer of the fused rollout kernel
+  float* scratch;      // ticket counter (4 floats) | nb * (2 + KU) | nb * k * 2 | nb * E * 2 | k * (2 + KU)
+  float* nominal_out; float* sigma_out; float* trace_out;  // trace_out: E x (2 + row)
+};
+__global__ __launch_bounds__(kUB) void k_update_tail(TailArgs a) {
+  __shared__ float sred[4];
+  __shared__ float sS;
+  __shared__ float sV[4][JH_MAX_KNOT_DIM];
+  __shared__ Cand cred[4];
+  __shared__ Cand chosen[JH_MAX_ELITES];
+  __shared__ int ichosen[JH_MAX_ELITES];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, nb = gridDim.x, KU = a.src.KU;
+  unsigned* counter = reinterpret_cast<unsigned*>(a.scratch);  // (a fixed place: the record layout behind it depends on the arguments; zero before the first launch)
+  float* s_mppi = a.scratch + 4;
+  float* s_topA = s_mppi + (size_t)nb * (2 + KU);
+  float* s_topB = s_topA + (size_t)nb * a.k * 2;
+  float* s_rec = s_topB + (size_t)nb * a.E * 2;
+  if (a.mode == 0) mppi_block_body(a.costs, a.src, a.N, a.inv_lambda, s_mppi, sred, sV);
+  else topk_block_body(a.costs, a.N, a.n_offset, a.k, a.tie_high, s_topA, cred);
+  if (a.E > 0) { __syncthreads(); topk_block_body(a.costs, a.N, a.n_offset, a.E, 1, s_topB, cred); }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(counter, 1u) == (unsigned)(nb - 1));
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (tid == 0) *counter = 0u;  // (the next launch on this stream finds it reset)
+  if (a.mode == 0) mppi_merge_body(s_mppi, nb, KU, a.inv_lambda, 1, a.nominal_out, sred, sS);
+  else {
+    topk_choose(s_topA, nb * a.k, a.k, a.tie_high, cred, chosen);
+    topk_records(chosen, a.k, a.src, a.n_offset, s_rec);
+    __threadfence_block();
+    __syncthreads();
+    elite_merge_body(s_rec, a.k, a.k, KU, a.tie_high, 0.f, INFINITY, a.nominal_out, a.sigma_out, ichosen);
+  }
+  if (a.E > 0) {
+    __syncthreads();
+    topk_choose(s_topB, nb * a.E, a.E, 1, cred, chosen);
+    for (int e = 0; e < a.E; e++) {
+      const float cost = chosen[e].c; const int gi = chosen[e].i, li = gi - a.n_offset;
+      float* o = a.trace_out + (size_t)e * (2 + a.row);
+      const bool ok = gi >= 0 && li >= 0 && li < a.N && cost < 3.0e38f;
+      if (tid == 0) { o[0] = ok ? cost : __int_as_float(0x7f800000); o[1] = __int_as_float(ok ? gi : -1); }
+      for (int i = tid; i < a.row; i += kUB) o[2 + i] = ok ? (a.colmajor ? a.trace[(size_t)i * a.N + li] : a.trace[(size_t)li * a.row + i]) : 0.f;
+    }
   }
 }
 
@@ -395,6 +474,32 @@ extern "C" int jh_trace_gather(const float* rec_in, int k, int stride_in, int n_
                                void* stream) {
   JH_REQUIRE(rec_in && trace && rec_out && k >= 1 && k <= JH_MAX_ELITES && stride_in >= 2 && row_floats >= 1 && n_local >= 1, "trace_gather: bad arguments");
   hipLaunchKernelGGL(k_trace_gather, dim3(k), dim3(256), 0, (hipStream_t)stream, rec_in, k, stride_in, n_offset, n_local, trace, row_floats, colmajor, rec_out);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" size_t jh_update_fused_scratch_floats(int N, int K, int nu) {
+  const size_t nb = (size_t)(N + kUB - 1) / kUB, KU = (size_t)K * nu;
+  return nb * (2 + KU) + nb * 4 * JH_MAX_ELITES + (size_t)JH_MAX_ELITES * (2 + KU) + 16;
+}
+
+extern "C" int jh_update_fused(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* lohi, int N,
+                               int n_offset, int K, int nu, int mode, float lambda, int k, int tie_high, int E, const float* trace, int row_floats, int colmajor,
+                               float* scratch, float* nominal_out, float* sigma_out, float* trace_out, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(costs && scratch && nominal_out, "update_fused: null pointer");
+  JH_REQUIRE(knots_nku || (nominal && noise && sigma), "update_fused: need either knots_nku or nominal+noise+sigma");
+  JH_REQUIRE(knots_nku || ldn >= N, "update_fused: ldn (%d) < N (%d)", ldn, N);
+  JH_REQUIRE(mode == 0 || mode == 1, "update_fused: mode must be 0 (MPPI) or 1 (elites)");
+  JH_REQUIRE(mode != 0 || lambda > 0.f, "update_fused: temperature must be positive");
+  JH_REQUIRE(mode != 1 || (k >= 1 && k <= JH_MAX_ELITES), "update_fused: k = %d outside [1, %d]", k, JH_MAX_ELITES);
+  JH_REQUIRE(E >= 0 && E <= JH_MAX_ELITES && (E == 0 || (trace && trace_out && row_floats >= 1)), "update_fused: bad trace arguments (E=%d)", E);
+  TailArgs a;
+  a.costs = costs; a.src = KnotSrc{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu}; a.N = N; a.n_offset = n_offset;
+  a.mode = mode; a.inv_lambda = mode == 0 ? 1.f / lambda : 0.f; a.k = mode == 1 ? k : 0; a.tie_high = tie_high; a.E = E;
+  a.trace = trace; a.row = row_floats; a.colmajor = colmajor; a.scratch = scratch; a.nominal_out = nominal_out; a.sigma_out = sigma_out; a.trace_out = trace_out;
+  const int nb = (N + kUB - 1) / kUB;
+  hipLaunchKernelGGL(k_update_tail, dim3(nb), dim3(kUB), 0, (hipStream_t)stream, a);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -230,6 +230,10 @@ class GpuMPPI(FusedOptimizer[MPPIConfig]):
                                         n_local, n_offset, K, self.nu, float(self.temperature), _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_mppi_partial")
 
+    def fused_update_args(self) -> tuple[int, float, int, int]:
+        """(mode, temperature, elites, tie rule) of jh_update_fused: the one-launch form of device_partial + device_merge on one GPU."""
+        return 0, float(self.temperature), 0, 0
+
     def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True, stream=None) -> None:
         K = K or self.num_nodes
         st = _lib.lib().jh_mppi_merge(_lib.ptr(recs), G, K, self.nu, float(self.temperature), _lib.ptr(nominal_out), current_stream_ptr() if stream is None else stream)
@@ -270,6 +274,9 @@ class _EliteOptimizer(FusedOptimizer[OptimizerConfigT]):
         st = _lib.lib().jh_topk_partial(_lib.ptr(costs), _lib.ptr(knots_nku), _lib.ptr(nominal), _lib.ptr(noise), ldn, _lib.ptr(sigma), _lib.ptr(lohi),
                                         n_local, n_offset, K, self.nu, self.num_keep(), self.tie_high, _lib.ptr(scratch), _lib.ptr(rec), current_stream_ptr() if stream is None else stream)
         _lib.check(st, "jh_topk_partial")
+
+    def fused_update_args(self) -> tuple[int, float, int, int]:
+        return 1, 0.0, int(self.num_keep()), int(self.tie_high)
 
     def device_merge(self, recs, G, nominal_out, sigma_out, K=None, clip_sigma=True, stream=None) -> None:
         """clip_sigma=False returns the raw population std: the controller clips it after mapping it back to the action normaliser's

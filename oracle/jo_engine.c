@@ -1095,6 +1095,17 @@ void jo_set_warmstart_mode(int mode) { g_wsmode = mode; }
 void jo_set_trace(int on) { g_trace = on; }
 void jo_solver_histogram(long* out32, int reset) { for (int i = 0; i < 32; i++) { out32[i] = g_iter_hist[i]; if (reset) g_iter_hist[i] = 0; } }
 void jo_set_solver(jo_model* m, double tol, int maxiter) { m->solver_tol = tol; m->solver_maxiter = maxiter; }
+/* line-search experiments (tools/proto/ls_experiment.py; single-threaded runs only): mode 0 = the oracle's search (default: to rounding), mode >= 1 = the KERNELS' search --
+   start at 1, stop at |slope| <= lstol |slope(0)|, at most lsmax evaluations, bisection when the Newton step leaves the bracket -- with, for mode 2, a trial at the zero
+   crossing of a dof friction-loss row inside the bracket instead of the bisection (the slope jumps there; the kernels' long searches are bisections onto such a jump).
+   Every solve appends (-1, number of rows) and per Newton iteration the number of slope evaluations to the log. */
+static int g_lsmode = 0, g_lsmax = 16; static double g_lstol = 1e-2, g_lskink = 0.1, g_lsshrink = 0.5;
+void jo_set_ls_shrink(double v) { g_lsshrink = v; }
+static long g_lstrouble = 0; long jo_ls_trouble(int reset) { long v = g_lstrouble; if (reset) g_lstrouble = 0; return v; }
+void jo_set_ls_kink(double v) { g_lskink = v; } static int* g_lslog = NULL; static long g_lslog_n = 0, g_lslog_cap = 0;
+void jo_set_ls_experiment(int mode, double lstol, int lsmax, int* log, long cap) { g_lsmode = mode; g_lstol = lstol; g_lsmax = lsmax; g_lslog = log; g_lslog_cap = cap; g_lslog_n = 0; }
+long jo_ls_log_size(void) { return g_lslog_n; }
+static void lslog(int v) { if (g_lslog && g_lslog_n < g_lslog_cap) g_lslog[g_lslog_n++] = v; }
 
 static void solve_constraints(const jo_model* m, jo_data* d) {
   int nv = m->nv, ne = d->nefc;
@@ -1134,6 +1145,93 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
     double pMp = 0, pMd = 0; for (int i = 0; i < nv; i++) { pMp += p[i] * Mp[i]; pMd += Mp[i] * (a[i] - d->qacc_smooth[i]); }
     double lo = 0, hi = -1, al = 1.0, dlo = 0;
     { double g0 = 0; for (int i = 0; i < nv; i++) g0 += grad[i] * p[i]; dlo = g0; if (g0 >= 0) break; }
+    if (it == 0) { lslog(-1); lslog(ne); }
+    if (g_lsmode >= 1) {
+      const double g0 = dlo; double dlo_v = g0, dhi_v = 0; int nev = 0, kink_tries = 0;
+      /* candidate step lengths at which the slope (all but) jumps or its curvature jumps: zero crossings of the dof friction-loss rows (mode >= 4); per contact the point where
+         the tangential part passes closest to zero, if it gets there close enough for Coulomb friction to reverse (mode >= 5); the crossings of the cone surface N = mu T,
+         where a contact switches on or off (mode >= 7) */
+      static __thread double cand[4 * JO_MAXEFC]; int ncand = 0;
+      if (g_lsmode >= 4) for (int r = 0; r < ne; r++) if (d->efc_type[r] == JO_EFC_FRICTION && jp[r] != 0) { const double a = -jar[r] / jp[r]; if (a > 0) cand[ncand++] = a; }
+      if (g_lsmode >= 5) for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3) {
+        const int r0 = d->con[c].efc_adr; const double f1 = d->con[c].friction[0], f2 = d->con[c].friction[1], mu = d->con[c].mu;
+        const double U1 = jar[r0 + 1] * f1, U2 = jar[r0 + 2] * f2, V1 = jp[r0 + 1] * f1, V2 = jp[r0 + 2] * f2, vv = V1 * V1 + V2 * V2, uv = U1 * V1 + U2 * V2, uu = U1 * U1 + U2 * U2;
+        if (vv > 0) {
+          const double a = -uv / vv, tm2 = uu + a * uv;  /* |U + a V|^2 at the minimum */
+          if (a > 0 && tm2 <= g_lskink * g_lskink * fmax(uu, uu + 2 * uv + vv)) cand[ncand++] = a;
+        }
+        if (g_lsmode >= 7) {  /* (N0 + a V0)^2 = mu^2 |U + a V|^2 with N0 + a V0 >= 0 */
+          const double N0 = jar[r0] * mu, V0 = jp[r0] * mu, A = V0 * V0 - mu * mu * vv, B = 2 * (N0 * V0 - mu * mu * uv), Cq = N0 * N0 - mu * mu * uu, disc = B * B - 4 * A * Cq;
+          if (fabs(A) > 1e-300 && disc >= 0) {
+            const double sq = sqrt(disc);
+            for (int sgn = -1; sgn <= 1; sgn += 2) { const double a = (-B + sgn * sq) / (2 * A); if (a > 0 && N0 + a * V0 >= 0) cand[ncand++] = a; }
+          } else if (fabs(A) <= 1e-300 && B != 0) { const double a = -Cq / B; if (a > 0 && N0 + a * V0 >= 0) cand[ncand++] = a; }
+        }
+      }
+      if (g_lsmode == 8) { double best = 1e300; for (int k = 0; k < ncand; k++) if (cand[k] < 1.0 && cand[k] < best) best = cand[k]; if (best < 1.0) al = best; }  /* (mode 8: the first candidate below 1 first) */
+      for (int ls = 0; ls < g_lsmax; ls++) {
+        for (int r = 0; r < ne; r++) jar2[r] = jar[r] + al * jp[r];
+        constraint_cost(m, d, jar2, frc2, Hd2, Hc2, cz2);
+        double d1 = pMd + al * pMp, d2 = pMp; nev++;
+        for (int r = 0; r < ne; r++) { d1 -= frc2[r] * jp[r]; d2 += Hd2[r] * jp[r] * jp[r]; }
+        for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3 && cz2[c]) {
+          int r0 = d->con[c].efc_adr; for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) d2 += Hc2[c][3 * u + v] * jp[r0 + u] * jp[r0 + v];
+        }
+        if (g_trace == 2) fprintf(stderr, "    ls %2d alpha %.9g d1 %.6e d2 %.6e (g0 %.3e) lo %.9g hi %.9g\n", ls, al, d1, d2, g0, lo, hi);
+        if (fabs(d1) <= g_lstol * fabs(g0)) break;
+        const double w_before = hi >= 0 ? hi - lo : -1;
+        if (d1 < 0) { lo = al; dlo_v = d1; } else { hi = al; dhi_v = d1; }
+        double nx = al - d1 / d2;
+        if (g_lsmode >= 10 && g_lsmode < 20) {  /* candidates only where the plain search is in trouble: a rejected Newton step, or a bracket that the last evaluation did not shrink to
+                                 g_lsshrink of its width */
+          const int bracketed = hi >= 0, rejected = bracketed ? (nx <= lo || nx >= hi) : (nx <= lo);
+          const int slow = bracketed && w_before > 0 && (hi - lo) > g_lsshrink * w_before;
+          if (!bracketed) { if (rejected) nx = 2 * al; }
+          else if (rejected || slow) {
+            g_lstrouble++;
+            const double mid = 0.5 * (lo + hi); double best = 1e300, ak = -1;
+            for (int k = 0; k < ncand; k++) if (cand[k] > lo && cand[k] < hi && fabs(cand[k] - lo) > 1e-9 * lo && fabs(hi - cand[k]) > 1e-9 * hi && fabs(cand[k] - mid) < best) { best = fabs(cand[k] - mid); ak = cand[k]; }
+            nx = ak > 0 ? ak : (rejected || g_lsmode == 11 ? mid : nx);
+          }
+          al = nx; continue;
+        }
+        if (hi < 0) { if (nx <= lo) nx = 2 * al; }
+        else if (nx <= lo || nx >= hi) {
+          nx = 0.5 * (lo + hi);
+          if (g_lsmode == 9) {  /* (mode 9: the first candidate from the point just evaluated towards the other end of the bracket) */
+            const double oth = d1 < 0 ? hi : lo; double best = 1e300, ak = -1;
+            for (int k = 0; k < ncand; k++) { const double a = cand[k]; const int between = oth > al ? (a > al && a < oth) : (a < al && a > oth);
+              if (between && fabs(a - al) > 1e-9 * (fabs(al) + 1e-30) && fabs(a - al) < best) { best = fabs(a - al); ak = a; } }
+            if (ak > 0) nx = ak;
+          } else
+          if (g_lsmode >= 6) {
+            double best = 1e300, ak = -1;
+            for (int k = 0; k < ncand; k++) if (cand[k] > lo && cand[k] < hi && fabs(cand[k] - nx) < best) { best = fabs(cand[k] - nx); ak = cand[k]; }
+            if (ak > 0) nx = ak;
+          } else
+          if (g_lsmode >= 2 && kink_tries < g_lsmode - 1) {  /* the friction-loss zero crossing inside the bracket that is closest to the secant estimate */
+            const double as = lo - dlo_v * (hi - lo) / (dhi_v - dlo_v); double best = 1e300, ak = -1;
+            for (int r = 0; r < ne; r++) if (d->efc_type[r] == JO_EFC_FRICTION && jp[r] != 0) {
+              const double a = -jar[r] / jp[r];
+              if (a > lo && a < hi && fabs(a - as) < best) { best = fabs(a - as); ak = a; }
+            }
+            if (ak > 0) { nx = ak; kink_tries++; }
+          }
+        }
+        if (g_lsmode >= 4) {  /* clip the step at the first candidate it passes: the slope model behind `nx` does not hold across it */
+          double best = 1e300, ak = -1;
+          for (int k = 0; k < ncand; k++) {
+            const double a = cand[k];
+            const int between = nx > al ? (a > al && a < nx) : (a < al && a > nx);
+            if (between && (hi < 0 || (a > lo && a < hi)) && fabs(a - al) > 1e-9 * (fabs(al) + 1e-30) && fabs(a - al) < best) { best = fabs(a - al); ak = a; }
+          }
+          if (ak > 0) nx = ak;
+        }
+        al = nx;
+      }
+      lslog(nev);
+      if (g_trace == 2) fprintf(stderr, "  == it %d: %d evaluations, ncon %d\n", it, nev, d->ncon);
+    } else
     for (int ls = 0; ls < 60; ls++) {
       for (int r = 0; r < ne; r++) jar2[r] = jar[r] + al * jp[r];
       constraint_cost(m, d, jar2, frc2, Hd2, Hc2, cz2);

@@ -184,6 +184,8 @@ void jo_solver_histogram(long* out32, int reset);
 void jo_set_solver(jo_model* m, double tol, int maxiter);
 /* contact-parameter priority of a geom (mjModel.geom_priority, default 0): the higher priority side supplies friction / solref / solimp / condim */
 int jo_set_geom_priority(jo_model* m, int geom, int priority);
+void jo_set_ls_experiment(int mode, double lstol, int lsmax, int* log, long cap); /* line-search experiments: see jo_engine.c (0 = off, the default) */
+long jo_ls_log_size(void);
 void jo_set_warmstart_mode(int mode); /* 0 = MuJoCo (better of previous qacc and qacc_smooth); 1 = also try qacc_smooth + previous constraint acceleration */
 
 #ifdef __cplusplus

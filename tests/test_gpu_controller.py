@@ -334,3 +334,34 @@ def test_full_size_configs_properties(gpu, task_name, opt_name, N, H):
         # the product's own threshold for "approximate" (Controller.solver_stats): the first plan step from reset closes many empty grippers -- round 2
         # dropped 5.8 contacts per rollout-step here
         assert st["contact_overflow"] < 1e-4 * st["steps"], st
+
+
+@pytest.mark.parametrize("task_name,opt_name,N", [("cartpole", "mppi", 4096), ("cylinder_push", "mppi", 1000), ("cartpole", "ps", 300), ("fr3_pick", "cem", 257), ("leap_cube", "mppi", 64),
+                                                  ("cartpole", "cem", 3)])
+def test_fused_update_is_bit_identical_to_the_separate_kernels(gpu, task_name, opt_name, N):
+    """jh_update_fused (one launch: block partials, merge, trace elites; one download) against jh_mppi_partial / jh_topk_partial + merge + jh_trace_gather: three consecutive
+    plan steps give the same nominal, sigma, costs and trace segments bit for bit (ragged last workgroup, fewer rollouts than trace elites, every optimizer)."""
+    import torch
+
+    from judo_amd.controller import make_controller
+
+    outs = []
+    for fused in (True, False):
+        ctrl = make_controller(task_name, opt_name)
+        ctrl.optimizer.config.num_rollouts = N
+        ctrl.reset()
+        ctrl.current_state = ctrl.task.default_state()
+        ctrl.optimizer.seed(21)
+        ctrl.fused_update = fused
+        rec = []
+        for step in range(3):
+            ctrl.time = 0.05 * step
+            ctrl.update_action()
+            tr = ctrl.traces
+            rec.append((ctrl.nominal_knots.copy(), np.array(getattr(ctrl.optimizer, "sigma", 0.0)).copy(), ctrl.costs_device.cpu().numpy().copy(), None if tr is None else tr.copy()))
+        torch.cuda.synchronize()
+        outs.append(rec)
+    for a, b in zip(*outs):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert (a[3] is None) == (b[3] is None) and (a[3] is None or (a[3].shape == b[3].shape and np.array_equal(a[3], b[3])))
+        assert np.isfinite(a[0]).all()

@@ -174,6 +174,48 @@ def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
         np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], atol=1e-5)
 
 
+def test_fr3_full_size_sampled_rollouts_match_oracle(gpu):
+    """BASELINE size (32 768 x 40, CEM, device noise): 256 of the plan step's own rollouts replayed through the fp64 oracle from the Philox columns the kernel read
+    (VERDICT round 3, item 2), with the cost tolerances of the 256-rollout plan-step test; nominal and sigma against an exact elite refit on the GPU's own
+    32 768 costs and candidates."""
+    import torch
+
+    from judo_amd.controller import make_controller
+    from oracle import oracle as O
+    from tests.conftest import record_margin
+    from tests.harness import oracle_plan_step
+
+    N, M = 32768, 256
+    ctrl = make_controller("fr3_pick", "cem")
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.horizon = 40 * ctrl.task.dt
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.optimizer.seed(12)
+    ctrl.prefetch_noise = False
+    ctrl.keep_candidates = True
+    nominal0 = ctrl.nominal_knots.copy()
+    sigma0 = ctrl.optimizer.sigma.copy()
+    ctrl.update_action()
+    torch.cuda.synchronize()
+    costs = ctrl.costs_device.cpu().numpy().astype(np.float64)
+    noise = ctrl.optimizer.last_noise
+    cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy().astype(np.float64)
+    assert costs.shape == (N,) and np.isfinite(costs).all() and cand.shape == (N, 4, 8)
+    idx = np.concatenate([[0], np.sort(np.random.default_rng(6).choice(np.arange(1, N), M - 1, replace=False))])
+    inj = noise[:, :, torch.as_tensor(idx[1:], device=noise.device)].permute(2, 0, 1).cpu().numpy()
+    ref = oracle_plan_step(O.Model("fr3_pick"), ctrl, nominal0, inj, "cem", sigma0)
+    np.testing.assert_allclose(cand[idx], ref["knots"], rtol=2e-6, atol=2e-6)
+    d = np.abs(costs[idx] + ref["rewards"])
+    record_margin("fr3_full_size_sampled", cost_median=np.median(d), cost_p95=np.percentile(d, 95), cost_max=d.max())
+    assert np.median(d) < 2e-4 and np.percentile(d, 95) < 1.5e-2, (np.median(d), np.percentile(d, 95))
+    exp_nom, exp_sig, _ = O.cem_update(cand, -costs, 3, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
+    np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=1e-4, atol=1e-6)
+    st = ctrl.solver_stats()
+    assert st["contact_overflow"] < 1e-4 * st["steps"], st
+
+
 def test_fr3_two_kernel_generations_agree(gpu):
     """The cooperative kernel (16 lanes per rollout, dense row-per-lane Hessian) and the one-lane-per-rollout generic kernel are
     independent implementations of the same step: on identical inputs their rollouts and sensors agree to solver tolerance over

@@ -177,6 +177,48 @@ def test_leap_full_size_properties(gpu):
     assert st["contact_overflow"] < 1e-4 * st["steps"]
 
 
+def test_leap_full_size_sampled_rollouts_match_oracle(gpu):
+    """BASELINE size (65 536 x 64, MPPI, device noise): 256 of the plan step's own rollouts -- global sample 0 and 255 picked at random -- replayed through the fp64
+    oracle from the Philox columns the kernel read, with the per-rollout cost tolerances of the 256-rollout plan-step test; the
+    returned nominal against an exact (fp64) MPPI update on the GPU's own 65 536 costs and candidates (judo/controller/controller.py:250-293)."""
+    import torch
+
+    from judo_amd.controller import make_controller
+    from oracle import oracle as O
+    from tests.conftest import record_margin
+    from tests.harness import oracle_plan_step
+
+    N, M = 65536, 256
+    ctrl = make_controller("leap_cube", "mppi")
+    ctrl.optimizer.config.num_rollouts = N
+    ctrl.controller_cfg.horizon = 0.64
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.system_metadata = dict(GOAL)
+    ctrl.optimizer.seed(11)
+    ctrl.prefetch_noise = False  # (the noise buffer of this iteration is read back below)
+    ctrl.keep_candidates = True
+    nominal0 = ctrl.nominal_knots.copy()
+    ctrl.update_action()
+    torch.cuda.synchronize()
+    costs = ctrl.costs_device.cpu().numpy().astype(np.float64)
+    noise = ctrl.optimizer.last_noise  # (K, nu, N), the columns the rollout kernel read
+    cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy().astype(np.float64)  # (N, K, nu), clipped
+    assert costs.shape == (N,) and np.isfinite(costs).all() and cand.shape == (N, 4, 16)
+    idx = np.concatenate([[0], np.sort(np.random.default_rng(5).choice(np.arange(1, N), M - 1, replace=False))])
+    inj = noise[:, :, torch.as_tensor(idx[1:], device=noise.device)].permute(2, 0, 1).cpu().numpy()
+    ref = oracle_plan_step(O.Model("leap_cube"), ctrl, nominal0, inj, "mppi")
+    np.testing.assert_allclose(cand[idx], ref["knots"], rtol=2e-6, atol=2e-6)
+    d = np.abs(costs[idx] + ref["rewards"])
+    record_margin("leap_full_size_sampled", cost_median=np.median(d), cost_p95=np.percentile(d, 95), cost_max=d.max())
+    assert np.median(d) < 2e-6 and np.percentile(d, 95) < 1e-5, (np.median(d), np.percentile(d, 95))
+    exp = O.mppi_update(cand, -costs, 0.0025)
+    record_margin("leap_full_size_sampled", nominal_vs_exact_update=np.abs(ctrl.nominal_knots - exp).max())
+    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=1e-5)
+    st = ctrl.model.stats()
+    assert st["contact_overflow"] < 1e-4 * st["steps"]
+
+
 def test_leap_two_kernel_generations_agree(gpu):
     """The cooperative kernel (16 lanes per rollout) and the one-lane-per-rollout kernel are independent implementations of
     the same step; on identical inputs their rollouts agree to solver tolerance."""

@@ -79,6 +79,7 @@ def test_self_collision_single_steps_match_oracle(gpu):
     has a cycle, the dense direction."""
     from judo_amd.rollout_backend import GpuRolloutBackend
     from oracle import oracle as O
+    from tests.conftest import record_margin
 
     om, xs, q = _tangled_states(600, seed=5)
     kinds = np.array([_contact_kinds(om, xs[i], q[i]) for i in range(len(xs))])
@@ -104,6 +105,7 @@ def test_self_collision_single_steps_match_oracle(gpu):
     for sel, name in ((within, "arrow"), (paired, "staged arrow, coupled pairs"), (forest, "staged arrow, a chain with two coupled neighbours"), (tangled, "dense direction"),
                       (ok & (kinds[:, :3].sum(1) == 0), "no contact")):
         ev = e[sel][:, 23:]
+        record_margin("self_collision_single_steps", path=name, n=int(sel.sum()), median=np.median(ev), p95=np.percentile(ev, 95), p99=np.percentile(ev, 99), max=ev.max())
         assert np.median(ev) < 2e-5 and np.percentile(ev, 95) < 2e-2, (name, np.median(ev), np.percentile(ev, 95))
     # the same steps WITHOUT the hand's own contacts are far off: the cube-only model moves the fingers through each other
     oc = O.Model("leap_cube", scope="cube")
