@@ -317,6 +317,7 @@ def main() -> None:
         t_plan += 1.0 / ctrl.controller_cfg.control_freq
     ctrl.kernel_events.clear()
     ctrl.exchange_events.clear()
+    ctrl.reserve_timing_events(4 * args.steps * max(1, ctrl.max_opt_iters) + 8)  # (the timed region records HIP events, it does not create them)
     ctrl.solver_warnings = False
     if not is_policy:
         ctrl.solver_stats()  # zero the kernels' counters: the line reports the timed steps alone

@@ -121,6 +121,7 @@ class Controller:
         self._noise_cur = 0
         self._noise_ahead = None
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
+        self.zero_copy_out = True  # jh_update_fused writes nominal | sigma | trace records into the pinned host block itself (no download command)
         self.fused_update = True  # one GPU: the whole update (block partials, merge, trace elites) in one launch and one download (jh_update_fused); False: the separate kernels
         self._prefetch_args = None
         self.keep_candidates = False
@@ -319,6 +320,14 @@ class Controller:
         self._noise_cur ^= 1
         return self._noise_bufs[self._noise_cur]
 
+    def reserve_timing_events(self, n: int) -> None:
+        """Create n timing events ahead of a measured region (`record_kernel_events`): creating them inside it costs a small plan step several microseconds each."""
+        self._event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+
+    def _timing_event(self):
+        pool = getattr(self, "_event_pool", None)
+        return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+
     def _draw_noise(self, n_local: int, n_offset: int) -> torch.Tensor:
         """The optimizer's noise for this shard, generated into a persistent (K, nu, n_local) buffer when it comes from the device noise stream -- or taken from
         the draw `_prefetch_noise` enqueued behind the last iteration's download (same stream, same draw number: the same numbers, earlier)."""
@@ -448,16 +457,19 @@ class Controller:
             lohi = np.where(np.isnan(lohi), np.concatenate([ctrl_lo, ctrl_hi]), lohi)
         return np.nan_to_num(lohi.astype(np.float32), posinf=3.0e38, neginf=-3.0e38)
 
-    def _fetch(self, b: _PlanBuffers, n: int, behind=None) -> np.ndarray:
+    def _fetch(self, b: _PlanBuffers, n: int, behind=None, in_place: bool = False) -> np.ndarray:
         """Device result -> pinned host memory, one wait: the only synchronisation of an iteration.  `behind` enqueues work that may run after the
-        copy (the trace records): it is launched while the copy is in flight and is not waited for."""
+        copy (the trace records): it is launched while the copy is in flight and is not waited for.  `in_place`: the update kernel wrote the pinned host
+        block itself (jh_update_fused with host pointers): no copy, the completion mark alone."""
         L = _lib.lib()
-        _lib.check(L.jh_download_begin(b.out_host_ptr, b.out.data_ptr(), 4 * n, self._stream), "jh_download_begin")
-        if behind is not None:
-            behind()
-        if self._prefetch_args is not None:
-            self._prefetch_noise(*self._prefetch_args)
-        _lib.check(L.jh_download_end(), "jh_download_end")
+        _lib.check(L.jh_download_begin(b.out_host_ptr, b.out.data_ptr(), 0 if in_place else 4 * n, self._stream), "jh_download_begin")
+        try:  # (the mark set by `begin` must be consumed whatever happens in between: `end` pops the oldest mark of this thread)
+            if behind is not None:
+                behind()
+            if self._prefetch_args is not None:
+                self._prefetch_noise(*self._prefetch_args)
+        finally:
+            _lib.check(L.jh_download_end(), "jh_download_end")
         return b.out_np[:n].astype(np.float64)
 
     def _fused_iteration(self, lib, b: _PlanBuffers, nrm: Normalizer, nominal_n: np.ndarray, W, shard: Shard, world: int, H: int, K: int, nu: int, N: int,
@@ -481,7 +493,7 @@ class Controller:
                 b.knots_out = torch.empty((K, nu, ldn), dtype=torch.float32, device=self.device)
             knots_out = b.knots_out[:, :, : shard.count]
         if self.record_kernel_events:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0, ev1 = self._timing_event(), self._timing_event()
             ev0.record()
         state["trace_buf"] = None
         if self.uses_fused_cost:
@@ -519,26 +531,28 @@ class Controller:
             b.size_out(n_out)
             mode, lam, k_el, tie = opt.fused_update_args()
             if self.record_kernel_events:
-                ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ex0, ex1 = self._timing_event(), self._timing_event()
                 ex0.record()
+            # the results go straight into the pinned host block (device-visible: hipHostMalloc): a few KB of stores from the last workgroup instead of a copy command
+            o = b.out_host_ptr if self.zero_copy_out else b.out.data_ptr()
             st = lib.jh_update_fused(_lib.ptr(costs), None, _lib.ptr(b.nominal), noise_p, ldn, _lib.ptr(b.sigma), _lib.ptr(b.lohi), shard.count, shard.offset, K, nu, mode, lam,
                                      k_el, tie, E_t, _lib.ptr(tb[0]) if E_t else None, row, int(self._trace_colmajor) if E_t else 0, _lib.ptr(b.fused_scratch),
-                                     b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, (b.out.data_ptr() + 8 * K * nu) if E_t else None, stream)
+                                     o, o + 4 * K * nu, (o + 8 * K * nu) if E_t else None, stream)
             _lib.check(st, "jh_update_fused")
             if self.record_kernel_events:
                 ex1.record()
                 self.exchange_events.append((ex0, ex1))
             if staging and E_t:
-                res = self._fetch(b, n_out)
+                res = self._fetch(b, n_out, in_place=self.zero_copy_out)
                 self._traces = None
                 self._trace_stage = dict(kind="sensors", recs=b.out_np[2 * K * nu : n_out].copy(), stride=2 + row, E=int(state["E"]), x0=state["x0"], times=np.array(state["new_times"]),
-                                         order=self.spline_order, H=H, K=K, nu=nu, index_is_bits=True)
+                                         order=self.spline_order, H=H, K=K, nu=nu, index_is_bits=True, sorted=True)
             else:
-                res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))
+                res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"), in_place=self.zero_copy_out)
         else:
             opt.device_partial(costs, None, b.nominal, noise_p, b.sigma, b.lohi, shard.count, shard.offset, b.scratch, b.rec, ldn=ldn, stream=stream)
             if self.record_kernel_events:  # the exchange of the per-rank records and the merge (bench.py attributes the plan step: kernel / exchange / host)
-                ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ex0, ex1 = self._timing_event(), self._timing_event()
                 ex0.record()
             recs = all_gather_records(b.rec, self.group)
             opt.device_merge(recs, world, b.out.data_ptr(), b.out.data_ptr() + 4 * K * nu, clip_sigma=False, stream=stream)
@@ -548,7 +562,7 @@ class Controller:
             res = self._fetch(b, 2 * K * nu if is_cem else K * nu, behind=state.get("stage"))
         nominal_n = (res[: K * nu].reshape(K, nu) - center[None, :]) / scale[None, :]  # the update acted on the normalised candidates
         if is_cem:  # CEM: refit in normalised units
-            opt.sigma = np.clip(res[K * nu :].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
+            opt.sigma = np.clip(res[K * nu : 2 * K * nu].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
         if nrm.needs_moments:  # running statistics over this iteration's raw candidates, all ranks (controller.py:290-291)
             if b.mom is None:
                 b.mom = torch.empty(2 * nu, dtype=torch.float32, device=self.device)
@@ -764,8 +778,17 @@ class Controller:
         S, H, E = len(self.trace_sensors), st["H"], st["E"]
         recs = st["recs"]
         recs = (recs.cpu().numpy() if torch.is_tensor(recs) else np.asarray(recs)).reshape(-1, st["stride"])
-        idx = recs[:, 1].view(np.int32).astype(np.int64) if st["index_is_bits"] else recs[:, 1].astype(np.int64)
-        cost = recs[:, 0].astype(np.float64)
+        idx = recs[:, 1].view(np.int32) if st["index_is_bits"] else recs[:, 1].astype(np.int64)
+        cost = recs[:, 0]
+        if st.get("sorted"):  # jh_update_fused: one rank's records, already best first (ties: higher index first), the empty ones last
+            n = int(np.count_nonzero((idx >= 0) & np.isfinite(cost)))
+            p = recs[: min(n, E), 2:].reshape(-1, H, S, 3).transpose(0, 2, 1, 3)  # (elites, S, H, 3)
+            segs = np.empty((p.shape[0], S, H - 1, 2, 3))
+            segs[:, :, :, 0] = p[:, :, :-1]
+            segs[:, :, :, 1] = p[:, :, 1:]
+            return segs.reshape(-1, 2, 3)  # elite-major, then sensor, then time
+        idx = idx.astype(np.int64)
+        cost = cost.astype(np.float64)
         ok = np.nonzero((idx >= 0) & np.isfinite(cost))[0]
         # best first; among equal costs the higher global index first (argsort(rewards)[-E:][::-1] with a stable sort)
         ok = ok[np.lexsort((-idx[ok], cost[ok]))][:E]

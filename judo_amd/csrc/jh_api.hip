@@ -215,7 +215,7 @@ extern "C" int jh_download_begin(void* dst, const void* src, size_t nbytes, void
     JH_HIP(e);
     g_dl_marks.push_back({stream, ev});
   }
-  JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (nbytes > 0) JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));  // (0 bytes: the kernels wrote the pinned host block themselves; the mark alone)
   JH_HIP(hipEventRecord(ev, (hipStream_t)stream));
   g_dl_pending.push_back(ev);
   return JH_OK;

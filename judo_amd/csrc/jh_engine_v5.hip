@@ -29,7 +29,10 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_LSMAX 16
 #endif
 #ifndef JH_V5_LSKINK
-#define JH_V5_LSKINK 1  // line search: where the plain safeguarded Newton search is in trouble it tries the step lengths at which the slope jumps (below)
+#define JH_V5_LSKINK 0  // 1: where the plain safeguarded Newton search is in trouble the line search tries the step lengths at which the slope jumps (below).  Round 4, recorded
+                        // inputs (profiles/r04_leap_experiments.txt): it does what the CPU prototype promised -- 3.65 instead of 4.68 slope evaluations per Newton iteration of a
+                        // wave, the 9..16-evaluation searches gone (15 % -> 3 % of the wave's searches) -- and the kernel is 2.1 % SLOWER (82.45 against 80.75 ms): a slope
+                        // evaluation is ~1 % of an iteration's issue slots, the candidates' registers and the extra block cost more than a fifth of them.  Off.
 #endif
 #ifndef JH_V5_LSSHRINK
 #define JH_V5_LSSHRINK 0.9f
@@ -468,8 +471,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
   float acc = 0.f;
 #ifdef JH_V5_TICKS  // shader-clock totals per phase (diagnostic builds; tools/diag/profile_v5.py): 0 kinematics+dynamics, 1 broad phase, 2 narrow phase, 3 rows+warm start,
                      // 4 gradient, 5 Newton matrix, 6 factorisation+direction, 7 line search+step and integration
-  long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
+  long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
 #define V5_TICK(slot) { long long t__ = clock64(); cyc[slot] += t__ - t0; t0 = t__; }
+  // finer split (tools/diag/profile_v5b.py reads stats[384..]): 8 convergence test + Hessian initialisation, 9 Schur complement + 6x6 + back-substitution (the rest of 6 is the chain
+  // blocks), 10 line-search set-up (M p, J p), 11 the slope evaluations, 12 step
 #else
 #define V5_TICK(slot)
 #endif
@@ -1010,6 +1015,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
         WSYNC();
+        V5_TICK(8)
 #pragma unroll
         for (int k = 0; k < NS; k++) {
           const Slot& t = sl[k];
@@ -1125,6 +1131,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           }
         }
         WSYNC();
+        V5_TICK(6)
         {
           // Schur complement: Hcc[q][r] -= sum over chains of Y_q . Y_r, rhs6[q] -= sum of Y_q . zb; lane s of a chain owns q in {s, s+4} and fetches Y_r from
           // its chain-mates; the four chains' terms are added with two row rotations and the first chain's lane applies the total
@@ -1326,7 +1333,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
 }
 #endif
-        V5_TICK(6)
+        V5_TICK(9)
         // ---- (5) exact line search along p
         if constexpr (OPQ > 3) forget_slots();
         float Mp_own = 0.f;
@@ -1361,6 +1368,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           }
         }
 #endif
+        V5_TICK(10)
         float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
 #ifdef JH_V5_CENSUS
         int cen_ls = 0, cen_lsw = 0; const bool cen_act = act;
@@ -1417,6 +1425,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #ifdef JH_V5_CENSUS
         if (stats) { if (l == 0 && live && cen_act) atomicAdd(stats + 256 + min(cen_ls, 31), 1); if (lane == 0) atomicAdd(stats + 288 + min(cen_lsw, 31), 1); }
 #endif
+        V5_TICK(11)
         // ---- (6) step
         if (act) {
           a_own += alpha * p_own; ac_own += alpha * xcl;
@@ -1426,6 +1435,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           if (-gp * alpha <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
         }
         WSYNC();
+        V5_TICK(12)
       }
       };
       // (the rare slot-count copy instantiates the dense-capable loop only -- it serves rollouts without a dense row as well: three copies of the loop instead of four, and
@@ -1505,7 +1515,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
   if (stats) { if (lane == 0) { atomicAdd(stats + 24, cnt_dense); atomicAdd(stats + 25, cnt_it); atomicAdd(stats + 26, cnt_l2); atomicAdd(stats + 28, H); } if (l == 0 && live) { atomicAdd(stats + 27, cnt_bp); atomicAdd(stats + 29, cnt_hh); for (int k = 0; k < 4; k++) atomicAdd(stats + 30 + k, cnt_cls[k]); } }
 #endif
 #ifdef JH_V5_TICKS
-  if (lane == 0 && stats) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)cyc[k]);
+  if (lane == 0 && stats) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)cyc[k]);
+                            for (int k = 0; k < 16; k++) atomicAdd((unsigned long long*)(stats + 384) + k, (unsigned long long)cyc[k]); }
 #endif
   if (!MATERIALIZE && live && l == 0) costs[n] = acc / (float)H;
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }

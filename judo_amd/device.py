@@ -21,7 +21,14 @@ def require_gpu() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream_ptr() -> int:
+    """The current HIP stream of the current device as an integer (what the C ABI takes).  `torch.cuda.current_stream()` builds a Stream object through several
+    layers of Python (10 us per call, a tenth of a small plan step); the raw accessor behind it returns the same handle in well under a microsecond."""
+    if _raw_stream is not None:
+        return int(_raw_stream(torch.cuda.current_device()))
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -106,7 +106,8 @@ def test_self_collision_single_steps_match_oracle(gpu):
                       (ok & (kinds[:, :3].sum(1) == 0), "no contact")):
         ev = e[sel][:, 23:]
         record_margin("self_collision_single_steps", path=name, n=int(sel.sum()), median=np.median(ev), p95=np.percentile(ev, 95), p99=np.percentile(ev, 99), max=ev.max())
-        assert np.median(ev) < 2e-5 and np.percentile(ev, 95) < 2e-2, (name, np.median(ev), np.percentile(ev, 95))
+        # observed (GPUTEST round 4, gpurun_out/test_margins.jsonl): median 1e-8 .. 4e-8, 95th percentile 1e-7 .. 4e-6, 99th 2e-7 .. 1.1e-5, max 6.5e-5 on every solver path
+        assert np.median(ev) < 1e-6 and np.percentile(ev, 95) < 5e-5 and np.percentile(ev, 99) < 2e-4, (name, np.median(ev), np.percentile(ev, 95), np.percentile(ev, 99))
     # the same steps WITHOUT the hand's own contacts are far off: the cube-only model moves the fingers through each other
     oc = O.Model("leap_cube", scope="cube")
     rc, _ = oc.rollout(xs[across], us[across])
