@@ -211,6 +211,19 @@ size_t jh_update_fused_scratch_floats(int N, int K, int nu);
 int jh_update_fused(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi, int N,
                     int n_offset, int K, int nu, int mode, float lambda, int k, int tie_high, int E, const float* trace, int row_floats, int colmajor, float* scratch,
                     float* nominal_out, float* sigma_out, float* trace_out, void* stream);
+/* One iteration of Controller.update_action's loop (judo/controller/controller.py:250-299) on ONE GPU as one call: upload of the packed host block
+ * [x0 | nominal | sigma | task params | ctrl bounds] (float offsets o_* into it) into blk_dev, jh_rollout_cost_traced, jh_update_fused with its outputs at
+ * out = [nominal K*nu | sigma K*nu | E x (2 + row_floats) trace records] (device memory, or device-visible pinned host memory: then no download is needed), and the
+ * completion mark of jh_download_begin (zero bytes).  Asynchronous on `stream`; jh_download_end waits.  `trace` NULL: no trace records (E ignored). */
+int jh_plan_step(const jh_model* m, void* blk_dev, const void* blk_host, size_t blk_bytes, int o_nominal, int o_sigma, int o_tp, int o_lohi, const float* noise, int ldn,
+                 const float* W, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, int mode, float lambda, int k, int tie_high, int E,
+                 int row_floats, int colmajor, float* scratch, float* out, void* out_host_mark, void* const* timing, void* stream);
+/* `timing`: NULL, or three events of jh_event_create recorded on `stream` before the rollout kernel, between it and the update, and behind the update
+ * (what bench.py's roofline leg reads: jh_event_elapsed_ms waits for its second event). */
+int jh_event_create(void** out);
+void jh_event_destroy(void* ev);
+int jh_event_record(void* ev, void* stream);
+int jh_event_elapsed_ms(void* a, void* b, float* ms);
 /* Merge G*k records -> global k elites -> mean and clipped population std (ddof 0).  sigma_out may be NULL (PS, k=1). */
 int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float sigma_min, float sigma_max, float* nominal_out,
                    float* sigma_out, void* stream);

@@ -61,6 +61,12 @@ _SIGNATURES = {
     "jh_update_fused_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "jh_update_fused": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int,
                                   f32p, f32p, f32p, f32p, C.c_void_p]),
+    "jh_plan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p,
+                               C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jh_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "jh_event_destroy": (None, [C.c_void_p]),
+    "jh_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jh_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "jh_elite_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
 }
 

@@ -21,6 +21,7 @@ nothing, does one asynchronous H2D copy of a < 2 KB block, one asynchronous D2H 
 
 from __future__ import annotations
 
+import ctypes as C
 import warnings
 from typing import Any
 
@@ -29,7 +30,7 @@ import torch
 
 from judo_amd import _lib
 from judo_amd.config import ControllerConfig, OptimizerConfig
-from judo_amd.device import current_stream_ptr, require_gpu
+from judo_amd.device import HipEvent, current_stream_ptr, require_gpu
 from judo_amd.distributed import Shard, all_gather_records, shard_rollouts, world_info
 from judo_amd.normalization import Normalizer, make_normalizer, normalizer_registry
 from judo_amd.optimizers import FusedOptimizer, Optimizer, get_registered_optimizers
@@ -322,11 +323,11 @@ class Controller:
 
     def reserve_timing_events(self, n: int) -> None:
         """Create n timing events ahead of a measured region (`record_kernel_events`): creating them inside it costs a small plan step several microseconds each."""
-        self._event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        self._event_pool = [HipEvent() for _ in range(n)]
 
-    def _timing_event(self):
+    def _timing_event(self) -> HipEvent:
         pool = getattr(self, "_event_pool", None)
-        return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+        return pool.pop() if pool else HipEvent()
 
     def _draw_noise(self, n_local: int, n_offset: int) -> torch.Tensor:
         """The optimizer's noise for this shard, generated into a persistent (K, nu, n_local) buffer when it comes from the device noise stream -- or taken from
@@ -431,7 +432,7 @@ class Controller:
         self.times = new_times
         self.update_spline(self.times, self.nominal_knots)
 
-    def _pack_block(self, b: _PlanBuffers, nominal_raw: np.ndarray, sigma_raw: np.ndarray | None, lohi: np.ndarray) -> None:
+    def _pack_block(self, b: _PlanBuffers, nominal_raw: np.ndarray, sigma_raw: np.ndarray | None, lohi: np.ndarray, upload: bool = True) -> None:
         """x0 | nominal | sigma | task params | ctrl bounds -> pinned host block -> device, one asynchronous copy."""
         h, o = b.host_np, 0
         n = b.sizes[0]; h[o : o + n] = self.current_state; o += n
@@ -439,7 +440,8 @@ class Controller:
         n = b.sizes[2]; h[o : o + n] = 0.0 if sigma_raw is None else sigma_raw.reshape(-1); o += n
         n = b.sizes[3]; h[o : o + n] = self.task.task_params(self.system_metadata); o += n
         h[o:] = lohi
-        _lib.check(_lib.lib().jh_upload_async(b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, self._stream), "jh_upload_async")
+        if upload:
+            _lib.check(_lib.lib().jh_upload_async(b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, self._stream), "jh_upload_async")
 
     def _raw_bounds(self, nrm: Normalizer) -> np.ndarray:
         r = self.task.actuator_ctrlrange
@@ -480,7 +482,9 @@ class Controller:
         scale, center = nrm.noise_scale(), nrm.denormalize(np.zeros(nu))
         nominal_raw = nrm.denormalize(nominal_n)
         sigma_raw = sigma_n * scale[None, :]
-        self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm))
+        fused_cost = self.uses_fused_cost
+        one_call = world == 1 and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
+        self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm), upload=not one_call)
         noise = self._draw_noise(shard.count, shard.offset)  # (K, nu, shard.count), possibly a view into the full draw
         self._prefetch_args = (shard.count, shard.offset)
         ldn, noise_p = int(noise.stride(1)), noise.data_ptr()
@@ -492,11 +496,57 @@ class Controller:
             if b.knots_out is None or b.knots_out.shape[2] != ldn:
                 b.knots_out = torch.empty((K, nu, ldn), dtype=torch.float32, device=self.device)
             knots_out = b.knots_out[:, :, : shard.count]
+        state["trace_buf"] = None
+        is_cem = hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray)
+        if one_call:
+            # ---- one GPU, shipped cost: the whole iteration is ONE library call (jh_plan_step: upload, rollout + cost kernel, one-launch update with the trace elites'
+            # records, results written straight into the pinned host block) and one wait
+            nfl = self._fused_trace_floats()
+            staging = state.get("stage") is not None
+            if nfl and (b.trace_buf is None or b.trace_buf.numel() != shard.count * H * nfl):
+                b.trace_buf = torch.empty(shard.count * H * nfl, dtype=torch.float32, device=self.device)
+            E_t = min(int(state.get("E", 0)), _lib.MAX_ELITES) if (staging and nfl) else 0
+            row = H * nfl if E_t else 0
+            n_out = 2 * K * nu + E_t * (2 + row)
+            b.size_out(n_out)
+            mode, lam, k_el, tie = opt.fused_update_args()
+            timing = None
+            if self.record_kernel_events:
+                evs = [self._timing_event() for _ in range(3)]
+                timing = (C.c_void_p * 3)(*[e.handle for e in evs])
+                self.kernel_events.append((evs[0], evs[1]))
+                self.exchange_events.append((evs[1], evs[2]))
+            off = np.cumsum([0] + b.sizes)
+            st = lib.jh_plan_step(self.model.handle, b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W), int(task.phase),
+                                  shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el, tie, E_t, row,
+                                  int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.out_host_ptr, timing, stream)
+            try:
+                _lib.check(st, "jh_plan_step")
+                if self._prefetch_args is not None:
+                    self._prefetch_noise(*self._prefetch_args)
+            finally:
+                if st == 0:
+                    _lib.check(lib.jh_download_end(), "jh_download_end")
+            res = b.out_np[:n_out].astype(np.float64)
+            if nfl:
+                state["trace_buf"] = (b.trace_buf, H * nfl)
+            state.update(costs=b.costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
+            if E_t:
+                self._traces = None
+                self._trace_stage = dict(kind="sensors", recs=b.out_np[2 * K * nu : n_out].copy(), stride=2 + row, E=int(state["E"]), x0=state["x0"], times=np.array(state["new_times"]),
+                                         order=self.spline_order, H=H, K=K, nu=nu, index_is_bits=True, sorted=True)
+            elif staging:
+                state["stage"]()  # (no trace buffer: the elites' knots, re-rolled when the traces are read)
+            nominal_n = (res[: K * nu].reshape(K, nu) - center[None, :]) / scale[None, :]
+            if is_cem:
+                opt.sigma = np.clip(res[K * nu : 2 * K * nu].reshape(K, nu) / scale[None, :], opt.sigma_min, opt.sigma_max)
+            self._rewards, self._candidate_knots = None, None
+            self._last_fused = dict(b=b, noise=noise, noise_p=noise_p, ldn=ldn, shard=shard, K=K, nu=nu)
+            return nominal_n
         if self.record_kernel_events:
             ev0, ev1 = self._timing_event(), self._timing_event()
             ev0.record()
-        state["trace_buf"] = None
-        if self.uses_fused_cost:
+        if fused_cost:
             nfl = self._fused_trace_floats()
             if nfl:  # the kernel also writes the trace sensors of every rollout: `traces` becomes a gather of the elites' rows instead of a second rollout
                 if b.trace_buf is None or b.trace_buf.numel() != shard.count * H * nfl:

@@ -262,6 +262,39 @@ extern "C" int jh_rollout_cost_traced(const jh_model* m, const float* x0, const 
   return g_xcheck.rollout_cost(m, m->kernel_gen, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, stream);
 }
 
+// One plan-step iteration on one GPU as ONE call (Controller.update_action's loop body, judo/controller/controller.py:250-299): the packed host block
+// x0 | nominal | sigma | task params | bounds goes up, the fused rollout + cost kernel runs, jh_update_fused reduces the costs to nominal | sigma | trace
+// records -- written where `out` points, normally the pinned host block itself -- and the completion mark of jh_download_begin is set: jh_download_end waits for
+// it.  Everything is enqueued on `stream`; nothing is waited for here.  Five ctypes calls less per plan step than the separate entry points: a tenth of a small one.
+extern "C" int jh_plan_step(const jh_model* m, void* blk_dev, const void* blk_host, size_t blk_bytes, int o_nominal, int o_sigma, int o_tp, int o_lohi, const float* noise, int ldn,
+                            const float* W, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, int mode, float lambda, int k, int tie_high, int E,
+                            int row_floats, int colmajor, float* scratch, float* out, void* out_host_mark, void* const* timing /* 3 events of jh_event_create, or NULL */, void* stream) {
+  JH_REQUIRE(m && blk_dev && blk_host && out && scratch, "plan_step: null pointer");
+  const float* b = (const float*)blk_dev;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = jh_upload_async(blk_dev, blk_host, blk_bytes, stream);
+  if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[0], st));
+  if (rc == JH_OK) rc = jh_rollout_cost_traced(m, b, b + o_nominal, noise, ldn, b + o_sigma, W, b + o_lohi, b + o_tp, phase, N, n_offset, H, K, costs, knots_out, trace, stream);
+  if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[1], st));
+  const int KU = K * m->nu;
+  if (rc == JH_OK) rc = jh_update_fused(costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace, row_floats,
+                                        colmajor, scratch, out, out + KU, (trace && E > 0) ? out + 2 * KU : nullptr, stream);
+  if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[2], st));
+  if (rc == JH_OK) rc = jh_download_begin(out_host_mark, out, 0, stream);
+  return rc;
+}
+
+// Timing events for callers that bracket kernels on the launch stream without torch (bench.py's roofline leg: the rollout kernel's duration inside a jh_plan_step call)
+extern "C" int jh_event_create(void** out) { JH_REQUIRE(out, "event_create: null pointer"); hipEvent_t e; JH_HIP(hipEventCreate(&e)); *out = e; return JH_OK; }
+extern "C" void jh_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int jh_event_record(void* ev, void* stream) { JH_REQUIRE(ev, "event_record: null pointer"); JH_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return JH_OK; }
+extern "C" int jh_event_elapsed_ms(void* a, void* b, float* ms) {  // waits for b
+  JH_REQUIRE(a && b && ms, "event_elapsed_ms: null pointer");
+  JH_HIP(hipEventSynchronize((hipEvent_t)b));
+  JH_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return JH_OK;
+}
+
 extern "C" int jh_rollout_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states,
                                       float* sensors, void* stream) {
   JH_REQUIRE(m && x0 && controls, "rollout_materialize: null pointer");

@@ -40,6 +40,12 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
+#ifndef JH_V5_GCUBE_ATOMIC
+#define JH_V5_GCUBE_ATOMIC 0
+#endif
+#ifndef JH_V5_LSRCP
+#define JH_V5_LSRCP 0
+#endif
 #ifndef JH_V5_WAVES_PER_EU
 #define JH_V5_WAVES_PER_EU 2
 #endif
@@ -969,6 +975,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
         if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
         if (act) S.g[6 + l] = g_own;
+#if JH_V5_GCUBE_ATOMIC
+        if (act && l < 6) S.g[l] = mck * dcl;
+#endif
         WSYNC();
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
         if (act) {
@@ -984,16 +993,25 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
             if (!SELF || t.la == CUBE) {  // cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
               float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
+#if JH_V5_GCUBE_ATOMIC
+              atomicAdd(&S.g[0], Fw[0]); atomicAdd(&S.g[1], Fw[1]); atomicAdd(&S.g[2], Fw[2]); atomicAdd(&S.g[3], tb[0]); atomicAdd(&S.g[4], tb[1]); atomicAdd(&S.g[5], tb[2]);
+#else
               gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
+#endif
             } else if (SELF && t.la > 0) link_force(S, t.la, pos, Fw, -1.f);
             if (t.lb > 0) link_force(S, t.lb, pos, Fw, 1.f);
           }
         }
         float gcl = 0.f;
+#if JH_V5_GCUBE_ATOMIC
+        WSYNC();
+        if (l < 6) gcl = S.g[l];
+#else
 #pragma unroll
         for (int q6 = 0; q6 < 6; q6++) { const float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
         gcl = fmaf(mck, dcl, gcl);  // lanes 6..15: mck = 0, gcl stays 0
         WSYNC();
+#endif
         V5_TICK(4)
         // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
         g_own = S.g[6 + l];
@@ -1414,7 +1432,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
               if (d1 < 0.f) { lo = alpha; dlo = d1; if (side < 0) dhi *= 0.5f; side = -1; } else { hi = alpha; dhi = d1; if (side > 0) dlo *= 0.5f; side = 1; }
+#if JH_V5_LSRCP
+              float nx = alpha - d1 * __builtin_amdgcn_rcpf(d2);
+#else
               float nx = alpha - d1 * __frcp_rn(d2);
+#endif
               if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
               else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
               alpha = nx;

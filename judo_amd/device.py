@@ -32,6 +32,34 @@ def current_stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class HipEvent:
+    """A timing event on the launch stream (jh_event_*): what `Controller.record_kernel_events` brackets the kernels with.  Same two methods as torch.cuda.Event, but the
+    handle exists from construction on, so the library can record it inside a multi-kernel call (jh_plan_step)."""
+
+    __slots__ = ("handle",)
+
+    def __init__(self) -> None:
+        h = C.c_void_p()
+        _lib.check(_lib.lib().jh_event_create(C.byref(h)), "jh_event_create")
+        self.handle = h.value
+
+    def record(self, stream: int | None = None) -> None:
+        _lib.check(_lib.lib().jh_event_record(self.handle, current_stream_ptr() if stream is None else stream), "jh_event_record")
+
+    def elapsed_time(self, other: "HipEvent") -> float:
+        ms = C.c_float()
+        _lib.check(_lib.lib().jh_event_elapsed_ms(self.handle, other.handle, C.byref(ms)), "jh_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self) -> None:
+        try:
+            if self.handle:
+                _lib.lib().jh_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def f32(x, device) -> torch.Tensor:
     """Host array -> contiguous fp32 device tensor."""
     return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(device, non_blocking=False)

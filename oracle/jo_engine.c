@@ -1101,6 +1101,8 @@ void jo_set_solver(jo_model* m, double tol, int maxiter) { m->solver_tol = tol; 
    Every solve appends (-1, number of rows) and per Newton iteration the number of slope evaluations to the log. */
 static int g_lsmode = 0, g_lsmax = 16; static double g_lstol = 1e-2, g_lskink = 0.1, g_lsshrink = 0.5;
 void jo_set_ls_shrink(double v) { g_lsshrink = v; }
+static int g_hreuse = 0; static __thread double g_last_alpha = 0; static long g_hreuse_count = 0;
+void jo_set_hessian_reuse(int mode) { g_hreuse = mode; g_hreuse_count = 0; } long jo_hessian_reuse_count(void) { return g_hreuse_count; }
 static long g_lstrouble = 0; long jo_ls_trouble(int reset) { long v = g_lstrouble; if (reset) g_lstrouble = 0; return v; }
 void jo_set_ls_kink(double v) { g_lskink = v; } static int* g_lslog = NULL; static long g_lslog_n = 0, g_lslog_cap = 0;
 void jo_set_ls_experiment(int mode, double lstol, int lsmax, int* log, long cap) { g_lsmode = mode; g_lstol = lstol; g_lsmax = lsmax; g_lslog = log; g_lslog_cap = cap; g_lslog_n = 0; }
@@ -1130,6 +1132,7 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
     double gn = 0; for (int i = 0; i < nv; i++) gn += grad[i] * grad[i]; gn = sqrt(gn);
     d->solver_cost = cost; d->solver_gradnorm = gn;
     if (gn * scale < m->solver_tol) break;
+    if (g_hreuse && it > 0 && ((g_hreuse == 1 && (it & 1)) || (g_hreuse == 2 && g_last_alpha > 0.8 && g_last_alpha < 1.25) || (g_hreuse == 3 && (it % 3) != 0))) { g_hreuse_count++; goto have_factor; }  /* (experiment: the previous factor) */
     for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) H[i][j] = d->M[i][j];
     for (int r = 0; r < ne; r++) if (Hd[r] != 0) for (int i = 0; i < nv; i++) { double ji = d->efc_J[r][i]; if (ji != 0) for (int j = 0; j < nv; j++) H[i][j] += Hd[r] * ji * d->efc_J[r][j]; }
     for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3 && cz[c]) {
@@ -1137,6 +1140,7 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
       for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) { double w = Hc[c][3 * u + v]; for (int i = 0; i < nv; i++) { double ji = d->efc_J[r0 + u][i]; if (ji != 0) for (int j = 0; j < nv; j++) H[i][j] += w * ji * d->efc_J[r0 + v][j]; } }
     }
     if (cholesky(nv, H, LH) != 0) break;
+    have_factor:
     for (int i = 0; i < nv; i++) p[i] = -grad[i];
     chol_solve(nv, LH, p);
     /* exact line search: phi(al) = cost(a + al p); safeguarded 1-D Newton on phi' */
@@ -1253,6 +1257,7 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
       fprintf(stderr, "  it %2d cost %.6e |g|s %.3e alpha %.4g  ncon %d nefc %d zones top(free)/middle/bottom(stick) %d/%d/%d\n", it, cost, gn * scale, al, d->ncon, ne, nz[0], nz[1], nz[2]);
     }
     for (int i = 0; i < nv; i++) a[i] += al * p[i];
+    g_last_alpha = al;
   }
   if (g_trace) fprintf(stderr, "solve done: %d iterations (warm start %s)\n", it, cw < cs ? "used" : "not used");
   d->solver_iter = it;
