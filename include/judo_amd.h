@@ -61,7 +61,8 @@ int jh_model_dims(const jh_model* m, int* dims /* HOST */);
  * out[0] contacts dropped because a rollout exceeded the per-rollout contact capacity, out[1] constraint solves that hit the
  * Newton iteration cap, out[2] Newton iterations (summed over rollouts), out[3] physics steps (summed over rollouts); leap_cube kernel generation 3 also:
  * out[4] Newton iterations executed by wavefronts (four rollouts advance in lock step: per step the maximum over the four), out[5] physics steps
- * summed over wavefronts; out[6], out[7] reserved (0).  The counters are 32-bit and wrap: reset them at least every ~10^9 rollout-steps.  HOST pointer. */
+ * summed over wavefronts; out[6] launches that ran without their overflow rows because the device's memory pool refused the scratch block (the contact capacity was then what
+ * the LDS pool holds), out[7] reserved (0).  The counters are 32-bit and wrap: reset them at least every ~10^9 rollout-steps.  HOST pointer. */
 int jh_model_stats(jh_model* m, int* out /* HOST, 8 ints */, int reset);
 
 /* Articulated-body engine kernel generation for this model: 3 (default, the only one in this library) = cooperative kernel on a register diet, two waves per

@@ -731,6 +731,9 @@ class Controller:
             st = {"contact_overflow": st["contacts_dropped"], "newton_cap_hits": st["steps_at_cap"], "newton_iters": st["newton_iterations"], "steps": st["steps"]}
         else:
             st = self.model.stats(reset)
+        if self.solver_warnings and st.get("overflow_pool_fallbacks", 0) > 0:
+            warnings.warn(f"{self.task.name}: {st['overflow_pool_fallbacks']} launches ran without their overflow rows (the device's memory pool refused the scratch block): "
+                          "contact capacity was what the LDS pool holds, not what jh_model_limits reports", stacklevel=2)
         if self.solver_warnings and st["steps"] > 0 and (st["contact_overflow"] > 1e-4 * st["steps"] or st["newton_cap_hits"] > 1e-2 * st["steps"]):
             warnings.warn(f"{self.task.name}: {st['contact_overflow']} contacts dropped above the kernel's per-rollout capacity and {st['newton_cap_hits']} "
                           f"constraint solves stopped at the iteration cap in {st['steps']} physics steps -- those rollouts are approximate", stacklevel=2)

@@ -40,11 +40,15 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
+#ifndef JH_V5_HXLAZY
+#define JH_V5_HXLAZY 0
+#endif
 #ifndef JH_V5_GCUBE_ATOMIC
-#define JH_V5_GCUBE_ATOMIC 0
+#define JH_V5_GCUBE_ATOMIC 1  // the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration:
+                              // 79.9 against 80.65 ms on the recorded inputs (round 4, profiles/r04_leap_experiments.txt); 0: the row sums
 #endif
 #ifndef JH_V5_LSRCP
-#define JH_V5_LSRCP 0
+#define JH_V5_LSRCP 1  // the line search's Newton step divides with v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence (10 instructions per evaluation): -0.2 %
 #endif
 #ifndef JH_V5_WAVES_PER_EU
 #define JH_V5_WAVES_PER_EU 2
@@ -1028,7 +1032,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
+#if JH_V5_HXLAZY
+          if (SELF && cmask != 0) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;  // (read and accumulated only by rollouts whose contacts couple two chains)
+#else
           if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
+#endif
           S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
@@ -1569,7 +1577,7 @@ int JH_V5_NAME(jh_engine5_rollout_cost)(const jh_model* m, const float* x0, cons
   const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;
   int grid = (N + per_block - 1) / per_block;
   float* ovf = nullptr;  // one row per rollout for the contacts above the LDS pool: stream-ordered allocation, no state on the model handle
-  if (NOVF > 0 && hipMallocAsync((void**)&ovf, (size_t)N * NOVF * POOL_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
+  if (NOVF > 0) ovf = jh_launch_scratch(m, (size_t)N * NOVF * POOL_F * sizeof(float), st);  // (nullptr: the LDS capacity alone, drops and the fallback counted)
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
                        knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
@@ -1587,7 +1595,7 @@ int JH_V5_NAME(jh_engine5_materialize)(const jh_model* m, const float* x0, int x
   const int dshift = jh_latency_shift(N, RPW); const int per_block = (RPW >> dshift) * JH_V5_WPB;
   int grid = (N + per_block - 1) / per_block;
   float* ovf = nullptr;  // one row per rollout for the contacts above the LDS pool: stream-ordered allocation, no state on the model handle
-  if (NOVF > 0 && hipMallocAsync((void**)&ovf, (size_t)N * NOVF * POOL_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
+  if (NOVF > 0) ovf = jh_launch_scratch(m, (size_t)N * NOVF * POOL_F * sizeof(float), st);  // (nullptr: the LDS capacity alone, drops and the fallback counted)
   if (m->self_collision && m->h_i[17] > 0)
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, true>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,

@@ -1128,7 +1128,7 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
   // one overflow row per rollout for the general contacts above the LDS pool: stream-ordered allocation (the pool hands the same block back launch after launch),
   // no state on the model handle
   float* ovf = nullptr;
-  if (hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
+  ovf = jh_launch_scratch(m, (size_t)N * NOVF * RAW_F * sizeof(float), st);  // (nullptr: the LDS capacity alone, drops and the fallback counted)
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
                      costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
   JH_HIP(hipGetLastError());
@@ -1144,7 +1144,7 @@ int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, c
   // one overflow row per rollout for the general contacts above the LDS pool: stream-ordered allocation (the pool hands the same block back launch after launch),
   // no state on the model handle
   float* ovf = nullptr;
-  if (hipMallocAsync((void**)&ovf, (size_t)N * NOVF * RAW_F * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); ovf = nullptr; }  // no pool: the LDS capacity alone, overflow counted
+  ovf = jh_launch_scratch(m, (size_t)N * NOVF * RAW_F * sizeof(float), st);  // (nullptr: the LDS capacity alone, drops and the fallback counted)
   hipLaunchKernelGGL(k_fr3_v6<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
                      (float*)nullptr, controls, states, sensors, m->d_stats, dshift, (float*)nullptr, ovf);

@@ -28,12 +28,24 @@ struct jh_model {
   int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int contact_capacity;  // leap_cube generation 3: 48 (all in LDS, jh_engine_v5.hip) or 64 (jh_engine_v5_cap64.hip); jh_model_set_contact_capacity
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
+  mutable int ovf_fallbacks = 0;  // launches that ran without their overflow rows (jh_launch_scratch)
   int* d_stats;  // JH_NSTATS diagnostic counters: [0..3] contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps; [20..21] wave-level iterations, steps; the rest: diagnostic builds
   std::vector<float> h_f;
   std::vector<int> h_i;
 };
 
 void jh_set_error(const char* fmt, ...);
+
+// Per-launch scratch of the cooperative kernels (the contacts above the LDS pool, one row per rollout): a stream-ordered allocation from the default pool of the MODEL's
+// device (not of whatever device is current in the calling thread).  nullptr when the pool refuses: the kernel then holds what its LDS pool holds, the drops are
+// counted, and the launch is counted in `ovf_fallbacks` (jh_model_stats out[6]) so that the lower capacity does not go unnoticed.
+inline float* jh_launch_scratch(const jh_model* m, size_t bytes, hipStream_t st) {
+  hipMemPool_t pool = nullptr; void* p = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, m->device) == hipSuccess && pool && hipMallocFromPoolAsync(&p, bytes, pool, st) == hipSuccess) return (float*)p;
+  (void)hipGetLastError();
+  m->ovf_fallbacks++;
+  return nullptr;
+}
 
 #define JH_HIP(call)                                                                      \
   do {                                                                                    \

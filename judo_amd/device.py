@@ -146,7 +146,7 @@ class GpuModel:
         out = (C.c_int * 8)()
         _lib.check(_lib.lib().jh_model_stats(self.handle, out, int(reset)), "jh_model_stats")
         u = [v & 0xFFFFFFFF for v in out]  # 32-bit counters: unsigned
-        return {"contact_overflow": u[0], "newton_cap_hits": u[1], "newton_iters": u[2], "steps": u[3], "wave_newton_iters": u[4], "wave_steps": u[5]}
+        return {"contact_overflow": u[0], "newton_cap_hits": u[1], "newton_iters": u[2], "steps": u[3], "wave_newton_iters": u[4], "wave_steps": u[5], "overflow_pool_fallbacks": u[6]}
 
     def __del__(self) -> None:
         try:

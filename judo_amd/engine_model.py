@@ -245,7 +245,10 @@ def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = No
     out = []
     for a in range(len(geoms)):
         for b in range(a + 1, len(geoms)):
-            ga, gb = geoms[a], geoms[b]
+            ia, ib = a, b
+            if geoms[a]["type"] == "capsule" and geoms[b]["type"] == "box":  # (box, capsule) is the order the kernels take, whichever geom the model lists first
+                ia, ib = b, a
+            ga, gb = geoms[ia], geoms[ib]
             ta, tb = ga["type"], gb["type"]
             if not ((ta == "box" and tb in ("box", "sphere", "capsule")) or (ta == "sphere" and tb == "box") or (ta == "sphere" and tb == "sphere" and cube_only is False)):
                 continue  # (sphere-sphere: the fingertips of two fingers; only jh_engine_v5.hip collides the hand with itself)
@@ -260,7 +263,7 @@ def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = No
             leap = desc.get("family", desc["task"]) == "leap_cube"
             if (leap if cube_only is None else cube_only) and free_fused not in (ga["body"], gb["body"]):
                 continue  # (the one-lane reference kernel and jh_engine_v2.hip model the cube's contacts only; jh_engine_v5.hip adds the hand's own)
-            out.append((a, b))
+            out.append((ia, ib))
     # order by importance for the fixed-capacity contact pools: pairs with the free body first, then pairs against static
     # geometry, pairs between two articulated bodies (e.g. the two fingers' pad stacks) last -- those are the ones dropped on overflow
     def rank(pr):

@@ -131,7 +131,8 @@ class Task(ABC, Generic[ConfigT]):
 
     @property
     def uses_locomotion_policy(self) -> bool:
-        return False
+        """judo/tasks/base.py:92-95: a task is a policy task exactly when it names a policy."""
+        return self.locomotion_policy_path is not None
 
     def pre_sim_step(self) -> None:
         """judo/tasks/base.py:140-144: hooks of the SIMULATION node around its own `mj_step`; the plan step never calls them (kept so that a plugin task written
