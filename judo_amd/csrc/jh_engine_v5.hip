@@ -40,9 +40,6 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
-#ifndef JH_V5_HXLAZY
-#define JH_V5_HXLAZY 0
-#endif
 #ifndef JH_V5_GCUBE_ATOMIC
 #define JH_V5_GCUBE_ATOMIC 1  // the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration:
                               // 79.9 against 80.65 ms on the recorded inputs (round 4, profiles/r04_leap_experiments.txt); 0: the row sums
@@ -1032,11 +1029,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
-#if JH_V5_HXLAZY
-          if (SELF && cmask != 0) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;  // (read and accumulated only by rollouts whose contacts couple two chains)
-#else
-          if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
-#endif
+          if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;  // (zeroing it only for rollouts with coupled chains changes nothing: 79.45 against 79.5 ms)
           S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
         }
