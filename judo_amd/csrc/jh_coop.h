@@ -301,4 +301,29 @@ __device__ __forceinline__ float box_box_distance(const float* p1, const float* 
   return best;
 }
 
+// two boxes overlap or touch (box_box_distance(...) <= 0), decided at the first of the same 15 axes that separates them: what a cost term needs that only asks whether a
+// distance sensor reads <= 0 (FR3Pick.reward's finger-table test, judo/tasks/fr3_pick.py:283-285) -- a pad above the table is done after a face axis or two
+__device__ __forceinline__ bool box_box_touching(const float* p1, const float* R1, const float* h1, const float* p2, const float* R2, const float* h2) {
+  float A[3][3], B[3][3], dv[3];
+  for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
+  bool apart = false;
+#pragma unroll 1
+  for (int i = 0; i < 3 && !apart; i++) {
+    float ra = h1[i], rb = 0.f; for (int k = 0; k < 3; k++) rb += h2[k] * fabsf(dot3(B[k], A[i]));
+    apart = fabsf(dot3(dv, A[i])) - ra - rb > 0.f;
+    ra = 0.f; rb = h2[i]; for (int k = 0; k < 3; k++) ra += h1[k] * fabsf(dot3(A[k], B[i]));
+    apart = apart || fabsf(dot3(dv, B[i])) - ra - rb > 0.f;
+  }
+#pragma unroll 1
+  for (int ij = 0; ij < 9 && !apart; ij++) {
+    const int i = ij / 3, j = ij - 3 * i;
+    float Ai[3], Bj[3], L[3]; pick_row(Ai, A, i); pick_row(Bj, B, j); cross3(L, Ai, Bj); const float l2 = dot3(L, L);
+    if (l2 < 1e-12f) continue;
+    const float il = rsqrtf(l2); L[0] *= il; L[1] *= il; L[2] *= il;
+    float ra = 0.f, rb = 0.f; for (int k = 0; k < 3; k++) { ra += h1[k] * fabsf(dot3(A[k], L)); rb += h2[k] * fabsf(dot3(B[k], L)); }
+    apart = fabsf(dot3(dv, L)) - ra - rb > 0.f;
+  }
+  return !apart;
+}
+
 }  // namespace jh_coop

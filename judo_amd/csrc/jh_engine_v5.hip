@@ -680,6 +680,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         nh += __popc(m16);
       }
       WSYNC();
+      V5_TICK(13)  // (fine split of the broad phase: 13 = the cube against the lane's geoms, 14 = hand body pairs, 1 = geom level of the surviving pairs)
       if constexpr (SELF) {
 #ifndef JH_V5_X_NOL1
       // hand self-collision, level 1: body pairs whose bounding spheres overlap (106 candidate pairs after MuJoCo's static filters, 16 per pass)
@@ -709,6 +710,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       const int nh_cube = nh;
 #endif
       WSYNC();
+      V5_TICK(14)
       // level 2, per surviving body pair: (a) every geom of either body against the OTHER body's bounding box (one pass: lanes 0..nA-1 take A's geoms,
       // the next nB lanes B's; nA + nB <= 16) -- usually nothing of one side comes near the other and the pair is done; (b) the near geoms of A against
       // the near geoms of B (bounding spheres, then the six face axes of their boxes)

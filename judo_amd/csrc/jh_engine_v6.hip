@@ -345,6 +345,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     for (int s = 0; s < m.NGS; s++) {
       const int* si = gI + m.oSensG + s * 4;
       if (si[0] != 4) continue;
+      // fused mode: the sensor array is never written out, and FR3Pick.reward (judo/tasks/fr3_pick.py:225-311, fr3_step_cost) reads the finger-table distances (2, 3) and, in
+      // the PLACE phase only, the object-table distance (4); the finger-object distances (0, 1) are not part of the cost: 10 of the 21 box pairs, and with them the second
+      // round of 15-axis separations per step.  The drop-in (materialise) mode evaluates all of them.
+      if (!MATERIALIZE && (si[3] < 2 || (si[3] == 4 && phase != 2))) { if (si[1] < 8) sDadr[si[1]] = -1; continue; }
       if (si[1] < 8) sDadr[si[1]] = si[3];
       const int* di = gI + m.oDistI + si[1] * 4;
       for (int a = 0; a < di[1]; a++) for (int b = 0; b < di[3]; b++) if (nt < MAXDT) { sDT[nt][0] = si[3]; sDT[nt][1] = gI[m.oGlist + di[0] + a]; sDT[nt][2] = gI[m.oGlist + di[2] + b]; nt++; }
@@ -479,11 +483,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           const float* fa = gF + m.oAGF + ga * GEOM_F; const float* fb = gF + m.oAGF + gb * GEOM_F;
           float pa[3], Ra[9], pb[3], Rb[9], ha[3] = {fa[GF_SIZE], fa[GF_SIZE + 1], fa[GF_SIZE + 2]}, hb[3] = {fb[GF_SIZE], fb[GF_SIZE + 1], fb[GF_SIZE + 2]};
           geom_pose3(S, fa, gI[m.oAGI + ga * GEOM_I], pa, Ra, true); geom_pose3(S, fb, gI[m.oAGI + gb * GEOM_I], pb, Rb, true);
-          dmin[k] = box_box_distance(pa, Ra, ha, pb, Rb, hb); dadr[k] = sDT[t][0];
+          dadr[k] = sDT[t][0];
+          // (fused mode: the cost asks of the finger-table sensors only whether they read <= 0 -- the sign, decided at the first separating axis)
+          if (!MATERIALIZE && (dadr[k] == 2 || dadr[k] == 3)) dmin[k] = box_box_touching(pa, Ra, ha, pb, Rb, hb) ? -1.f : 1.f;
+          else dmin[k] = box_box_distance(pa, Ra, ha, pb, Rb, hb);
         }
       }
       for (int s = 0; s < m.NDIST; s++) {  // per sensor: minimum over its box pairs, clipped at the cutoff
         const int adr = sDadr[s < 8 ? s : 7];
+        if (adr < 0) continue;  // (not evaluated in this mode: above)
         float v = fminf(dadr[0] == adr ? dmin[0] : 3.0e38f, dadr[1] == adr ? dmin[1] : 3.0e38f);
         v = fminf(gmin(v), gF[m.oDistF + s]);
         if (l == 0 && adr >= 0) S.y[adr] = v;
@@ -957,7 +965,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
             else {
               if (d1 < 0.f) lo = alpha; else hi = alpha;
-              float nx = alpha - d1 * __frcp_rn(d2);
+              float nx = alpha - d1 * __builtin_amdgcn_rcpf(d2);  // (1 ulp: the correctly rounded division is ten instructions per slope evaluation)
               if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
               else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
               alpha = nx;

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 traffic = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --task <task> --steps 5 --warmup 3 "
@@ -57,6 +57,9 @@ for name in sorted(os.listdir(src)):
             open(os.path.join(dst, f"{tag}_{name}"), "w").write(lines[-1] + "\n")
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in traffic.items() if k != "method"}, indent=1))
-sweep = os.path.join(ROOT, "gpurun_out", "sweep", "sweep.txt")
-if os.path.exists(sweep):
-    shutil.copy(sweep, os.path.join(dst, f"{tag}_tolerance_sweep.txt"))
+for name, out in (("spot_summary.txt", "spot_policy_rollout_rocprofv3_summary.txt"), ("spot_under_rocprof.txt", "spot_policy_rollout_timing.txt"), ("benchmark_sweep.txt", "benchmark_sweep.txt")):
+    if os.path.exists(os.path.join(src, name)):  # (tools/profile_spot.sh, python -m judo_amd.benchmark)
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{out}"))
+        stale = os.path.join(dst, f"{tag}_{name[:-len('_summary.txt')]}_rocprofv3_summary.txt") if name.endswith("_summary.txt") else None
+        if stale and stale != os.path.join(dst, f"{tag}_{out}") and os.path.exists(stale):
+            os.remove(stale)
