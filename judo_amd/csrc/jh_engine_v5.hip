@@ -40,6 +40,9 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
+#ifndef JH_V5_SCHUR_ATOMIC
+#define JH_V5_SCHUR_ATOMIC 1
+#endif
 #ifndef JH_V5_GCUBE_ATOMIC
 #define JH_V5_GCUBE_ATOMIC 1  // the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration:
                               // 79.9 against 80.65 ms on the recorded inputs (round 4, profiles/r04_leap_experiments.txt); 0: the row sums
@@ -218,9 +221,33 @@ __device__ __forceinline__ bool obb_face_overlap(const float* ca, const float* R
   return ok;
 }
 
+// The three functions below visit the joints above a finger link.  JH_V5_LINKBATCH (round 4): all four joints of the chain are loaded and their columns
+// axis_j x (pos - anchor_j) computed UNCONDITIONALLY, the depth of the link only masks what is accumulated.  The per-joint form (`if (j <= dep) { load; compute; }`) put every
+// joint's LDS loads under its own exec mask, so each of them was a round trip of its own -- 50 of the 80 `s_waitcnt lgkmcnt(0)` of a Newton iteration sat in these loops;
+// the batched form waits once per call and has no branches (the wasted columns of the shallower links are cheaper than the waits).  Same expressions: same bits.
+#ifndef JH_V5_LINKBATCH
+#define JH_V5_LINKBATCH 0  // measured: 83.0 against 79.4 ms -- the 24 joint floats live at once and the wasted columns cost more than the waits they save (the second wave of the SIMD
+                           // hides most of those); together with the atomics of the Schur update even 86.3.  Off.
+#endif
+__device__ __forceinline__ void link_c3(const RS& S, int ch, const float* pos, float (*c3)[3]) {
+#pragma unroll
+  for (int j = 0; j < NLK; j++) {
+    const float* pj = S.pa[1 + 4 * ch + j];
+    const float rb[3] = {pos[0] - pj[0], pos[1] - pj[1], pos[2] - pj[2]};
+    cross3(c3[j], pj + 4, rb);
+  }
+}
 // velocity of the point `pos` carried by finger link `code` for the joint-rate vector `vec` (22-vector in LDS), times `sign`, added to w
 __device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos, const float* vec, float sign, float* w) {
   const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
+#if JH_V5_LINKBATCH
+  float c3[NLK][3]; link_c3(S, ch, pos, c3);
+#pragma unroll
+  for (int j = 0; j < NLK; j++) {
+    const float xj = j <= dep ? sign * vec[6 + 4 * ch + j] : 0.f;
+    w[0] = fmaf(c3[j][0], xj, w[0]); w[1] = fmaf(c3[j][1], xj, w[1]); w[2] = fmaf(c3[j][2], xj, w[2]);
+  }
+#else
 #pragma unroll
   for (int j = 0; j < NLK; j++) if (j <= dep) {
     const float* pj = S.pa[1 + 4 * ch + j];
@@ -229,10 +256,19 @@ __device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos
     const float xj = sign * vec[6 + 4 * ch + j];
     w[0] = fmaf(c3[0], xj, w[0]); w[1] = fmaf(c3[1], xj, w[1]); w[2] = fmaf(c3[2], xj, w[2]);
   }
+#endif
 }
 // -J'F for the joints of finger link `code` (F = world force on side B; sign = +1 for side B, -1 for side A): LDS float atomics into g
 __device__ __forceinline__ void link_force(RS& S, int code, const float* pos, const float* Fw, float sign) {
   const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
+#if JH_V5_LINKBATCH
+  float c3[NLK][3]; link_c3(S, ch, pos, c3);
+  float v[NLK];
+#pragma unroll
+  for (int j = 0; j < NLK; j++) v[j] = -sign * dot3(c3[j], Fw);
+#pragma unroll
+  for (int j = 0; j < NLK; j++) if (j <= dep) atomicAdd(&S.g[6 + 4 * ch + j], v[j]);
+#else
 #pragma unroll
   for (int j = 0; j < NLK; j++) if (j <= dep) {
     const float* pj = S.pa[1 + 4 * ch + j];
@@ -240,10 +276,19 @@ __device__ __forceinline__ void link_force(RS& S, int code, const float* pos, co
     cross3(c3, pj + 4, rb);
     atomicAdd(&S.g[6 + 4 * ch + j], -sign * dot3(c3, Fw));
   }
+#endif
 }
 // Jacobian columns (contact frame) of the joints of finger link `code`, times `sign`, added to Jb[j] (j = depth in the chain)
 __device__ __forceinline__ void link_cols(const RS& S, int code, const float* pos, const float* fr, float sign, float (*Jb)[3]) {
   const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
+#if JH_V5_LINKBATCH
+  float c3[NLK][3]; link_c3(S, ch, pos, c3);
+#pragma unroll
+  for (int j = 0; j < NLK; j++) {
+    const float sg = j <= dep ? sign : 0.f;
+    Jb[j][0] = fmaf(sg, dot3(fr, c3[j]), Jb[j][0]); Jb[j][1] = fmaf(sg, dot3(fr + 3, c3[j]), Jb[j][1]); Jb[j][2] = fmaf(sg, dot3(fr + 6, c3[j]), Jb[j][2]);
+  }
+#else
 #pragma unroll
   for (int j = 0; j < NLK; j++) if (j <= dep) {
     const float* pj = S.pa[1 + 4 * ch + j];
@@ -251,6 +296,7 @@ __device__ __forceinline__ void link_cols(const RS& S, int code, const float* po
     cross3(c3, pj + 4, rb);
     Jb[j][0] = fmaf(sign, dot3(fr, c3), Jb[j][0]); Jb[j][1] = fmaf(sign, dot3(fr + 3, c3), Jb[j][1]); Jb[j][2] = fmaf(sign, dot3(fr + 6, c3), Jb[j][2]);
   }
+#endif
 }
 
 // contact-frame image of the relative point velocity (side B minus side A) for the generalised velocity whose cube part is (xl = linear, world;
@@ -1161,16 +1207,35 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             float Yr[NLK];
 #pragma unroll
             for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
-            const float da = qsum4(Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3]);
-            const float db = qsum4(Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3]);
-            if (aact && c == 0) {
+            float da = Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3], db = Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3];
+#if JH_V5_SCHUR_ATOMIC == 2  // every chain's lanes add their own terms: four-way conflicts in the LDS instead of two row rotations per entry
+            const bool app = aact;
+#else
+            da = qsum4(da); db = qsum4(db);
+            const bool app = aact && c == 0;
+#endif
+            if (app) {
+              // (LDS atomics, not `S.Hcc[..] -= da`: the compiler cannot prove the addresses distinct and turns every read-modify-write into its own LDS round trip --
+              // ds_read, wait, ds_write -- fourteen of them in a row per iteration; x + (-da) is the same number, and ds_add_f32 is not waited for: 78.4 against 79.4 ms)
+#if JH_V5_SCHUR_ATOMIC
+              if (r6 <= s) atomicAdd(&S.Hcc[tri(s, r6)], -da);
+              if (hasb && r6 <= 4 + s) atomicAdd(&S.Hcc[tri(4 + s, r6)], -db);
+#else
               if (r6 <= s) S.Hcc[tri(s, r6)] -= da;
               if (hasb && r6 <= 4 + s) S.Hcc[tri(4 + s, r6)] -= db;
+#endif
             }
           }
-          const float ra = qsum4(Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3]);
-          const float rb = qsum4(Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3]);
+          float ra = Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3], rb = Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3];
+#if JH_V5_SCHUR_ATOMIC == 2
+          if (aact) { atomicAdd(&S.rhs6[s], -ra); if (hasb) atomicAdd(&S.rhs6[4 + s], -rb); }
+#elif JH_V5_SCHUR_ATOMIC
+          ra = qsum4(ra); rb = qsum4(rb);
+          if (aact && c == 0) { atomicAdd(&S.rhs6[s], -ra); if (hasb) atomicAdd(&S.rhs6[4 + s], -rb); }
+#else
+          ra = qsum4(ra); rb = qsum4(rb);
           if (aact && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
+#endif
         }
         WSYNC();
         {
