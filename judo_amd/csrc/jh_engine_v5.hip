@@ -44,8 +44,9 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_SCHUR_ATOMIC 1
 #endif
 #ifndef JH_V5_GCUBE_ATOMIC
-#define JH_V5_GCUBE_ATOMIC 1  // the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration:
-                              // 79.9 against 80.65 ms on the recorded inputs (round 4, profiles/r04_leap_experiments.txt); 0: the row sums
+#define JH_V5_GCUBE_ATOMIC 0  // 1: the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration.
+                              // With packed-fp32 code (SLP vectorizer on) the atomics were 1 % faster (79.9 against 80.65 ms); without it (-fno-slp-vectorize, the build since
+                              // round 4) the row sums are 1.7 % faster (70.2 against 71.4 ms): profiles/r04_leap_experiments.txt
 #endif
 #ifndef JH_V5_LSRCP
 #define JH_V5_LSRCP 1  // the line search's Newton step divides with v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence (10 instructions per evaluation): -0.2 %
@@ -81,7 +82,7 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_OPAQUE_LANE 1
 #endif
 #ifndef JH_V5_OPAQUE
-#define JH_V5_OPAQUE -1  // -1: per instantiation (3 with the hand's own contacts, 2 without: measured fastest, tools/diag/ab_variants.sh); 0 = off, 1 = the sides, 2 = + lever arm, 3 = + frame,
+#define JH_V5_OPAQUE -1  // -1: per instantiation (2 for both since round 4's -fno-slp-vectorize build: 71.4 against 72.9 ms with 3; rounds 2-3: 3 with the hand's own contacts); 0 = off, 1 = the sides, 2 = + lever arm, 3 = + frame,
                          // 4 = 3 and again before the Hessian assembly and before the line search
 #endif
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -226,8 +227,8 @@ __device__ __forceinline__ bool obb_face_overlap(const float* ca, const float* R
 // joint's LDS loads under its own exec mask, so each of them was a round trip of its own -- 50 of the 80 `s_waitcnt lgkmcnt(0)` of a Newton iteration sat in these loops;
 // the batched form waits once per call and has no branches (the wasted columns of the shallower links are cheaper than the waits).  Same expressions: same bits.
 #ifndef JH_V5_LINKBATCH
-#define JH_V5_LINKBATCH 0  // measured: 83.0 against 79.4 ms -- the 24 joint floats live at once and the wasted columns cost more than the waits they save (the second wave of the SIMD
-                           // hides most of those); together with the atomics of the Schur update even 86.3.  Off.
+#define JH_V5_LINKBATCH 1  // (with packed-fp32 code this was 4.5 % SLOWER -- 83.0 against 79.4 ms: the register pairs of the packed operands left no room for 24 joint floats at once;
+                           // without the SLP vectorizer it is 1-2.5 % faster: 72.2 against 72.9, and 70.0 against 71.8 ms in the adopted combination)
 #endif
 __device__ __forceinline__ void link_c3(const RS& S, int ch, const float* pos, float (*c3)[3]) {
 #pragma unroll
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       V5_TICK(3)
       // The Newton loop exists twice: waves in which some rollout needs the dense direction this step run the copy that contains it, all others a copy
       // without that code (the register needs of the rare path would otherwise make the allocator spill inside every iteration of every rollout)
-      constexpr int OPQ = JH_V5_OPAQUE >= 0 ? JH_V5_OPAQUE : (SELF ? 3 : 2);
+      constexpr int OPQ = JH_V5_OPAQUE >= 0 ? JH_V5_OPAQUE : 2;
       auto forget_slots = [&]() __attribute__((always_inline)) {
         if constexpr (OPQ > 0) {
 #pragma unroll
