@@ -40,6 +40,10 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
+#ifndef JH_V5_KEEPW
+#define JH_V5_KEEPW 1  // the cone weights of the gradient pass are kept in registers for the Hessian pass instead of a second cone_eval: 69.65 against 70.05 ms (with the packed-fp32 build of
+                       // rounds 2-3 the same idea through LDS measured -0.2 / +0.4 %)
+#endif
 #ifndef JH_V5_SCHUR_ATOMIC
 #define JH_V5_SCHUR_ATOMIC 1
 #endif
@@ -1030,11 +1034,20 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #endif
         WSYNC();
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
+#if JH_V5_KEEPW
+        float Wkeep[NS][6];  // the cone weights of this pass, kept for the Hessian pass instead of a second cone_eval (12 registers across the convergence test)
+#pragma unroll
+        for (int k = 0; k < NS; k++) for (int e6 = 0; e6 < 6; e6++) Wkeep[k][e6] = 0.f;
+#endif
         if (act) {
 #pragma unroll
           for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
             const Slot& t = sl[k];
+#if JH_V5_KEEPW
+            float f[3]; float* Wt = Wkeep[k];
+#else
             float f[3], Wt[6];
+#endif
             const float D[3] = {t.D0, t.D1, t.D1};
             cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wt);
             if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
@@ -1090,9 +1103,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           float Wk[6] = {0, 0, 0, 0, 0, 0};
           bool on = aact && t.la >= 0;
           if (on) {
+#if JH_V5_KEEPW
+            for (int e6 = 0; e6 < 6; e6++) Wk[e6] = Wkeep[k][e6];
+#else
             float f[3];
             const float D[3] = {t.D0, t.D1, t.D1};
             cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
+#endif
             on = !(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f);
           }
           if (!__any(on)) continue;  // (the second slot is empty in most waves)
