@@ -40,6 +40,9 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
+#ifndef JH_V5_MERGE
+#define JH_V5_MERGE 0
+#endif
 #ifndef JH_V5_KEEPW
 #define JH_V5_KEEPW 1  // the cone weights of the gradient pass are kept in registers for the Hessian pass instead of a second cone_eval: 69.65 against 70.05 ms (with the packed-fp32 build of
                        // rounds 2-3 the same idea through LDS measured -0.2 / +0.4 %)
@@ -1032,13 +1035,115 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #if JH_V5_GCUBE_ATOMIC
         if (act && l < 6) S.g[l] = mck * dcl;
 #endif
+#if JH_V5_MERGE
+        // One pass over the contacts builds the gradient AND the Hessian of this iterate: the joint columns axis x (pos - anchor), the world force and the cone weights are
+        // computed once instead of once per pass.  The pass that finds a rollout converged has then assembled a Hessian nobody reads (one iteration in ten).
+        const bool aact0 = act && !(DENSE && dense_row);
+        if (aact0) {
+#pragma unroll
+          for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
+          for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
+          if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
+          S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
+          if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
+        }
+#endif
         WSYNC();
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
-#if JH_V5_KEEPW
+#if JH_V5_KEEPW && !JH_V5_MERGE
         float Wkeep[NS][6];  // the cone weights of this pass, kept for the Hessian pass instead of a second cone_eval (12 registers across the convergence test)
 #pragma unroll
         for (int k = 0; k < NS; k++) for (int e6 = 0; e6 < 6; e6++) Wkeep[k][e6] = 0.f;
 #endif
+#if JH_V5_MERGE
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
+            const Slot& t = sl[k];
+            float f[3], Wk[6];
+            const float D[3] = {t.D0, t.D1, t.D1};
+            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
+            const bool on = aact0 && !(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f);
+            if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f && !on) continue;  // separated contact
+            const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
+            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
+            const bool cube = !SELF || t.la == CUBE;
+            float Jc[6][3];
+            if (cube) {
+              float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
+#if JH_V5_GCUBE_ATOMIC
+              atomicAdd(&S.g[0], Fw[0]); atomicAdd(&S.g[1], Fw[1]); atomicAdd(&S.g[2], Fw[2]); atomicAdd(&S.g[3], tb[0]); atomicAdd(&S.g[4], tb[1]); atomicAdd(&S.g[5], tb[2]);
+#else
+              gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
+#endif
+              if (on) {
+                for (int q3 = 0; q3 < 3; q3++) {
+                  Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
+                  float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+                  Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
+                }
+#pragma unroll
+                for (int v6 = 0; v6 < 6; v6++) {
+                  const float* j3 = Jc[v6];
+                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                  for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
+                }
+              }
+            }
+            if (t.lb > 0) {
+              const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
+              const bool linkA = SELF && !cube && t.la > 0;
+              const int cha = linkA ? (t.la - 1) >> 2 : 0, depa = linkA ? (t.la - 1) & 3 : -1;
+              const bool same = linkA && cha == ch;
+              float c3b[NLK][3]; link_c3(S, ch, pos, c3b);
+              float Jb[NLK][3];
+#pragma unroll
+              for (int j = 0; j < NLK; j++) {
+                const float fj = dot3(c3b[j], Fw);
+                if (j <= dep) atomicAdd(&S.g[6 + 4 * ch + j], -fj);       // side B: -J'f
+                if (same && j <= depa) atomicAdd(&S.g[6 + 4 * ch + j], fj);  // side A of the same chain: the opposite force
+                const float sg = (j <= dep ? 1.f : 0.f) - ((same && j <= depa) ? 1.f : 0.f);
+                Jb[j][0] = sg * dot3(t.fr, c3b[j]); Jb[j][1] = sg * dot3(t.fr + 3, c3b[j]); Jb[j][2] = sg * dot3(t.fr + 6, c3b[j]);
+              }
+              if (on) {
+#pragma unroll
+                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+                  const float* j3 = Jb[u4];
+                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+                  if (cube) {
+#pragma unroll
+                    for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
+                  }
+                }
+              }
+              if (linkA && !same) {  // side A sits in another chain: its own block, and the pair's coupling block -Jb'W Ja in Hx (B's chain is always the higher one)
+                float c3a[NLK][3]; link_c3(S, cha, pos, c3a);
+                float Ja[NLK][3];
+#pragma unroll
+                for (int j = 0; j < NLK; j++) {
+                  if (j <= depa) atomicAdd(&S.g[6 + 4 * cha + j], dot3(c3a[j], Fw));
+                  const float sg = j <= depa ? 1.f : 0.f;
+                  Ja[j][0] = sg * dot3(t.fr, c3a[j]); Ja[j][1] = sg * dot3(t.fr + 3, c3a[j]); Ja[j][2] = sg * dot3(t.fr + 6, c3a[j]);
+                }
+                if (on) {
+#pragma unroll
+                  for (int u4 = 0; u4 < NLK; u4++) if (u4 <= depa) {
+                    const float* j3 = Ja[u4];
+                    const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
+#pragma unroll
+                    for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[cha][tri(u4, v4)], Ja[v4][0] * G0 + Ja[v4][1] * G1 + Ja[v4][2] * G2);
+#pragma unroll
+                    for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[pidx(cha, ch)][v4 * 4 + u4], -(Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2));
+                  }
+                }
+              }
+            }
+          }
+        }
+#else
         if (act) {
 #pragma unroll
           for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
@@ -1065,6 +1170,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             if (t.lb > 0) link_force(S, t.lb, pos, Fw, 1.f);
           }
         }
+#endif
         float gcl = 0.f;
 #if JH_V5_GCUBE_ATOMIC
         WSYNC();
@@ -1087,6 +1193,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
         if constexpr (OPQ > 3) forget_slots();
         const bool aact = act && !(DENSE && dense_row);
+#if !JH_V5_MERGE
         if (aact) {
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
@@ -1170,6 +1277,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           }
         }
         WSYNC();
+#endif
         V5_TICK(5)
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly); the coupling columns Y_q = L^-1 Hcb[:,q] are shared
         // by the chain's lanes (lane s: columns s and s+4); 6x6 Schur complement on the cube, solved by every lane
