@@ -36,6 +36,13 @@ __device__ __forceinline__ float qsum4(float v) {
   v += dppf<0x124>(v); v += dppf<0x128>(v);
   return v;
 }
+// the same sum with the rotation by 8 first: lanes c and c+2 then hold the same pair sum (a + b = b + a bit for bit), and the rotation by 4 adds the two pair sums in
+// either order -- the result is bit-identical in all four lanes (qsum4's order gives four different associations), which a value every lane branches or solves on needs
+__device__ __forceinline__ float qsum4_same(float v) {
+  asm volatile("" : "+v"(v));
+  v += dppf<0x128>(v); v += dppf<0x124>(v);
+  return v;
+}
 __device__ __forceinline__ int gor(int v) {
   v |= dppi<DPP_XOR1>(v); v |= dppi<DPP_XOR2>(v); v |= dppi<DPP_HALF_MIRROR>(v); v |= dppi<DPP_MIRROR>(v);
   return v;

@@ -44,6 +44,10 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_MERGE 1  // gradient and Hessian of an iterate from ONE pass over the contacts (the joint columns, world force and cone weights computed once; one fence less):
                        // 68.15 against 69.1 ms on recorded inputs, same iterates bit for bit (the sums run in the same order)
 #endif
+#ifndef JH_V5_HCC_ROWSUM
+#define JH_V5_HCC_ROWSUM 1  // the cube block of J'WJ as 21 row sums per iteration instead of 21 LDS atomics per cube contact: all cube contacts of a rollout hit the same 21 addresses and
+                            // same-address atomics serialise (68.2 -> 64.5 ms on recorded inputs)
+#endif
 #ifndef JH_V5_KEEPW
 #define JH_V5_KEEPW 1  // the cone weights of the gradient pass are kept in registers for the Hessian pass instead of a second cone_eval: 69.65 against 70.05 ms (with the packed-fp32 build of
                        // rounds 2-3 the same idea through LDS measured -0.2 / +0.4 %)
@@ -1045,9 +1049,17 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
           if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
+#if !JH_V5_HCC_ROWSUM
           S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
           if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
+#endif
         }
+#if JH_V5_HCC_ROWSUM
+        float hcp[21];  // the cube block J'WJ of this lane's contacts: every cube contact of the rollout lands on the same 21 entries -> row sums instead of 21 conflicting atomics per contact
+#pragma unroll
+        for (int e = 0; e < 21; e++) hcp[e] = 0.f;
+        bool hcany = false;
+#endif
 #endif
         WSYNC();
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
@@ -1088,8 +1100,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                   const float* j3 = Jc[v6];
                   const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
 #pragma unroll
+#if JH_V5_HCC_ROWSUM
+                  for (int u6 = v6; u6 < 6; u6++) hcp[tri(u6, v6)] += Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2;
+#else
                   for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
+#endif
                 }
+#if JH_V5_HCC_ROWSUM
+                hcany = true;
+#endif
               }
             }
             if (t.lb > 0) {
@@ -1113,10 +1132,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                   const float* j3 = Jb[u4];
                   const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
 #pragma unroll
-                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+                  for (int v4 = 0; v4 <= u4; v4++) { atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
+#ifdef JH_V5_X_DUPBB  // (cost probe: the same atomic once more, adding zero)
+                    atomicAdd(&S.Hbb[ch][tri(u4, v4)], 0.f);
+#endif
+                  }
                   if (cube) {
 #pragma unroll
-                    for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
+                    for (int q6 = 0; q6 < 6; q6++) { atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
+#ifdef JH_V5_X_DUPCB
+                      atomicAdd(&S.Hcb[ch][u4 * 6 + q6], 0.f);
+#endif
+                    }
                   }
                 }
               }
@@ -1180,6 +1207,19 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
         for (int q6 = 0; q6 < 6; q6++) { const float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
         gcl = fmaf(mck, dcl, gcl);  // lanes 6..15: mck = 0, gcl stays 0
+#if JH_V5_MERGE && JH_V5_HCC_ROWSUM
+        {
+          float h0 = 0.f, h1 = 0.f;
+          if (__any(hcany)) {
+#pragma unroll
+            for (int e = 0; e < 21; e++) { const float v = gsum(hcp[e]); if (e < 16) { if (l == e) h0 = v; } else if (l == e - 16) h1 = v; }
+          }
+          if (aact0) {
+            S.Hcc[l] = h0 + ((l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f)));
+            if (l < 5) S.Hcc[16 + l] = h1 + (l == 4 ? cI[2] : 0.f);
+          }
+        }
+#endif
         WSYNC();
 #endif
         V5_TICK(4)
@@ -1329,12 +1369,19 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         {
           // Schur complement: Hcc[q][r] -= sum over chains of Y_q . Y_r, rhs6[q] -= sum of Y_q . zb; lane s of a chain owns q in {s, s+4} and fetches Y_r from
           // its chain-mates; the four chains' terms are added with two row rotations and the first chain's lane applies the total
+#if JH_V5_SCHUR_ATOMIC == 3
+          float dar[6], dbr[6];  // the four chains' terms of row s (dar) and row 4 + s (dbr), column r6, summed over the chains: the same numbers in every chain's lane s
+#endif
 #pragma unroll
           for (int r6 = 0; r6 < 6; r6++) {
             float Yr[NLK];
 #pragma unroll
             for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
             float da = Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3], db = Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3];
+#if JH_V5_SCHUR_ATOMIC == 3
+            dar[r6] = qsum4_same(da); dbr[r6] = qsum4_same(db);
+            continue;
+#endif
 #if JH_V5_SCHUR_ATOMIC == 2  // every chain's lanes add their own terms: four-way conflicts in the LDS instead of two row rotations per entry
             const bool app = aact;
 #else
@@ -1354,7 +1401,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             }
           }
           float ra = Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3], rb = Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3];
-#if JH_V5_SCHUR_ATOMIC == 2
+#if JH_V5_SCHUR_ATOMIC == 3
+          ra = qsum4_same(ra); rb = qsum4_same(rb);
+          // the complement stays in registers: every lane needs all of it for the redundant 6 x 6 solve anyway -- 27 quad broadcasts instead of 27 atomics, a fence and
+          // the wait for them
+          float Lc[21];
+#pragma unroll
+          for (int q6 = 0; q6 < 6; q6++) {
+#pragma unroll
+            for (int r6 = 0; r6 <= q6; r6++) Lc[tri(q6, r6)] = S.Hcc[tri(q6, r6)] - (q6 < 4 ? quad_get(dar[r6], q6) : quad_get(dbr[r6], q6 - 4));
+            xc6[q6] = S.rhs6[q6] - (q6 < 4 ? quad_get(ra, q6) : quad_get(rb, q6 - 4));
+          }
+#elif JH_V5_SCHUR_ATOMIC == 2
           if (aact) { atomicAdd(&S.rhs6[s], -ra); if (hasb) atomicAdd(&S.rhs6[4 + s], -rb); }
 #elif JH_V5_SCHUR_ATOMIC
           ra = qsum4(ra); rb = qsum4(rb);
@@ -1363,12 +1421,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           ra = qsum4(ra); rb = qsum4(rb);
           if (aact && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
 #endif
+#if JH_V5_SCHUR_ATOMIC != 3
         }
         WSYNC();
         {
           float Lc[21];
           for (int k = 0; k < 21; k++) Lc[k] = S.Hcc[k];
           for (int k = 0; k < 6; k++) xc6[k] = S.rhs6[k];
+#endif
           float ci[6];
 #pragma unroll
           for (int i = 0; i < 6; i++)
