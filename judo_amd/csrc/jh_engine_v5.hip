@@ -53,7 +53,10 @@ constexpr int NCH = 4, NLK = 4;
                        // rounds 2-3 the same idea through LDS measured -0.2 / +0.4 %)
 #endif
 #ifndef JH_V5_SCHUR_ATOMIC
-#define JH_V5_SCHUR_ATOMIC 1
+#define JH_V5_SCHUR_ATOMIC 3  // 0: `S.Hcc[..] -= da` (every read-modify-write its own LDS round trip); 1: LDS atomics by the first chain's lanes (79.4 -> 78.4 ms); 2: by every chain's
+                              // lanes (+9.7 %); 3: the complement never goes back to the LDS -- the chain sums are bit-identical in all four chains' lanes (qsum4_same), every lane
+                              // subtracts them from the assembled block with 27 quad broadcasts: no atomics, one fence less (64.6 -> 63.4 ms).  With qsum4's association, which
+                              // differs from chain to chain, the lanes of a rollout solved four slightly different 6 x 6 systems: +0.3 % iterations and 2 000 rollout-steps at the cap.
 #endif
 #ifndef JH_V5_GCUBE_ATOMIC
 #define JH_V5_GCUBE_ATOMIC 0  // 1: the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration.

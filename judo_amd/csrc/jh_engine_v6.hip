@@ -862,6 +862,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         if (!__any(act)) break;
         if (act) iters_this++;
         // ---- (3) Hessian row r (columns 0..r): M + dof rows + equality + sum_c J_c[:,r]' W_c J_c[:,0..r]; lane 15 holds -g
+        PH6(5)
         if (hasdof) S.vec[1][l] = -g_own;
         float Hrow[16];
 #pragma unroll
@@ -897,6 +898,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) if (j <= l) Hrow[j] = S.H[tri(l, j)];
         }
+        PH6(7)  // (the Hessian assembly alone; the rest of the solve stays in slot 5)
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) hdiag = Hrow[j];
         if (l == 15) {

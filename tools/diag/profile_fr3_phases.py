@@ -14,8 +14,8 @@ torch.cuda.synchronize(); c.model.stats()
 c.time = t; c.update_action(); torch.cuda.synchronize()
 L = _lib.lib(); L.jh_model_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 out = (C.c_longlong * 8)(); L.jh_model_profile(c.model.handle, out)
-names = ["integrate+cost(prev) + controls + kinematics", "sensors (incl. geom distances)", "arm dynamics + a0", "collision", "constraint rows", "newton", "tail"]
-tot = sum(out[:7])
+names = ["integrate+cost(prev) + controls + kinematics", "sensors (incl. geom distances)", "arm dynamics + a0", "collision", "constraint rows", "newton without the assembly", "tail", "newton: Hessian assembly"]
+tot = sum(out[:8])
 for n, v in zip(names, out):
     print(f"  {n:46s} {v / (N // 4) / 40 / 1e3:8.1f} kcyc/step/wave {100 * v / tot:5.1f}%")
 print(c.model.stats())
