@@ -44,6 +44,9 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_MERGE 1  // gradient and Hessian of an iterate from ONE pass over the contacts (the joint columns, world force and cone weights computed once; one fence less):
                        // 68.15 against 69.1 ms on recorded inputs, same iterates bit for bit (the sums run in the same order)
 #endif
+#ifndef JH_V5_AFORM
+#define JH_V5_AFORM 1  // J'WJ from world-frame columns and A = Fr' W Fr (one symmetric 3 x 3 per contact) instead of frame-space columns times W: 63.3 -> 61.6 ms
+#endif
 #ifndef JH_V5_HCC_ROWSUM
 #define JH_V5_HCC_ROWSUM 1  // the cube block of J'WJ as 21 row sums per iteration instead of 21 LDS atomics per cube contact: all cube contacts of a rollout hit the same 21 addresses and
                             // same-address atomics serialise (68.2 -> 64.5 ms on recorded inputs)
@@ -62,6 +65,9 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_GCUBE_ATOMIC 0  // 1: the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration.
                               // With packed-fp32 code (SLP vectorizer on) the atomics were 1 % faster (79.9 against 80.65 ms); without it (-fno-slp-vectorize, the build since
                               // round 4) the row sums are 1.7 % faster (70.2 against 71.4 ms): profiles/r04_leap_experiments.txt
+#endif
+#if JH_V5_AFORM && !(JH_V5_MERGE && JH_V5_HCC_ROWSUM && !JH_V5_GCUBE_ATOMIC)
+#error "JH_V5_AFORM is written for the merged pass with row sums"
 #endif
 #ifndef JH_V5_LSRCP
 #define JH_V5_LSRCP 1  // the line search's Newton step divides with v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence (10 instructions per evaluation): -0.2 %
@@ -1084,6 +1090,96 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
             const bool cube = !SELF || t.la == CUBE;
+#if JH_V5_AFORM
+            // J'WJ in the world frame: every dof column of the contact is a world 3-vector col_x (J[w][x] = fr_w . col_x), so the entry (x, y) is col_x' A col_y with
+            // A = Fr' W Fr, a symmetric 3 x 3 formed once per contact.  The cube's translation columns are -e_q: their block is A itself and their coupling to a column c is
+            // -(A c)_q, both free; a third fewer multiply-adds than frame-space columns times W (the fr3 kernel's formulation).
+            float A[6];
+            if (on) {
+              float T0[3], T1[3], T2[3];
+#pragma unroll
+              for (int q = 0; q < 3; q++) {
+                T0[q] = Wk[0] * t.fr[q] + Wk[1] * t.fr[3 + q] + Wk[3] * t.fr[6 + q];
+                T1[q] = Wk[1] * t.fr[q] + Wk[2] * t.fr[3 + q] + Wk[4] * t.fr[6 + q];
+                T2[q] = Wk[3] * t.fr[q] + Wk[4] * t.fr[3 + q] + Wk[5] * t.fr[6 + q];
+              }
+#pragma unroll
+              for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) A[tri(i, j)] = t.fr[i] * T0[j] + t.fr[3 + i] * T1[j] + t.fr[6 + i] * T2[j];
+            }
+            auto Amul = [&](const float* v, float* y) __attribute__((always_inline)) {
+              y[0] = A[0] * v[0] + A[1] * v[1] + A[3] * v[2]; y[1] = A[1] * v[0] + A[2] * v[1] + A[4] * v[2]; y[2] = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+            };
+            float cq[3][3];  // the cube's rotation columns (body axes x arm), up to the sign
+            if (cube) {
+              float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
+              gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
+              if (on) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) { float ea[3]; col3(ea, S.xR[0], q); cross3(cq[q], ea, t.rc); }
+#pragma unroll
+                for (int e = 0; e < 6; e++) hcp[e] += A[e];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                  float z[3]; Amul(cq[q], z);
+#pragma unroll
+                  for (int r2 = 0; r2 < 3; r2++) hcp[tri(3 + q, r2)] += z[r2];
+#pragma unroll
+                  for (int r2 = 0; r2 <= q; r2++) hcp[tri(3 + q, 3 + r2)] += dot3(cq[r2], z);
+                }
+                hcany = true;
+              }
+            }
+            if (t.lb > 0) {
+              const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
+              const bool linkA = SELF && !cube && t.la > 0;
+              const int cha = linkA ? (t.la - 1) >> 2 : 0, depa = linkA ? (t.la - 1) & 3 : -1;
+              const bool same = linkA && cha == ch;
+              float cb[NLK][3]; link_c3(S, ch, pos, cb);
+#pragma unroll
+              for (int j = 0; j < NLK; j++) {
+                const float fj = dot3(cb[j], Fw);
+                if (j <= dep) atomicAdd(&S.g[6 + 4 * ch + j], -fj);       // side B: -J'f
+                if (same && j <= depa) atomicAdd(&S.g[6 + 4 * ch + j], fj);  // side A of the same chain: the opposite force
+                const float sg = (j <= dep ? 1.f : 0.f) - ((same && j <= depa) ? 1.f : 0.f);
+                cb[j][0] *= sg; cb[j][1] *= sg; cb[j][2] *= sg;
+              }
+              if (on) {
+#pragma unroll
+                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+                  float y[3]; Amul(cb[u4], y);
+#pragma unroll
+                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], dot3(cb[v4], y));
+                  if (cube) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + q], -y[q]);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + 3 + q], -dot3(cq[q], y));
+                  }
+                }
+              }
+              if (linkA && !same) {  // side A sits in another chain: its own block, and the pair's coupling block -Jb'W Ja in Hx (B's chain is always the higher one)
+                float ca[NLK][3]; link_c3(S, cha, pos, ca);
+#pragma unroll
+                for (int j = 0; j < NLK; j++) {
+                  if (j <= depa) atomicAdd(&S.g[6 + 4 * cha + j], dot3(ca[j], Fw));
+                  const float sg = j <= depa ? 1.f : 0.f;
+                  ca[j][0] *= sg; ca[j][1] *= sg; ca[j][2] *= sg;
+                }
+                if (on) {
+#pragma unroll
+                  for (int u4 = 0; u4 < NLK; u4++) if (u4 <= depa) {
+                    float y[3]; Amul(ca[u4], y);
+#pragma unroll
+                    for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[cha][tri(u4, v4)], dot3(ca[v4], y));
+#pragma unroll
+                    for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[pidx(cha, ch)][v4 * 4 + u4], -dot3(cb[v4], y));
+                  }
+                }
+              }
+            }
+#else
             float Jc[6][3];
             if (cube) {
               float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
@@ -1172,6 +1268,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                 }
               }
             }
+#endif
           }
         }
 #else
