@@ -42,6 +42,9 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 #define JH_V6_OPAQUE 1
 #endif
 #define OPAQUE6(x) asm volatile("" : "+v"(x))
+#ifndef JH_V6_CUBE_ROWSUM
+#define JH_V6_CUBE_ROWSUM 1  // the free box's entries of -J'f (6) and J'WJ (21) as row sums instead of same-address LDS atomics: 9.77 -> 9.57 ms on recorded inputs
+#endif
 #ifndef JH_V6_LSCAP
 #define JH_V6_LSCAP 12  // line-search evaluations per Newton iteration
 #endif
@@ -144,12 +147,18 @@ __device__ __forceinline__ void slot_Jx(const Slot6& t, const RS6& S, const floa
   out[0] = dot3(t.fr, w); out[1] = dot3(t.fr + 3, w); out[2] = dot3(t.fr + 6, w);
 }
 // -J'F of body b (F = world force on side B; sign = +1 for side B, -1 for side A): float atomics into the gradient
-__device__ __forceinline__ void body_force(RS6& S, int b, const float* pos, const float* Fw, float sign) {
+// (the free box's six entries: every contact of the rollout that touches the box lands on the same six addresses, and same-address LDS atomics serialise -- they are summed
+// over the rollout's lanes instead, JH_V6_CUBE_ROWSUM; the leap kernel's cube block taught this: jh_engine_v5.hip JH_V5_HCC_ROWSUM)
+__device__ __forceinline__ void body_force(RS6& S, int b, const float* pos, const float* Fw, float sign, float* gcp) {
   if (b == 0) {
     float rc[3] = {pos[0] - S.xpos[0][0], pos[1] - S.xpos[0][1], pos[2] - S.xpos[0][2]}, tq[3], tb[3];
     cross3(tq, rc, Fw); mulMTV(tb, S.xR[0], tq);
+#if JH_V6_CUBE_ROWSUM
+    gcp[0] -= sign * Fw[0]; gcp[1] -= sign * Fw[1]; gcp[2] -= sign * Fw[2]; gcp[3] -= sign * tb[0]; gcp[4] -= sign * tb[1]; gcp[5] -= sign * tb[2];
+#else
     atomicAdd(&S.g[0], -sign * Fw[0]); atomicAdd(&S.g[1], -sign * Fw[1]); atomicAdd(&S.g[2], -sign * Fw[2]);
     atomicAdd(&S.g[3], -sign * tb[0]); atomicAdd(&S.g[4], -sign * tb[1]); atomicAdd(&S.g[5], -sign * tb[2]);
+#endif
   } else if (b >= 1) {
 #pragma unroll
     for (int j = 0; j < NCHAIN; j++) if (j < b) {
@@ -163,7 +172,7 @@ __device__ __forceinline__ void body_force(RS6& S, int b, const float* pos, cons
 // J'WJ of one slot into the dof-space Hessian.  Every dof column of the contact is a world 3-vector col_x with J[w][x] = fr_w . col_x, so the contribution
 // to H[x][y] is col_x' A col_y with A = Fr' W Fr (symmetric 3 x 3).  A general contact has at most one side on the free box and at most one on the arm
 // (arm against arm is the finger-finger case, handled in its own slots): up to 6 + 8 columns.
-__device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const float* Wk) {
+__device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const float* Wk, float* hcp) {
   float A[6];
   {
     float T0[3], T1[3], T2[3];
@@ -189,6 +198,18 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
     const float rc[3] = {t.pos[0] - S.xpos[0][0], t.pos[1] - S.xpos[0][1], t.pos[2] - S.xpos[0][2]};
 #pragma unroll
     for (int q = 0; q < 3; q++) { float ea[3]; col3(ea, S.xR[0], q); cross3(c3[q], ea, rc); }
+#if JH_V6_CUBE_ROWSUM
+#pragma unroll
+    for (int e = 0; e < 6; e++) hcp[e] += A[e];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      float z[3]; Amul(c3[q], z);
+#pragma unroll
+      for (int r2 = 0; r2 < 3; r2++) hcp[tri(3 + q, r2)] += z[r2];
+#pragma unroll
+      for (int r2 = 0; r2 <= q; r2++) hcp[tri(3 + q, 3 + r2)] += dot3(c3[r2], z);
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -201,6 +222,7 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
 #pragma unroll
       for (int r2 = 0; r2 <= q; r2++) atomicAdd(&S.H[tri(3 + q, 3 + r2)], dot3(c3[r2], z));
     }
+#endif
   }
   if (ab >= 1) {
 #pragma unroll 1
@@ -833,6 +855,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         // the general contacts' -J'f: the owner lane of a contact adds its force to the rows of the dofs it acts on (float atomics, matrix-free columns)
         if (hasdof) S.g[l] = g_own;
         __syncthreads();
+        float gcp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (act) {
 #pragma unroll
           for (int k = 0; k < NS; k++) if (sl[k].sa > -2) {
@@ -840,12 +863,16 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             float f[3], Wm[6]; pyramid_eval(t.jar, t.D, t.mu, f, Wm);
             if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
-            body_force(S, t.sa, t.pos, Fw, -1.f);
-            body_force(S, t.sb, t.pos, Fw, 1.f);
+            body_force(S, t.sa, t.pos, Fw, -1.f, gcp);
+            body_force(S, t.sb, t.pos, Fw, 1.f, gcp);
           }
         }
         __syncthreads();
         if (hasdof) g_own = S.g[l];
+#if JH_V6_CUBE_ROWSUM
+#pragma unroll
+        for (int q = 0; q < 6; q++) { const float v = gsum(gcp[q]); if (l == q) g_own += v; }
+#endif
         // ---- (2) convergence on the scaled gradient; leave before any Hessian work once every rollout of the wave is done
         // fp32 floor of the gradient: one ulp of the iterate moves row l of the gradient by H_ll * eps * |a_l|.  Stiff rows (sum D J'J ~ 1e4..1e5 on a finger
         // of 0.2 kg against an acceleration of a few hundred m/s^2: a closing gripper whose pad stacks meet at 1 m/s) put that far above tol * |smooth force|;
@@ -885,12 +912,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           for (int j = 0; j < NVT; j++) if (j <= l) S.H[tri(l, j)] = Hrow[j];
         }
         __syncthreads();
+        float hcp[21];
+#pragma unroll
+        for (int e = 0; e < 21; e++) hcp[e] = 0.f;
         if (act) {
 #pragma unroll
           for (int k = 0; k < NS; k++) if (sl[k].sa > -2) {
             float f[3], Wm[6]; pyramid_eval(sl[k].jar, sl[k].D, sl[k].mu, f, Wm);
             if (Wm[0] == 0.f && Wm[2] == 0.f && Wm[5] == 0.f) continue;  // no active pyramid row
-            slot_assemble(S, sl[k], Wm);
+            slot_assemble(S, sl[k], Wm, hcp);
           }
         }
         __syncthreads();
@@ -898,6 +928,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) if (j <= l) Hrow[j] = S.H[tri(l, j)];
         }
+#if JH_V6_CUBE_ROWSUM
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+          for (int r2 = 0; r2 <= q; r2++) { const float v = gsum(hcp[tri(q, r2)]); if (l == q && act) Hrow[r2] += v; }
+#endif
         PH6(7)  // (the Hessian assembly alone; the rest of the solve stays in slot 5)
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) hdiag = Hrow[j];
