@@ -44,6 +44,12 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_MERGE 1  // gradient and Hessian of an iterate from ONE pass over the contacts (the joint columns, world force and cone weights computed once; one fence less):
                        // 68.15 against 69.1 ms on recorded inputs, same iterates bit for bit (the sums run in the same order)
 #endif
+#ifndef JH_V5_RSCAT
+#define JH_V5_RSCAT 1  // the 21 + 6 row sums of the cube block and the cube gradient as two reduce-scatters (row_scatter16: lane l receives the sum of entry l) instead of 27 all-lane sums: 61.85 -> 61.25 ms
+#endif
+#ifndef JH_V5_L2DUAL
+#define JH_V5_L2DUAL 0
+#endif
 #ifndef JH_V5_AFORM
 #define JH_V5_AFORM 1  // J'WJ from world-frame columns and A = Fr' W Fr (one symmetric 3 x 3 per contact) instead of frame-space columns times W: 63.3 -> 61.6 ms
 #endif
@@ -782,6 +788,75 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       // level 2, per surviving body pair: (a) every geom of either body against the OTHER body's bounding box (one pass: lanes 0..nA-1 take A's geoms,
       // the next nB lanes B's; nA + nB <= 16) -- usually nothing of one side comes near the other and the pair is done; (b) the near geoms of A against
       // the near geoms of B (bounding spheres, then the six face axes of their boxes)
+#if JH_V5_L2DUAL
+      // two surviving pairs per pass when both have at most 8 geoms (na + nb): lanes 0..7 of the rollout take the first, lanes 8..15 the second.  3.5-4.2 pairs survive per
+      // rollout-step (4.1-5.3 passes per wave-step, the maximum over the wave's four rollouts) and a finger link has one to three geoms: most passes used a quarter of the lanes.
+      // The candidates come out in a different order than pair by pair (the two pairs' geom pairs interleave): the same set, another order of the contacts in the pool.
+      for (int i = 0; __any(i < nbl);) {
+#ifdef JH_V5_COUNT
+        if (lane == 0) cnt_l2++;
+#endif
+        int ba = 0, bb = 0, ga0 = 0, na = 0, gb0 = 0, nb = 0; bool dual = false;
+        if (i < nbl) {
+          const int p0 = S.bpl[i], p1 = i + 1 < nbl ? S.bpl[i + 1] : p0;
+          const int ba0 = sBP[2 * p0], bb0 = sBP[2 * p0 + 1], ba1 = sBP[2 * p1], bb1 = sBP[2 * p1 + 1];
+          const int na0 = sBG[2 * ba0 + 1], nb0 = sBG[2 * bb0 + 1], na1 = sBG[2 * ba1 + 1], nb1 = sBG[2 * bb1 + 1];
+          dual = i + 1 < nbl && na0 + nb0 <= 8 && na1 + nb1 <= 8;
+          const bool second = dual && l >= 8;
+          ba = second ? ba1 : ba0; bb = second ? bb1 : bb0; na = second ? na1 : na0; nb = second ? nb1 : nb0;
+          ga0 = sBG[2 * ba]; gb0 = sBG[2 * bb];
+        }
+        const int lw = dual ? (l & 7) : l, sh = (dual && l >= 8) ? 8 : 0;  // lane within the group that serves the pair, the group's first bit in the rollout's ballot
+        bool near = false;
+        if (lw < na + nb) {
+          const bool isA = lw < na;
+          const int g = isA ? ga0 + lw : gb0 + (lw - na), own = isA ? ba : bb, oth = isA ? bb : ba;
+          const float* gf = sGeomF + g * GEOM_F;
+          float cw[3];
+          if (static_code(own)) { cw[0] = gf[GF_POS]; cw[1] = gf[GF_POS + 1]; cw[2] = gf[GF_POS + 2]; }
+          else { mulMV(cw, S.xR[own], gf + GF_POS); cw[0] += S.pa[own][0]; cw[1] += S.pa[own][1]; cw[2] += S.pa[own][2]; }
+          const float dw[3] = {cw[0] - S.bs[oth][0], cw[1] - S.bs[oth][1], cw[2] - S.bs[oth][2]};
+          float dl[3];
+          if (static_code(oth)) { dl[0] = dw[0]; dl[1] = dw[1]; dl[2] = dw[2]; } else mulMTV(dl, S.xR[oth], dw);
+          const float* hb = sBB + 8 * oth + 4;
+          const float ex = fmaxf(fabsf(dl[0]) - hb[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hb[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hb[2], 0.f);
+          near = ex * ex + ey * ey + ez * ez <= gf[GF_RBOUND] * gf[GF_RBOUND];
+        }
+        const unsigned m16 = (unsigned)((__ballot(near) >> (16 * r)) & 0xFFFFull);
+        const unsigned mg = dual ? (m16 >> sh) & 0xFFu : m16;
+        const unsigned mB = (mg >> na) & ((1u << nb) - 1u);
+        unsigned rem = mB != 0 ? (mg & ((1u << na) - 1u)) : 0u;
+        while (__any(rem != 0)) {
+          const int ia = rem != 0 ? __ffs(rem) - 1 : 0;
+          bool hit = false;
+          const int ga = ga0 + ia, gb = gb0 + lw;
+          if (rem != 0 && lw < nb && ((mB >> lw) & 1u)) {
+            const float* fa = sGeomF + ga * GEOM_F; const float* fb = sGeomF + gb * GEOM_F;
+            float ca[3], cb[3];
+            if (static_code(ba)) { ca[0] = fa[GF_POS]; ca[1] = fa[GF_POS + 1]; ca[2] = fa[GF_POS + 2]; }
+            else { mulMV(ca, S.xR[ba], fa + GF_POS); ca[0] += S.pa[ba][0]; ca[1] += S.pa[ba][1]; ca[2] += S.pa[ba][2]; }
+            mulMV(cb, S.xR[bb], fb + GF_POS); cb[0] += S.pa[bb][0]; cb[1] += S.pa[bb][1]; cb[2] += S.pa[bb][2];
+            const float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]}, rs = fa[GF_RBOUND] + fb[GF_RBOUND];
+            hit = dot3(d, d) <= rs * rs;
+            if (hit) {  // the geoms' own boxes (a sphere counts as the cube around it)
+              float RA[9], RB[9];
+              if (static_code(ba)) { for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; } else mulMM(RA, S.xR[ba], fa + GF_R);
+              mulMM(RB, S.xR[bb], fb + GF_R);
+              const bool sphA = sGeomI[ga * GEOM_I + 1] != GBOX, sphB = sGeomI[gb * GEOM_I + 1] != GBOX;
+              const float hA[3] = {fa[GF_SIZE], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 1], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 2]};
+              const float hB[3] = {fb[GF_SIZE], sphB ? fb[GF_SIZE] : fb[GF_SIZE + 1], sphB ? fb[GF_SIZE] : fb[GF_SIZE + 2]};
+              hit = obb_face_overlap(ca, RA, hA, cb, RB, hB);
+            }
+          }
+          const unsigned h16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+          const int pos = nh + __popc(h16 & ((1u << l) - 1u));
+          if (hit && pos < MAXHIT) S.hits[pos] = (unsigned short)(HITPAIR + (ga << 7 | gb));
+          nh += __popc(h16);
+          rem &= rem - 1u;
+        }
+        i += dual ? 2 : 1;
+      }
+#else
       for (int i = 0; __any(i < nbl); i++) {
 #ifdef JH_V5_COUNT
         if (lane == 0) cnt_l2++;
@@ -835,6 +910,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           rem &= rem - 1u;
         }
       }
+#endif
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_hh += nh - nh_cube;
 #endif
@@ -1304,16 +1380,31 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         WSYNC();
         if (l < 6) gcl = S.g[l];
 #else
+#if JH_V5_MERGE && JH_V5_HCC_ROWSUM && JH_V5_RSCAT
+        float h0 = 0.f, h1;
+        {  // two reduce-scatters: entries 16..20 of the cube block (to lanes 0..4) with the six gradient sums (to lanes 8..13, moved to 0..5 by a rotation), and entries 0..15
+          const float v2[16] = {hcp[16], hcp[17], hcp[18], hcp[19], hcp[20], 0.f, 0.f, 0.f, gcp[0], gcp[1], gcp[2], gcp[3], gcp[4], gcp[5], 0.f, 0.f};
+          h1 = row_scatter16(v2, l);
+          const float gq = dppf<0x128>(h1);
+          gcl = l < 6 ? gq : 0.f;
+          if (__any(hcany)) h0 = row_scatter16(hcp, l);
+        }
+        gcl = fmaf(mck, dcl, gcl);
+        {
+#else
 #pragma unroll
         for (int q6 = 0; q6 < 6; q6++) { const float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
         gcl = fmaf(mck, dcl, gcl);  // lanes 6..15: mck = 0, gcl stays 0
+#endif
 #if JH_V5_MERGE && JH_V5_HCC_ROWSUM
+#if !JH_V5_RSCAT
         {
           float h0 = 0.f, h1 = 0.f;
           if (__any(hcany)) {
 #pragma unroll
             for (int e = 0; e < 21; e++) { const float v = gsum(hcp[e]); if (e < 16) { if (l == e) h0 = v; } else if (l == e - 16) h1 = v; }
           }
+#endif
           if (aact0) {
             S.Hcc[l] = h0 + ((l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f)));
             if (l < 5) S.Hcc[16 + l] = h1 + (l == 4 ? cI[2] : 0.f);
