@@ -48,7 +48,8 @@ constexpr int NCH = 4, NLK = 4;
 #define JH_V5_RSCAT 1  // the 21 + 6 row sums of the cube block and the cube gradient as two reduce-scatters (row_scatter16: lane l receives the sum of entry l) instead of 27 all-lane sums: 61.85 -> 61.25 ms
 #endif
 #ifndef JH_V5_L2DUAL
-#define JH_V5_L2DUAL 0
+#define JH_V5_L2DUAL 0  // 1: two surviving hand body pairs per level-2 pass when both have at most 8 geoms.  Measured: the pass count does not move (4.07 / 5.32 / 4.63 per wave-step on three
+                        // recorded plan steps either way) -- the pairs that survive level 1 involve the palm's geom groups -- and the kernel is 0.8 % slower (62.4 against 61.8 ms)
 #endif
 #ifndef JH_V5_AFORM
 #define JH_V5_AFORM 1  // J'WJ from world-frame columns and A = Fr' W Fr (one symmetric 3 x 3 per contact) instead of frame-space columns times W: 63.3 -> 61.6 ms
