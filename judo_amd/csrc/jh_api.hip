@@ -229,9 +229,9 @@ extern "C" int jh_download_end(void) {
   return JH_OK;
 }
 
-extern "C" int jh_model_profile(jh_model* m, long long* out /* 8 phase cycle totals; zero unless built with JH_ENGINE_PROFILE */) {
+extern "C" int jh_model_profile(jh_model* m, long long* out /* 10 phase cycle totals; zero unless the kernel was built with its phase clock (JH_V6_PHASES) */) {
   JH_REQUIRE(m && out, "model_profile: null pointer");
-  JH_HIP(hipMemcpy(out, m->d_stats + 4, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  JH_HIP(hipMemcpy(out, m->d_stats + 4, 10 * sizeof(long long), hipMemcpyDeviceToHost));
   return JH_OK;
 }
 

@@ -42,6 +42,11 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 #define JH_V6_OPAQUE 1
 #endif
 #define OPAQUE6(x) asm volatile("" : "+v"(x))
+#ifndef JH_V6_RIGHTLOOK
+#define JH_V6_RIGHTLOOK 0  // 1: right-looking row Cholesky (one LDS write per lane and step, independent updates) + column-oriented backward solve.  Measured: 9.54 against 9.60 ms, within
+                           // the noise -- the factorisation (19 % of the kernel, tools/diag/profile_fr3_phases.py) is bound by its fifteen LDS exchanges, not by the dependent chains
+                           // of the left-looking form; with per-lane masks on the updates it was 13 % SLOWER (10.85 ms).  A two-column block form would halve the exchanges: not built.
+#endif
 #ifndef JH_V6_CUBE_ROWSUM
 #define JH_V6_CUBE_ROWSUM 1  // the free box's entries of -J'f (6) and J'WJ (21) as row sums instead of same-address LDS atomics: 9.77 -> 9.57 ms on recorded inputs
 #endif
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
   const int ndt = sNDT;
 
 #ifdef JH_V6_PHASES
-  long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long ph_t = __builtin_readcyclecounter(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PH6(i) { const long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
 #else
 #define PH6(i)
@@ -941,6 +946,37 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) Hrow[j] = S.vec[1][j];
         }
+#if JH_V6_RIGHTLOOK
+        // ---- (4) right-looking row Cholesky: at step k every row publishes its entry of column k (ONE LDS write per lane and step, two alternating 16-float buffers at the head
+        // of Lp), takes the pivot and the column back and updates its remaining entries -- independent multiply-adds, where the left-looking form had a k-long dependent
+        // chain in the pivot row and another in every row below it at every step.  The rows go to Lp once at the end.
+#pragma unroll
+        for (int k = 0; k < NVT; k++) {
+          float* col = S.Lp + 16 * (k & 1);
+          col[l] = Hrow[k];  // (rows above k publish an entry nobody reads)
+          __syncthreads();
+          const float rinv = __frsqrt_rn(fmaxf(col[k], 1e-30f));
+          const float ck = Hrow[k] * rinv;
+          Hrow[k] = l == k ? rinv : ck;
+          // no masks: a row's entries right of its diagonal, and everything in the rows above k, are never read -- what lands there does not matter
+#pragma unroll
+          for (int j = k + 1; j < NVT; j++) Hrow[j] = fmaf(-ck, col[j] * rinv, Hrow[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NVT; j++) if (j <= l) S.Lp[tri(l, j)] = Hrow[j];
+        __syncthreads();
+        // ---- (5) backward solve, redundantly and column by column: p_j is final once the columns above it are taken out; the updates of one column are independent
+        float p[NVT];
+#pragma unroll
+        for (int k = 0; k < NVT; k++) p[k] = S.Lp[tri(15, k)];
+#pragma unroll
+        for (int j = NVT - 1; j >= 0; j--) {
+          p[j] *= S.Lp[tri(j, j)];
+#pragma unroll
+          for (int k = 0; k < j; k++) p[k] -= S.Lp[tri(j, k)] * p[j];
+        }
+#else
         // ---- (4) left-looking row Cholesky through LDS: at step k lane k finishes and publishes row k, rows below take column k
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
@@ -975,10 +1011,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           for (int j = k + 1; j < NVT; j++) s -= S.Lp[tri(j, k)] * p[j];
           p[k] = s * S.Lp[tri(k, k)];
         }
+#endif
         float p_own = 0.f;
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
         // ---- (6) exact line search along p
+        PH6(8)  // (row Cholesky + backward solve)
         float Mp_own = 0.f;
         if (isarm) {
 #pragma unroll
@@ -1010,6 +1048,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             }
           }
         }
+        PH6(9)  // (line search: set-up and slope evaluations)
         // ---- (7) step
 #ifdef JH_V6_TRACE
         if (lane == 0 && it >= 6 && it < 22) printf("step %d it %d gn %.3e gtol %.3e gp %.3e alpha %.5g sff %.6f spf %.3e lo %.4g hi %.4g\n", hh, it, gn, gtol, gp, alpha, sff, spf, lo, hi);
@@ -1120,7 +1159,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
   if (stats && live && l == 0) for (int k = 0; k < 5; k++) atomicAdd(stats + 24 + k, n_x[k]);
 #ifdef JH_V6_PHASES
   PH6(6)
-  if (stats && lane == 0) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)ph_acc[k]);
+  if (stats && lane == 0) for (int k = 0; k < 10; k++) atomicAdd((unsigned long long*)(stats + 4) + k, (unsigned long long)ph_acc[k]);
 #endif
 #endif
   if (stats && live && l == 0) { if (n_maxed) atomicAdd(stats + 1, n_maxed); atomicAdd(stats + 2, n_iters); atomicAdd(stats + 3, H); }

@@ -17,7 +17,7 @@ for i in range(int(os.environ.get("STEPS", "12"))):
     c.time = t; c.update_action(); t += 1.0 / c.controller_cfg.control_freq; torch.cuda.synchronize()
     ms = c.kernel_events[-1][0].elapsed_time(c.kernel_events[-1][1])
     out = (C.c_int * 40)(); L.jh_model_hist(c.model.handle, out)
-    prof = (C.c_longlong * 8)(); L.jh_model_profile(c.model.handle, prof)
+    prof = (C.c_longlong * 10)(); L.jh_model_profile(c.model.handle, prof)
     st = c.model.stats(reset=False)
     dense, its, l2, bp, ws, hh = out[0], out[1], out[2], out[3], out[4], out[5]
     nw = 65536 // 4 * 64; tot = sum(prof)

@@ -13,9 +13,9 @@ for _ in range(3):
 torch.cuda.synchronize(); c.model.stats()
 c.time = t; c.update_action(); torch.cuda.synchronize()
 L = _lib.lib(); L.jh_model_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-out = (C.c_longlong * 8)(); L.jh_model_profile(c.model.handle, out)
-names = ["integrate+cost(prev) + controls + kinematics", "sensors (incl. geom distances)", "arm dynamics + a0", "collision", "constraint rows", "newton without the assembly", "tail", "newton: Hessian assembly"]
-tot = sum(out[:8])
+out = (C.c_longlong * 10)(); L.jh_model_profile(c.model.handle, out)
+names = ["integrate+cost(prev) + controls + kinematics", "sensors (incl. geom distances)", "arm dynamics + a0", "collision", "constraint rows", "newton: gradient pass, convergence test, step", "tail", "newton: Hessian assembly", "newton: row Cholesky + backward solve", "newton: line search"]
+tot = sum(out[:10])
 for n, v in zip(names, out):
     print(f"  {n:46s} {v / (N // 4) / 40 / 1e3:8.1f} kcyc/step/wave {100 * v / tot:5.1f}%")
 print(c.model.stats())

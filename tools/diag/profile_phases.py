@@ -17,7 +17,7 @@ for i in range(2):
 torch.cuda.synchronize(); ctrl.model.stats()
 t = time.perf_counter(); ctrl.update_action(); torch.cuda.synchronize(); dt = time.perf_counter() - t
 L = _lib.lib(); L.jh_model_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-out = (C.c_longlong * 8)(); L.jh_model_profile(ctrl.model.handle, out)
+out = (C.c_longlong * 10)(); L.jh_model_profile(ctrl.model.handle, out)
 names = ['kinematics', 'dynamics', 'collision', 'rows+warmstart', 'newton:assemble', 'newton:factor', 'newton:linesearch', 'integrate+cost']
 tot = sum(out)
 print(f'N={N} plan step {dt*1e3:.1f} ms; waves={N//4}; stats={ctrl.model.stats(reset=False)}')

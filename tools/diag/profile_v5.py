@@ -15,6 +15,6 @@ for self_on in (False, True):
         c.model.stats()
         c.optimizer.seed(1000 + i); c.nominal_knots = d["knots"][i].copy(); c.times = d["times"][i].copy(); c.update_spline(c.times, c.nominal_knots); c.time = float(d["t"][i])
         c.update_action(); torch.cuda.synchronize()
-        out = (C.c_longlong * 8)(); L.jh_model_profile(c.model.handle, out)
+        out = (C.c_longlong * 10)(); L.jh_model_profile(c.model.handle, out)
         tot = sum(out); nw = 65536 // 4 * 64
         print(f"self-collision {'on ' if self_on else 'off'} plan step {i:2d}: {tot / nw / 1e3:7.1f} kcycles per wave-step | " + " | ".join(f"{n} {100 * v / tot:.0f}% ({v / nw / 1e3:.1f}k)" for n, v in zip(names, out)))
