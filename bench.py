@@ -456,7 +456,7 @@ def main() -> None:
         replay = {"kernel_ms": float(kk.mean()), "kernel_ms_first10": float(kk[:10].mean()), "kernel_ms_last10": float(kk[-10:].mean()), "plan_step_ms": (time.perf_counter() - tr0) / (nrep - 2) * 1e3,
                   "plan_steps": int(nrep), "inputs": os.path.relpath(rfile, ROOT),
                   "note": "recorded plan inputs of 40 consecutive plan steps replayed with fixed seeds: deterministic workload, the figure to compare builds and rounds by "
-                          "(round 2's kernels: leap_cube 80.9 ms, fr3_pick 19.2 ms approximate / 21.1 ms exact)"}
+                          "(round 3's kernels on round 4's boxes: leap_cube 80.65 ms, fr3_pick 11.13 ms; round 2's: 80.9 / 19.2)"}
     n_local = ctrl.last_shard.count
     substeps = ctrl.task.physics_substeps
     if is_policy:  # per control step the tree kernel reads state + control + warm start and writes state + warm start; H launches inside the timed region
@@ -497,8 +497,9 @@ def main() -> None:
             "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
                        "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters,
                        "noise_seed": args.seed,
-                       "closed_loop": "every plan step starts from the previous plan: ms_per_step depends on where the noise stream leads it, chaotically (leap_cube, eight seeds, final "
-                                      "round-3 build: 74.0-87.8 ms, mean 81.9 over 20 steps; 85.8-96.8, mean 89.4 over 100 steps; profiles/r03_seed_sweep.txt)",
+                       "closed_loop": "every plan step starts from the previous plan: ms_per_step depends on where the noise stream leads it, chaotically (leap_cube, final "
+                                      "round-4 build: eight seeds 57.6-72.4 ms, mean 63.2 over 20 steps; four seeds 63.4-68.8, mean 66.4 over 100 steps; profiles/r04_seed_sweep.txt; "
+                                      "round 3: 74.0-87.8, mean 81.9; 85.8-96.8, mean 89.4)",
                        "hand_self_collision": self_on if args.task.startswith("leap") else None,
                        "traces": ("read inside every timed plan step (update_traces is part of the reference's update_action): the fused kernel writes every rollout's trace sensors, "
                                   "the elites' rows are gathered on the device" if traces_in_step else "not read inside the timed steps; see plan_step_ms_with_traces")},
