@@ -40,42 +40,22 @@ constexpr int NCH = 4, NLK = 4;
 #ifndef JH_V5_LSREV
 #define JH_V5_LSREV 0.03f
 #endif
-#ifndef JH_V5_MERGE
-#define JH_V5_MERGE 1  // gradient and Hessian of an iterate from ONE pass over the contacts (the joint columns, world force and cone weights computed once; one fence less):
-                       // 68.15 against 69.1 ms on recorded inputs, same iterates bit for bit (the sums run in the same order)
-#endif
-#ifndef JH_V5_RSCAT
-#define JH_V5_RSCAT 1  // the 21 + 6 row sums of the cube block and the cube gradient as two reduce-scatters (row_scatter16: lane l receives the sum of entry l) instead of 27 all-lane sums: 61.85 -> 61.25 ms
-#endif
-#ifndef JH_V5_L2DUAL
-#define JH_V5_L2DUAL 0  // 1: two surviving hand body pairs per level-2 pass when both have at most 8 geoms.  Measured: the pass count does not move (4.07 / 5.32 / 4.63 per wave-step on three
-                        // recorded plan steps either way) -- the pairs that survive level 1 involve the palm's geom groups -- and the kernel is 0.8 % slower (62.4 against 61.8 ms)
-#endif
-#ifndef JH_V5_AFORM
-#define JH_V5_AFORM 1  // J'WJ from world-frame columns and A = Fr' W Fr (one symmetric 3 x 3 per contact) instead of frame-space columns times W: 63.3 -> 61.6 ms
-#endif
-#ifndef JH_V5_HCC_ROWSUM
-#define JH_V5_HCC_ROWSUM 1  // the cube block of J'WJ as 21 row sums per iteration instead of 21 LDS atomics per cube contact: all cube contacts of a rollout hit the same 21 addresses and
-                            // same-address atomics serialise (68.2 -> 64.5 ms on recorded inputs)
-#endif
-#ifndef JH_V5_KEEPW
-#define JH_V5_KEEPW 1  // the cone weights of the gradient pass are kept in registers for the Hessian pass instead of a second cone_eval: 69.65 against 70.05 ms (with the packed-fp32 build of
-                       // rounds 2-3 the same idea through LDS measured -0.2 / +0.4 %)
-#endif
-#ifndef JH_V5_SCHUR_ATOMIC
-#define JH_V5_SCHUR_ATOMIC 3  // 0: `S.Hcc[..] -= da` (every read-modify-write its own LDS round trip); 1: LDS atomics by the first chain's lanes (79.4 -> 78.4 ms); 2: by every chain's
-                              // lanes (+9.7 %); 3: the complement never goes back to the LDS -- the chain sums are bit-identical in all four chains' lanes (qsum4_same), every lane
-                              // subtracts them from the assembled block with 27 quad broadcasts: no atomics, one fence less (64.6 -> 63.4 ms).  With qsum4's association, which
-                              // differs from chain to chain, the lanes of a rollout solved four slightly different 6 x 6 systems: +0.3 % iterations and 2 000 rollout-steps at the cap.
-#endif
-#ifndef JH_V5_GCUBE_ATOMIC
-#define JH_V5_GCUBE_ATOMIC 0  // 1: the cube part of the gradient -J'f as six LDS float atomics per contact (like the finger part) instead of six 16-lane row sums per iteration.
-                              // With packed-fp32 code (SLP vectorizer on) the atomics were 1 % faster (79.9 against 80.65 ms); without it (-fno-slp-vectorize, the build since
-                              // round 4) the row sums are 1.7 % faster (70.2 against 71.4 ms): profiles/r04_leap_experiments.txt
-#endif
-#if JH_V5_AFORM && !(JH_V5_MERGE && JH_V5_HCC_ROWSUM && !JH_V5_GCUBE_ATOMIC)
-#error "JH_V5_AFORM is written for the merged pass with row sums"
-#endif
+// ---- The Newton iteration's formulation (round 4).  The alternatives below were A/B-measured on the recorded plan inputs within one GPU box each
+// (profiles/r04_leap_experiments.txt) and then taken out of the source (the git history has them as JH_V5_* switches):
+//  * gradient and Hessian of an iterate from ONE pass over the contacts (joint columns, world force and cone weights computed once, one fence less) instead of a gradient pass,
+//    the convergence test, and a Hessian pass that re-used the cone weights: 69.1 -> 68.2 ms, same iterates bit for bit;
+//  * the cube block of J'WJ (21 entries) and the cube part of -J'f (6) as sums over the rollout's lanes instead of LDS float atomics: every cube contact of a rollout adds to
+//    the same addresses and same-address atomics serialise: 68.2 -> 64.5 ms.  (With packed-fp32 code, rounds 2-3, six atomics for the gradient were 1 % faster than six row
+//    sums; without the SLP vectorizer the row sums are 1.7 % faster.)  Cost probes on the atomics that remain -- the instruction issued twice, the second adding zero -- put the
+//    24 Hcb atomics of a contact at 3.4 % and the 10 Hbb ones at 1.4 % of the kernel;
+//  * the 27 sums as two 16-value reduce-scatters (jh_coop.h row_scatter16: lane l receives entry l; 45 instructions per 16 sums instead of 80): 61.85 -> 61.25 ms;
+//  * the Schur complement Hcc - sum over chains of Y'Y never goes back to the LDS: the four chains' terms are summed with qsum4_same, whose result is bit-identical in every
+//    lane, and each lane subtracts them from the assembled block with 27 quad broadcasts: 64.6 -> 63.4 ms.  Earlier forms: `S.Hcc[..] -= da` (every read-modify-write its own
+//    LDS round trip, fourteen in a row), LDS atomics by the first chain's lanes (79.4 -> 78.4 ms), by every chain's lanes (+9.7 %).  With qsum4's association, which differs
+//    from chain to chain, the lanes of a rollout solved four slightly different 6 x 6 systems: +0.3 % iterations and 2 000 rollout-steps at the iteration cap;
+//  * J'WJ from world-frame dof columns and A = Fr' W Fr (one symmetric 3 x 3 per contact; the cube's translation columns are unit vectors) instead of frame-space columns
+//    times W: 63.3 -> 61.7 ms;
+//  * two surviving hand body pairs per level-2 broad-phase pass when both have at most 8 geoms: never applies (the survivors involve the palm's geom groups), +0.8 %.
 #ifndef JH_V5_LSRCP
 #define JH_V5_LSRCP 1  // the line search's Newton step divides with v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence (10 instructions per evaluation): -0.2 %
 #endif
@@ -789,75 +769,6 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       // level 2, per surviving body pair: (a) every geom of either body against the OTHER body's bounding box (one pass: lanes 0..nA-1 take A's geoms,
       // the next nB lanes B's; nA + nB <= 16) -- usually nothing of one side comes near the other and the pair is done; (b) the near geoms of A against
       // the near geoms of B (bounding spheres, then the six face axes of their boxes)
-#if JH_V5_L2DUAL
-      // two surviving pairs per pass when both have at most 8 geoms (na + nb): lanes 0..7 of the rollout take the first, lanes 8..15 the second.  3.5-4.2 pairs survive per
-      // rollout-step (4.1-5.3 passes per wave-step, the maximum over the wave's four rollouts) and a finger link has one to three geoms: most passes used a quarter of the lanes.
-      // The candidates come out in a different order than pair by pair (the two pairs' geom pairs interleave): the same set, another order of the contacts in the pool.
-      for (int i = 0; __any(i < nbl);) {
-#ifdef JH_V5_COUNT
-        if (lane == 0) cnt_l2++;
-#endif
-        int ba = 0, bb = 0, ga0 = 0, na = 0, gb0 = 0, nb = 0; bool dual = false;
-        if (i < nbl) {
-          const int p0 = S.bpl[i], p1 = i + 1 < nbl ? S.bpl[i + 1] : p0;
-          const int ba0 = sBP[2 * p0], bb0 = sBP[2 * p0 + 1], ba1 = sBP[2 * p1], bb1 = sBP[2 * p1 + 1];
-          const int na0 = sBG[2 * ba0 + 1], nb0 = sBG[2 * bb0 + 1], na1 = sBG[2 * ba1 + 1], nb1 = sBG[2 * bb1 + 1];
-          dual = i + 1 < nbl && na0 + nb0 <= 8 && na1 + nb1 <= 8;
-          const bool second = dual && l >= 8;
-          ba = second ? ba1 : ba0; bb = second ? bb1 : bb0; na = second ? na1 : na0; nb = second ? nb1 : nb0;
-          ga0 = sBG[2 * ba]; gb0 = sBG[2 * bb];
-        }
-        const int lw = dual ? (l & 7) : l, sh = (dual && l >= 8) ? 8 : 0;  // lane within the group that serves the pair, the group's first bit in the rollout's ballot
-        bool near = false;
-        if (lw < na + nb) {
-          const bool isA = lw < na;
-          const int g = isA ? ga0 + lw : gb0 + (lw - na), own = isA ? ba : bb, oth = isA ? bb : ba;
-          const float* gf = sGeomF + g * GEOM_F;
-          float cw[3];
-          if (static_code(own)) { cw[0] = gf[GF_POS]; cw[1] = gf[GF_POS + 1]; cw[2] = gf[GF_POS + 2]; }
-          else { mulMV(cw, S.xR[own], gf + GF_POS); cw[0] += S.pa[own][0]; cw[1] += S.pa[own][1]; cw[2] += S.pa[own][2]; }
-          const float dw[3] = {cw[0] - S.bs[oth][0], cw[1] - S.bs[oth][1], cw[2] - S.bs[oth][2]};
-          float dl[3];
-          if (static_code(oth)) { dl[0] = dw[0]; dl[1] = dw[1]; dl[2] = dw[2]; } else mulMTV(dl, S.xR[oth], dw);
-          const float* hb = sBB + 8 * oth + 4;
-          const float ex = fmaxf(fabsf(dl[0]) - hb[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hb[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hb[2], 0.f);
-          near = ex * ex + ey * ey + ez * ez <= gf[GF_RBOUND] * gf[GF_RBOUND];
-        }
-        const unsigned m16 = (unsigned)((__ballot(near) >> (16 * r)) & 0xFFFFull);
-        const unsigned mg = dual ? (m16 >> sh) & 0xFFu : m16;
-        const unsigned mB = (mg >> na) & ((1u << nb) - 1u);
-        unsigned rem = mB != 0 ? (mg & ((1u << na) - 1u)) : 0u;
-        while (__any(rem != 0)) {
-          const int ia = rem != 0 ? __ffs(rem) - 1 : 0;
-          bool hit = false;
-          const int ga = ga0 + ia, gb = gb0 + lw;
-          if (rem != 0 && lw < nb && ((mB >> lw) & 1u)) {
-            const float* fa = sGeomF + ga * GEOM_F; const float* fb = sGeomF + gb * GEOM_F;
-            float ca[3], cb[3];
-            if (static_code(ba)) { ca[0] = fa[GF_POS]; ca[1] = fa[GF_POS + 1]; ca[2] = fa[GF_POS + 2]; }
-            else { mulMV(ca, S.xR[ba], fa + GF_POS); ca[0] += S.pa[ba][0]; ca[1] += S.pa[ba][1]; ca[2] += S.pa[ba][2]; }
-            mulMV(cb, S.xR[bb], fb + GF_POS); cb[0] += S.pa[bb][0]; cb[1] += S.pa[bb][1]; cb[2] += S.pa[bb][2];
-            const float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]}, rs = fa[GF_RBOUND] + fb[GF_RBOUND];
-            hit = dot3(d, d) <= rs * rs;
-            if (hit) {  // the geoms' own boxes (a sphere counts as the cube around it)
-              float RA[9], RB[9];
-              if (static_code(ba)) { for (int k = 0; k < 9; k++) RA[k] = fa[GF_R + k]; } else mulMM(RA, S.xR[ba], fa + GF_R);
-              mulMM(RB, S.xR[bb], fb + GF_R);
-              const bool sphA = sGeomI[ga * GEOM_I + 1] != GBOX, sphB = sGeomI[gb * GEOM_I + 1] != GBOX;
-              const float hA[3] = {fa[GF_SIZE], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 1], sphA ? fa[GF_SIZE] : fa[GF_SIZE + 2]};
-              const float hB[3] = {fb[GF_SIZE], sphB ? fb[GF_SIZE] : fb[GF_SIZE + 1], sphB ? fb[GF_SIZE] : fb[GF_SIZE + 2]};
-              hit = obb_face_overlap(ca, RA, hA, cb, RB, hB);
-            }
-          }
-          const unsigned h16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
-          const int pos = nh + __popc(h16 & ((1u << l) - 1u));
-          if (hit && pos < MAXHIT) S.hits[pos] = (unsigned short)(HITPAIR + (ga << 7 | gb));
-          nh += __popc(h16);
-          rem &= rem - 1u;
-        }
-        i += dual ? 2 : 1;
-      }
-#else
       for (int i = 0; __any(i < nbl); i++) {
 #ifdef JH_V5_COUNT
         if (lane == 0) cnt_l2++;
@@ -911,7 +822,6 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           rem &= rem - 1u;
         }
       }
-#endif
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_hh += nh - nh_cube;
 #endif
@@ -1123,10 +1033,6 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
         if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
         if (act) S.g[6 + l] = g_own;
-#if JH_V5_GCUBE_ATOMIC
-        if (act && l < 6) S.g[l] = mck * dcl;
-#endif
-#if JH_V5_MERGE
         // One pass over the contacts builds the gradient AND the Hessian of this iterate: the joint columns axis x (pos - anchor), the world force and the cone weights are
         // computed once instead of once per pass.  The pass that finds a rollout converged has then assembled a Hessian nobody reads (one iteration in ten).
         const bool aact0 = act && !(DENSE && dense_row);
@@ -1135,26 +1041,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
           if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
-#if !JH_V5_HCC_ROWSUM
-          S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
-          if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
-#endif
         }
-#if JH_V5_HCC_ROWSUM
         float hcp[21];  // the cube block J'WJ of this lane's contacts: every cube contact of the rollout lands on the same 21 entries -> row sums instead of 21 conflicting atomics per contact
 #pragma unroll
         for (int e = 0; e < 21; e++) hcp[e] = 0.f;
         bool hcany = false;
-#endif
-#endif
         WSYNC();
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
-#if JH_V5_KEEPW && !JH_V5_MERGE
-        float Wkeep[NS][6];  // the cone weights of this pass, kept for the Hessian pass instead of a second cone_eval (12 registers across the convergence test)
-#pragma unroll
-        for (int k = 0; k < NS; k++) for (int e6 = 0; e6 < 6; e6++) Wkeep[k][e6] = 0.f;
-#endif
-#if JH_V5_MERGE
         if (act) {
 #pragma unroll
           for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
@@ -1167,7 +1060,6 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
             const bool cube = !SELF || t.la == CUBE;
-#if JH_V5_AFORM
             // J'WJ in the world frame: every dof column of the contact is a world 3-vector col_x (J[w][x] = fr_w . col_x), so the entry (x, y) is col_x' A col_y with
             // A = Fr' W Fr, a symmetric 3 x 3 formed once per contact.  The cube's translation columns are -e_q: their block is A itself and their coupling to a column c is
             // -(A c)_q, both free; a third fewer multiply-adds than frame-space columns times W (the fr3 kernel's formulation).
@@ -1256,132 +1148,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                 }
               }
             }
-#else
-            float Jc[6][3];
-            if (cube) {
-              float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
-#if JH_V5_GCUBE_ATOMIC
-              atomicAdd(&S.g[0], Fw[0]); atomicAdd(&S.g[1], Fw[1]); atomicAdd(&S.g[2], Fw[2]); atomicAdd(&S.g[3], tb[0]); atomicAdd(&S.g[4], tb[1]); atomicAdd(&S.g[5], tb[2]);
-#else
-              gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
-#endif
-              if (on) {
-                for (int q3 = 0; q3 < 3; q3++) {
-                  Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
-                  float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
-                  Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
-                }
-#pragma unroll
-                for (int v6 = 0; v6 < 6; v6++) {
-                  const float* j3 = Jc[v6];
-                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-#if JH_V5_HCC_ROWSUM
-                  for (int u6 = v6; u6 < 6; u6++) hcp[tri(u6, v6)] += Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2;
-#else
-                  for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
-#endif
-                }
-#if JH_V5_HCC_ROWSUM
-                hcany = true;
-#endif
-              }
-            }
-            if (t.lb > 0) {
-              const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
-              const bool linkA = SELF && !cube && t.la > 0;
-              const int cha = linkA ? (t.la - 1) >> 2 : 0, depa = linkA ? (t.la - 1) & 3 : -1;
-              const bool same = linkA && cha == ch;
-              float c3b[NLK][3]; link_c3(S, ch, pos, c3b);
-              float Jb[NLK][3];
-#pragma unroll
-              for (int j = 0; j < NLK; j++) {
-                const float fj = dot3(c3b[j], Fw);
-                if (j <= dep) atomicAdd(&S.g[6 + 4 * ch + j], -fj);       // side B: -J'f
-                if (same && j <= depa) atomicAdd(&S.g[6 + 4 * ch + j], fj);  // side A of the same chain: the opposite force
-                const float sg = (j <= dep ? 1.f : 0.f) - ((same && j <= depa) ? 1.f : 0.f);
-                Jb[j][0] = sg * dot3(t.fr, c3b[j]); Jb[j][1] = sg * dot3(t.fr + 3, c3b[j]); Jb[j][2] = sg * dot3(t.fr + 6, c3b[j]);
-              }
-              if (on) {
-#pragma unroll
-                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
-                  const float* j3 = Jb[u4];
-                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-                  for (int v4 = 0; v4 <= u4; v4++) { atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
-#ifdef JH_V5_X_DUPBB  // (cost probe: the same atomic once more, adding zero)
-                    atomicAdd(&S.Hbb[ch][tri(u4, v4)], 0.f);
-#endif
-                  }
-                  if (cube) {
-#pragma unroll
-                    for (int q6 = 0; q6 < 6; q6++) { atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
-#ifdef JH_V5_X_DUPCB
-                      atomicAdd(&S.Hcb[ch][u4 * 6 + q6], 0.f);
-#endif
-                    }
-                  }
-                }
-              }
-              if (linkA && !same) {  // side A sits in another chain: its own block, and the pair's coupling block -Jb'W Ja in Hx (B's chain is always the higher one)
-                float c3a[NLK][3]; link_c3(S, cha, pos, c3a);
-                float Ja[NLK][3];
-#pragma unroll
-                for (int j = 0; j < NLK; j++) {
-                  if (j <= depa) atomicAdd(&S.g[6 + 4 * cha + j], dot3(c3a[j], Fw));
-                  const float sg = j <= depa ? 1.f : 0.f;
-                  Ja[j][0] = sg * dot3(t.fr, c3a[j]); Ja[j][1] = sg * dot3(t.fr + 3, c3a[j]); Ja[j][2] = sg * dot3(t.fr + 6, c3a[j]);
-                }
-                if (on) {
-#pragma unroll
-                  for (int u4 = 0; u4 < NLK; u4++) if (u4 <= depa) {
-                    const float* j3 = Ja[u4];
-                    const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-                    for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[cha][tri(u4, v4)], Ja[v4][0] * G0 + Ja[v4][1] * G1 + Ja[v4][2] * G2);
-#pragma unroll
-                    for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[pidx(cha, ch)][v4 * 4 + u4], -(Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2));
-                  }
-                }
-              }
-            }
-#endif
           }
         }
-#else
-        if (act) {
-#pragma unroll
-          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
-            const Slot& t = sl[k];
-#if JH_V5_KEEPW
-            float f[3]; float* Wt = Wkeep[k];
-#else
-            float f[3], Wt[6];
-#endif
-            const float D[3] = {t.D0, t.D1, t.D1};
-            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wt);
-            if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
-            // world force on side B; side A gets the opposite.  gradient = -J'f with J = J_B - J_A
-            const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
-            const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-            if (!SELF || t.la == CUBE) {  // cube linear columns are -fr, rotational columns -(R e_a x rc) . fr
-              float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
-#if JH_V5_GCUBE_ATOMIC
-              atomicAdd(&S.g[0], Fw[0]); atomicAdd(&S.g[1], Fw[1]); atomicAdd(&S.g[2], Fw[2]); atomicAdd(&S.g[3], tb[0]); atomicAdd(&S.g[4], tb[1]); atomicAdd(&S.g[5], tb[2]);
-#else
-              gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
-#endif
-            } else if (SELF && t.la > 0) link_force(S, t.la, pos, Fw, -1.f);
-            if (t.lb > 0) link_force(S, t.lb, pos, Fw, 1.f);
-          }
-        }
-#endif
         float gcl = 0.f;
-#if JH_V5_GCUBE_ATOMIC
-        WSYNC();
-        if (l < 6) gcl = S.g[l];
-#else
-#if JH_V5_MERGE && JH_V5_HCC_ROWSUM && JH_V5_RSCAT
         float h0 = 0.f, h1;
         {  // two reduce-scatters: entries 16..20 of the cube block (to lanes 0..4) with the six gradient sums (to lanes 8..13, moved to 0..5 by a rotation), and entries 0..15
           const float v2[16] = {hcp[16], hcp[17], hcp[18], hcp[19], hcp[20], 0.f, 0.f, 0.f, gcp[0], gcp[1], gcp[2], gcp[3], gcp[4], gcp[5], 0.f, 0.f};
@@ -1392,28 +1161,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
         gcl = fmaf(mck, dcl, gcl);
         {
-#else
-#pragma unroll
-        for (int q6 = 0; q6 < 6; q6++) { const float v = gsum(gcp[q6]); if (q6 == l) gcl = v; }
-        gcl = fmaf(mck, dcl, gcl);  // lanes 6..15: mck = 0, gcl stays 0
-#endif
-#if JH_V5_MERGE && JH_V5_HCC_ROWSUM
-#if !JH_V5_RSCAT
-        {
-          float h0 = 0.f, h1 = 0.f;
-          if (__any(hcany)) {
-#pragma unroll
-            for (int e = 0; e < 21; e++) { const float v = gsum(hcp[e]); if (e < 16) { if (l == e) h0 = v; } else if (l == e - 16) h1 = v; }
-          }
-#endif
           if (aact0) {
             S.Hcc[l] = h0 + ((l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f)));
             if (l < 5) S.Hcc[16 + l] = h1 + (l == 4 ? cI[2] : 0.f);
           }
         }
-#endif
         WSYNC();
-#endif
         V5_TICK(4)
         // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
         g_own = S.g[6 + l];
@@ -1426,91 +1179,6 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
         if constexpr (OPQ > 3) forget_slots();
         const bool aact = act && !(DENSE && dense_row);
-#if !JH_V5_MERGE
-        if (aact) {
-#pragma unroll
-          for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
-          for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
-          if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;  // (zeroing it only for rollouts with coupled chains changes nothing: 79.45 against 79.5 ms)
-          S.Hcc[l] = (l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f));
-          if (l < 5) S.Hcc[16 + l] = l == 4 ? cI[2] : 0.f;
-        }
-        WSYNC();
-        V5_TICK(8)
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-          const Slot& t = sl[k];
-          float Wk[6] = {0, 0, 0, 0, 0, 0};
-          bool on = aact && t.la >= 0;
-          if (on) {
-#if JH_V5_KEEPW
-            for (int e6 = 0; e6 < 6; e6++) Wk[e6] = Wkeep[k][e6];
-#else
-            float f[3];
-            const float D[3] = {t.D0, t.D1, t.D1};
-            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
-#endif
-            on = !(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f);
-          }
-          if (!__any(on)) continue;  // (the second slot is empty in most waves)
-          if (on) {
-            const bool cube = !SELF || t.la == CUBE;
-            float Jc[6][3];
-            if (cube) {  // cube columns in the contact frame
-              for (int q3 = 0; q3 < 3; q3++) {
-                Jc[q3][0] = -t.fr[q3]; Jc[q3][1] = -t.fr[3 + q3]; Jc[q3][2] = -t.fr[6 + q3];
-                float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
-                Jc[3 + q3][0] = -dot3(t.fr, c3); Jc[3 + q3][1] = -dot3(t.fr + 3, c3); Jc[3 + q3][2] = -dot3(t.fr + 6, c3);
-              }
-#pragma unroll
-              for (int v6 = 0; v6 < 6; v6++) {
-                const float* j3 = Jc[v6];
-                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-                for (int u6 = v6; u6 < 6; u6++) atomicAdd(&S.Hcc[tri(u6, v6)], Jc[u6][0] * G0 + Jc[u6][1] * G1 + Jc[u6][2] * G2);
-              }
-            }
-            if (t.lb > 0) {  // finger columns: side B; side A joins the same block when both links sit in one chain, else its chain gets its own block and the
-                             // pair's coupling block -Jb'W Ja goes to Hx (B's chain is always the higher one)
-              const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
-              const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-              const bool linkA = SELF && !cube && t.la > 0;
-              const bool same = linkA && ((t.la - 1) >> 2) == ch;
-              float Jb[NLK][3];
-              for (int j = 0; j < NLK; j++) Jb[j][0] = Jb[j][1] = Jb[j][2] = 0.f;
-              link_cols(S, t.lb, pos, t.fr, 1.f, Jb);
-              if (same) link_cols(S, t.la, pos, t.fr, -1.f, Jb);  // (A's depth <= B's: pairs are ordered by body index)
-#pragma unroll
-              for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
-                const float* j3 = Jb[u4];
-                const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-                for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2);
-                if (cube) {
-#pragma unroll
-                  for (int q6 = 0; q6 < 6; q6++) atomicAdd(&S.Hcb[ch][u4 * 6 + q6], Jc[q6][0] * G0 + Jc[q6][1] * G1 + Jc[q6][2] * G2);
-                }
-              }
-              if (linkA && !same) {
-                const int cha = (t.la - 1) >> 2, depa = (t.la - 1) & 3;
-                float Ja[NLK][3];
-                for (int j = 0; j < NLK; j++) Ja[j][0] = Ja[j][1] = Ja[j][2] = 0.f;
-                link_cols(S, t.la, pos, t.fr, 1.f, Ja);
-#pragma unroll
-                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= depa) {
-                  const float* j3 = Ja[u4];
-                  const float G0 = Wk[0] * j3[0] + Wk[1] * j3[1] + Wk[3] * j3[2], G1 = Wk[1] * j3[0] + Wk[2] * j3[1] + Wk[4] * j3[2], G2 = Wk[3] * j3[0] + Wk[4] * j3[1] + Wk[5] * j3[2];
-#pragma unroll
-                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[cha][tri(u4, v4)], Ja[v4][0] * G0 + Ja[v4][1] * G1 + Ja[v4][2] * G2);
-#pragma unroll
-                  for (int v4 = 0; v4 < NLK; v4++) if (v4 <= dep) atomicAdd(&S.Hx[pidx(cha, ch)][v4 * 4 + u4], -(Jb[v4][0] * G0 + Jb[v4][1] * G1 + Jb[v4][2] * G2));
-                }
-              }
-            }
-          }
-        }
-        WSYNC();
-#endif
         V5_TICK(5)
         // ---- (4) arrow factorisation: chain blocks first (each chain's 4 lanes redundantly); the coupling columns Y_q = L^-1 Hcb[:,q] are shared
         // by the chain's lanes (lane s: columns s and s+4); 6x6 Schur complement on the cube, solved by every lane
@@ -1561,39 +1229,25 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         {
           // Schur complement: Hcc[q][r] -= sum over chains of Y_q . Y_r, rhs6[q] -= sum of Y_q . zb; lane s of a chain owns q in {s, s+4} and fetches Y_r from
           // its chain-mates; the four chains' terms are added with two row rotations and the first chain's lane applies the total
-#if JH_V5_SCHUR_ATOMIC == 3
           float dar[6], dbr[6];  // the four chains' terms of row s (dar) and row 4 + s (dbr), column r6, summed over the chains: the same numbers in every chain's lane s
-#endif
 #pragma unroll
           for (int r6 = 0; r6 < 6; r6++) {
             float Yr[NLK];
 #pragma unroll
             for (int j = 0; j < NLK; j++) Yr[j] = r6 < 4 ? quad_get(Ya[j], r6) : quad_get(Yb[j], r6 - 4);
             float da = Ya[0] * Yr[0] + Ya[1] * Yr[1] + Ya[2] * Yr[2] + Ya[3] * Yr[3], db = Yb[0] * Yr[0] + Yb[1] * Yr[1] + Yb[2] * Yr[2] + Yb[3] * Yr[3];
-#if JH_V5_SCHUR_ATOMIC == 3
             dar[r6] = qsum4_same(da); dbr[r6] = qsum4_same(db);
             continue;
-#endif
-#if JH_V5_SCHUR_ATOMIC == 2  // every chain's lanes add their own terms: four-way conflicts in the LDS instead of two row rotations per entry
-            const bool app = aact;
-#else
             da = qsum4(da); db = qsum4(db);
             const bool app = aact && c == 0;
-#endif
             if (app) {
               // (LDS atomics, not `S.Hcc[..] -= da`: the compiler cannot prove the addresses distinct and turns every read-modify-write into its own LDS round trip --
               // ds_read, wait, ds_write -- fourteen of them in a row per iteration; x + (-da) is the same number, and ds_add_f32 is not waited for: 78.4 against 79.4 ms)
-#if JH_V5_SCHUR_ATOMIC
               if (r6 <= s) atomicAdd(&S.Hcc[tri(s, r6)], -da);
               if (hasb && r6 <= 4 + s) atomicAdd(&S.Hcc[tri(4 + s, r6)], -db);
-#else
-              if (r6 <= s) S.Hcc[tri(s, r6)] -= da;
-              if (hasb && r6 <= 4 + s) S.Hcc[tri(4 + s, r6)] -= db;
-#endif
             }
           }
           float ra = Ya[0] * zb[0] + Ya[1] * zb[1] + Ya[2] * zb[2] + Ya[3] * zb[3], rb = Yb[0] * zb[0] + Yb[1] * zb[1] + Yb[2] * zb[2] + Yb[3] * zb[3];
-#if JH_V5_SCHUR_ATOMIC == 3
           ra = qsum4_same(ra); rb = qsum4_same(rb);
           // the complement stays in registers: every lane needs all of it for the redundant 6 x 6 solve anyway -- 27 quad broadcasts instead of 27 atomics, a fence and
           // the wait for them
@@ -1604,23 +1258,6 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             for (int r6 = 0; r6 <= q6; r6++) Lc[tri(q6, r6)] = S.Hcc[tri(q6, r6)] - (q6 < 4 ? quad_get(dar[r6], q6) : quad_get(dbr[r6], q6 - 4));
             xc6[q6] = S.rhs6[q6] - (q6 < 4 ? quad_get(ra, q6) : quad_get(rb, q6 - 4));
           }
-#elif JH_V5_SCHUR_ATOMIC == 2
-          if (aact) { atomicAdd(&S.rhs6[s], -ra); if (hasb) atomicAdd(&S.rhs6[4 + s], -rb); }
-#elif JH_V5_SCHUR_ATOMIC
-          ra = qsum4(ra); rb = qsum4(rb);
-          if (aact && c == 0) { atomicAdd(&S.rhs6[s], -ra); if (hasb) atomicAdd(&S.rhs6[4 + s], -rb); }
-#else
-          ra = qsum4(ra); rb = qsum4(rb);
-          if (aact && c == 0) { S.rhs6[s] -= ra; if (hasb) S.rhs6[4 + s] -= rb; }
-#endif
-#if JH_V5_SCHUR_ATOMIC != 3
-        }
-        WSYNC();
-        {
-          float Lc[21];
-          for (int k = 0; k < 21; k++) Lc[k] = S.Hcc[k];
-          for (int k = 0; k < 6; k++) xc6[k] = S.rhs6[k];
-#endif
           float ci[6];
 #pragma unroll
           for (int i = 0; i < 6; i++)

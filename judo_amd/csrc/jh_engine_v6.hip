@@ -153,7 +153,7 @@ __device__ __forceinline__ void slot_Jx(const Slot6& t, const RS6& S, const floa
 }
 // -J'F of body b (F = world force on side B; sign = +1 for side B, -1 for side A): float atomics into the gradient
 // (the free box's six entries: every contact of the rollout that touches the box lands on the same six addresses, and same-address LDS atomics serialise -- they are summed
-// over the rollout's lanes instead, JH_V6_CUBE_ROWSUM; the leap kernel's cube block taught this: jh_engine_v5.hip JH_V5_HCC_ROWSUM)
+// over the rollout's lanes instead, JH_V6_CUBE_ROWSUM; the leap kernel's cube block taught this: jh_engine_v5.hip, the note on the Newton iteration's formulation)
 __device__ __forceinline__ void body_force(RS6& S, int b, const float* pos, const float* Fw, float sign, float* gcp) {
   if (b == 0) {
     float rc[3] = {pos[0] - S.xpos[0][0], pos[1] - S.xpos[0][1], pos[2] - S.xpos[0][2]}, tq[3], tb[3];
