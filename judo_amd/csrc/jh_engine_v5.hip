@@ -56,6 +56,14 @@ constexpr int NCH = 4, NLK = 4;
 //  * J'WJ from world-frame dof columns and A = Fr' W Fr (one symmetric 3 x 3 per contact; the cube's translation columns are unit vectors) instead of frame-space columns
 //    times W: 63.3 -> 61.7 ms;
 //  * two surviving hand body pairs per level-2 broad-phase pass when both have at most 8 geoms: never applies (the survivors involve the palm's geom groups), +0.8 %.
+#ifndef JH_V5_HCSPLIT
+#define JH_V5_HCSPLIT 1  // wave-steps without a candidate pair off the cube (two thirds of them on the headline workload) take a copy of the solver compiled without the code for the
+                         // hand's own contacts: 61.1 -> 59.4 ms.  The same contacts through the hand-capable copy cost 14 % more (48.5 against 42.5 ms with the hand's broad phase
+                         // switched off) for the registers its extra paths hold.  The two copies must give the same bits for a cube contact (a rollout's result may not depend on
+                         // its wave-mates: tests/test_gpu_leap.py permutes them): with -ffp-contract=fast they do not -- the backend fuses a product into an add only when the
+                         // product has no other use, and the hand paths are such uses -- so this file is built with -ffp-contract=on (fusion within a source expression only:
+                         // +0.7 % on its own, jh_engine_v5.flags).
+#endif
 #ifndef JH_V5_LSRCP
 #define JH_V5_LSRCP 1  // the line search's Newton step divides with v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence (10 instructions per evaluation): -0.2 %
 #endif
@@ -699,6 +707,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     WSYNC();
     V5_TICK(0)
     // ================================================================ collision: broad phase (cube vs the lane's geoms; hand body pairs), balanced narrow phase
+    bool hand_hits = false;  // this rollout has candidate geom pairs of the hand against itself or the static geometry this step (a superset of its contacts off the cube)
     {
       int nh = 0;
       float Rc[9]; for (int k = 0; k < 9; k++) Rc[k] = S.xR[0][k];
@@ -762,8 +771,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       if (nbl > MAXBPL) { if (l == 0 && live && stats) atomicAdd(stats, nbl - MAXBPL); nbl = MAXBPL; }  // (counted with the dropped contacts)
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_bp += nbl;
-      const int nh_cube = nh;
 #endif
+      const int nh_cube = nh;
       WSYNC();
       V5_TICK(14)
       // level 2, per surviving body pair: (a) every geom of either body against the OTHER body's bounding box (one pass: lanes 0..nA-1 take A's geoms,
@@ -825,6 +834,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #ifdef JH_V5_COUNT
       if (l == 0 && live) cnt_hh += nh - nh_cube;
 #endif
+      hand_hits = nh > nh_cube;
 #endif
       }
       if (nh > MAXHIT) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT); nh = MAXHIT; }  // (candidate pairs lost: counted with the dropped contacts)
@@ -888,7 +898,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       if (lane == 0) atomicAdd(stats + 128 + min(mx, 63), 1);
     }
 #endif
-    auto solve_step = [&](auto NS_) __attribute__((always_inline)) -> bool {
+    auto solve_step = [&](auto NS_, auto HC_) __attribute__((always_inline)) -> bool {
+    constexpr bool HC = decltype(HC_)::value;  // hand contacts (a side that is not the cube) possible in this wave-step: false = the copy without their code (see the dispatch below)
     constexpr int NS = decltype(NS_)::value;
     const int ncap = (NOVF > 0 && (ovf_all == nullptr || n >= N) && 16 * NS > NCP) ? NCP : 16 * NS;  // (no overflow row: what the LDS pool holds)
     const int ncon = S.ncon < ncap ? S.ncon : ncap;
@@ -907,13 +918,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           sl[k].fr[0] = e[3]; sl[k].fr[1] = e[4]; sl[k].fr[2] = e[5];
           make_frame(sl[k].fr);
           float dist = e[6], mu = e[7], tran = e[9]; const int sides = __float_as_int(e[8]);
-          sl[k].la = SELF ? (sides & 0xFF) : CUBE; sl[k].lb = sides >> 8;
+          sl[k].la = HC ? (sides & 0xFF) : CUBE; sl[k].lb = sides >> 8;
           float imp = impedance(csi, dist);
           float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran), R1 = R0 / fmaxf(1e-15f, impratio);
           sl[k].D0 = 1.f / R0; sl[k].D1 = 1.f / R1;
           sl[k].fri = mu; sl[k].mu = mu * sqrtf(R1 / R0);
           { float m2 = sl[k].mu * sl[k].mu; sl[k].Dm = sl[k].D0 / (m2 * (1.f + m2)); }
-          float vel[3]; slot_Jx<SELF>(sl[k], S, qc, vc, wv3, S.qv, vel);
+          float vel[3]; slot_Jx<HC>(sl[k], S, qc, vc, wv3, S.qv, vel);
           sl[k].aref[0] = -cB * vel[0] - cK * imp * dist; sl[k].aref[1] = -cB * vel[1]; sl[k].aref[2] = -cB * vel[2];
         }
       }
@@ -935,10 +946,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       anyslot |= sl[k].la >= 0;
-      if (SELF && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2)) cmask |= 1 << (4 * ((sl[k].la - 1) >> 2) + ((sl[k].lb - 1) >> 2));
+      if (HC && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2)) cmask |= 1 << (4 * ((sl[k].la - 1) >> 2) + ((sl[k].lb - 1) >> 2));
     }
     int lvl = 0, par = -1, nlev = 0; bool dense_row = false;
-    if constexpr (SELF) {
+    if constexpr (HC) {
       cmask = gor(cmask);
       if (__any(cmask != 0)) dense_row = !chain_elim_order(cmask, c, lvl, par, nlev);
 #ifdef JH_V5_COUNT
@@ -949,7 +960,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       }
 #endif
     }
-    if constexpr (SELF && NS < NSLOT) { if (__any(dense_row)) return false; }  // (the one-slot copy has no dense direction: the wave takes the NSLOT copy; nothing was written yet)
+    if constexpr (HC && NS < NSLOT) { if (__any(dense_row)) return false; }  // (the one-slot copy has no dense direction: the wave takes the NSLOT copy; nothing was written yet)
 #if JH_V5_PARK
     S.pk_q[l] = q; S.pk_fs[l] = fs_own;
     if (l == 0) { S.pk_cq[0] = qc[3]; S.pk_cq[1] = qc[4]; S.pk_cq[2] = qc[5]; S.pk_cq[3] = qc[6]; S.pk_acc = acc; }
@@ -969,7 +980,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         float cs = 0.f, jx[3], jar_ws[NS][3];
 #pragma unroll
         for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
-          slot_Jx<SELF>(sl[k], S, qc, xl, wa, S.ws, jx);
+          slot_Jx<HC>(sl[k], S, qc, xl, wa, S.ws, jx);
           for (int rw = 0; rw < 3; rw++) { sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; jar_ws[k][rw] = sl[k].jar[rw]; }
           cs += cone_cost(sl[k]);
         }
@@ -988,7 +999,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         cs = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
-          slot_Jx<SELF>(sl[k], S, qc, xl0, wa, S.p, jx);
+          slot_Jx<HC>(sl[k], S, qc, xl0, wa, S.p, jx);
           for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw];
           cs += cone_cost(sl[k]);
         }
@@ -1040,7 +1051,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
           for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
-          if (SELF) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
+          if (HC) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
         }
         float hcp[21];  // the cube block J'WJ of this lane's contacts: every cube contact of the rollout lands on the same 21 entries -> row sums instead of 21 conflicting atomics per contact
 #pragma unroll
@@ -1059,7 +1070,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f && !on) continue;  // separated contact
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
-            const bool cube = !SELF || t.la == CUBE;
+            const bool cube = !HC || t.la == CUBE;
             // J'WJ in the world frame: every dof column of the contact is a world 3-vector col_x (J[w][x] = fr_w . col_x), so the entry (x, y) is col_x' A col_y with
             // A = Fr' W Fr, a symmetric 3 x 3 formed once per contact.  The cube's translation columns are -e_q: their block is A itself and their coupling to a column c is
             // -(A c)_q, both free; a third fewer multiply-adds than frame-space columns times W (the fr3 kernel's formulation).
@@ -1102,7 +1113,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             }
             if (t.lb > 0) {
               const int ch = (t.lb - 1) >> 2, dep = (t.lb - 1) & 3;
-              const bool linkA = SELF && !cube && t.la > 0;
+              const bool linkA = HC && !cube && t.la > 0;
               const int cha = linkA ? (t.la - 1) >> 2 : 0, depa = linkA ? (t.la - 1) & 3 : -1;
               const bool same = linkA && cha == ch;
               float cb[NLK][3]; link_c3(S, ch, pos, cb);
@@ -1195,7 +1206,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         factor_block();
         if (aact && l < 6) S.rhs6[l] = -gcl;
         float Xs[NLK] = {0.f, 0.f, 0.f, 0.f};  // column s of X = L^-1 H(a,P) of a chain a with a parent P
-        if constexpr (SELF) {
+        if constexpr (HC) {
 #pragma unroll 1
           for (int st = 1; st < NCH; st++) {
             if (!__any(aact && nlev >= st)) break;
@@ -1283,7 +1294,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           const float xa = sel4(xc6, s), xb = s == 0 ? xc6[4] : xc6[5];
 #pragma unroll
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
-          if constexpr (SELF) {
+          if constexpr (HC) {
             if (__any(aact && nlev > 0)) {
               // p_a = L_a^-T (zb_a - Y_a x_c - X p_P): parents finish first (last stage first) and publish their part of the direction
 #pragma unroll 1
@@ -1312,7 +1323,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
         // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
 #ifndef JH_V5_X_NODENSE
-        if constexpr (SELF && DENSE) {
+        if constexpr (HC && DENSE) {
 #ifdef JH_V5_COUNT
         if (lane == 0) { cnt_it++; cnt_dense += __any(act && dense_row) ? 1 : 0; }
 #endif
@@ -1448,7 +1459,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         {
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
 #pragma unroll
-          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<SELF>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<HC>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
 #if JH_V5_LSKINK
@@ -1546,8 +1557,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       };
       // (the rare slot-count copy instantiates the dense-capable loop only -- it serves rollouts without a dense row as well: three copies of the loop instead of four, and
       // the common one came out 0.9 % faster for it)
-      if constexpr (SELF && NS > NSLOT) newton_loop(std::true_type{});
-      else if constexpr (SELF && NS == NSLOT) { if (__any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{}); }
+      if constexpr (HC && NS > NSLOT) newton_loop(std::true_type{});
+      else if constexpr (HC && NS == NSLOT) { if (__any(dense_row)) newton_loop(std::true_type{}); else newton_loop(std::false_type{}); }
       else newton_loop(std::false_type{});
       if (l == 0) { n_iters += iters_this; n_maxed += (iters_this >= cap); }
     }
@@ -1555,13 +1566,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     };
     if (__builtin_expect_with_probability(NSBIG > NSLOT && __any(S.ncon > 16 * NSLOT), 0, JH_V5_BIGPROB)) {
       if (NOVF > 0 && __any(S.ncon > NCP)) __threadfence();  // the overflow rows were written with plain global stores by other lanes of this wave
-      solve_step(std::integral_constant<int, NSBIG>{});
+      solve_step(std::integral_constant<int, NSBIG>{}, std::integral_constant<bool, SELF>{});
     } else {
       bool done = false;
       if constexpr (JH_V5_NS1 && NSLOT > 1) {
-        if (__builtin_expect_with_probability(!__any(S.ncon > 16), 1, JH_V5_NS1PROB)) done = solve_step(std::integral_constant<int, 1>{});
+        if (__builtin_expect_with_probability(!__any(S.ncon > 16), 1, JH_V5_NS1PROB)) done = solve_step(std::integral_constant<int, 1>{}, std::integral_constant<bool, SELF>{});
       }
-      if (!done) solve_step(std::integral_constant<int, NSLOT>{});
+#if JH_V5_HCSPLIT
+      // A wave-step in which no rollout has a candidate pair off the cube has cube contacts only: it takes the copy of the solver compiled without the code for the hand's own
+      // contacts (link on side A, chain-coupling blocks, staged elimination, dense direction) -- the same expressions for what remains, fewer live values around them.
+      if constexpr (SELF) { if (!done && !__any(hand_hits)) done = solve_step(std::integral_constant<int, NSLOT>{}, std::false_type{}); }
+#endif
+      if (!done) solve_step(std::integral_constant<int, NSLOT>{}, std::integral_constant<bool, SELF>{});
     }
 #ifdef JH_V5_CENSUS
     if (stats) { if (l == 0 && live) atomicAdd(stats + 192 + min(iters_this, 31), 1); if (lane == 0) atomicAdd(stats + 224 + min(n_wave_iters - wave_it0, 31), 1); }
