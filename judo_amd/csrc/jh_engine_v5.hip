@@ -1569,8 +1569,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       solve_step(std::integral_constant<int, NSBIG>{}, std::integral_constant<bool, SELF>{});
     } else {
       bool done = false;
-      if constexpr (JH_V5_NS1 && NSLOT > 1) {
+      if constexpr (JH_V5_NS1 == 1 && NSLOT > 1) {
         if (__builtin_expect_with_probability(!__any(S.ncon > 16), 1, JH_V5_NS1PROB)) done = solve_step(std::integral_constant<int, 1>{}, std::integral_constant<bool, SELF>{});
+      }
+      if constexpr (JH_V5_NS1 == 2 && NSLOT > 1 && SELF) {  // (the one-slot copy only without the hand's code)
+        if (!__any(hand_hits) && !__any(S.ncon > 16)) done = solve_step(std::integral_constant<int, 1>{}, std::false_type{});
       }
 #if JH_V5_HCSPLIT
       // A wave-step in which no rollout has a candidate pair off the cube has cube contacts only: it takes the copy of the solver compiled without the code for the hand's own
