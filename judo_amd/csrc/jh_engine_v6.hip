@@ -42,6 +42,10 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 #define JH_V6_OPAQUE 1
 #endif
 #define OPAQUE6(x) asm volatile("" : "+v"(x))
+#ifndef JH_V6_FFSPLIT
+#define JH_V6_FFSPLIT 1  // wave-steps without a finger-finger contact take a copy of rows + solver without the six finger-finger slots per lane (48 registers): 9.59 -> 9.37 ms, and 8.99 ms
+                         // with -ffp-contract=on (jh_engine_v6.flags), under which the two copies also round alike (the leap kernel's note on JH_V5_HCSPLIT)
+#endif
 #ifndef JH_V6_RIGHTLOOK
 #define JH_V6_RIGHTLOOK 0  // 1: right-looking row Cholesky (one LDS write per lane and step, independent updates) + column-oriented backward solve.  Measured: 9.54 against 9.60 ms, within
                            // the noise -- the factorisation (19 % of the kernel, tools/diag/profile_fr3_phases.py) is bound by its fifteen LDS exchanges, not by the dependent chains
@@ -259,11 +263,11 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
   }
 }
 
-template <int NS>
+template <int NS, int NF>
 __device__ __forceinline__ float lane_rows_cost(const Slot6* sl, const SlotF* sf, float sff, const DofRows6& dr, bool eq_lane, float eD, float ejar) {
   float cs = 0.f;
 #pragma unroll
-  for (int k = 0; k < NFS; k++) if (sf[k].D > 0.f) {  // sff = a13 + a14 of the point the cost is taken at
+  for (int k = 0; k < NF; k++) if (sf[k].D > 0.f) {  // sff = a13 + a14 of the point the cost is taken at
     const float jar[3] = {fmaf(sf[k].Jf[0], sff, -sf[k].aref[0]), fmaf(sf[k].Jf[1], sff, -sf[k].aref[1]), fmaf(sf[k].Jf[2], sff, -sf[k].aref[2])};
     float f[3], W[6]; cs += pyramid_eval(jar, sf[k].D, sf[k].mu, f, W);
   }
@@ -278,12 +282,12 @@ __device__ __forceinline__ float lane_rows_cost(const Slot6* sl, const SlotF* sf
   return cs;
 }
 
-template <int NS>
+template <int NS, int NF>
 __device__ __forceinline__ void lane_rows_dir(const Slot6* sl, const SlotF* sf, float sff, float spf, const DofRows6& dr, bool eq_lane, float eD, float ejar, float ejp, float al, float* d1, float* d2) {
   float g1 = 0.f, g2 = 0.f;
   const float sal = fmaf(al, spf, sff);  // a13 + a14 at the trial point
 #pragma unroll
-  for (int k = 0; k < NFS; k++) if (sf[k].D > 0.f) {
+  for (int k = 0; k < NF; k++) if (sf[k].D > 0.f) {
     const float jp[3] = {sf[k].Jf[0] * spf, sf[k].Jf[1] * spf, sf[k].Jf[2] * spf};
     const float jar[3] = {fmaf(sf[k].Jf[0], sal, -sf[k].aref[0]), fmaf(sf[k].Jf[1], sal, -sf[k].aref[1]), fmaf(sf[k].Jf[2], sal, -sf[k].aref[2])};
     pyramid_dir(jar, jp, sf[k].D, sf[k].mu, &g1, &g2);
@@ -691,9 +695,16 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     PH6(3)
     // ================================================================ constraint rows
     const int nff = S.nff < NFF ? S.nff : NFF;
-    SlotF sf[NFS];
+    __syncthreads();
+    // The constraint rows and the Newton solver exist once per slot count (jh_engine_v5.hip does the same): a wave in which some rollout has more general contacts than the
+    // LDS pool holds runs the copy with NSBIG slots per lane, whose upper slots come from the rollout's row of the global overflow pool; every other wave the copy with NSL.
+    float a_own; int iters_this = 0;
+    auto solve_step = [&](auto NS_, auto NF_) __attribute__((always_inline)) {
+    constexpr int NS = decltype(NS_)::value;
+    constexpr int NF = decltype(NF_)::value;  // finger-finger slots per lane: NFS, or 0 in the copy for wave-steps without a finger-finger contact (48 registers less)
+    SlotF sf[NF > 0 ? NF : 1];
 #pragma unroll
-    for (int k = 0; k < NFS; k++) {  // finger-finger contacts go straight into registers of their owner lane
+    for (int k = 0; k < NF; k++) {  // finger-finger contacts go straight into registers of their owner lane
       const int c = l + 16 * k;
       sf[k].D = 0.f; sf[k].mu = 0.f;
       for (int w = 0; w < 3; w++) sf[k].aref[w] = sf[k].Jf[w] = 0.f;
@@ -721,12 +732,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         for (int w = 0; w < 3; w++) { const float vel = sf[k].Jf[w] * vff; sf[k].aref[w] = -cB * vel - (w == 0 ? cK * imp * dist : 0.f); }
       }
     }
-    __syncthreads();
-    // The constraint rows and the Newton solver exist once per slot count (jh_engine_v5.hip does the same): a wave in which some rollout has more general contacts than the
-    // LDS pool holds runs the copy with NSBIG slots per lane, whose upper slots come from the rollout's row of the global overflow pool; every other wave the copy with NSL.
-    float a_own; int iters_this = 0;
-    auto solve_step = [&](auto NS_) __attribute__((always_inline)) {
-    constexpr int NS = decltype(NS_)::value;
     const int ncon = S.ncon < 16 * NS ? S.ncon : 16 * NS;
     Slot6 sl[NS];
 #pragma unroll
@@ -795,14 +800,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         ejar = has_eq ? quad_get(qws, 1) - e_a1 * quad_get(qws, 2) - earef : 0.f;
         float mdw = 0.f;
         if (isarm) { for (int a = 0; a < NA; a++) mdw += S.M[ai][a] * S.vec[2][6 + a]; } else if (iscube) mdw = Md_own * (qws - a0_own);
-        const float cost_ws = gsum(lane_rows_cost<NS>(sl, sf, sff_ws, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
+        const float cost_ws = gsum(lane_rows_cost<NS, NF>(sl, sf, sff_ws, dr, eq_lane, eD, ejar) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
         for (int k = 0; k < NS; k++) for (int w = 0; w < 3; w++) jar_ws[k][w] = sl[k].jar[w];
         const float jf_ws = dr.jf, jl_ws = dr.jl, ej_ws = ejar;
         for (int k = 0; k < 6; k++) xc[k] = S.vec[1][k];
         for (int k = 0; k < NS; k++) if (sl[k].sa > -2) { float jx[3]; slot_Jx(sl[k], S, xc, S.vec[1] + 6, jx); for (int w = 0; w < 3; w++) sl[k].jar[w] = jx[w] - sl[k].aref[w]; }
         dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
         ejar = has_eq ? quad_get(a0_own, 1) - e_a1 * quad_get(a0_own, 2) - earef : 0.f;
-        const float cost_0 = gsum(lane_rows_cost<NS>(sl, sf, sff_0, dr, eq_lane, eD, ejar));
+        const float cost_0 = gsum(lane_rows_cost<NS, NF>(sl, sf, sff_0, dr, eq_lane, eD, ejar));
         if (cost_ws < cost_0) {
           a_own = qws;
           for (int k = 0; k < NS; k++) for (int w = 0; w < 3; w++) sl[k].jar[w] = jar_ws[k][w];
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
       bool has_rows_l = dr.fl > 0.f || dr.lims != 0.f || has_eq;
       for (int k = 0; k < NS; k++) has_rows_l |= sl[k].sa > -2;
-      for (int k = 0; k < NFS; k++) has_rows_l |= sf[k].D > 0.f;
+      for (int k = 0; k < NF; k++) has_rows_l |= sf[k].D > 0.f;
       bool act = gor((int)has_rows_l) != 0;
       if (!act) { a_own = a0_own; sff = 0.f; }
       float hdiag = 0.f;  // own diagonal entry of the last assembled Hessian
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           OPAQUE6(sl[k].D); OPAQUE6(sl[k].mu);
         }
 #pragma unroll
-        for (int k = 0; k < NFS; k++) { OPAQUE6(sf[k].D); OPAQUE6(sf[k].mu); for (int w = 0; w < 3; w++) { OPAQUE6(sf[k].Jf[w]); OPAQUE6(sf[k].aref[w]); } }
+        for (int k = 0; k < NF; k++) { OPAQUE6(sf[k].D); OPAQUE6(sf[k].mu); for (int w = 0; w < 3; w++) { OPAQUE6(sf[k].Jf[w]); OPAQUE6(sf[k].aref[w]); } }
 #endif
         // ---- (1) gradient row: M (a - a0) + dof rows + equality - J' f
         const float da_own = a_own - a0_own;
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         if (has_eq) { if (l == 13) g_own += eD * ejar; if (l == 14) g_own -= e_a1 * eD * ejar; }
         float ffg = 0.f, ffh = 0.f;  // finger-finger contacts: -Jf'f and Jf'W Jf, the same number on both finger dofs and on their coupling
 #pragma unroll
-        for (int k = 0; k < NFS; k++) if (sf[k].D > 0.f) {
+        for (int k = 0; k < NF; k++) if (sf[k].D > 0.f) {
           const float* jf = sf[k].Jf;
           const float jar[3] = {fmaf(jf[0], sff, -sf[k].aref[0]), fmaf(jf[1], sff, -sf[k].aref[1]), fmaf(jf[2], sff, -sf[k].aref[2])};
           float f[3], Wm[6]; pyramid_eval(jar, sf[k].D, sf[k].mu, f, Wm);
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
         for (int ls = 0; ls < JH_V6_LSCAP && __any(lsact); ls++) {
           float d1, d2;
-          lane_rows_dir<NS>(sl, sf, sff, spf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
+          lane_rows_dir<NS, NF>(sl, sf, sff, spf, dr, eq_lane, eD, ejar, ejp, alpha, &d1, &d2);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
           if (lsact) {
             if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
@@ -1076,8 +1081,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     };
     if (__builtin_expect_with_probability(ovf_all != nullptr && __any(S.ncon > NCP), 0, JH_V6_BIGPROB)) {
       __threadfence();  // the overflow rows were written with plain global stores by other lanes of this wave
-      solve_step(std::integral_constant<int, NSBIG>{});
-    } else solve_step(std::integral_constant<int, NSL>{});
+      solve_step(std::integral_constant<int, NSBIG>{}, std::integral_constant<int, NFS>{});
+    }
+#if JH_V6_FFSPLIT
+    else if (!__any(S.nff > 0)) solve_step(std::integral_constant<int, NSL>{}, std::integral_constant<int, 0>{});
+#endif
+    else solve_step(std::integral_constant<int, NSL>{}, std::integral_constant<int, NFS>{});
     PH6(5)
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     float qc[7], vc[6];  // the free body's state after the step (registers from here to the end of the step only)
