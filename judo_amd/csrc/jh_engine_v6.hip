@@ -42,6 +42,9 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 #define JH_V6_OPAQUE 1
 #endif
 #define OPAQUE6(x) asm volatile("" : "+v"(x))
+#ifndef JH_V6_NS1
+#define JH_V6_NS1 1  // among the wave-steps without a finger-finger contact, those with at most 16 general contacts per rollout take a one-slot copy: 8.98 -> 8.79 ms
+#endif
 #ifndef JH_V6_FFSPLIT
 #define JH_V6_FFSPLIT 1  // wave-steps without a finger-finger contact take a copy of rows + solver without the six finger-finger slots per lane (48 registers): 9.59 -> 9.37 ms, and 8.99 ms
                          // with -ffp-contract=on (jh_engine_v6.flags), under which the two copies also round alike (the leap kernel's note on JH_V5_HCSPLIT)
@@ -1084,6 +1087,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       solve_step(std::integral_constant<int, NSBIG>{}, std::integral_constant<int, NFS>{});
     }
 #if JH_V6_FFSPLIT
+#if JH_V6_NS1
+    else if (!__any(S.nff > 0) && !__any(S.ncon > G)) solve_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});  // (and at most 16 general contacts per rollout)
+#endif
     else if (!__any(S.nff > 0)) solve_step(std::integral_constant<int, NSL>{}, std::integral_constant<int, 0>{});
 #endif
     else solve_step(std::integral_constant<int, NSL>{}, std::integral_constant<int, NFS>{});
