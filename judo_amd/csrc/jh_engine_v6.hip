@@ -42,20 +42,16 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 #define JH_V6_OPAQUE 1
 #endif
 #define OPAQUE6(x) asm volatile("" : "+v"(x))
+// Measured and taken out of the source in round 4 (profiles/r04_leap_experiments.txt; the git history has it as JH_V6_RIGHTLOOK): a right-looking row Cholesky (one LDS write per
+// lane and step, independent updates) with a column-oriented backward solve: 9.54 against 9.60 ms, within the noise -- the factorisation (19 % of the kernel,
+// tools/diag/profile_fr3_phases.py) is bound by its fifteen LDS exchanges, not by the dependent chains of the left-looking form; with per-lane masks on the updates it was 13 %
+// slower.  A two-column block form would halve the exchanges: not built.
 #ifndef JH_V6_NS1
 #define JH_V6_NS1 1  // among the wave-steps without a finger-finger contact, those with at most 16 general contacts per rollout take a one-slot copy: 8.98 -> 8.79 ms
 #endif
 #ifndef JH_V6_FFSPLIT
 #define JH_V6_FFSPLIT 1  // wave-steps without a finger-finger contact take a copy of rows + solver without the six finger-finger slots per lane (48 registers): 9.59 -> 9.37 ms, and 8.99 ms
                          // with -ffp-contract=on (jh_engine_v6.flags), under which the two copies also round alike (the leap kernel's note on JH_V5_HCSPLIT)
-#endif
-#ifndef JH_V6_RIGHTLOOK
-#define JH_V6_RIGHTLOOK 0  // 1: right-looking row Cholesky (one LDS write per lane and step, independent updates) + column-oriented backward solve.  Measured: 9.54 against 9.60 ms, within
-                           // the noise -- the factorisation (19 % of the kernel, tools/diag/profile_fr3_phases.py) is bound by its fifteen LDS exchanges, not by the dependent chains
-                           // of the left-looking form; with per-lane masks on the updates it was 13 % SLOWER (10.85 ms).  A two-column block form would halve the exchanges: not built.
-#endif
-#ifndef JH_V6_CUBE_ROWSUM
-#define JH_V6_CUBE_ROWSUM 1  // the free box's entries of -J'f (6) and J'WJ (21) as row sums instead of same-address LDS atomics: 9.77 -> 9.57 ms on recorded inputs
 #endif
 #ifndef JH_V6_LSCAP
 #define JH_V6_LSCAP 12  // line-search evaluations per Newton iteration
@@ -160,17 +156,12 @@ __device__ __forceinline__ void slot_Jx(const Slot6& t, const RS6& S, const floa
 }
 // -J'F of body b (F = world force on side B; sign = +1 for side B, -1 for side A): float atomics into the gradient
 // (the free box's six entries: every contact of the rollout that touches the box lands on the same six addresses, and same-address LDS atomics serialise -- they are summed
-// over the rollout's lanes instead, JH_V6_CUBE_ROWSUM; the leap kernel's cube block taught this: jh_engine_v5.hip, the note on the Newton iteration's formulation)
+// over the rollout's lanes instead: 9.77 -> 9.57 ms on recorded inputs; the leap kernel's cube block taught this: jh_engine_v5.hip, the note on the Newton iteration's formulation)
 __device__ __forceinline__ void body_force(RS6& S, int b, const float* pos, const float* Fw, float sign, float* gcp) {
   if (b == 0) {
     float rc[3] = {pos[0] - S.xpos[0][0], pos[1] - S.xpos[0][1], pos[2] - S.xpos[0][2]}, tq[3], tb[3];
     cross3(tq, rc, Fw); mulMTV(tb, S.xR[0], tq);
-#if JH_V6_CUBE_ROWSUM
     gcp[0] -= sign * Fw[0]; gcp[1] -= sign * Fw[1]; gcp[2] -= sign * Fw[2]; gcp[3] -= sign * tb[0]; gcp[4] -= sign * tb[1]; gcp[5] -= sign * tb[2];
-#else
-    atomicAdd(&S.g[0], -sign * Fw[0]); atomicAdd(&S.g[1], -sign * Fw[1]); atomicAdd(&S.g[2], -sign * Fw[2]);
-    atomicAdd(&S.g[3], -sign * tb[0]); atomicAdd(&S.g[4], -sign * tb[1]); atomicAdd(&S.g[5], -sign * tb[2]);
-#endif
   } else if (b >= 1) {
 #pragma unroll
     for (int j = 0; j < NCHAIN; j++) if (j < b) {
@@ -210,7 +201,6 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
     const float rc[3] = {t.pos[0] - S.xpos[0][0], t.pos[1] - S.xpos[0][1], t.pos[2] - S.xpos[0][2]};
 #pragma unroll
     for (int q = 0; q < 3; q++) { float ea[3]; col3(ea, S.xR[0], q); cross3(c3[q], ea, rc); }
-#if JH_V6_CUBE_ROWSUM
 #pragma unroll
     for (int e = 0; e < 6; e++) hcp[e] += A[e];
 #pragma unroll
@@ -221,20 +211,6 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
 #pragma unroll
       for (int r2 = 0; r2 <= q; r2++) hcp[tri(3 + q, 3 + r2)] += dot3(c3[r2], z);
     }
-#else
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-#pragma unroll
-      for (int r2 = 0; r2 <= q; r2++) atomicAdd(&S.H[tri(q, r2)], A[tri(q, r2)]);
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      float z[3]; Amul(c3[q], z);
-#pragma unroll
-      for (int r2 = 0; r2 < 3; r2++) atomicAdd(&S.H[tri(3 + q, r2)], z[r2]);
-#pragma unroll
-      for (int r2 = 0; r2 <= q; r2++) atomicAdd(&S.H[tri(3 + q, 3 + r2)], dot3(c3[r2], z));
-    }
-#endif
   }
   if (ab >= 1) {
 #pragma unroll 1
@@ -882,10 +858,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         }
         __syncthreads();
         if (hasdof) g_own = S.g[l];
-#if JH_V6_CUBE_ROWSUM
 #pragma unroll
         for (int q = 0; q < 6; q++) { const float v = gsum(gcp[q]); if (l == q) g_own += v; }
-#endif
         // ---- (2) convergence on the scaled gradient; leave before any Hessian work once every rollout of the wave is done
         // fp32 floor of the gradient: one ulp of the iterate moves row l of the gradient by H_ll * eps * |a_l|.  Stiff rows (sum D J'J ~ 1e4..1e5 on a finger
         // of 0.2 kg against an acceleration of a few hundred m/s^2: a closing gripper whose pad stacks meet at 1 m/s) put that far above tol * |smooth force|;
@@ -941,12 +915,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) if (j <= l) Hrow[j] = S.H[tri(l, j)];
         }
-#if JH_V6_CUBE_ROWSUM
 #pragma unroll
         for (int q = 0; q < 6; q++)
 #pragma unroll
           for (int r2 = 0; r2 <= q; r2++) { const float v = gsum(hcp[tri(q, r2)]); if (l == q && act) Hrow[r2] += v; }
-#endif
         PH6(7)  // (the Hessian assembly alone; the rest of the solve stays in slot 5)
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) hdiag = Hrow[j];
@@ -954,37 +926,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) Hrow[j] = S.vec[1][j];
         }
-#if JH_V6_RIGHTLOOK
-        // ---- (4) right-looking row Cholesky: at step k every row publishes its entry of column k (ONE LDS write per lane and step, two alternating 16-float buffers at the head
-        // of Lp), takes the pivot and the column back and updates its remaining entries -- independent multiply-adds, where the left-looking form had a k-long dependent
-        // chain in the pivot row and another in every row below it at every step.  The rows go to Lp once at the end.
-#pragma unroll
-        for (int k = 0; k < NVT; k++) {
-          float* col = S.Lp + 16 * (k & 1);
-          col[l] = Hrow[k];  // (rows above k publish an entry nobody reads)
-          __syncthreads();
-          const float rinv = __frsqrt_rn(fmaxf(col[k], 1e-30f));
-          const float ck = Hrow[k] * rinv;
-          Hrow[k] = l == k ? rinv : ck;
-          // no masks: a row's entries right of its diagonal, and everything in the rows above k, are never read -- what lands there does not matter
-#pragma unroll
-          for (int j = k + 1; j < NVT; j++) Hrow[j] = fmaf(-ck, col[j] * rinv, Hrow[j]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NVT; j++) if (j <= l) S.Lp[tri(l, j)] = Hrow[j];
-        __syncthreads();
-        // ---- (5) backward solve, redundantly and column by column: p_j is final once the columns above it are taken out; the updates of one column are independent
-        float p[NVT];
-#pragma unroll
-        for (int k = 0; k < NVT; k++) p[k] = S.Lp[tri(15, k)];
-#pragma unroll
-        for (int j = NVT - 1; j >= 0; j--) {
-          p[j] *= S.Lp[tri(j, j)];
-#pragma unroll
-          for (int k = 0; k < j; k++) p[k] -= S.Lp[tri(j, k)] * p[j];
-        }
-#else
         // ---- (4) left-looking row Cholesky through LDS: at step k lane k finishes and publishes row k, rows below take column k
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
@@ -1019,7 +960,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           for (int j = k + 1; j < NVT; j++) s -= S.Lp[tri(j, k)] * p[j];
           p[k] = s * S.Lp[tri(k, k)];
         }
-#endif
         float p_own = 0.f;
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
