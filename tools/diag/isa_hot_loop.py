@@ -1,13 +1,19 @@
 """Per-source-line instruction and LDS-wait counts of ONE inlined copy of the leap kernel's Newton loop (the common one: two slots, no dense code), from an assembly
 listing with line tables (hipcc ... -gline-tables-only -S).  The copy is recognised by the call-site columns in the `.loc` inlined-at chains.
-usage: python tools/diag/isa_hot_loop.py build/isa/v5.s [call-site marker, default the NSLOT non-dense copy]"""
+usage: python tools/diag/isa_hot_loop.py build/isa/v5.s [hand|lean]"""
 import collections, re, sys
 asm = sys.argv[1]
 src = open("judo_amd/csrc/jh_engine_v5.hip").read().split("\n")
 # call sites: newton_loop(std::false_type{}) inside `else if constexpr (SELF && NS == NSLOT)` and solve_step(NSLOT)
-l_loop = next(i + 1 for i, l in enumerate(src) if "NS == NSLOT" in l and "newton_loop(std::false_type{})" in l)
+# which copy of the solver: "hand" (default) = the hand-capable copy, "lean" = the copy without the hand-contact code (JH_V5_HCSPLIT dispatch)
+which = sys.argv[2] if len(sys.argv) > 2 else "hand"
+pat = "done = solve_step(std::integral_constant<int, NSLOT>{}, std::false_type{})" if which == "lean" else "if (!done) solve_step(std::integral_constant<int, NSLOT>{}, std::integral_constant<bool, SELF>{})"
+l_solve = next(i + 1 for i, l in enumerate(src) if pat in l)
+if which == "lean":  # HC = false: the loop is instantiated by the last branch, `else newton_loop(std::false_type{});`
+    l_loop = next(i + 1 for i, l in enumerate(src) if l.strip().startswith("else newton_loop(std::false_type{});"))
+else:
+    l_loop = next(i + 1 for i, l in enumerate(src) if "NS == NSLOT" in l and "newton_loop(std::false_type{})" in l)
 c_loop = src[l_loop - 1].rindex("newton_loop(std::false_type{})") + 1
-l_solve = next(i + 1 for i, l in enumerate(src) if "if (!done) solve_step(std::integral_constant<int, NSLOT>{})" in l)
 lines = open(asm).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "k_leap_v5ILb0ELi4ELb1" in l)
 end = next(i for i, l in enumerate(lines) if i > start and l.startswith("_ZN") and "k_leap_v5" in l)
