@@ -45,7 +45,7 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 // Measured and taken out of the source in round 4 (profiles/r04_leap_experiments.txt; the git history has it as JH_V6_RIGHTLOOK): a right-looking row Cholesky (one LDS write per
 // lane and step, independent updates) with a column-oriented backward solve: 9.54 against 9.60 ms, within the noise -- the factorisation (19 % of the kernel,
 // tools/diag/profile_fr3_phases.py) is bound by its fifteen LDS exchanges, not by the dependent chains of the left-looking form; with per-lane masks on the updates it was 13 %
-// slower.  A two-column block form (eight exchanges instead of fifteen, both columns of L formed redundantly by every row; JH_V6_CHOL2 in the history): correct and 2.8 % slower (8.72 against
+// slower.  A two-column block form (eight exchanges instead of fifteen, both columns of L formed redundantly by every row): correct and 2.8 % slower (8.72 against
 // 8.48 ms) -- the exchanges do not bound the factorisation either; what is left is its 15-step dependent structure on one wave.
 #ifndef JH_V6_NS1
 #define JH_V6_NS1 1  // among the wave-steps without a finger-finger contact, those with at most 16 general contacts per rollout take a one-slot copy: 8.98 -> 8.79 ms
