@@ -478,6 +478,53 @@ static int collide_sphere_sphere(const double* c1, double r1, const double* c2, 
   return 1;
 }
 
+/* capsule against capsule (MuJoCo's primitive mjc_CapsuleCapsule, `engine_collision_primitive.c`; the pairs of the Spot robot against itself,
+ * `judo/models/xml/spot_primitive/contact.xml:4-14` lists the 11 it excludes): the closest points of the two axis SEGMENTS, then sphere against sphere there.
+ * Non-parallel axes: the unconstrained minimiser of |c1 + x1 a1 - c2 - x2 a2|^2 (a_i = half length times axis, x_i in [-1, 1]), x1 clamped with x2 re-solved, then x2
+ * clamped with x1 re-solved.  Parallel axes (determinant below mjMINVAL): each end of capsule 1 against the nearest point of segment 2, then each end of capsule 2
+ * against segment 1, at most two contacts -- a capsule lying along another rests on two points, not one.  size = (radius, half length), axis = local z. */
+static int collide_capsule_capsule(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin, rawcon* out) {
+  double a1[3], a2[3]; col(a1, R1, 2); col(a2, R2, 2);
+  for (int k = 0; k < 3; k++) { a1[k] *= s1[1]; a2[k] *= s2[1]; }
+  const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+  const double det = ma * mc - mb * mb;
+  if (fabs(det) >= MINVAL) {
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; } else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
+    if (x2 > 1) { x2 = 1; x1 = (u - mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+    else if (x2 < -1) { x2 = -1; x1 = (u + mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+    double v1[3], v2[3];
+    for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k] * x1; v2[k] = p2[k] + a2[k] * x2; }
+    return collide_sphere_sphere(v1, s1[0], v2, s2[0], margin, out);
+  }
+  int n = 0;
+  for (int e = 0; e < 2 && n < 2; e++) {  /* the two ends of capsule 1 against segment 2 */
+    const double x1 = e == 0 ? 1.0 : -1.0;
+    double x2 = (v - x1 * mb) / mc; if (x2 > 1) x2 = 1; else if (x2 < -1) x2 = -1;
+    double v1[3], v2[3];
+    for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k] * x1; v2[k] = p2[k] + a2[k] * x2; }
+    n += collide_sphere_sphere(v1, s1[0], v2, s2[0], margin, out + n);
+  }
+  for (int e = 0; e < 2 && n < 2; e++) {  /* the two ends of capsule 2 against segment 1 */
+    const double x2 = e == 0 ? 1.0 : -1.0;
+    double x1 = (u - x2 * mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1;
+    double v1[3], v2[3];
+    for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k] * x1; v2[k] = p2[k] + a2[k] * x2; }
+    n += collide_sphere_sphere(v1, s1[0], v2, s2[0], margin, out + n);
+  }
+  return n;
+}
+
+/* sphere against capsule (mjc_SphereCapsule): the point of the capsule's axis segment nearest to the centre, then sphere against sphere; normal from the sphere to the capsule */
+static int collide_sphere_capsule(const double* ps, double rs, const double* pc, const double* Rc, const double* sc, double margin, rawcon* out) {
+  double a[3]; col(a, Rc, 2);
+  const double d[3] = {ps[0] - pc[0], ps[1] - pc[1], ps[2] - pc[2]};
+  double x = dot3(a, d); if (x > sc[1]) x = sc[1]; else if (x < -sc[1]) x = -sc[1];
+  const double v[3] = {pc[0] + a[0] * x, pc[1] + a[1] * x, pc[2] + a[2] * x};
+  return collide_sphere_sphere(ps, rs, v, sc[0], margin, out);
+}
+
 /* two cylinders with parallel axes whose heights overlap: radial contact (the only cylinder case in the four models,
  * cylinder_push.xml:23,30; MuJoCo itself routes cylinder-cylinder through its general convex collider) */
 static int collide_cyl_cyl_parallel(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin, rawcon* out) {
@@ -817,6 +864,9 @@ static int collide_geoms(int t1, const double* s1, const double* p1, const doubl
   else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_CYLINDER) { n = collide_cylinder_sphere(p2, R2, s2, p1, s1[0], margin, rc); *flip = 1; }
   else if ((t1 == JO_GEOM_CYLINDER && (t2 == JO_GEOM_BOX || t2 == JO_GEOM_CAPSULE)) || (t2 == JO_GEOM_CYLINDER && (t1 == JO_GEOM_BOX || t1 == JO_GEOM_CAPSULE)))
     n = collide_convex(t1, s1, p1, R1, t2, s2, p2, R2, margin, rc);
+  else if (t1 == JO_GEOM_CAPSULE && t2 == JO_GEOM_CAPSULE) n = collide_capsule_capsule(p1, R1, s1, p2, R2, s2, margin, rc);
+  else if (t1 == JO_GEOM_SPHERE && t2 == JO_GEOM_CAPSULE) n = collide_sphere_capsule(p1, s1[0], p2, R2, s2, margin, rc);
+  else if (t1 == JO_GEOM_CAPSULE && t2 == JO_GEOM_SPHERE) { n = collide_sphere_capsule(p2, s2[0], p1, R1, s1, margin, rc); *flip = 1; }
   else if (t1 == JO_GEOM_BOX && t2 == JO_GEOM_CAPSULE) n = collide_box_capsule(p1, R1, s1, p2, R2, s2, margin, rc);
   else if (t1 == JO_GEOM_CAPSULE && t2 == JO_GEOM_BOX) { n = collide_box_capsule(p2, R2, s2, p1, R1, s1, margin, rc); *flip = 1; }
   return n;

@@ -124,6 +124,9 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
     excl = {tuple(sorted(e)) for e in desc["excludes"]}
     supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("sphere", "sphere"), ("cylinder", "cylinder"), ("box", "capsule"), ("capsule", "box"),
                  ("plane", "sphere"), ("plane", "capsule"), ("plane", "box"), ("sphere", "plane"), ("capsule", "plane"), ("box", "plane")}
+    spot = desc.get("family", desc["task"]) == "spot"
+    if spot:  # the robot against itself (judo/models/xml/spot_primitive/contact.xml:4-14 lists the 11 body pairs it excludes): capsule-capsule, sphere-capsule on top
+        supported = supported | {("capsule", "capsule"), ("sphere", "capsule"), ("capsule", "sphere")}
     pairs = []
     for g1 in range(len(geoms)):
         for g2 in range(g1 + 1, len(geoms)):
@@ -138,7 +141,7 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
                 continue
             if (geoms[g1]["type"], geoms[g2]["type"]) not in supported:
                 continue
-            if {geoms[g1]["type"], geoms[g2]["type"]} == {"capsule", "box"}:
+            if {geoms[g1]["type"], geoms[g2]["type"]} == {"capsule", "box"} and not spot:
                 # fr3_pick: the capsules stand in for the arm links' collision meshes (absent from the reference repository).  They collide with static geometry
                 # (table) and with the free body (cube); link-against-link and link-against-gripper pairs are left out -- hulls fitted by eye overlap their
                 # neighbours and would inject contact forces the reference does not have

@@ -74,13 +74,16 @@ STANDING_HEIGHT = 0.52                                                          
 DEFAULT_POLICY_COMMAND = np.concatenate([[0, 0, 0], ARM_STOWED_POS, np.zeros(12), [0, 0, STANDING_HEIGHT]])  # judo/tasks/spot/spot_base.py:159-161
 
 
-def spot_model():
-    """The Spot model (judo/models/xml/spot_primitive/robot.xml) in the oracle engine.  Scope of this round: robot geoms against the ground
-    plane (sphere / capsule / box vs plane); robot self-collision pairs (capsule-capsule, capsule-box) are not generated; the model's
-    sensors (relative frame positions, frame axes) are not evaluated."""
+def spot_model(self_collision: bool = False):
+    """The Spot model (judo/models/xml/spot_primitive/robot.xml) in the oracle engine.  Default scope (what jh_engine_v4.hip models): robot geoms against the
+    ground plane (sphere / capsule / box vs plane).  `self_collision=True` adds the robot's own pairs after MuJoCo's static filters and the 11 excludes of
+    `spot_primitive/contact.xml:4-14` (capsule-capsule, sphere-capsule, box-capsule, box-box, box-sphere, sphere-sphere): the oracle half of that feature --
+    no kernel models them yet.  The model's sensors (relative frame positions, frame axes) are not evaluated."""
     from oracle import oracle as O
 
     desc = O.load_description("spot")
+    if self_collision:
+        return O.Model("spot", desc=desc, pairs=O.collision_pairs(desc, scope="all"))
     plane = next(i for i, g in enumerate(desc["geoms"]) if g["type"] == "plane")
     pairs = [(min(plane, i), max(plane, i)) for i, g in enumerate(desc["geoms"]) if i != plane]
     return O.Model("spot", desc=desc, pairs=pairs)

@@ -169,14 +169,17 @@ def _quat_of(R):
     return np.array([w, x, y, z])
 
 
-@pytest.mark.parametrize("kinds", [("box", "box"), ("box", "sphere"), ("sphere", "sphere"), ("box", "capsule"), ("capsule", "plane"), ("box", "cylinder"), ("sphere", "cylinder"), ("cylinder", "cylinder"), ("capsule", "cylinder")])
+@pytest.mark.parametrize("kinds", [("box", "box"), ("box", "sphere"), ("sphere", "sphere"), ("box", "capsule"), ("capsule", "plane"), ("box", "cylinder"), ("sphere", "cylinder"), ("cylinder", "cylinder"), ("capsule", "cylinder"),
+                                   ("capsule", "capsule"), ("sphere", "capsule")])
 def test_narrow_phase_agrees_with_support_function_geometry(kinds):
     """Deepest penetration and normal of the oracle's collision routine against the signed distance of the two shapes computed from support functions
     (`tests/independent.py::signed_distance`), and every contact point inside both shapes (to the penetration)."""
     ka, kb = kinds
     if not O.supports_pair(ka, kb):
         pytest.skip(f"the oracle has no {ka}-{kb} routine (not needed by any shipped model)")
-    rng = np.random.default_rng(hash(kinds) % 2**32)
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32("-".join(kinds).encode()))  # (a stable seed: `hash` of a str tuple changes from process to process)
     done = 0
     for trial in range(220):
         def mk(kind):
@@ -229,6 +232,9 @@ def test_narrow_phase_agrees_with_support_function_geometry(kinds):
             assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd), (kinds, trial, deepest, sd)
         if set(kinds) <= {"box", "sphere"}:
             assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd) + slack, (kinds, trial, deepest, sd)   # exact routines (sampling error of the reference only)
+        if kinds in (("capsule", "capsule"), ("sphere", "capsule")) and sd > -0.98 * (A[1][0] + B[1][0]):
+            # the axis segments (the sphere's centre) do not meet: segment distance minus the radii is the exact signed distance, and the closed form must find it
+            assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd), (kinds, trial, deepest, sd)
         if kinds == ("box", "capsule") and sd > -0.98 * B[1][0]:
             # the capsule's axis stays outside the box: segment-to-box distance minus the radius is the exact signed distance, and the routine must find it
             assert abs(deepest - sd) < 5e-6 + 2e-3 * abs(sd), (kinds, trial, deepest, sd)
@@ -240,3 +246,35 @@ def test_narrow_phase_agrees_with_support_function_geometry(kinds):
             assert I.separation_along(SA, SB, nrm) <= dist + 1e-6 + 1e-3 * abs(dist), (kinds, trial, dist, I.separation_along(SA, SB, nrm))
         done += 1
     assert done >= 40, (kinds, done)
+
+
+def test_capsule_capsule_known_answers():
+    """Closed-form cases of the oracle's capsule-capsule routine (MuJoCo's mjc_CapsuleCapsule; groundwork for the Spot robot's own contact pairs,
+    judo/models/xml/spot_primitive/contact.xml:4-14): crossed axes -> one contact at the closest points; parallel axes -> two contacts, at the ends of the
+    shorter capsule; end to end -> one contact on the common axis."""
+    q0 = np.array([1.0, 0, 0, 0])
+    qx = np.array([np.sqrt(0.5), 0.0, np.sqrt(0.5), 0.0])  # local z -> world x
+    r1, h1, r2, h2 = 0.02, 0.10, 0.03, 0.05
+    # crossed at right angles, axes 0.04 apart along y: one contact, normal +y, dist = 0.04 - r1 - r2
+    out = O.collide_pair("capsule", [r1, h1], np.zeros(3), q0, "capsule", [r2, h2], np.array([0.0, 0.04, 0.0]), qx)
+    assert len(out) == 1
+    d, pos, n = out[0]
+    assert abs(d - (0.04 - r1 - r2)) < 1e-12 and np.allclose(n, [0, 1, 0], atol=1e-12) and np.allclose(pos, [0, r1 + 0.5 * d, 0], atol=1e-12)
+    # parallel, side by side 0.04 apart, capsule 2 shorter and shifted by 0.02 along the axis: two contacts at the ends of capsule 2's segment
+    out = O.collide_pair("capsule", [r1, h1], np.zeros(3), q0, "capsule", [r2, h2], np.array([0.04, 0.0, 0.02]), q0)
+    assert len(out) == 2
+    zs = sorted(o[1][2] for o in out)
+    assert np.allclose(zs, [0.02 - h2, 0.02 + h2], atol=1e-12)
+    for d, pos, n in out:
+        assert abs(d - (0.04 - r1 - r2)) < 1e-12 and np.allclose(n, [1, 0, 0], atol=1e-12)
+    # end to end on one axis, the caps 0.01 into each other
+    gap = h1 + h2 + r1 + r2 - 0.01
+    out = O.collide_pair("capsule", [r1, h1], np.zeros(3), q0, "capsule", [r2, h2], np.array([0.0, 0.0, gap]), q0)
+    assert len(out) >= 1 and all(abs(o[0] + 0.01) < 1e-12 and np.allclose(o[2], [0, 0, 1], atol=1e-12) for o in out)
+    # apart by more than the radii: nothing
+    assert O.collide_pair("capsule", [r1, h1], np.zeros(3), q0, "capsule", [r2, h2], np.array([0.06, 0.0, 0.0]), q0) == []
+    # sphere against capsule: beside the cylinder part and beyond the cap
+    out = O.collide_pair("sphere", [0.02], np.array([0.04, 0.0, 0.03]), q0, "capsule", [r2, h2], np.zeros(3), q0)
+    assert len(out) == 1 and abs(out[0][0] - (0.04 - 0.02 - r2)) < 1e-12 and np.allclose(out[0][2], [-1, 0, 0], atol=1e-12)
+    out = O.collide_pair("capsule", [r2, h2], np.zeros(3), q0, "sphere", [0.02], np.array([0.0, 0.0, h2 + 0.04]), q0)
+    assert len(out) == 1 and abs(out[0][0] - (0.04 - 0.02 - r2)) < 1e-12 and np.allclose(out[0][2], [0, 0, 1], atol=1e-12)

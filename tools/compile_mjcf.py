@@ -278,6 +278,13 @@ def compile_model(xml_name: str, task: str) -> dict:
                     )
                     fr = fl(a["friction"])
                     g["friction"] = [fr[0], fr[1] if len(fr) > 1 else 0.005, fr[2] if len(fr) > 2 else 0.0001]
+                    if "euler" in a:
+                        # `euler` (spot_primitive/arm.xml: nine collision geoms of the arm): the compiler's default sequence "xyz" = intrinsic rotations about x, the new y,
+                        # the new z, i.e. q = qx (x) qy (x) qz; radians (the files that use it declare <compiler angle="radian">)
+                        assert comp.get("angle", "degree") == "radian" and comp.get("eulerseq", "xyz") == "xyz", "euler: only radians and the default sequence are implemented"
+                        ex, ey, ez = fl(a["euler"])
+                        qx = [math.cos(ex / 2), math.sin(ex / 2), 0.0, 0.0]; qy = [math.cos(ey / 2), 0.0, math.sin(ey / 2), 0.0]; qz = [math.cos(ez / 2), 0.0, 0.0, math.sin(ez / 2)]
+                        g["quat"] = qnorm(quat_mul(quat_mul(qx, qy), qz))
                     size = fl(a["size"]) if "size" in a else []
                     if "fromto" in a:
                         ft = fl(a["fromto"])
