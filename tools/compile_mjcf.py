@@ -206,8 +206,20 @@ def geom_inertia(g: dict) -> tuple[float, list[float]]:
     return mass, I
 
 
+def _check_orientation_attributes(root: ET.Element) -> None:
+    """The orientation attributes this compiler does not implement must not appear at all (rounds 1-3 silently dropped `euler` on nine geoms of the Spot arm):
+    `axisangle` / `xyaxes` / `zaxis` anywhere, `euler` on anything but a geom."""
+    for el in root.iter():
+        for k in ("axisangle", "xyaxes", "zaxis"):
+            if k in el.attrib:
+                raise NotImplementedError(f"<{el.tag} name={el.get('name')!r}>: orientation attribute {k!r} is not implemented")
+        if "euler" in el.attrib and el.tag != "geom":
+            raise NotImplementedError(f"<{el.tag} name={el.get('name')!r}>: `euler` is implemented for geoms only")
+
+
 def compile_model(xml_name: str, task: str) -> dict:
     root = load_xml(os.path.join(REF_XML, xml_name))
+    _check_orientation_attributes(root)
     dfl = Defaults(root)
     comp = {}
     for c in root.findall("compiler"):
