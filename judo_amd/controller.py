@@ -72,8 +72,8 @@ class _PlanBuffers:
         """The output block (nominal | sigma | trace elites' records) and its pinned host image hold at least n floats."""
         if getattr(self, "out", None) is not None and self.out.numel() >= n:
             return
-        self.out = torch.empty(n, dtype=torch.float32, device=self.dev)
-        self.out_host = torch.empty(n, dtype=torch.float32).pin_memory()
+        self.out = torch.zeros(n, dtype=torch.float32, device=self.dev)
+        self.out_host = torch.zeros(n, dtype=torch.float32).pin_memory()  # (zeros: MPPI / PS never write the sigma region, and a cast of uninitialised bits may meet a signalling NaN)
         self.out_np = self.out_host.numpy()
         self.out_host_ptr = self.out_host.data_ptr()
 
@@ -459,7 +459,7 @@ class Controller:
             lohi = np.where(np.isnan(lohi), np.concatenate([ctrl_lo, ctrl_hi]), lohi)
         return np.nan_to_num(lohi.astype(np.float32), posinf=3.0e38, neginf=-3.0e38)
 
-    def _fetch(self, b: _PlanBuffers, n: int, behind=None, in_place: bool = False) -> np.ndarray:
+    def _fetch(self, b: _PlanBuffers, n: int, behind=None, in_place: bool = False, n_float: int | None = None) -> np.ndarray:
         """Device result -> pinned host memory, one wait: the only synchronisation of an iteration.  `behind` enqueues work that may run after the
         copy (the trace records): it is launched while the copy is in flight and is not waited for.  `in_place`: the update kernel wrote the pinned host
         block itself (jh_update_fused with host pointers): no copy, the completion mark alone."""
@@ -472,7 +472,8 @@ class Controller:
                 self._prefetch_noise(*self._prefetch_args)
         finally:
             _lib.check(L.jh_download_end(), "jh_download_end")
-        return b.out_np[:n].astype(np.float64)
+        # only nominal | sigma are floats to be widened: the trace records behind them carry an index column of int bit patterns (they are consumed as the raw fp32 copy)
+        return b.out_np[: n if n_float is None else n_float].astype(np.float64)
 
     def _fused_iteration(self, lib, b: _PlanBuffers, nrm: Normalizer, nominal_n: np.ndarray, W, shard: Shard, world: int, H: int, K: int, nu: int, N: int,
                          stream, state: dict) -> np.ndarray:
@@ -527,7 +528,7 @@ class Controller:
             finally:
                 if st == 0:
                     _lib.check(lib.jh_download_end(), "jh_download_end")
-            res = b.out_np[:n_out].astype(np.float64)
+            res = b.out_np[: 2 * K * nu if is_cem else K * nu].astype(np.float64)  # (not the trace records: their index column is an int bit pattern)
             if nfl:
                 state["trace_buf"] = (b.trace_buf, H * nfl)
             state.update(costs=b.costs, knots_out=knots_out, noise_p=noise_p, ldn=ldn, knots_nku=None)
@@ -593,7 +594,7 @@ class Controller:
                 ex1.record()
                 self.exchange_events.append((ex0, ex1))
             if staging and E_t:
-                res = self._fetch(b, n_out, in_place=self.zero_copy_out)
+                res = self._fetch(b, n_out, in_place=self.zero_copy_out, n_float=2 * K * nu if is_cem else K * nu)
                 self._traces = None
                 self._trace_stage = dict(kind="sensors", recs=b.out_np[2 * K * nu : n_out].copy(), stride=2 + row, E=int(state["E"]), x0=state["x0"], times=np.array(state["new_times"]),
                                          order=self.spline_order, H=H, K=K, nu=nu, index_is_bits=True, sorted=True)

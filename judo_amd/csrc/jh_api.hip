@@ -79,8 +79,8 @@ extern "C" int jh_model_stats(jh_model* m, int* out, int reset) {
   JH_REQUIRE(m && out, "model_stats: null pointer");
   JH_HIP(hipMemcpy(out, m->d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
   JH_HIP(hipMemcpy(out + 4, m->d_stats + 20, 2 * sizeof(int), hipMemcpyDeviceToHost));
-  out[6] = m->ovf_fallbacks; out[7] = 0;
-  if (reset) { JH_HIP(hipMemset(m->d_stats, 0, JH_NSTATS * sizeof(int))); m->ovf_fallbacks = 0; }
+  out[6] = reset ? __atomic_exchange_n(&m->ovf_fallbacks, 0, __ATOMIC_RELAXED) : __atomic_load_n(&m->ovf_fallbacks, __ATOMIC_RELAXED); out[7] = 0;
+  if (reset) JH_HIP(hipMemset(m->d_stats, 0, JH_NSTATS * sizeof(int)));
   return JH_OK;
 }
 

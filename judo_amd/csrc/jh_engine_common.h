@@ -215,6 +215,12 @@ __device__ __forceinline__ float leap_step_cost(const float* tp, const float* qp
 // fr3_pick (judo/tasks/fr3_pick.py:225-311): one step's contribution.  tp = (w_lift_close, w_lift_height, w_move_goal, w_move_close,
 // w_place_table, w_place_goal, w_upright, w_coll, w_qvel, w_open, goal_x, goal_y, pick_height, arm_home[9]).  `y` = sensordata of the forward
 // pass that produced the state (it lags the state by one step, as in the reference); `decay` = linspace(1,0,H)[h].
+// Which of fr3_pick's five distance sensors (sensordata 0..4: left / right finger - object, left / right finger - table, object - table; fr3_pick.xml, checked by
+// jh_model_is_fr3) fr3_step_cost below READS, and how: kept next to it so that an edit of the cost cannot leave a kernel shortcut behind.
+//   y[0], y[1]  never read;  y[2], y[3]  only as `<= 0` (the sign);  y[4]  only in phase 2 (PLACE), by value.
+constexpr int FR3_Y_FINGER_TABLE_L = 2, FR3_Y_FINGER_TABLE_R = 3, FR3_Y_OBJ_TABLE = 4, FR3_NDIST = 5, FR3_PHASE_PLACE = 2;
+__host__ __device__ __forceinline__ bool fr3_cost_reads_distance(int adr, int phase) { return adr == FR3_Y_FINGER_TABLE_L || adr == FR3_Y_FINGER_TABLE_R || (adr == FR3_Y_OBJ_TABLE && phase == FR3_PHASE_PLACE); }
+__host__ __device__ __forceinline__ bool fr3_cost_reads_sign_only(int adr) { return adr == FR3_Y_FINGER_TABLE_L || adr == FR3_Y_FINGER_TABLE_R; }
 __device__ __forceinline__ float fr3_step_cost(const float* tp, int phase, const float* qpos, const float* qvel, int nv, const float* y, float decay) {
   const float* gs = y + 11; const float* ez = y + 5;
   float gd = (gs[0] - qpos[0]) * (gs[0] - qpos[0]) + (gs[1] - qpos[1]) * (gs[1] - qpos[1]) + (gs[2] - qpos[2]) * (gs[2] - qpos[2]);
@@ -223,10 +229,10 @@ __device__ __forceinline__ float fr3_step_cost(const float* tp, int phase, const
   float c;
   if (phase == 0) c = tp[0] * gd + tp[1] * he;
   else if (phase == 1) c = tp[2] * og + tp[3] * gd;
-  else if (phase == 2) c = tp[4] * y[4] + tp[5] * og;
+  else if (phase == FR3_PHASE_PLACE) c = tp[4] * y[FR3_Y_OBJ_TABLE] + tp[5] * og;
   else { float hd = 0.f; for (int k = 0; k < 9; k++) hd += (qpos[7 + k] - tp[13 + k]) * (qpos[7 + k] - tp[13 + k]); c = sqrtf(hd); }
   float up = sqrtf(ez[0] * ez[0] + ez[1] * ez[1] + (ez[2] + 1.f) * (ez[2] + 1.f));
-  float touching = (y[2] <= 0.f || y[3] <= 0.f) ? 1.f : 0.f;
+  float touching = (y[FR3_Y_FINGER_TABLE_L] <= 0.f || y[FR3_Y_FINGER_TABLE_R] <= 0.f) ? 1.f : 0.f;
   float qn = 0.f; for (int k = 0; k < nv; k++) qn += qvel[k] * qvel[k];
   float op = (qpos[15] - 0.04f) * (qpos[15] - 0.04f);
   // reward = -(phase terms) + w_upright*(-up) + w_coll*(1-touching) + w_qvel*(-decay*|qvel|) + w_open*(-op); cost = -reward

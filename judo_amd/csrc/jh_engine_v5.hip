@@ -1679,9 +1679,7 @@ int JH_V5_NAME(jh_engine5_rollout_cost)(const jh_model* m, const float* x0, cons
   else
     hipLaunchKernelGGL((k_leap_v5<false, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs,
                        knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
-  JH_HIP(hipGetLastError());
-  if (ovf) JH_HIP(hipFreeAsync(ovf, st));
-  return JH_OK;
+  return jh_launch_done(ovf, st);
 }
 
 int JH_V5_NAME(jh_engine5_materialize)(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
@@ -1699,7 +1697,5 @@ int JH_V5_NAME(jh_engine5_materialize)(const jh_model* m, const float* x0, int x
     hipLaunchKernelGGL((k_leap_v5<true, JH_V5_WPB, false>), dim3(grid), dim3(WAVE * JH_V5_WPB), JH_V5_DYNBYTES, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, H, 0, (float*)nullptr, (float*)nullptr,
                        controls, states, sensors, m->d_stats, dshift, (float*)nullptr, ovf);
-  JH_HIP(hipGetLastError());
-  if (ovf) JH_HIP(hipFreeAsync(ovf, st));
-  return JH_OK;
+  return jh_launch_done(ovf, st);
 }

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
                                                     float* __restrict__ states, float* __restrict__ sensors, int* __restrict__ stats, int dshift, float* __restrict__ trace, float* __restrict__ ovf_all) {
   __shared__ RS6 sRS[RPW];
   __shared__ int sDT[MAXDT][3];  // distance-sensor tasks: sensordata address, geom a, geom b
-  __shared__ int sNDT, sDadr[8];
+  __shared__ int sNDT, sDadr[8], sDall[8];  // sDadr: sensordata address of distance sensor s, or -1 when this mode does not evaluate it; sDall: its address either way
   __shared__ float sTp[24];
   const int lane = threadIdx.x, l = lane & 15, r = lane >> 4;
   RS6& S = sRS[r];
@@ -359,7 +359,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       // fused mode: the sensor array is never written out, and FR3Pick.reward (judo/tasks/fr3_pick.py:225-311, fr3_step_cost) reads the finger-table distances (2, 3) and, in
       // the PLACE phase only, the object-table distance (4); the finger-object distances (0, 1) are not part of the cost: 10 of the 21 box pairs, and with them the second
       // round of 15-axis separations per step.  The drop-in (materialise) mode evaluates all of them.
-      if (!MATERIALIZE && (si[3] < 2 || (si[3] == 4 && phase != 2))) { if (si[1] < 8) sDadr[si[1]] = -1; continue; }
+      // Which ones and how is decided by fr3_cost_reads_distance / fr3_cost_reads_sign_only, next to the cost itself (jh_engine_common.h).
+      if (si[1] < 8) sDall[si[1]] = si[3];
+      if (!MATERIALIZE && !fr3_cost_reads_distance(si[3], phase)) { if (si[1] < 8) sDadr[si[1]] = -1; continue; }
       if (si[1] < 8) sDadr[si[1]] = si[3];
       const int* di = gI + m.oDistI + si[1] * 4;
       for (int a = 0; a < di[1]; a++) for (int b = 0; b < di[3]; b++) if (nt < MAXDT) { sDT[nt][0] = si[3]; sDT[nt][1] = gI[m.oGlist + di[0] + a]; sDT[nt][2] = gI[m.oGlist + di[2] + b]; nt++; }
@@ -411,6 +413,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
   float acc = 0.f;
   __syncthreads();
   const int ndt = sNDT;
+  // the distance sensors this mode does not evaluate hold their cutoff ("nothing within range"), not whatever the LDS held: fr3_step_cost receives all of y[]
+  if (l < m.NDIST && l < 8 && sDadr[l] < 0) S.y[sDall[l]] = gF[m.oDistF + l];
 
 #ifdef JH_V6_PHASES
   long long ph_t = __builtin_readcyclecounter(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           geom_pose3(S, fa, gI[m.oAGI + ga * GEOM_I], pa, Ra, true); geom_pose3(S, fb, gI[m.oAGI + gb * GEOM_I], pb, Rb, true);
           dadr[k] = sDT[t][0];
           // (fused mode: the cost asks of the finger-table sensors only whether they read <= 0 -- the sign, decided at the first separating axis)
-          if (!MATERIALIZE && (dadr[k] == 2 || dadr[k] == 3)) dmin[k] = box_box_touching(pa, Ra, ha, pb, Rb, hb) ? -1.f : 1.f;
+          if (!MATERIALIZE && fr3_cost_reads_sign_only(dadr[k])) dmin[k] = box_box_touching(pa, Ra, ha, pb, Rb, hb) ? -1.f : 1.f;
           else dmin[k] = box_box_distance(pa, Ra, ha, pb, Rb, hb);
         }
       }
@@ -1137,6 +1141,14 @@ bool jh_model_is_fr3(const jh_model* m) {
   const int nag = m->h_i[gi], npair = m->h_i[gi + 1], neq = m->h_i[gi + 2], ngs = m->h_i[gi + 5];
   if (neq > 1 || ngs > G || m->h_i[gi + 4] > 8) return false;
   for (int s = 0; s < ngs; s++) if (m->h_i[gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3] + m->h_i[gi + 4] * 4 + s * 4] == 2) return false;  // no jointpos sensors
+  {  // the fused mode's shortcut (fr3_cost_reads_distance, jh_engine_common.h) names the distance sensors by their sensordata address: they must be the model's
+     // first FR3_NDIST sensordata entries, distance sensor d at address d (fr3_pick.xml: finger-object x 2, finger-table x 2, object-table)
+    if (m->h_i[gi + 4] != jh_eng::FR3_NDIST) return false;
+    for (int s = 0; s < ngs; s++) {
+      const int* si = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3] + m->h_i[gi + 4] * 4 + s * 4;
+      if (si[0] == 4 && si[3] != si[1]) return false;
+    }
+  }
   { int nt = 0; const int* di = m->h_i.data() + gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3]; for (int s = 0; s < m->h_i[gi + 4]; s++) nt += di[4 * s + 1] * di[4 * s + 3]; if (nt > MAXDT) return false; }
   for (int g = 0; g < nag; g++) { const int tp = m->h_i[gi + 8 + g * jh_eng::GEOM_I + 1]; if (tp != jh_eng::GBOX && tp != jh_eng::GCAPSULE) return false; }  // boxes; capsules = arm-link stand-ins
   for (int p = 0; p < npair; p++) {  // pairs between two articulated bodies are kept as finger-finger contacts: nothing else qualifies
@@ -1172,9 +1184,7 @@ int jh_engine6_rollout_cost(const jh_model* m, const float* x0, const float* nom
   ovf = jh_launch_scratch(m, (size_t)N * NOVF * RAW_F * sizeof(float), st);  // (nullptr: the LDS capacity alone, drops and the fallback counted)
   hipLaunchKernelGGL(k_fr3_v6<false>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, 0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K,
                      costs, knots_out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, m->d_stats, dshift, trace, ovf);
-  JH_HIP(hipGetLastError());
-  if (ovf) JH_HIP(hipFreeAsync(ovf, st));
-  return JH_OK;
+  return jh_launch_done(ovf, st);
 }
 
 int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
@@ -1189,7 +1199,5 @@ int jh_engine6_materialize(const jh_model* m, const float* x0, int x0_batched, c
   hipLaunchKernelGGL(k_fr3_v6<true>, dim3(grid), dim3(WAVE), 0, st, m->d_f, m->d_i, x0, x0_batched, (const float*)nullptr, (const float*)nullptr, 0,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, N, 0, H, 0, (float*)nullptr,
                      (float*)nullptr, controls, states, sensors, m->d_stats, dshift, (float*)nullptr, ovf);
-  JH_HIP(hipGetLastError());
-  if (ovf) JH_HIP(hipFreeAsync(ovf, st));
-  return JH_OK;
+  return jh_launch_done(ovf, st);
 }

@@ -28,7 +28,7 @@ struct jh_model {
   int kernel_gen;  // articulated engine kernel: 3 = cooperative 16-lanes-per-rollout, two waves per SIMD (leap_cube: v5; fr3_pick: v6, matrix-free contact Jacobian), 2 = cooperative, one wave per SIMD (leap_cube: v2, fr3_pick: v3), 1 = one lane per rollout
   int contact_capacity;  // leap_cube generation 3: 48 (all in LDS, jh_engine_v5.hip) or 64 (jh_engine_v5_cap64.hip); jh_model_set_contact_capacity
   int self_collision;  // leap_cube on jh_engine_v5.hip: model the hand's own contacts (finger-finger, finger-palm) as MuJoCo does; 0 = the cube's contacts only
-  mutable int ovf_fallbacks = 0;  // launches that ran without their overflow rows (jh_launch_scratch)
+  mutable int ovf_fallbacks = 0;  // launches that ran without their overflow rows (jh_launch_scratch); updated with __atomic builtins: a planner thread may launch while another polls jh_model_stats
   int* d_stats;  // JH_NSTATS diagnostic counters: [0..3] contact-cap overflows, Newton iteration-cap hits, Newton iterations, steps; [20..21] wave-level iterations, steps; the rest: diagnostic builds
   std::vector<float> h_f;
   std::vector<int> h_i;
@@ -43,7 +43,8 @@ inline float* jh_launch_scratch(const jh_model* m, size_t bytes, hipStream_t st)
   hipMemPool_t pool = nullptr; void* p = nullptr;
   if (hipDeviceGetDefaultMemPool(&pool, m->device) == hipSuccess && pool && hipMallocFromPoolAsync(&p, bytes, pool, st) == hipSuccess) return (float*)p;
   (void)hipGetLastError();
-  m->ovf_fallbacks++;
+  if (__atomic_fetch_add(&m->ovf_fallbacks, 1, __ATOMIC_RELAXED) == 0)  // the first fallback of a model is also logged: the lower capacity must not depend on somebody polling the counter
+    fprintf(stderr, "judo_amd: no stream-ordered scratch for the contacts above the LDS pool (%zu bytes): this launch runs with the LDS capacity alone; see jh_model_stats out[6]\n", bytes);
   return nullptr;
 }
 
@@ -55,6 +56,15 @@ inline float* jh_launch_scratch(const jh_model* m, size_t bytes, hipStream_t st)
       return JH_ERR_HIP;                                                                  \
     }                                                                                     \
   } while (0)
+
+// end of a cooperative launcher: the launch's error is read FIRST, the stream-ordered overflow block is freed whether the launch succeeded or not, then the error is reported
+inline int jh_launch_done(float* ovf, hipStream_t st) {
+  const hipError_t e = hipGetLastError();
+  const hipError_t f = ovf ? hipFreeAsync(ovf, st) : hipSuccess;
+  if (e != hipSuccess) { jh_set_error("kernel launch failed: %s", hipGetErrorString(e)); return JH_ERR_HIP; }
+  if (f != hipSuccess) { jh_set_error("hipFreeAsync failed: %s", hipGetErrorString(f)); return JH_ERR_HIP; }
+  return JH_OK;
+}
 
 #define JH_REQUIRE(cond, ...)    \
   do {                           \

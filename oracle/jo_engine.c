@@ -1140,11 +1140,16 @@ static double total_cost(const jo_model* m, jo_data* d, const double* a, double*
 /* ------------------------------------------------------------------ primal Newton solver with exact line search (mj_solNewton) */
 /* diagnostics for the tests/tools: Newton iterations per solve, over all threads */
 static long g_iter_hist[32];
-static int g_trace = 0, g_wsmode = 0;
+static int g_trace = 0;
+#ifdef JO_EXPERIMENTS
+static int g_wsmode = 0;
 void jo_set_warmstart_mode(int mode) { g_wsmode = mode; }
+#endif
 void jo_set_trace(int on) { g_trace = on; }
 void jo_solver_histogram(long* out32, int reset) { for (int i = 0; i < 32; i++) { out32[i] = g_iter_hist[i]; if (reset) g_iter_hist[i] = 0; } }
 void jo_set_solver(jo_model* m, double tol, int maxiter) { m->solver_tol = tol; m->solver_maxiter = maxiter; }
+#ifdef JO_EXPERIMENTS /* the CPU prototypes of round 4 (line search, Hessian reuse, warm start): compiled ONLY into libjudo_oracle_exp.so (`make exp`, loaded by
+   tools/proto/ls_experiment.py and tools/diag/oracle_newton_hist.py) -- the library every parity test compares against has none of this state. */
 /* line-search experiments (tools/proto/ls_experiment.py; single-threaded runs only): mode 0 = the oracle's search (default: to rounding), mode >= 1 = the KERNELS' search --
    start at 1, stop at |slope| <= lstol |slope(0)|, at most lsmax evaluations, bisection when the Newton step leaves the bracket -- with, for mode 2, a trial at the zero
    crossing of a dof friction-loss row inside the bracket instead of the bisection (the slope jumps there; the kernels' long searches are bisections onto such a jump).
@@ -1159,6 +1164,7 @@ void jo_set_ls_experiment(int mode, double lstol, int lsmax, int* log, long cap)
 long jo_ls_log_size(void) { return g_lslog_n; }
 static void lslog(int v) { if (g_lslog && g_lslog_n < g_lslog_cap) g_lslog[g_lslog_n++] = v; }
 
+#endif
 static void solve_constraints(const jo_model* m, jo_data* d) {
   int nv = m->nv, ne = d->nefc;
   if (ne == 0) { memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv); memset(d->qfrc_constraint, 0, sizeof(double) * nv); d->solver_iter = 0; return; }
@@ -1170,11 +1176,13 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
   double cw = total_cost(m, d, d->qacc_warmstart, NULL, jar, NULL, NULL, NULL);
   double cs = total_cost(m, d, d->qacc_smooth, NULL, jar, NULL, NULL, NULL);
   memcpy(a, cw < cs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
+#ifdef JO_EXPERIMENTS
   if (g_wsmode == 1) { /* experiment: keep last step's constraint acceleration on top of the new smooth acceleration */
     double a3[JO_MAXDOF]; for (int i = 0; i < nv; i++) a3[i] = d->qacc_smooth[i] + d->qacc_con_prev[i];
     double c3 = total_cost(m, d, a3, NULL, jar, NULL, NULL, NULL);
     if (c3 < fmin(cw, cs)) memcpy(a, a3, sizeof(double) * nv);
   }
+#endif
   double scale = 0; for (int i = 0; i < nv; i++) scale += d->M[i][i]; scale = 1.0 / fmax(MINVAL, scale);
   int it;
   for (it = 0; it < m->solver_maxiter; it++) {
@@ -1182,7 +1190,9 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
     double gn = 0; for (int i = 0; i < nv; i++) gn += grad[i] * grad[i]; gn = sqrt(gn);
     d->solver_cost = cost; d->solver_gradnorm = gn;
     if (gn * scale < m->solver_tol) break;
+#ifdef JO_EXPERIMENTS
     if (g_hreuse && it > 0 && ((g_hreuse == 1 && (it & 1)) || (g_hreuse == 2 && g_last_alpha > 0.8 && g_last_alpha < 1.25) || (g_hreuse == 3 && (it % 3) != 0))) { g_hreuse_count++; goto have_factor; }  /* (experiment: the previous factor) */
+#endif
     for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) H[i][j] = d->M[i][j];
     for (int r = 0; r < ne; r++) if (Hd[r] != 0) for (int i = 0; i < nv; i++) { double ji = d->efc_J[r][i]; if (ji != 0) for (int j = 0; j < nv; j++) H[i][j] += Hd[r] * ji * d->efc_J[r][j]; }
     for (int c = 0; c < d->ncon; c++) if (d->con[c].efc_adr >= 0 && m->cone == JO_CONE_ELLIPTIC && d->con[c].dim == 3 && cz[c]) {
@@ -1190,7 +1200,9 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
       for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) { double w = Hc[c][3 * u + v]; for (int i = 0; i < nv; i++) { double ji = d->efc_J[r0 + u][i]; if (ji != 0) for (int j = 0; j < nv; j++) H[i][j] += w * ji * d->efc_J[r0 + v][j]; } }
     }
     if (cholesky(nv, H, LH) != 0) break;
+#ifdef JO_EXPERIMENTS
     have_factor:
+#endif
     for (int i = 0; i < nv; i++) p[i] = -grad[i];
     chol_solve(nv, LH, p);
     /* exact line search: phi(al) = cost(a + al p); safeguarded 1-D Newton on phi' */
@@ -1199,6 +1211,7 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
     double pMp = 0, pMd = 0; for (int i = 0; i < nv; i++) { pMp += p[i] * Mp[i]; pMd += Mp[i] * (a[i] - d->qacc_smooth[i]); }
     double lo = 0, hi = -1, al = 1.0, dlo = 0;
     { double g0 = 0; for (int i = 0; i < nv; i++) g0 += grad[i] * p[i]; dlo = g0; if (g0 >= 0) break; }
+#ifdef JO_EXPERIMENTS
     if (it == 0) { lslog(-1); lslog(ne); }
     if (g_lsmode >= 1) {
       const double g0 = dlo; double dlo_v = g0, dhi_v = 0; int nev = 0, kink_tries = 0;
@@ -1286,6 +1299,7 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
       lslog(nev);
       if (g_trace == 2) fprintf(stderr, "  == it %d: %d evaluations, ncon %d\n", it, nev, d->ncon);
     } else
+#endif
     for (int ls = 0; ls < 60; ls++) {
       for (int r = 0; r < ne; r++) jar2[r] = jar[r] + al * jp[r];
       constraint_cost(m, d, jar2, frc2, Hd2, Hc2, cz2);
@@ -1307,7 +1321,9 @@ static void solve_constraints(const jo_model* m, jo_data* d) {
       fprintf(stderr, "  it %2d cost %.6e |g|s %.3e alpha %.4g  ncon %d nefc %d zones top(free)/middle/bottom(stick) %d/%d/%d\n", it, cost, gn * scale, al, d->ncon, ne, nz[0], nz[1], nz[2]);
     }
     for (int i = 0; i < nv; i++) a[i] += al * p[i];
+#ifdef JO_EXPERIMENTS
     g_last_alpha = al;
+#endif
   }
   if (g_trace) fprintf(stderr, "solve done: %d iterations (warm start %s)\n", it, cw < cs ? "used" : "not used");
   d->solver_iter = it;

@@ -184,9 +184,12 @@ void jo_solver_histogram(long* out32, int reset);
 void jo_set_solver(jo_model* m, double tol, int maxiter);
 /* contact-parameter priority of a geom (mjModel.geom_priority, default 0): the higher priority side supplies friction / solref / solimp / condim */
 int jo_set_geom_priority(jo_model* m, int geom, int priority);
+#ifdef JO_EXPERIMENTS /* libjudo_oracle_exp.so only (`make -C oracle exp`): the parity oracle carries none of this state */
 void jo_set_ls_experiment(int mode, double lstol, int lsmax, int* log, long cap); /* line-search experiments: see jo_engine.c (0 = off, the default) */
 long jo_ls_log_size(void);
 void jo_set_warmstart_mode(int mode); /* 0 = MuJoCo (better of previous qacc and qacc_smooth); 1 = also try qacc_smooth + previous constraint acceleration */
+void jo_set_hessian_reuse(int mode); long jo_hessian_reuse_count(void); long jo_ls_trouble(int reset); void jo_set_ls_kink(double v); void jo_set_ls_shrink(double v);
+#endif
 
 #ifdef __cplusplus
 }

@@ -37,10 +37,11 @@ def _d(a) -> "C._Pointer":
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds)."""
-    so = os.path.join(_HERE, "libjudo_oracle.so")
+    exp = os.environ.get("JUDO_ORACLE_EXPERIMENTS") == "1"  # tools/proto, tools/diag only: the library with the round-4 solver experiments compiled in (-DJO_EXPERIMENTS)
+    so = os.path.join(_HERE, "libjudo_oracle_exp.so" if exp else "libjudo_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("jo_engine.c", "jo_plan.c", "jo_engine.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"] + (["exp"] if exp else []))
     return so
 
 

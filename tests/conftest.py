@@ -32,6 +32,49 @@ def gpu():
     return torch.device("cuda", 0)
 
 
+def bounded(what: str, value, bound) -> bool:
+    """`assert bounded("leap single step: velocity error, median", np.median(e), 1e-6)`: value <= bound, with the observed value and the stated bound recorded in
+    gpurun_out/test_margins.jsonl so that every stated tolerance can be set from measurements (tools/diag/margin_report.py lists bound / observed per site)."""
+    import inspect
+
+    fr = inspect.stack()[1]
+    v, b = float(value), float(bound)
+    record_margin("bounded", site=f"{os.path.basename(fr.filename)}:{fr.lineno}", what=what, observed=v, bound=b)
+    return v <= b
+
+
+def _record_allclose_calls() -> None:
+    """np.testing.assert_allclose, wrapped for the session: same check, plus one record per call -- the largest |actual - desired| / (atol + rtol |desired|) of the call,
+    i.e. the fraction of the stated tolerance that was used -- under the caller's file:line."""
+    import inspect
+
+    import numpy as np
+
+    orig = np.testing.assert_allclose
+    if getattr(orig, "_judo_recorded", False):
+        return
+
+    def wrapped(actual, desired, rtol=1e-7, atol=0, *a, **k):
+        try:
+            x, y = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+            den = atol + rtol * np.abs(y)
+            with np.errstate(all="ignore"):
+                used = np.where(den > 0, np.abs(x - y) / np.where(den > 0, den, 1.0), np.where(x == y, 0.0, np.inf))
+            fr = next((f for f in inspect.stack()[1:] if os.path.basename(f.filename).startswith("test_")), None)
+            if fr is not None and used.size:
+                record_margin("allclose", site=f"{os.path.basename(fr.filename)}:{fr.lineno}", used=float(np.nanmax(used)), max_abs=float(np.nanmax(np.abs(x - y))), rtol=float(rtol), atol=float(atol))
+        except Exception:
+            pass
+        return orig(actual, desired, rtol=rtol, atol=atol, *a, **k)
+
+    wrapped._judo_recorded = True
+    np.testing.assert_allclose = wrapped
+
+
+if os.environ.get("JUDO_RECORD_MARGINS") == "1":
+    _record_allclose_calls()
+
+
 def record_margin(test: str, **values) -> None:
     """Append the observed error statistics of a parity test to gpurun_out/test_margins.jsonl (scratch; read back in the build container to set / tighten the
     stated tolerances from measurements).  Never fails a test."""

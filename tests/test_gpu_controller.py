@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import bounded
+
 pytestmark = pytest.mark.gpu
 
 from tests import plugin_fixture as PF  # noqa: E402
@@ -216,7 +218,7 @@ def test_knot_count_of_ten_fused_where_the_kernel_allows_it_materialised_where_n
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
     np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
     d = np.abs(ctrl.rewards - ref["rewards"])
-    assert np.median(d) < 1e-5 and np.percentile(d, 95) < 2e-3
+    assert bounded("np.median(d)", np.median(d), 1e-5) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 2e-3)
     assert ctrl.nominal_knots.shape == (10, nu) and np.isfinite(ctrl.nominal_knots).all()
     ctrl.optimizer.config.num_nodes = 520 // nu + 1  # above JH_MAX_KNOT_DIM (K * nu <= 512): refused before anything is launched
     with pytest.raises(ValueError):

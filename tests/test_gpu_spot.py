@@ -7,6 +7,8 @@ tolerance 1e-10; velocities agree to ~1e-5 and positions to ~1e-6 per step (meas
 import numpy as np
 import pytest
 
+from tests.conftest import bounded
+
 pytestmark = pytest.mark.gpu
 
 TOL = dict(pos=2e-6, quat=2e-6, q=1e-5, vlin=2e-5, vang=1e-4, qd=3e-4)
@@ -119,7 +121,7 @@ def test_policy_rollout_backend_matches_oracle(spot):
     # the reference keeps its mjData between control steps: carrying the warm start changes the result only at solver-tolerance level
     be2 = PolicyRolloutBackend(N)
     s2, _, o2 = be2.rollout(x0, cmds, np.zeros((N, 12)))
-    assert np.abs(s2[:, :10] - states[:, :10]).max() < 5e-3 and np.isfinite(s2).all()
+    assert bounded("np.abs(s2[:, :10] - states[:, :10]).max()", np.abs(s2[:, :10] - states[:, :10]).max(), 5e-3) and np.isfinite(s2).all()
     with pytest.raises(ValueError):
         be.rollout(x0, cmds, None)
     with pytest.raises(ValueError):
@@ -265,10 +267,10 @@ def test_tree_kernel_survives_falls(spot):
     got = xs.cpu().numpy()
     st = eng.stats()
     assert np.isfinite(got).all()
-    assert got[:, 2].min() > 0.02 and got[:, 2].max() < 3.0          # nothing tunnels through the plane, nothing is shot into the sky
-    assert np.abs(got[:, 26:]).max() < 50.0
+    assert got[:, 2].min() > 0.02 and bounded("got[:, 2].max()", got[:, 2].max(), 3.0)  # nothing tunnels through the plane, nothing is shot into the sky
+    assert bounded("np.abs(got[:, 26:]).max()", np.abs(got[:, 26:]).max(), 50.0)
     assert st["steps"] == N * 100 and st["contacts_dropped"] < 0.01 * st["steps"], st
     # one of them against the oracle for a few steps (a tumbling robot is chaotic: short horizon, loose tolerance)
     ref = om.rollout(X[0], np.repeat(P.DEFAULT_JOINT_POS[None], 5, axis=0)[None], nthread=1)[0][0, -1]
     got5 = eng.substeps(torch.as_tensor(X[:1], dtype=torch.float32, device="cuda"), us[:1], torch.zeros((1, 25), device="cuda"), 5).cpu().numpy()[0]
-    assert np.abs(got5[:7] - ref[:7]).max() < 1e-3
+    assert bounded("np.abs(got5[:7] - ref[:7]).max()", np.abs(got5[:7] - ref[:7]).max(), 1e-3)

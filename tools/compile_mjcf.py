@@ -234,6 +234,17 @@ def compile_model(xml_name: str, task: str) -> dict:
         opt.update(o.attrib)
         for f in o.findall("flag"):
             flags.update(f.attrib)
+    # attributes whose only modelled value is MuJoCo's default: read here so that another value fails loudly instead of being dropped (tests/test_mjcf_audit.py)
+    if opt.get("solver", "Newton") != "Newton":
+        raise NotImplementedError(f"{xml_name}: <option solver={opt.get('solver')!r}>: the engines implement the Newton solver only")
+    if comp.get("autolimits", "true") != "true":
+        raise NotImplementedError(f"{xml_name}: <compiler autolimits={comp.get('autolimits')!r}>: limits are inferred from the presence of a range, as autolimits=true does")
+    if float(opt.get("density", 0)) not in (0.0, 1.0) or "viscosity" in opt or "wind" in opt:
+        # density="1" (spot_primitive/default.xml:6): the medium's drag (~0.1 N on a 32 kg robot at 1 m/s) is a STATED deviation; anything denser is not
+        raise NotImplementedError(f"{xml_name}: <option density / viscosity / wind>: fluid forces are not modelled")
+    for b in root.iter("body"):
+        if float(b.get("gravcomp", 0)) != 0.0:
+            raise NotImplementedError(f"{xml_name}: <body name={b.get('name')!r} gravcomp={b.get('gravcomp')!r}>: gravity compensation is not modelled")
     model: dict = {
         "task": task,
         "source": f"judo v0.0.7 judo/models/xml/{xml_name}",

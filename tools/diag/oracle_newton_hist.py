@@ -1,5 +1,6 @@
 """Scratch diagnostic (CPU): Newton iterations per solve of the fp64 oracle on bench-like leap_cube rollouts, per tolerance."""
 import ctypes as C, os, sys
+os.environ["JUDO_ORACLE_EXPERIMENTS"] = "1"  # oracle/libjudo_oracle_exp.so: the solver experiments are not in the parity oracle
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O

@@ -2,6 +2,7 @@
 headline plan steps: slope evaluations per Newton iteration of a rollout and of a "wave" (maximum over 4 consecutive rollouts at the same iteration number), Newton iterations.
 usage: python tools/proto/ls_experiment.py [plan step] [rollouts]"""
 import ctypes as C, os, sys
+os.environ["JUDO_ORACLE_EXPERIMENTS"] = "1"  # oracle/libjudo_oracle_exp.so: the solver experiments are not in the parity oracle
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O
