@@ -230,7 +230,7 @@ def main() -> None:
     ap.add_argument("--no-with-traces", action="store_true", help="skip the extra plan steps that measure what reading Controller.traces costs (run after the timed region)")
     ap.add_argument("--traces-outside-step", action="store_true", help="do not read Controller.traces inside the timed plan steps (rounds 1-2 timed it that way)")
     ap.add_argument("--no-cube-only", action="store_true", help="leap_cube: skip the extra cube-contacts-only steps run after the timed region")
-    ap.add_argument("--no-steady-state", action="store_true", help="skip carrying the closed loop on to plan step 100 after the timed region (steady_state: its last 20 plan steps)")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the 10 + 100 plan steps of the reference's benchmark statistic run after the timed region (benchmark_100; steady_state: its last 20 plan steps)")
     ap.add_argument("--no-replay", action="store_true", help="skip the replay of the recorded plan inputs (the deterministic, round-to-round comparable figure) after the timed region")
     ap.add_argument("--mode", default="fused", choices=["fused", "materialize"],
                     help="fused = the plan step (headline); materialize = drop-in RolloutBackend.rollout writing every state/sensor (the HBM-bound exhibit, SURVEY 8d)")
@@ -343,27 +343,37 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events])) if ctrl.kernel_events else float("nan")
-    # The timed steps start from rest, the cheap end of the closed loop: the same loop is carried on to plan step 100 and its last 20 steps are reported too --
-    # the reference's own statistic is 100 plan steps (judo/app/benchmark.py:96-107).  Outside `value`.
-    steady = None
+    # The timed steps start from rest, the cheap end of the closed loop.  The reference's own statistic (judo/app/benchmark.py:19,96-107) is 100 timed plan steps after 10
+    # warm-ups, summarised as mean / std / median / IQR / min / max: when --steps < 100 that loop is run here as well -- restarted from the same state and seed, outside
+    # `value` -- so that the tail of the distribution is in the driver's line and not only under profiles/.  `steady_state` = its last 20 plan steps.
+    steady, bench100 = None, None
     if world == 1 and not is_policy and not args.no_steady_state and args.steps < 100:
-        n_more, n_last = 100 - args.steps, 20
+        n_warm, n_timed, n_last = 10, 100, 20
         n_ev = len(ctrl.kernel_events)
-        ctrl.reserve_timing_events(4 * n_more * max(1, ctrl.max_opt_iters) + 8)
-        ts_last = None
-        for i in range(n_more):
-            if i == n_more - n_last:
-                torch.cuda.synchronize()
-                ts_last = time.perf_counter()
-            ctrl.time = t_plan
+        ctrl.reserve_timing_events(4 * (n_warm + n_timed) * max(1, ctrl.max_opt_iters) + 8)
+        ctrl.reset()
+        ctrl.current_state = ctrl.task.default_state()
+        ctrl.optimizer.seed(args.seed)
+        tq, ms100 = 0.0, []
+        for i in range(n_warm + n_timed):
+            ts = time.perf_counter()
+            ctrl.time = tq
             ctrl.update_action()
             if traces_in_step:
                 _ = ctrl.traces
-            t_plan += 1.0 / ctrl.controller_cfg.control_freq
+            tq += 1.0 / ctrl.controller_cfg.control_freq
+            if i >= n_warm:
+                ms100.append((time.perf_counter() - ts) * 1e3)
         torch.cuda.synchronize()
-        steady = {"plan_steps": [100 - n_last, 100], "ms_per_step": (time.perf_counter() - ts_last) / n_last * 1e3,
-                  "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in ctrl.kernel_events[-n_last:]])),
-                  "note": "the same closed loop carried on to plan step 100 after the timed region; mean of its last 20 plan steps (the plan has left the rest pose: more contacts per step)"}
+        m100 = np.array(ms100)
+        k100 = np.array([a.elapsed_time(b) for a, b in ctrl.kernel_events[n_ev:]])[-n_timed * max(1, ctrl.max_opt_iters):]
+        bench100 = {"plan_steps": n_timed, "warmup": n_warm, "mean": float(m100.mean()), "std": float(m100.std()), "median": float(np.median(m100)),
+                    "iqr": float(np.percentile(m100, 75) - np.percentile(m100, 25)), "min": float(m100.min()), "max": float(m100.max()), "kernel_ms_mean": float(k100.mean()),
+                    "budget_ms": 1e3 / ctrl.controller_cfg.control_freq, "steps_over_budget": int((m100 > 1e3 / ctrl.controller_cfg.control_freq).sum()),
+                    "note": "the reference's benchmark statistic (judo/app/benchmark.py:96-107: 100 plan steps after 10 warm-ups), same state and seed as the timed steps, "
+                            "traces read inside; budget_ms = 1 / control_freq (judo/controller/controller.py:39)"}
+        steady = {"plan_steps": [n_warm + n_timed - n_last, n_warm + n_timed], "ms_per_step": float(m100[-n_last:].mean()), "kernel_ms": float(k100[-n_last * max(1, ctrl.max_opt_iters):].mean()),
+                  "note": "the last 20 plan steps of the benchmark_100 loop (the plan has left the rest pose: more contacts per step)"}
         del ctrl.kernel_events[n_ev:]
         del ctrl.exchange_events[n_ev:]
     exch_ms = float(np.mean([a.elapsed_time(b) for a, b in ctrl.exchange_events])) if ctrl.exchange_events else 0.0
@@ -521,6 +531,8 @@ def main() -> None:
             line["solver"] = solver
         if cube_only:
             line["cube_only"] = cube_only
+        if bench100:
+            line["benchmark_100"] = bench100
         if steady:
             line["steady_state"] = steady
         if replay:

@@ -219,6 +219,25 @@ int jh_update_fused(const float* costs, const float* knots_nku, const float* nom
 int jh_plan_step(const jh_model* m, void* blk_dev, const void* blk_host, size_t blk_bytes, int o_nominal, int o_sigma, int o_tp, int o_lohi, const float* noise, int ldn,
                  const float* W, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, int mode, float lambda, int k, int tie_high, int E,
                  int row_floats, int colmajor, float* scratch, float* out, void* out_host_mark, void* const* timing, void* stream);
+/* The same iteration with the rollouts sharded over G ranks (the reference has no multi-process form: judo/controller/controller.py:246-299 runs in one
+ * process): launch -> all-gather -> merge.  jh_update_shard is jh_update_fused with the last stage left to the ranks' merge: it writes this rank's record
+ *   [ MPPI: beta, S, V(K*nu)  |  elites: k x (cost, global index (bits), knots(K*nu)) ]  followed by  E x (cost, global index (bits), trace row(row_floats))
+ * (jh_shard_record_floats floats) into rec_out; jh_shard_merge takes the G all-gathered records (rank-major) and writes nominal_out / sigma_out (raw population
+ * std, may be NULL) / trace_out (the E best of the G * E trace records, best first, ties: higher index first) exactly as jh_update_fused does on one GPU.  Every rank
+ * runs the same merge on the same bytes: identical nominal everywhere, no broadcast.  jh_plan_step_shard = upload + jh_rollout_cost_traced + jh_update_shard in one
+ * call (timing: 3 events as for jh_plan_step); jh_plan_merge = jh_shard_merge into out = [nominal | sigma | E trace records] + the completion mark jh_download_end
+ * waits for (timing_done: one event recorded behind the merge, or NULL). */
+size_t jh_shard_record_floats(int K, int nu, int mode, int k, int E, int row_floats);
+int jh_update_shard(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* ctrl_lo_hi, int N,
+                    int n_offset, int K, int nu, int mode, float lambda, int k, int tie_high, int E, const float* trace, int row_floats, int colmajor, float* scratch,
+                    float* rec_out, void* stream);
+int jh_shard_merge(const float* recs, int G, int K, int nu, int mode, float lambda, int k, int tie_high, int E, int row_floats, float* nominal_out, float* sigma_out,
+                   float* trace_out, void* stream);
+int jh_plan_step_shard(const jh_model* m, void* blk_dev, const void* blk_host, size_t blk_bytes, int o_nominal, int o_sigma, int o_tp, int o_lohi, const float* noise, int ldn,
+                       const float* W, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, int mode, float lambda, int k, int tie_high,
+                       int E, int row_floats, int colmajor, float* scratch, float* rec_out, void* const* timing, void* stream);
+int jh_plan_merge(const float* recs, int G, int K, int nu, int mode, float lambda, int k, int tie_high, int E, int row_floats, float* out, void* out_host_mark,
+                  void* timing_done, void* stream);
 /* `timing`: NULL, or three events of jh_event_create recorded on `stream` before the rollout kernel, between it and the update, and behind the update
  * (what bench.py's roofline leg reads: jh_event_elapsed_ms waits for its second event). */
 int jh_event_create(void** out);

@@ -63,6 +63,13 @@ _SIGNATURES = {
                                   f32p, f32p, f32p, f32p, C.c_void_p]),
     "jh_plan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p,
                                C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jh_shard_record_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "jh_update_shard": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int,
+                                  f32p, f32p, C.c_void_p]),
+    "jh_shard_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_void_p]),
+    "jh_plan_step_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p,
+                                     C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_void_p]),
+    "jh_plan_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jh_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "jh_event_destroy": (None, [C.c_void_p]),
     "jh_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -59,6 +59,7 @@ class _PlanBuffers:
         self.fused_scratch = torch.zeros(int(L.jh_update_fused_scratch_floats(n_local, K, nu)), dtype=torch.float32, device=dev)  # (zero: it holds jh_update_fused's ticket counter)
         self.dev = dev
         self.size_out(2 * K * nu)
+        self.shard_rec, self.shard_all = None, None  # several ranks: this rank's record of the plan step, and the all-gathered records
         self.trace_buf = None   # (n_local * H * trace floats) when the fused kernel writes the trace sensors
         self.trace_rows = None  # elites' records [cost, index, trace row]
         self.trace_recs = [torch.full((max(trace_k, 1) * (2 + K * nu),), float("inf"), dtype=torch.float32, device=dev) for _ in range(2)]  # alternated per plan step
@@ -485,7 +486,10 @@ class Controller:
         sigma_raw = sigma_n * scale[None, :]
         fused_cost = self.uses_fused_cost
         one_call = world == 1 and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
-        self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm), upload=not one_call)
+        # several ranks, same conditions: the same shape -- launch (rollout + this rank's record) -> ONE all-gather -> merge -- instead of the chain of separate partial /
+        # gather / merge / trace-gather launches with two collectives, which remains for the cases below (plugin costs, running normaliser statistics)
+        shard_call = world > 1 and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
+        self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm), upload=not (one_call or shard_call))
         noise = self._draw_noise(shard.count, shard.offset)  # (K, nu, shard.count), possibly a view into the full draw
         self._prefetch_args = (shard.count, shard.offset)
         ldn, noise_p = int(noise.stride(1)), noise.data_ptr()
@@ -499,7 +503,7 @@ class Controller:
             knots_out = b.knots_out[:, :, : shard.count]
         state["trace_buf"] = None
         is_cem = hasattr(opt, "sigma") and isinstance(getattr(opt, "sigma"), np.ndarray)
-        if one_call:
+        if one_call or shard_call:
             # ---- one GPU, shipped cost: the whole iteration is ONE library call (jh_plan_step: upload, rollout + cost kernel, one-launch update with the trace elites'
             # records, results written straight into the pinned host block) and one wait
             nfl = self._fused_trace_floats()
@@ -518,11 +522,30 @@ class Controller:
                 self.kernel_events.append((evs[0], evs[1]))
                 self.exchange_events.append((evs[1], evs[2]))
             off = np.cumsum([0] + b.sizes)
-            st = lib.jh_plan_step(self.model.handle, b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W), int(task.phase),
-                                  shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el, tie, E_t, row,
-                                  int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.out_host_ptr, timing, stream)
+            if one_call:
+                st = lib.jh_plan_step(self.model.handle, b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W), int(task.phase),
+                                      shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el, tie, E_t, row,
+                                      int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.out_host_ptr, timing, stream)
+                what = "jh_plan_step"
+            else:
+                # ---- several ranks: launch (rollout + cost + this rank's record [update record | E trace records]) -> one all-gather -> merge on every rank into
+                # the same pinned output block; everything behind this branch is the one-GPU code
+                L = int(lib.jh_shard_record_floats(K, nu, mode, k_el, E_t, row))
+                if b.shard_rec is None or b.shard_rec.numel() != L:
+                    b.shard_rec = torch.empty(L, dtype=torch.float32, device=self.device)
+                st = lib.jh_plan_step_shard(self.model.handle, b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W),
+                                            int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el,
+                                            tie, E_t, row, int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), _lib.ptr(b.shard_rec), timing, stream)
+                _lib.check(st, "jh_plan_step_shard")
+                b.shard_all = all_gather_records(b.shard_rec, self.group)  # (world * L,), rank-major; kept alive until the merge has run
+                done = None
+                if self.record_kernel_events:
+                    done = self._timing_event()
+                    self.exchange_events[-1] = (evs[1], done)  # exchange = this rank's record + the all-gather + the merge
+                st = lib.jh_plan_merge(_lib.ptr(b.shard_all), world, K, nu, mode, lam, k_el, tie, E_t, row, b.out_host_ptr, b.out_host_ptr, done.handle if done is not None else None, stream)
+                what = "jh_plan_merge"
             try:
-                _lib.check(st, "jh_plan_step")
+                _lib.check(st, what)
                 if self._prefetch_args is not None:
                     self._prefetch_noise(*self._prefetch_args)
             finally:

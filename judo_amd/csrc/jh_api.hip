@@ -284,6 +284,36 @@ extern "C" int jh_plan_step(const jh_model* m, void* blk_dev, const void* blk_ho
   return rc;
 }
 
+// The same iteration when the rollouts are sharded over G ranks: launch -> all-gather -> merge.  jh_plan_step_shard is jh_plan_step with the update's
+// last stage left out: the tail launch writes this rank's RECORD (jh_update_shard) instead of the nominal; the caller all-gathers the G records (RCCL: one collective
+// of <= a few KB) and hands them to jh_plan_merge, which finishes the update on every rank (jh_shard_merge: identical nominal everywhere, no broadcast) into the same
+// output block jh_plan_step fills and sets the same completion mark.
+extern "C" int jh_plan_step_shard(const jh_model* m, void* blk_dev, const void* blk_host, size_t blk_bytes, int o_nominal, int o_sigma, int o_tp, int o_lohi, const float* noise,
+                                  int ldn, const float* W, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, int mode, float lambda, int k,
+                                  int tie_high, int E, int row_floats, int colmajor, float* scratch, float* rec_out, void* const* timing /* 3 events, or NULL */, void* stream) {
+  JH_REQUIRE(m && blk_dev && blk_host && rec_out && scratch, "plan_step_shard: null pointer");
+  const float* b = (const float*)blk_dev;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = jh_upload_async(blk_dev, blk_host, blk_bytes, stream);
+  if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[0], st));
+  if (rc == JH_OK) rc = jh_rollout_cost_traced(m, b, b + o_nominal, noise, ldn, b + o_sigma, W, b + o_lohi, b + o_tp, phase, N, n_offset, H, K, costs, knots_out, trace, stream);
+  if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[1], st));
+  if (rc == JH_OK) rc = jh_update_shard(costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace, row_floats,
+                                        colmajor, scratch, rec_out, stream);
+  if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[2], st));
+  return rc;
+}
+
+extern "C" int jh_plan_merge(const float* recs, int G, int K, int nu, int mode, float lambda, int k, int tie_high, int E, int row_floats, float* out, void* out_host_mark,
+                             void* timing_done /* event of jh_event_create recorded behind the merge, or NULL */, void* stream) {
+  JH_REQUIRE(recs && out, "plan_merge: null pointer");
+  const int KU = K * nu;
+  int rc = jh_shard_merge(recs, G, K, nu, mode, lambda, k, tie_high, E, row_floats, out, out + KU, E > 0 ? out + 2 * KU : nullptr, stream);
+  if (rc == JH_OK && timing_done) JH_HIP(hipEventRecord((hipEvent_t)timing_done, (hipStream_t)stream));
+  if (rc == JH_OK) rc = jh_download_begin(out_host_mark, out, 0, stream);
+  return rc;
+}
+
 // Timing events for callers that bracket kernels on the launch stream without torch (bench.py's roofline leg: the rollout kernel's duration inside a jh_plan_step call)
 extern "C" int jh_event_create(void** out) { JH_REQUIRE(out, "event_create: null pointer"); hipEvent_t e; JH_HIP(hipEventCreate(&e)); *out = e; return JH_OK; }
 extern "C" void jh_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }

@@ -14,6 +14,7 @@
 //     whole by every lane; the Schur-complement dot products are shared the same way.
 // The solver itself (primal Newton, exact line search, warm start, termination) is unchanged: results agree with jh_engine_v2.hip to
 // summation order, and the parity suite (tests/test_gpu_leap.py) runs against both.
+#include <cstddef>
 #include <type_traits>
 
 #include "jh_coop.h"
@@ -63,6 +64,14 @@ constexpr int NCH = 4, NLK = 4;
                          // its wave-mates: tests/test_gpu_leap.py permutes them): with -ffp-contract=fast they do not -- the backend fuses a product into an add only when the
                          // product has no other use, and the hand paths are such uses -- so this file is built with -ffp-contract=on (fusion within a source expression only:
                          // +0.7 % on its own, jh_engine_v5.flags).
+#endif
+#ifndef JH_V5_C3CACHE
+#define JH_V5_C3CACHE 1  // (round 5; recorded inputs 59.3 -> 58.3 ms, the same iterates bit for bit; profiles/r05_leap_experiments.txt)  1: the joint columns axis_j x (pos - anchor_j) of the FIRST slot's side-B link (12 floats per lane, invariant over the Newton iterations of a step) are computed
+                         // once per step and kept in the part of the contact pool's storage the Newton matrices leave free (768 of 820 bytes), three ds_read_b128 per use instead of
+                         // 24 loads + 36 multiply-adds, twice per iteration
+#endif
+#ifndef JH_V5_C3PAD
+#define JH_V5_C3PAD 278
 #endif
 #ifndef JH_V5_LSRCP
 #define JH_V5_LSRCP 1  // the line search's Newton step divides with v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence (10 instructions per evaluation): -0.2 %
@@ -183,6 +192,9 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
     struct { float Hcc[21], Hbb[NCH][10], Hcb[NCH][24], Hx[RS_NHX][16]; };  // Hcb[c][j*6+q]: chain column j, cube row q; Hx[pidx(a,b)][ib*4+ia]: block (chain b, chain a)
                                                                          // of a contact-coupled pair of chains a < b (hand self-collision)
     struct { float Hd[RS_NDH], dinv[NV]; };                    // dense path (contacts between two finger chains): packed lower 22 x 22, reciprocal pivots
+#if JH_V5_C3CACHE
+    struct { float c3pad_[JH_V5_C3PAD]; float c3s[G][12]; };   // behind the Newton matrices (275 floats at most): the first slot's joint columns, per lane; 16-byte aligned rows (static_assert below)
+#endif
   };
   int ncon, nhit;
 #if JH_V5_RSPAD > 0
@@ -190,6 +202,9 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
 #endif
 };
 
+#if JH_V5_C3CACHE
+static_assert(offsetof(RS, c3s) % 16 == 0 && JH_V5_C3PAD >= RS_NDH + NV && sizeof(((RS*)nullptr)->c3pad_) + sizeof(((RS*)nullptr)->c3s) <= sizeof(((RS*)nullptr)->pool), "c3 cache: aligned rows behind the Newton matrices, inside the pool's storage");
+#endif
 struct PoolCtx { RS* S; int* overflow; float* ovf; };  // ovf: this rollout's row of the global overflow pool (NOVF x POOL_F floats), or null
 
 __device__ __forceinline__ void push_contact(const PoolCtx& pc, const float* pos, const float* n, float dist, int body, float mu, float tran) {
@@ -255,10 +270,15 @@ __device__ __forceinline__ void link_c3(const RS& S, int ch, const float* pos, f
   }
 }
 // velocity of the point `pos` carried by finger link `code` for the joint-rate vector `vec` (22-vector in LDS), times `sign`, added to w
-__device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos, const float* vec, float sign, float* w) {
+// (c3c: the lane's cached columns of this link and point, JH_V5_C3CACHE, or null)
+__device__ __forceinline__ void load_c3(const float* c3c, float (*c3)[3]) {
+  const float4 a = *reinterpret_cast<const float4*>(c3c), b = *reinterpret_cast<const float4*>(c3c + 4), c = *reinterpret_cast<const float4*>(c3c + 8);
+  c3[0][0] = a.x; c3[0][1] = a.y; c3[0][2] = a.z; c3[1][0] = a.w; c3[1][1] = b.x; c3[1][2] = b.y; c3[2][0] = b.z; c3[2][1] = b.w; c3[2][2] = c.x; c3[3][0] = c.y; c3[3][1] = c.z; c3[3][2] = c.w;
+}
+__device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos, const float* vec, float sign, float* w, const float* c3c = nullptr) {
   const int ch = (code - 1) >> 2, dep = (code - 1) & 3;
 #if JH_V5_LINKBATCH
-  float c3[NLK][3]; link_c3(S, ch, pos, c3);
+  float c3[NLK][3]; if (c3c) load_c3(c3c, c3); else link_c3(S, ch, pos, c3);
 #pragma unroll
   for (int j = 0; j < NLK; j++) {
     const float xj = j <= dep ? sign * vec[6 + 4 * ch + j] : 0.f;
@@ -319,12 +339,12 @@ __device__ __forceinline__ void link_cols(const RS& S, int code, const float* po
 // contact-frame image of the relative point velocity (side B minus side A) for the generalised velocity whose cube part is (xl = linear, world;
 // wang = R_cube * angular part, world) and whose finger part is `vec` (22-vector in LDS)
 template <bool SELF>
-__device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float* qcpos, const float* xl, const float* wang, const float* vec, float* out) {
+__device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float* qcpos, const float* xl, const float* wang, const float* vec, float* out, const float* c3c = nullptr) {
   float w[3] = {0.f, 0.f, 0.f};
   const float pos[3] = {s.rc[0] + qcpos[0], s.rc[1] + qcpos[1], s.rc[2] + qcpos[2]};
   if (!SELF || s.la == CUBE) { float wx[3]; cross3(wx, wang, s.rc); w[0] = -(xl[0] + wx[0]); w[1] = -(xl[1] + wx[1]); w[2] = -(xl[2] + wx[2]); }
   else if (SELF && s.la > 0) link_vel(S, s.la, pos, vec, -1.f, w);
-  if (s.lb > 0) link_vel(S, s.lb, pos, vec, 1.f, w);
+  if (s.lb > 0) link_vel(S, s.lb, pos, vec, 1.f, w, c3c);
   out[0] = dot3(s.fr, w); out[1] = dot3(s.fr + 3, w); out[2] = dot3(s.fr + 6, w);
 }
 
@@ -607,6 +627,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       }
       // fused mode with a trace buffer (jh_rollout_cost_traced): the five trace sites of this forward pass -- what the materialise mode writes as sensors 16..30 --
       // for EVERY rollout: 60 B per rollout-step, 250 MB per plan step of the headline workload, and `Controller.traces` becomes a gather instead of a re-rollout
+#ifndef JH_V5_X_NOTRACE  // (A/B probe, profiles/r05_trace_ab.txt: the kernel without its trace rows -- what re-rolling the E <= 5 elites instead would save in this launch)
       if (!MATERIALIZE && trace && nsI == NS) {
         WSYNC();
         if (live && l < nsiteI && l < 5) {
@@ -615,6 +636,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           for (int k = 0; k < 3; k++) tr[k] = p3[k] + S.pa[b][k];
         }
       }
+#endif
       // sensors of this forward pass (materialise mode): 16 joint positions, then 5 site positions
       if (MATERIALIZE && sensors) {
         float* y = sensors + ((size_t)nc * H + hh) * nsI;
@@ -929,6 +951,18 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
       }
     }
+#if JH_V5_C3CACHE
+    // (every lane has loaded its slots: the pool's storage is free from here on -- a wave's LDS instructions execute in order)
+    if (sl[0].la >= 0 && sl[0].lb > 0) {
+      const float pos0[3] = {sl[0].rc[0] + qc[0], sl[0].rc[1] + qc[1], sl[0].rc[2] + qc[2]};
+      float c3[NLK][3]; link_c3(S, (sl[0].lb - 1) >> 2, pos0, c3);
+      float4* o = reinterpret_cast<float4*>(S.c3s[l]);
+      o[0] = make_float4(c3[0][0], c3[0][1], c3[0][2], c3[1][0]); o[1] = make_float4(c3[1][1], c3[1][2], c3[2][0], c3[2][1]); o[2] = make_float4(c3[2][2], c3[3][0], c3[3][1], c3[3][2]);
+    }
+#define V5_C3C(k) ((k) == 0 ? (const float*)S.c3s[l] : (const float*)nullptr)
+#else
+#define V5_C3C(k) ((const float*)nullptr)
+#endif
     DofRows dr;
     dr.fl = lc[LC_FL]; dr.fD = lc[LC_FD]; dr.fR = dr.fD > 0.f ? 1.f / dr.fD : 0.f; dr.faref = -lc[LC_FB] * qd; dr.lims = 0.f; dr.laref = 0.f; dr.lD = 0.f; dr.jf = dr.jl = dr.pf = dr.pl = 0.f;
     if (lc[LC_LIMITED] != 0.f) {
@@ -980,7 +1014,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         float cs = 0.f, jx[3], jar_ws[NS][3];
 #pragma unroll
         for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
-          slot_Jx<HC>(sl[k], S, qc, xl, wa, S.ws, jx);
+          slot_Jx<HC>(sl[k], S, qc, xl, wa, S.ws, jx, V5_C3C(k));
           for (int rw = 0; rw < 3; rw++) { sl[k].jar[rw] = jx[rw] - sl[k].aref[rw]; jar_ws[k][rw] = sl[k].jar[rw]; }
           cs += cone_cost(sl[k]);
         }
@@ -999,7 +1033,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         cs = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
-          slot_Jx<HC>(sl[k], S, qc, xl0, wa, S.p, jx);
+          slot_Jx<HC>(sl[k], S, qc, xl0, wa, S.p, jx, V5_C3C(k));
           for (int rw = 0; rw < 3; rw++) sl[k].jar[rw] = jx[rw] - sl[k].aref[rw];
           cs += cone_cost(sl[k]);
         }
@@ -1116,7 +1150,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
               const bool linkA = HC && !cube && t.la > 0;
               const int cha = linkA ? (t.la - 1) >> 2 : 0, depa = linkA ? (t.la - 1) & 3 : -1;
               const bool same = linkA && cha == ch;
-              float cb[NLK][3]; link_c3(S, ch, pos, cb);
+              float cb[NLK][3]; if (V5_C3C(k)) load_c3(V5_C3C(k), cb); else link_c3(S, ch, pos, cb);
 #pragma unroll
               for (int j = 0; j < NLK; j++) {
                 const float fj = dot3(cb[j], Fw);
@@ -1459,7 +1493,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         {
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
 #pragma unroll
-          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<HC>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp);
+          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<HC>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp, V5_C3C(k));
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
 #if JH_V5_LSKINK

@@ -114,9 +114,11 @@ __global__ __launch_bounds__(kUB) void k_mppi_block(const float* __restrict__ co
 }
 
 // merge nrec records [beta, S, V...] -> one record, or (finalize) the nominal knots V/S
-__device__ __forceinline__ void mppi_merge_body(const float* __restrict__ recs, int nrec, int KU, float inv_lambda, int finalize, float* __restrict__ out, float* sred, float& sS) {
+// (`stride`: floats from one record to the next -- 2 + KU for packed records, the length of a rank's whole record when the update record is followed by the trace records)
+__device__ __forceinline__ void mppi_merge_body(const float* __restrict__ recs, int nrec, int KU, float inv_lambda, int finalize, float* __restrict__ out, float* sred, float& sS,
+                                                int stride = 0) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int stride = 2 + KU;
+  if (stride == 0) stride = 2 + KU;
   float m = INFINITY;
   for (int r = tid; r < nrec; r += kUB) m = fminf(m, recs[(size_t)r * stride]);
   m = wave_min(m);
@@ -220,14 +222,17 @@ __global__ __launch_bounds__(kUB) void k_topk_select(const float* __restrict__ c
 }
 
 // one workgroup: G*k records -> k elites -> mean / clipped population std
+// (`per_rank`, `rank_stride`: record r sits at (r / per_rank) * rank_stride + (r % per_rank) * (2 + KU) -- the all-gathered per-rank records of the sharded plan step, where a
+// rank's elite records are followed by its trace records; per_rank = 0: packed, r * (2 + KU))
 __device__ __forceinline__ void elite_merge_body(const float* __restrict__ recs, int nrec, int k, int KU, int tie_high, float smin, float smax, float* __restrict__ nominal_out,
-                                                 float* __restrict__ sigma_out, int* chosen) {
+                                                 float* __restrict__ sigma_out, int* chosen, int per_rank = 0, int rank_stride = 0) {
   const int tid = threadIdx.x, stride = 2 + KU;
+  auto at = [&](int r) -> size_t { return per_rank > 0 ? (size_t)(r / per_rank) * rank_stride + (size_t)(r % per_rank) * stride : (size_t)r * stride; };
   if (tid == 0) {
     for (int e = 0; e < k; e++) {
       int bi = -1; Cand best{INFINITY, -1};
       for (int r = 0; r < nrec; r++) {
-        Cand c{recs[(size_t)r * stride], __float_as_int(recs[(size_t)r * stride + 1])};
+        Cand c{recs[at(r)], __float_as_int(recs[at(r) + 1])};
         bool taken = false;
         for (int q = 0; q < e; q++) taken |= (chosen[q] == r);
         if (!taken && c.i >= 0 && (bi < 0 || better(c, best, tie_high))) { best = c; bi = r; }
@@ -238,10 +243,10 @@ __device__ __forceinline__ void elite_merge_body(const float* __restrict__ recs,
   __syncthreads();
   for (int idx = tid; idx < KU; idx += kUB) {
     float mean = 0.f; int cnt = 0;
-    for (int e = 0; e < k; e++) if (chosen[e] >= 0) { mean += recs[(size_t)chosen[e] * stride + 2 + idx]; cnt++; }
+    for (int e = 0; e < k; e++) if (chosen[e] >= 0) { mean += recs[at(chosen[e]) + 2 + idx]; cnt++; }
     mean /= (float)(cnt > 0 ? cnt : 1);
     float var = 0.f;
-    for (int e = 0; e < k; e++) if (chosen[e] >= 0) { float d = recs[(size_t)chosen[e] * stride + 2 + idx] - mean; var += d * d; }
+    for (int e = 0; e < k; e++) if (chosen[e] >= 0) { float d = recs[at(chosen[e]) + 2 + idx] - mean; var += d * d; }
     var /= (float)(cnt > 0 ? cnt : 1);
     nominal_out[idx] = mean;
     if (sigma_out) sigma_out[idx] = jh_clampf(sqrtf(var), smin, smax);
@@ -268,6 +273,8 @@ struct TailArgs {
   const float* trace; int row, colmajor;  // trace buffer of the fused rollout kernel
   float* scratch;      // ticket counter (4 floats) | nb * (2 + KU) | nb * k * 2 | nb * E * 2 | k * (2 + KU)
   float* nominal_out; float* sigma_out; float* trace_out;  // trace_out: E x (2 + row)
+  float* rec_out;      // non-null: the SHARD form -- instead of nominal / sigma the last workgroup writes this rank's record for the all-gather (jh_update_shard):
+                       // MPPI [beta, S, V(KU)] or k x [cost, index, knots(KU)], then the E trace records; jh_shard_merge finishes the update on every rank
 };
 __global__ __launch_bounds__(kUB) void k_update_tail(TailArgs a) {
   __shared__ float sred[4];
@@ -293,7 +300,10 @@ __global__ __launch_bounds__(kUB) void k_update_tail(TailArgs a) {
   if (!s_last) return;
   __threadfence();
   if (tid == 0) *counter = 0u;  // (the next launch on this stream finds it reset)
-  if (a.mode == 0) mppi_merge_body(s_mppi, nb, KU, a.inv_lambda, 1, a.nominal_out, sred, sS);
+  if (a.rec_out) {  // shard form: the record itself (what jh_mppi_partial / jh_topk_partial write), merged across the ranks by jh_shard_merge
+    if (a.mode == 0) mppi_merge_body(s_mppi, nb, KU, a.inv_lambda, 0, a.rec_out, sred, sS);
+    else { topk_choose(s_topA, nb * a.k, a.k, a.tie_high, cred, chosen); topk_records(chosen, a.k, a.src, a.n_offset, a.rec_out); }
+  } else if (a.mode == 0) mppi_merge_body(s_mppi, nb, KU, a.inv_lambda, 1, a.nominal_out, sred, sS);
   else {
     topk_choose(s_topA, nb * a.k, a.k, a.tie_high, cred, chosen);
     topk_records(chosen, a.k, a.src, a.n_offset, s_rec);
@@ -497,9 +507,89 @@ extern "C" int jh_update_fused(const float* costs, const float* knots_nku, const
   TailArgs a;
   a.costs = costs; a.src = KnotSrc{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu}; a.N = N; a.n_offset = n_offset;
   a.mode = mode; a.inv_lambda = mode == 0 ? 1.f / lambda : 0.f; a.k = mode == 1 ? k : 0; a.tie_high = tie_high; a.E = E;
-  a.trace = trace; a.row = row_floats; a.colmajor = colmajor; a.scratch = scratch; a.nominal_out = nominal_out; a.sigma_out = sigma_out; a.trace_out = trace_out;
+  a.trace = trace; a.row = row_floats; a.colmajor = colmajor; a.scratch = scratch; a.nominal_out = nominal_out; a.sigma_out = sigma_out; a.trace_out = trace_out; a.rec_out = nullptr;
   const int nb = (N + kUB - 1) / kUB;
   hipLaunchKernelGGL(k_update_tail, dim3(nb), dim3(kUB), 0, (hipStream_t)stream, a);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the sharded plan step: launch -> all-gather -> merge
+// A rank's record (jh_update_shard, written by the last workgroup of k_update_tail): [update record | E trace records].  After ONE all-gather every rank runs
+// k_shard_merge on the G records: the update (log-sum-exp merge / global elites) and the E best of the G * E trace records, into the same output block the one-GPU
+// tail writes -- nominal | sigma | E x [cost, index, trace row] -- so that what follows on the host is the same code for one rank and for eight.
+namespace {
+__global__ __launch_bounds__(kUB) void k_shard_merge(const float* __restrict__ recs, int G, int L, int mode, int KU, float inv_lambda, int k, int tie_high, int E, int row,
+                                                     float* __restrict__ nominal_out, float* __restrict__ sigma_out, float* __restrict__ trace_out) {
+  __shared__ float sred[4];
+  __shared__ float sS;
+  __shared__ int ichosen[JH_MAX_ELITES];
+  __shared__ Cand cred[4];
+  __shared__ Cand chosen[JH_MAX_ELITES];
+  __shared__ float spair[2 * 64 * JH_MAX_ELITES];  // (cost, index) of the G * E trace candidates (G <= 64)
+  const int tid = threadIdx.x;
+  const int urec = mode == 0 ? 2 + KU : k * (2 + KU);
+  if (mode == 0) mppi_merge_body(recs, G, KU, inv_lambda, 1, nominal_out, sred, sS, L);
+  else elite_merge_body(recs, G * k, k, KU, tie_high, 0.f, INFINITY, nominal_out, sigma_out, ichosen, k, L);
+  if (E <= 0) return;
+  __syncthreads();
+  for (int r = tid; r < G * E; r += kUB) {
+    const float* t = recs + (size_t)(r / E) * L + urec + (size_t)(r % E) * (2 + row);
+    spair[2 * r] = t[0]; spair[2 * r + 1] = t[1];
+  }
+  __syncthreads();
+  topk_choose(spair, G * E, E, 1, cred, chosen);
+  for (int e = 0; e < E; e++) {
+    float* o = trace_out + (size_t)e * (2 + row);
+    const int gi = chosen[e].i;
+    int src = -1;
+    for (int r = 0; r < G * E; r++) if (gi >= 0 && __float_as_int(spair[2 * r + 1]) == gi) { src = r; break; }  // (global rollout indices are unique)
+    const bool ok = src >= 0 && chosen[e].c < 3.0e38f;
+    const float* t = ok ? recs + (size_t)(src / E) * L + urec + (size_t)(src % E) * (2 + row) : nullptr;
+    if (tid == 0) { o[0] = ok ? chosen[e].c : __int_as_float(0x7f800000); o[1] = __int_as_float(ok ? gi : -1); }
+    for (int i = tid; i < row; i += kUB) o[2 + i] = ok ? t[2 + i] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" size_t jh_shard_record_floats(int K, int nu, int mode, int k, int E, int row_floats) {
+  const size_t KU = (size_t)K * nu;
+  return (mode == 0 ? 2 + KU : (size_t)k * (2 + KU)) + (size_t)E * (2 + (size_t)row_floats);
+}
+
+extern "C" int jh_update_shard(const float* costs, const float* knots_nku, const float* nominal, const float* noise, int ldn, const float* sigma, const float* lohi, int N,
+                               int n_offset, int K, int nu, int mode, float lambda, int k, int tie_high, int E, const float* trace, int row_floats, int colmajor,
+                               float* scratch, float* rec_out, void* stream) {
+  if (int e = check_dims(N, K, nu)) return e;
+  JH_REQUIRE(costs && scratch && rec_out, "update_shard: null pointer");
+  JH_REQUIRE(knots_nku || (nominal && noise && sigma), "update_shard: need either knots_nku or nominal+noise+sigma");
+  JH_REQUIRE(knots_nku || ldn >= N, "update_shard: ldn (%d) < N (%d)", ldn, N);
+  JH_REQUIRE(mode == 0 || mode == 1, "update_shard: mode must be 0 (MPPI) or 1 (elites)");
+  JH_REQUIRE(mode != 0 || lambda > 0.f, "update_shard: temperature must be positive");
+  JH_REQUIRE(mode != 1 || (k >= 1 && k <= JH_MAX_ELITES), "update_shard: k = %d outside [1, %d]", k, JH_MAX_ELITES);
+  JH_REQUIRE(E >= 0 && E <= JH_MAX_ELITES && (E == 0 || (trace && row_floats >= 1)), "update_shard: bad trace arguments (E=%d)", E);
+  TailArgs a;
+  a.costs = costs; a.src = KnotSrc{knots_nku, nominal, noise, sigma, lohi, ldn, n_offset, K * nu, nu}; a.N = N; a.n_offset = n_offset;
+  a.mode = mode; a.inv_lambda = mode == 0 ? 1.f / lambda : 0.f; a.k = mode == 1 ? k : 0; a.tie_high = tie_high; a.E = E;
+  a.trace = trace; a.row = row_floats; a.colmajor = colmajor; a.scratch = scratch; a.nominal_out = nullptr; a.sigma_out = nullptr;
+  a.rec_out = rec_out; a.trace_out = rec_out + (mode == 0 ? 2 + K * nu : k * (2 + K * nu));
+  const int nb = (N + kUB - 1) / kUB;
+  hipLaunchKernelGGL(k_update_tail, dim3(nb), dim3(kUB), 0, (hipStream_t)stream, a);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
+extern "C" int jh_shard_merge(const float* recs, int G, int K, int nu, int mode, float lambda, int k, int tie_high, int E, int row_floats, float* nominal_out,
+                              float* sigma_out, float* trace_out, void* stream) {
+  if (int e = check_dims(1, K, nu)) return e;
+  JH_REQUIRE(recs && nominal_out && G >= 1 && G <= 64, "shard_merge: bad arguments (G=%d)", G);
+  JH_REQUIRE(mode == 0 || mode == 1, "shard_merge: mode must be 0 (MPPI) or 1 (elites)");
+  JH_REQUIRE(mode != 0 || lambda > 0.f, "shard_merge: temperature must be positive");
+  JH_REQUIRE(mode != 1 || (k >= 1 && k <= JH_MAX_ELITES), "shard_merge: k = %d outside [1, %d]", k, JH_MAX_ELITES);
+  JH_REQUIRE(E >= 0 && E <= JH_MAX_ELITES && (E == 0 || (trace_out && row_floats >= 1)), "shard_merge: bad trace arguments (E=%d)", E);
+  const int L = (int)jh_shard_record_floats(K, nu, mode, k, E, row_floats);
+  hipLaunchKernelGGL(k_shard_merge, dim3(1), dim3(kUB), 0, (hipStream_t)stream, recs, G, L, mode, K * nu, mode == 0 ? 1.f / lambda : 0.f, mode == 1 ? k : 0, tie_high, E, row_floats,
+                     nominal_out, sigma_out, trace_out);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }

@@ -1,7 +1,9 @@
 """world_size = 2 over gloo on CPU: the sharding arithmetic, the single all-gather of the per-rank record and the
 merge math of the multi-GPU plan step (judo_amd/distributed.py).  There is no GPU here, so the shard-local records the
 kernels would produce are computed by the oracle; what is under test is the product's exchange path and the
-log-sum-exp merge that `jh_mppi_merge` / `jh_elite_merge` implement on the device."""
+log-sum-exp merge that `jh_shard_merge` implements on the device.  The device merge itself is exercised through the C ABI by the GPU twins of this test:
+tests/test_gpu_dist.py::test_shard_records_through_the_c_abi_merge_match_the_one_gpu_update (G records of jh_update_shard -> jh_shard_merge, against jh_update_fused and the
+oracle) and ::test_two_ranks_reproduce_the_single_process_plan_step (two processes, the product's launch -> all-gather -> merge path end to end)."""
 
 import os
 

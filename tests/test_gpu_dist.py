@@ -86,7 +86,7 @@ def test_two_ranks_reproduce_the_single_process_plan_step(gpu, tmp_path):
         np.testing.assert_array_equal(r0["tr"], tr1)
         assert tr1.shape[0] > 0 or task.startswith("caltech")
         # vs one process only the reduction is regrouped (two block records instead of one): fp32 summation order in the MPPI average
-        np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=5e-6 if opt == "mppi" else 0)
+        np.testing.assert_allclose(r0["nom"], nom1, rtol=0, atol=1.5e-6 if opt == "mppi" else 0)  # observed 2.4e-7
         np.testing.assert_allclose(r0["sig"], sig1, rtol=1e-6, atol=1e-7)
 
 
@@ -112,3 +112,72 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
     assert lines[2]["n_gpus"] == 2 and lines[1]["n_gpus"] == 1 and lines[2]["steps"] == 3 and lines[2]["value"] > 0
     assert lines[2]["config"]["parallelism"] == "rollout-shard x2" and lines[2]["config"]["rollouts"] == 1024
     assert "cpu_baseline" not in lines[2] and "roofline" in lines[2]
+
+
+@pytest.mark.parametrize("mode,N,G,k,E", [(0, 1000, 3, 0, 2), (1, 1000, 3, 3, 2), (1, 257, 8, 1, 1), (0, 8192, 8, 0, 5), (1, 7, 3, 3, 5)])
+def test_shard_records_through_the_c_abi_merge_match_the_one_gpu_update(gpu, mode, N, G, k, E):
+    """The sharded plan step's update through the C ABI, in one process: jh_update_shard on G contiguous shards of the same costs / noise writes G records, their
+    concatenation (what the all-gather delivers, rank-major) goes through jh_shard_merge -- and must give what jh_update_fused gives on the unsharded arrays and what
+    the oracle's update gives: elites, sigma and trace records bit for bit (selection and copies), the MPPI average to fp32 summation order."""
+    import torch
+
+    from judo_amd import _lib
+    from judo_amd.distributed import shard_rollouts
+    from oracle import oracle as O
+
+    L = _lib.lib()
+    K, nu, row = 4, 3, 10
+    KU = K * nu
+    rng = np.random.default_rng(100 * mode + N + G)
+    dev = gpu
+    noise = torch.from_numpy(rng.standard_normal((K, nu, N)).astype(np.float32)).to(dev)
+    nominal = torch.from_numpy(rng.standard_normal(KU).astype(np.float32)).to(dev)
+    sigma = torch.from_numpy((0.1 + rng.random(KU)).astype(np.float32)).to(dev)
+    lohi = torch.from_numpy(np.concatenate([-1.5 * np.ones(nu), 1.5 * np.ones(nu)]).astype(np.float32)).to(dev)
+    costs_np = (np.abs(rng.standard_normal(N)) * 0.01).astype(np.float32)
+    costs_np[N // 3] = costs_np[N // 2]  # a tie among the candidates
+    costs = torch.from_numpy(costs_np).to(dev)
+    trace = torch.from_numpy(rng.standard_normal((N, row)).astype(np.float32)).to(dev)  # row-major trace buffer, one row per rollout
+    lam, tie = 0.0025, 1
+    st = torch.cuda.current_stream().cuda_stream
+    # one GPU: jh_update_fused
+    scr = torch.zeros(int(L.jh_update_fused_scratch_floats(N, K, nu)), dtype=torch.float32, device=dev)
+    out1 = torch.zeros(2 * KU + E * (2 + row), dtype=torch.float32, device=dev)
+    p = out1.data_ptr()
+    _lib.check(L.jh_update_fused(costs.data_ptr(), None, nominal.data_ptr(), noise.data_ptr(), N, sigma.data_ptr(), lohi.data_ptr(), N, 0, K, nu, mode, lam, k, tie, E, trace.data_ptr(), row, 0,
+                                 scr.data_ptr(), p, p + 4 * KU, p + 8 * KU, st), "jh_update_fused")
+    # G shards -> G records -> merge
+    Lrec = int(L.jh_shard_record_floats(K, nu, mode, k, E, row))
+    recs = torch.zeros(G * Lrec, dtype=torch.float32, device=dev)
+    for g in range(G):
+        sh = shard_rollouts(N, G, g)
+        scr_g = torch.zeros(int(L.jh_update_fused_scratch_floats(sh.count, K, nu)), dtype=torch.float32, device=dev)
+        _lib.check(L.jh_update_shard(costs.data_ptr() + 4 * sh.offset, None, nominal.data_ptr(), noise.data_ptr() + 4 * sh.offset, N, sigma.data_ptr(), lohi.data_ptr(), sh.count, sh.offset,
+                                     K, nu, mode, lam, k, tie, E, trace.data_ptr() + 4 * row * sh.offset, row, 0, scr_g.data_ptr(), recs.data_ptr() + 4 * g * Lrec, st), "jh_update_shard")
+        torch.cuda.synchronize()
+    outG = torch.zeros_like(out1)
+    q = outG.data_ptr()
+    _lib.check(L.jh_shard_merge(recs.data_ptr(), G, K, nu, mode, lam, k, tie, E, row, q, q + 4 * KU, q + 8 * KU, st), "jh_shard_merge")
+    torch.cuda.synchronize()
+    a, b = out1.cpu().numpy(), outG.cpu().numpy()
+    # the candidates the kernels see: clip(nominal + sigma * noise), global sample 0 = the nominal
+    cand = np.clip(nominal.cpu().numpy()[None] + sigma.cpu().numpy()[None] * noise.cpu().numpy().reshape(KU, N).T, -1.5, 1.5).astype(np.float64)
+    cand[0] = np.clip(nominal.cpu().numpy(), -1.5, 1.5)
+    cand = cand.reshape(N, K, nu)
+    if mode == 0:
+        np.testing.assert_allclose(b[:KU], a[:KU], rtol=0, atol=6e-7)  # regrouped fp32 sums
+        np.testing.assert_allclose(b[:KU].reshape(K, nu), O.mppi_update(cand, -costs_np.astype(np.float64), lam), rtol=0, atol=1e-6)
+    else:
+        np.testing.assert_array_equal(b[: 2 * KU], a[: 2 * KU])
+        ref_nom, ref_sig, ref_idx = O.cem_update(cand, -costs_np.astype(np.float64), min(k, N), 0.0, np.inf)
+        np.testing.assert_allclose(b[:KU].reshape(K, nu), ref_nom, rtol=7e-7, atol=7e-8)
+        np.testing.assert_allclose(b[KU : 2 * KU].reshape(K, nu), ref_sig, rtol=2e-6, atol=2e-8)
+    # trace records: the E best rollouts (ties: higher index first), their rows, bit for bit -- and the right ones
+    np.testing.assert_array_equal(b[2 * KU :].view(np.int32), a[2 * KU :].view(np.int32))
+    rec = b[2 * KU :].reshape(E, 2 + row)
+    order = sorted(range(N), key=lambda i: (costs_np[i], -i))[:E]
+    for e, i in enumerate(order):
+        assert rec[e, 1:2].view(np.int32)[0] == i and rec[e, 0] == costs_np[i]
+        np.testing.assert_array_equal(rec[e, 2:], trace.cpu().numpy()[i])
+    for e in range(len(order), E):  # fewer rollouts than trace elites: empty records
+        assert rec[e, 1:2].view(np.int32)[0] == -1 and np.isinf(rec[e, 0])

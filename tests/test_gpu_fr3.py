@@ -37,7 +37,7 @@ def test_fr3_reward_kernel_matches_reference_golden(gpu):
     for ph in Phase:
         t.phase = ph
         out = t.reward(g[f"fr3_{ph.name}_states"], g[f"fr3_{ph.name}_sensors"], None)
-        np.testing.assert_allclose(out, g[f"fr3_{ph.name}_reward"], rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(out, g[f"fr3_{ph.name}_reward"], rtol=6e-7, atol=6e-7)
 
 
 @pytest.mark.parametrize("x0_kind", ["home", "grasping"])
@@ -57,11 +57,11 @@ def test_fr3_rollout_backend_matches_oracle(gpu, x0_kind):
     assert gs.shape == (N, H, 31) and gsens.shape == (N, H, 14) and np.isfinite(gs).all()
     # observed (tools/diag/fr3_parity_margins.py): first step 9e-7, all entries median 3e-9, joint / cube positions at the 40-step horizon 95th percentile 7e-7,
     # sensors median 2e-8, 99th percentile 2e-5 (the box-box distance sensors)
-    np.testing.assert_allclose(gs[:, 0], rs[:, 0], atol=2e-5)  # one step: servo gains of 4500 on fp32 positions
+    np.testing.assert_allclose(gs[:, 0], rs[:, 0], atol=6e-6)  # one step: servo gains of 4500 on fp32 positions
     e = np.abs(gs - rs)
-    assert bounded("np.median(e)", np.median(e), 2e-7) and bounded("np.percentile(e[:, -1, :16], 95)", np.percentile(e[:, -1, :16], 95), 2e-5)
+    assert bounded("np.median(e)", np.median(e), 2e-8) and bounded("np.percentile(e[:, -1, :16], 95)", np.percentile(e[:, -1, :16], 95), 5e-6)
     es = np.abs(gsens - rsens)
-    assert bounded("np.median(es)", np.median(es), 1e-6) and bounded("np.percentile(es, 99)", np.percentile(es, 99), 5e-4)
+    assert bounded("np.median(es)", np.median(es), 1.5e-7) and bounded("np.percentile(es, 99)", np.percentile(es, 99), 7e-5)
     st = be.model.stats()
     # closing the empty gripper slams the two pad stacks together: for 1-2 steps the oracle sees up to 72 contacts (36 box pairs); the kernel holds 96
     # finger-finger + 32 other contacts per rollout since round 3, so nothing is dropped any more
@@ -98,8 +98,8 @@ def test_fr3_closed_empty_gripper_keeps_every_pad_contact(gpu):
     dv = np.abs(rs[:, 0, 16 + 13 : 16 + 15] - x0[:, 16 + 13 : 16 + 15]).max(axis=1) + 1e-3
     ev = np.abs(gs[:, 0, 16 + 13 : 16 + 15] - rs[:, 0, 16 + 13 : 16 + 15]).max(axis=1) / dv
     # observed: median 4e-6 .. 2.4e-5 by contact count, max 9e-5 (the solve ends on the fp32 resolution of the finger accelerations)
-    assert bounded("np.median(ev[~deep])", np.median(ev[~deep]), 5e-5) and bounded("ev[~deep].max()", ev[~deep].max(), 5e-4), (np.median(ev[~deep]), ev[~deep].max())
-    np.testing.assert_allclose(gs[~deep, 0, :16], rs[~deep, 0, :16], atol=1e-6)
+    assert bounded("np.median(ev[~deep])", np.median(ev[~deep]), 5e-6) and bounded("ev[~deep].max()", ev[~deep].max(), 5e-4), (np.median(ev[~deep]), ev[~deep].max())
+    np.testing.assert_allclose(gs[~deep, 0, :16], rs[~deep, 0, :16], atol=7e-7)
     # Beyond 4 mm the pad boxes have been pushed THROUGH one another: contacts with opposite normals fight each other, the constraint cost at the optimum is
     # ~6e7 (5e2 just below 4 mm) and the finger accelerations of ~50 m/s^2 are the difference of row forces ~1e6.  The problem itself is ill-conditioned there:
     # the fp64 oracle's own answer moves by 1-4 m/s^2 when its inputs are merely rounded to fp32 (measured below), so that is the yardstick, not 1e-5.
@@ -127,7 +127,7 @@ def test_fr3_closed_empty_gripper_keeps_every_pad_contact(gpu):
     ok = np.arange(H)[None, :] <= first_deep[:, None]
     assert ok.sum() > 0.5 * M * H and (first_deep < H).sum() >= 4
     e = np.abs(gs2 - rs2)
-    assert bounded("np.median(e[ok])", np.median(e[ok]), 2e-7) and bounded("e[:, :, 14:16][ok].max()", e[:, :, 14:16][ok].max(), 2e-5) and bounded("np.percentile(e[:, :, 16 + 13 :][ok], 99)", np.percentile(e[:, :, 16 + 13 :][ok], 99), 5e-3), (np.median(e[ok]), e[:, :, 14:16][ok].max(), np.percentile(e[:, :, 16 + 13 :][ok], 99))
+    assert bounded("np.median(e[ok])", np.median(e[ok]), 5e-9) and bounded("e[:, :, 14:16][ok].max()", e[:, :, 14:16][ok].max(), 5e-6) and bounded("np.percentile(e[:, :, 16 + 13 :][ok], 99)", np.percentile(e[:, :, 16 + 13 :][ok], 99), 7e-5), (np.median(e[ok]), e[:, :, 14:16][ok].max(), np.percentile(e[:, :, 16 + 13 :][ok], 99))
 
 
 @pytest.mark.parametrize("phase", [0, 1, 2, 3])
@@ -163,17 +163,17 @@ def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
     assert ctrl.task.phase == phase == Phase(phase).value
     ref = oracle_plan_step(O.Model("fr3_pick"), ctrl, nominal0, noise, "cem", sigma0)
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
-    np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(cand, ref["knots"], rtol=4e-7, atol=4e-7)
     costs = -ctrl.rewards_local
     d = np.abs(costs + ref["rewards"])
-    assert bounded("np.median(d)", np.median(d), 2e-4) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 1.5e-2)  # costs are sums of O(1..40) terms of size O(1..100); observed median 2e-6..5e-5, 95th percentile 2e-3..6e-3
+    assert bounded("np.median(d)", np.median(d), 2e-4) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 0.015)  # costs are sums of O(1..40) terms of size O(1..100); observed median 2e-6..5e-5, 95th percentile 2e-3..6e-3
     exp_nom, exp_sig, _ = O.cem_update(ref["knots"], -costs.astype(np.float64), 3, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
-    np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=7e-7, atol=7e-8)
+    np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=5e-6, atol=5e-8)
     # the elite set agrees with the oracle's unless two candidates are closer in cost than the fp32 rollout error
     gap = np.sort(ref["rewards"])[::-1]
     if gap[2] - gap[3] > 5 * np.percentile(d, 99):
-        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], atol=1e-5)
+        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], atol=7e-7)
 
 
 def test_fr3_full_size_sampled_rollouts_match_oracle(gpu):
@@ -207,13 +207,13 @@ def test_fr3_full_size_sampled_rollouts_match_oracle(gpu):
     idx = np.concatenate([[0], np.sort(np.random.default_rng(6).choice(np.arange(1, N), M - 1, replace=False))])
     inj = noise[:, :, torch.as_tensor(idx[1:], device=noise.device)].permute(2, 0, 1).cpu().numpy()
     ref = oracle_plan_step(O.Model("fr3_pick"), ctrl, nominal0, inj, "cem", sigma0)
-    np.testing.assert_allclose(cand[idx], ref["knots"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(cand[idx], ref["knots"], rtol=4e-7, atol=4e-7)
     d = np.abs(costs[idx] + ref["rewards"])
     record_margin("fr3_full_size_sampled", cost_median=np.median(d), cost_p95=np.percentile(d, 95), cost_max=d.max())
-    assert bounded("np.median(d)", np.median(d), 2e-4) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 1.5e-2), (np.median(d), np.percentile(d, 95))
+    assert bounded("np.median(d)", np.median(d), 5e-5) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 0.007), (np.median(d), np.percentile(d, 95))
     exp_nom, exp_sig, _ = O.cem_update(cand, -costs, 3, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
-    np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=3e-7, atol=3e-8)
+    np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=5e-7, atol=5e-9)
     st = ctrl.solver_stats()
     assert st["contact_overflow"] < 1e-4 * st["steps"], st
 
@@ -234,8 +234,8 @@ def test_fr3_two_kernel_generations_agree(gpu):
     b1 = GpuRolloutBackend("fr3_pick", N)
     b1.model.set_kernel(1)
     s1, y1, _ = b1.rollout(x0, U)
-    np.testing.assert_allclose(s2[:, :3], s1[:, :3], atol=2e-4)
-    np.testing.assert_allclose(y2[:, :3], y1[:, :3], atol=2e-4)
+    np.testing.assert_allclose(s2[:, :3], s1[:, :3], atol=3e-6)
+    np.testing.assert_allclose(y2[:, :3], y1[:, :3], atol=4e-7)
     e = np.abs(s2 - s1)
     assert bounded("np.median(e)", np.median(e), 2e-6) and bounded("np.percentile(e[:, -1, :3], 90)", np.percentile(e[:, -1, :3], 90), 5e-3)
     # generation 2 (jh_engine_v3.hip: contact Jacobian in LDS, row-per-lane assembly, one wave per SIMD) against the default generation 3
@@ -243,7 +243,7 @@ def test_fr3_two_kernel_generations_agree(gpu):
     b3 = GpuRolloutBackend("fr3_pick", N)
     b3.model.set_kernel(2)
     s3, y3, _ = b3.rollout(x0, U)
-    np.testing.assert_allclose(s3[:, :3], s2[:, :3], atol=2e-5)
+    np.testing.assert_allclose(s3[:, :3], s2[:, :3], atol=1e-6)
     e = np.abs(s3 - s2)
     assert bounded("np.median(e)", np.median(e), 5e-7) and bounded("np.percentile(e[:, -1, :3], 90)", np.percentile(e[:, -1, :3], 90), 2e-3), (np.median(e), np.percentile(e[:, -1, :3], 90))
 
@@ -282,18 +282,18 @@ def test_fr3_arm_links_collide_with_table_and_cube(gpu):
     # one step: velocities relative to the step's own velocity scale (links dug 1-4 cm into the table are thrown out at several rad/s)
     sc = np.maximum(1.0, np.abs(rs[:, 0, 16:]).max(axis=1, keepdims=True))
     e1 = (np.abs(gs[:, 0, 16:] - rs[:, 0, 16:]) / sc).max(axis=1)
-    assert bounded("np.median(e1[ok])", np.median(e1[ok]), 2e-5) and bounded("e1[ok].max()", e1[ok].max(), 2e-3), (np.median(e1[ok]), e1[ok].max())
+    assert bounded("np.median(e1[ok])", np.median(e1[ok]), 7e-6) and bounded("e1[ok].max()", e1[ok].max(), 0.001), (np.median(e1[ok]), e1[ok].max())
     np.testing.assert_allclose(gs[ok, 0, :16], rs[ok, 0, :16], atol=2e-5)
     assert be.model.stats()["contact_overflow"] <= 64 * H * int((ncon > 90).sum() + 1)  # nothing is dropped below the capacity
     few = ok & (ncon <= 20)
     eH = np.abs(gs[few, -1, :16] - rs[few, -1, :16]).max(axis=1)
-    assert few.sum() >= 10 and bounded("np.median(eH)", np.median(eH), 1e-4) and bounded("np.percentile(eH, 75)", np.percentile(eH, 75), 5e-3), (few.sum(), np.median(eH), np.percentile(eH, 75))
+    assert few.sum() >= 10 and bounded("np.median(eH)", np.median(eH), 7e-6) and bounded("np.percentile(eH, 75)", np.percentile(eH, 75), 1.5e-5), (few.sum(), np.median(eH), np.percentile(eH, 75))
     # the generic one-lane kernel: an independent second implementation of the same pair list
     b1 = GpuRolloutBackend("fr3_pick", N)
     b1.model.set_kernel(1)
     g1, _, _ = b1.rollout(x0, U[:, :2])
     e = (np.abs(g1[:, 0, 16:] - gs[:, 0, 16:]) / sc).max(axis=1)
-    assert bounded("np.median(e[ok32])", np.median(e[ok32]), 2e-5) and bounded("e[ok32].max()", e[ok32].max(), 5e-3), (np.median(e[ok32]), e[ok32].max())
+    assert bounded("np.median(e[ok32])", np.median(e[ok32]), 5e-6) and bounded("e[ok32].max()", e[ok32].max(), 0.001), (np.median(e[ok32]), e[ok32].max())
 
 
 def test_fr3_general_contacts_beyond_the_lds_pool(gpu):
@@ -349,5 +349,5 @@ def test_fr3_general_contacts_beyond_the_lds_pool(gpu):
     sc = np.maximum(1.0, np.abs(ref[:, 0, 16:]).max(axis=1, keepdims=True))
     e = (np.abs(g[:, 0, 16:] - ref[:, 0, 16:]) / sc).max(axis=1)
     # (a gripper pressed flat onto the table with 60-90 contacts is a stiff, nearly rank-deficient solve: the worst of these states sits at 2e-3 of its velocity scale)
-    assert bounded("np.median(e)", np.median(e), 2e-5) and bounded("e.max()", e.max(), 5e-3), (np.median(e), e.max())
+    assert bounded("np.median(e)", np.median(e), 3e-6) and bounded("e.max()", e.max(), 0.005), (np.median(e), e.max())
     np.testing.assert_allclose(g[:, 0, :16], ref[:, 0, :16], atol=5e-5)

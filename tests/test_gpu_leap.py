@@ -41,8 +41,8 @@ def test_leap_reward_kernel_matches_reference_golden(gpu):
     for i in (0, 1, 2):
         out = t.reward(g[f"leap{i}_states"], None, None, {"goal_quat": g[f"leap{i}_goal_quat"]})
         # fp32 atan2 / quaternion products; antipodal & identity cases included
-        np.testing.assert_allclose(out, g[f"leap{i}_reward"], rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(t.reward(g["leap0_states"], None, None, None), g["leap_default_reward"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(out, g[f"leap{i}_reward"], rtol=6e-7, atol=6e-7)
+    np.testing.assert_allclose(t.reward(g["leap0_states"], None, None, None), g["leap_default_reward"], rtol=4e-7, atol=4e-7)
 
 
 def test_leap_single_step_matches_oracle(gpu):
@@ -59,10 +59,10 @@ def test_leap_single_step_matches_oracle(gpu):
     e = np.abs(g1[:, 0] - nxt)
     # positions move by h * velocity error; velocities carry the solver error (Newton tolerance 1e-5, fp32).  Observed (tools/diag/leap_parity_margins.py):
     # velocity median 4e-8, 99th percentile 3e-6, 99.9th 9e-6, max 1.4e-3 (one stiff contact); position max 7e-6
-    assert bounded("np.median(e[:, 23:])", np.median(e[:, 23:]), 1e-6) and bounded("np.percentile(e[:, 23:], 99)", np.percentile(e[:, 23:], 99), 1e-4) and bounded("np.percentile(e[:, 23:], 99.9)", np.percentile(e[:, 23:], 99.9), 5e-4) and bounded("e[:, 23:].max()", e[:, 23:].max(), 3e-2)
-    assert bounded("e[:, :23].max()", e[:, :23].max(), 3e-4) and bounded("np.percentile(e[:, :23], 99.9)", np.percentile(e[:, :23], 99.9), 5e-6)
+    assert bounded("np.median(e[:, 23:])", np.median(e[:, 23:]), 3e-7) and bounded("np.percentile(e[:, 23:], 99)", np.percentile(e[:, 23:], 99), 1.5e-5) and bounded("np.percentile(e[:, 23:], 99.9)", np.percentile(e[:, 23:], 99.9), 5e-5) and bounded("e[:, 23:].max()", e[:, 23:].max(), 0.007)
+    assert bounded("e[:, :23].max()", e[:, :23].max(), 3e-5) and bounded("np.percentile(e[:, :23], 99.9)", np.percentile(e[:, :23], 99.9), 5e-7)
     # sensors are those of the forward pass at the start of the step (pre-integration state)
-    np.testing.assert_allclose(s1[:, 0], rsens[:, 1:].reshape(-1, 31), atol=2e-6)
+    np.testing.assert_allclose(s1[:, 0], rsens[:, 1:].reshape(-1, 31), atol=3e-7)
     st = be.model.stats()
     assert st["contact_overflow"] == 0 and st["newton_cap_hits"] < 0.02 * st["steps"]
 
@@ -79,13 +79,13 @@ def test_leap_rollouts_and_costs_match_oracle(gpu):
     be = GpuRolloutBackend("leap_cube", N)
     gs, gsens, _ = be.rollout(x0, U)
     assert gs.shape == rs.shape and gsens.shape == rsens.shape and np.isfinite(gs).all()
-    np.testing.assert_allclose(gs[:, :5], rs[:, :5], atol=5e-5)  # cube ballistic, fingers under friction-loss rows (observed 2.4e-6)
+    np.testing.assert_allclose(gs[:, :5], rs[:, :5], atol=1.5e-5)  # cube ballistic, fingers under friction-loss rows (observed 2.4e-6)
     err = np.abs(gs - rs)
     # cube position at the horizon (64 steps of contact dynamics): observed median 6e-9, 95th percentile 9e-8
-    assert bounded("np.median(err[:, -1, :3])", np.median(err[:, -1, :3]), 1e-6) and bounded("np.percentile(err[:, -1, :3], 95)", np.percentile(err[:, -1, :3], 95), 1e-5)
+    assert bounded("np.median(err[:, -1, :3])", np.median(err[:, -1, :3]), 3e-8) and bounded("np.percentile(err[:, -1, :3], 95)", np.percentile(err[:, -1, :3], 95), 5e-7)
     cr = -O.reward_leap(rs, GOAL["goal_quat"])
     cg = -LeapCube().reward(gs, gsens, U, GOAL)
-    assert bounded("np.median(np.abs(cr - cg))", np.median(np.abs(cr - cg)), 2e-6) and bounded("np.percentile(np.abs(cr - cg), 95)", np.percentile(np.abs(cr - cg), 95), 1e-5)  # observed 7e-8 / 2.4e-7 (max 7e-4: one rollout through a stiff contact)
+    assert bounded("np.median(np.abs(cr - cg))", np.median(np.abs(cr - cg)), 5e-7) and bounded("np.percentile(np.abs(cr - cg), 95)", np.percentile(np.abs(cr - cg), 95), 1.5e-6)  # observed 7e-8 / 2.4e-7 (max 7e-4: one rollout through a stiff contact)
     rank = np.corrcoef(np.argsort(np.argsort(cr)), np.argsort(np.argsort(cg)))[0, 1]
     assert rank > 0.995
 
@@ -113,15 +113,15 @@ def test_leap_plan_step_matches_oracle(gpu):
     torch.cuda.synchronize()
     ref = oracle_plan_step(O.Model("leap_cube"), ctrl, nominal0, noise, "mppi")
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
-    np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(cand, ref["knots"], rtol=4e-7, atol=4e-7)
     costs = -ctrl.rewards_local
     d = np.abs(costs + ref["rewards"])
-    assert bounded("np.median(d)", np.median(d), 2e-6) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 1e-5)  # observed 6e-8 / 3e-7
+    assert bounded("np.median(d)", np.median(d), 5e-7) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 1.5e-6)  # observed 6e-8 / 3e-7
     # lambda = 0.0025 amplifies cost differences by 400x in the exponent: the stated tolerance on the returned nominal
     # knots (rad, range ~2.5 rad) is 2e-4 against the fp64 oracle (observed 1.1e-6), 1e-5 against an exact update on the GPU's own costs (observed 1.6e-7)
     exp = O.mppi_update(ref["knots"], -costs.astype(np.float64), 0.0025)
-    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=1e-5)
-    np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=7e-7)
+    np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=3e-6)
     ctrl.update_traces()
     E, S, H = 1, len(ctrl.trace_sensors), ctrl.num_timesteps
     assert ctrl.traces.shape == (E * S * (H - 1), 2, 3) and np.isfinite(ctrl.traces).all()
@@ -160,7 +160,7 @@ def test_leap_full_size_properties(gpu):
     ctrl2.optimizer.injected_noise = inj
     ctrl2.update_action()
     assert torch.equal(ctrl2.costs_device, c1[perm])
-    np.testing.assert_allclose(ctrl2.nominal_knots, ctrl.nominal_knots, atol=2e-5)  # same weighted average, different summation order
+    np.testing.assert_allclose(ctrl2.nominal_knots, ctrl.nominal_knots, atol=6e-7)  # same weighted average, different summation order
     # idempotence: sigma = 0 -> every rollout is the nominal rollout, the update returns the nominal
     ctrl3 = make_controller("leap_cube", "mppi")
     ctrl3.optimizer.config.num_rollouts = 4096
@@ -172,7 +172,7 @@ def test_leap_full_size_properties(gpu):
     ctrl3.update_action()
     c3 = ctrl3.costs_device
     assert torch.equal(c3, c3[0].expand_as(c3)) and float(c3[0]) == float(c1[0])
-    np.testing.assert_allclose(ctrl3.nominal_knots, nominal0, atol=1e-6)
+    np.testing.assert_allclose(ctrl3.nominal_knots, nominal0, atol=7e-7)
     st = ctrl.model.stats()
     # the 32-contact pool: on the first plan step from rest 2e-6 .. 2.2e-5 contacts per rollout-step are dropped, depending on the noise
     # stream (round 3's counter-based stream: 91 of 4.2 M); the bound is the product's own "approximate" threshold (Controller.solver_stats)
@@ -210,13 +210,13 @@ def test_leap_full_size_sampled_rollouts_match_oracle(gpu):
     idx = np.concatenate([[0], np.sort(np.random.default_rng(5).choice(np.arange(1, N), M - 1, replace=False))])
     inj = noise[:, :, torch.as_tensor(idx[1:], device=noise.device)].permute(2, 0, 1).cpu().numpy()
     ref = oracle_plan_step(O.Model("leap_cube"), ctrl, nominal0, inj, "mppi")
-    np.testing.assert_allclose(cand[idx], ref["knots"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(cand[idx], ref["knots"], rtol=3e-7, atol=3e-7)
     d = np.abs(costs[idx] + ref["rewards"])
     record_margin("leap_full_size_sampled", cost_median=np.median(d), cost_p95=np.percentile(d, 95), cost_max=d.max())
-    assert bounded("np.median(d)", np.median(d), 2e-6) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 1e-5), (np.median(d), np.percentile(d, 95))
+    assert bounded("np.median(d)", np.median(d), 5e-7) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 1.5e-6), (np.median(d), np.percentile(d, 95))
     exp = O.mppi_update(cand, -costs, 0.0025)
     record_margin("leap_full_size_sampled", nominal_vs_exact_update=np.abs(ctrl.nominal_knots - exp).max())
-    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=7e-7)
     st = ctrl.model.stats()
     assert st["contact_overflow"] < 1e-4 * st["steps"]
 
@@ -241,7 +241,7 @@ def test_leap_two_kernel_generations_agree(gpu):
     torch.cuda.synchronize()
     np.testing.assert_allclose(y2, y1, atol=5e-3)
     e = np.abs(s2 - s1)
-    assert bounded("np.median(e)", np.median(e), 1e-6) and bounded("np.percentile(e[:, -1, :3], 95)", np.percentile(e[:, -1, :3], 95), 5e-3)
+    assert bounded("np.median(e)", np.median(e), 2e-8) and bounded("np.percentile(e[:, -1, :3], 95)", np.percentile(e[:, -1, :3], 95), 5e-7)
     with pytest.raises(ValueError):
         b1.model.set_kernel(4)
 
@@ -267,8 +267,8 @@ def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):
         be.model.set_self_collision(False)
         gs, gsens, _ = be.rollout(x0, U)
         e = np.abs(gs - rs)
-        assert bounded("np.median(e)", np.median(e), 1e-5) and bounded("np.percentile(e[:, -1, :3], 95)", np.percentile(e[:, -1, :3], 95), 5e-3), gen
-        np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=1e-4)
+        assert bounded("np.median(e)", np.median(e), 5e-7) and bounded("np.percentile(e[:, -1, :3], 95)", np.percentile(e[:, -1, :3], 95), 2e-6), gen
+        np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=1e-6)
     # the default kernel with the hand's own contacts against the oracle with every pair (palm-down: the fingers close under the palm)
     oa = O.Model("leap_cube_down")
     ra, _ = oa.rollout(x0, U)
@@ -278,7 +278,7 @@ def test_leap_cube_down_variant_runs_on_the_leap_kernels(gpu):
     ga, _, _ = bea.rollout(x0, U)
     ea = np.abs(ga - ra)
     gap = np.abs(rs - ra)  # what leaving the hand's own contacts out costs on the same controls (p95 of the cube position at the horizon: 2 cm)
-    assert bounded("np.median(ea)", np.median(ea), 1e-5) and bounded("np.percentile(ea[:, -1, :3], 75)", np.percentile(ea[:, -1, :3], 75), 5e-3) and np.percentile(ea[:, -1, :3], 90) < 0.5 * np.percentile(gap[:, -1, :3], 90)
+    assert bounded("np.median(ea)", np.median(ea), 5e-7) and bounded("np.percentile(ea[:, -1, :3], 75)", np.percentile(ea[:, -1, :3], 75), 1.5e-6) and np.percentile(ea[:, -1, :3], 90) < 0.5 * np.percentile(gap[:, -1, :3], 90)
     ctrl = make_controller("leap_cube_down", "mppi")
     assert ctrl.optimizer.config.num_rollouts == 64 and ctrl.task.config.w_rot == 0.05
     ctrl.update_action()
@@ -309,13 +309,13 @@ def test_caltech_leap_cube_runs_on_the_leap_kernel(gpu):
         gs, gsens, _ = be.rollout(x0, U)
         assert gsens.shape == (N, H, 23)
         e = np.abs(gs - rs)
-        assert bounded("np.median(e)", np.median(e), 1e-5) and bounded("np.percentile(e[:, -1, :3], 90)", np.percentile(e[:, -1, :3], 90), 5e-3), (scope, np.median(e), np.percentile(e[:, -1, :3], 90))
-        np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=1e-4)  # all 23 sensor values of the first steps
+        assert bounded("np.median(e)", np.median(e), 5e-7) and bounded("np.percentile(e[:, -1, :3], 90)", np.percentile(e[:, -1, :3], 90), 1e-5), (scope, np.median(e), np.percentile(e[:, -1, :3], 90))
+        np.testing.assert_allclose(gsens[:, :4], rsens[:, :4], atol=5e-7)  # all 23 sensor values of the first steps
         es = np.abs(gsens - rsens)
-        assert bounded("np.median(es)", np.median(es), 1e-5) and bounded("np.percentile(es[:, -1, 16:19], 90)", np.percentile(es[:, -1, 16:19], 90), 5e-3)
+        assert bounded("np.median(es)", np.median(es), 2e-7) and bounded("np.percentile(es[:, -1, 16:19], 90)", np.percentile(es[:, -1, 16:19], 90), 7e-6)
         # sensor values are consistent with the states of the same forward pass: y[16:19] = cube position - grasp site, y[19:23] = cube quaternion (goal at identity)
-        np.testing.assert_allclose(gsens[:, 1:, 16:19], gs[:, :-1, 0:3] - np.array([0.11, 0.005, 0.03]), atol=2e-6)
-        np.testing.assert_allclose(gsens[:, 1:, 19:23], gs[:, :-1, 3:7], atol=2e-6)
+        np.testing.assert_allclose(gsens[:, 1:, 16:19], gs[:, :-1, 0:3] - np.array([0.11, 0.005, 0.03]), atol=4e-8)
+        np.testing.assert_allclose(gsens[:, 1:, 19:23], gs[:, :-1, 3:7], atol=3e-7)
     st = be.model.stats()
     assert st["contact_overflow"] == 0
     be.model.set_self_collision(True)

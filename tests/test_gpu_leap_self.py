@@ -109,7 +109,7 @@ def test_self_collision_single_steps_match_oracle(gpu):
         ev = e[sel][:, 23:]
         record_margin("self_collision_single_steps", path=name, n=int(sel.sum()), median=np.median(ev), p95=np.percentile(ev, 95), p99=np.percentile(ev, 99), max=ev.max())
         # observed (GPUTEST round 4, gpurun_out/test_margins.jsonl): median 1e-8 .. 4e-8, 95th percentile 1e-7 .. 4e-6, 99th 2e-7 .. 1.1e-5, max 6.5e-5 on every solver path
-        assert bounded("np.median(ev)", np.median(ev), 1e-6) and bounded("np.percentile(ev, 95)", np.percentile(ev, 95), 5e-5) and bounded("np.percentile(ev, 99)", np.percentile(ev, 99), 2e-4), (name, np.median(ev), np.percentile(ev, 95), np.percentile(ev, 99))
+        assert bounded("np.median(ev)", np.median(ev), 3e-7) and bounded("np.percentile(ev, 95)", np.percentile(ev, 95), 2e-5) and bounded("np.percentile(ev, 99)", np.percentile(ev, 99), 5e-5), (name, np.median(ev), np.percentile(ev, 95), np.percentile(ev, 99))
     # the same steps WITHOUT the hand's own contacts are far off: the cube-only model moves the fingers through each other
     oc = O.Model("leap_cube", scope="cube")
     rc, _ = oc.rollout(xs[across], us[across])
@@ -118,7 +118,7 @@ def test_self_collision_single_steps_match_oracle(gpu):
     # switching the hand's own contacts off reproduces exactly that cube-only model
     be.model.set_self_collision(False)
     g0, _, _ = be.rollout(xs[across], us[across])
-    assert bounded("np.median(np.abs(g0[:, 0] - rc[:, 0])[:, 23:] / scale[across])", np.median(np.abs(g0[:, 0] - rc[:, 0])[:, 23:] / scale[across]), 2e-5)
+    assert bounded("np.median(np.abs(g0[:, 0] - rc[:, 0])[:, 23:] / scale[across])", np.median(np.abs(g0[:, 0] - rc[:, 0])[:, 23:] / scale[across]), 5e-8)
     be.model.set_self_collision(True)
     st = be.model.stats()
     assert st["contact_overflow"] <= int((~ok).sum()) * 64
@@ -149,7 +149,7 @@ def test_self_collision_rollouts_match_oracle(gpu):
     gap = np.abs(rc - rs)[:, :, 7:23]  # what ignoring the hand's self-collision costs
     assert np.median(gap[:, -1].max(1)) > 1e-2
     assert np.median(err[:, -1].max(1)) < 0.05 * np.median(gap[:, -1].max(1))
-    assert bounded("np.percentile(err[:, -1], 90)", np.percentile(err[:, -1], 90), 5e-3)
+    assert bounded("np.percentile(err[:, -1], 90)", np.percentile(err[:, -1], 90), 1.5e-6)
 
 
 def test_caltech_self_collision_single_steps_match_oracle(gpu):
@@ -177,7 +177,7 @@ def test_caltech_self_collision_single_steps_match_oracle(gpu):
     assert np.isfinite(g1).all()
     scale = np.maximum(1.0, np.abs(nxt[:, 0, 23:]).max(axis=1, keepdims=True))
     e = (np.abs(g1[:, 0] - nxt[:, 0])[:, 23:] / scale)[ok]
-    assert bounded("np.median(e)", np.median(e), 2e-5) and bounded("np.percentile(e, 95)", np.percentile(e, 95), 2e-2), (np.median(e), np.percentile(e, 95))
+    assert bounded("np.median(e)", np.median(e), 7e-8) and bounded("np.percentile(e, 95)", np.percentile(e, 95), 3e-6), (np.median(e), np.percentile(e, 95))
 
 
 @pytest.mark.parametrize("capacity", [48, 64])
@@ -212,5 +212,5 @@ def test_random_states_with_the_cube_jammed_into_the_hand(gpu, capacity):
     ev = (np.abs(g[:, 0] - ref[:, 0])[:, 23:] / scale).max(1)
     for name, sel in (("cube only", ok & (kinds[:, 0] > 0) & (kinds[:, 1] + kinds[:, 2] == 0)), ("cube and coupled chains", ok & (kinds[:, 0] > 0) & (kinds[:, 2] > 0)),
                       ("above 32 contacts", big), ("all", ok)):
-        assert bounded("np.median(ev[sel])", np.median(ev[sel]), 5e-6) and bounded("np.percentile(ev[sel], 95)", np.percentile(ev[sel], 95), 1e-4) and bounded("ev[sel].max()", ev[sel].max(), 5e-2), (name, np.median(ev[sel]), np.percentile(ev[sel], 95), ev[sel].max())
+        assert bounded("np.median(ev[sel])", np.median(ev[sel]), 5e-6) and bounded("np.percentile(ev[sel], 95)", np.percentile(ev[sel], 95), 1e-4) and bounded("ev[sel].max()", ev[sel].max(), 0.0007), (name, np.median(ev[sel]), np.percentile(ev[sel], 95), ev[sel].max())
     assert be.model.stats()["newton_cap_hits"] == 0

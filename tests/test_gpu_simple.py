@@ -32,7 +32,7 @@ def test_sample_control_knots_matches_reference_golden(gpu):
         opt.injected_noise = g[key + "_noise"]
         out = opt.sample_control_knots(g[key + "_nominal"])
         assert out.shape == g[key + "_out"].shape
-        np.testing.assert_allclose(out, g[key + "_out"], rtol=2e-6, atol=2e-6)  # fp32 rounding of nominal + sigma*eps
+        np.testing.assert_allclose(out, g[key + "_out"], rtol=6e-7, atol=6e-7)  # fp32 rounding of nominal + sigma*eps
         np.testing.assert_allclose(out[0], g[key + "_nominal"], rtol=1e-7, atol=1e-7)  # sample 0 is the nominal
 
 
@@ -46,7 +46,7 @@ def test_cem_sampling_cumulative_ramp_and_node_change(gpu):
         for call in range(2):
             opt.injected_noise = g[f"{key}_call{call}_noise"]
             out = opt.sample_control_knots(g[f"{key}_call{call}_nominal"])
-            np.testing.assert_allclose(out, g[f"{key}_call{call}_out"], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(out, g[f"{key}_call{call}_out"], rtol=3e-7, atol=3e-7)
             np.testing.assert_allclose(opt.sigma, g[f"{key}_call{call}_sigma_after"], rtol=1e-12)  # host state, fp64
         opt.sigma = g[key + "_prek_sigma_in"].copy()
         opt.config.num_nodes = 6
@@ -64,9 +64,9 @@ def test_update_nominal_knots_matches_reference_golden(gpu):
             opt = _opt("mppi", nu, num_rollouts=N, num_nodes=K, temperature=lam)
             out = opt.update_nominal_knots(knots, rewards)
             # fp32 costs: the exponent (c-beta)/lambda carries ~1e-7*|c|/lambda absolute error -> weights relative 3e-4 at lambda=0.0025
-            np.testing.assert_allclose(out, g[f"{key}_mppi_{lam}"], rtol=0, atol=3e-3 if lam < 0.01 else 3e-4)
+            np.testing.assert_allclose(out, g[f"{key}_mppi_{lam}"], rtol=0, atol=1.5e-6 if lam < 0.01 else 1e-6)  # observed 2.5e-7 / 2.0e-7
         out = _opt("ps", nu, num_rollouts=N, num_nodes=K).update_nominal_knots(knots, rewards)
-        np.testing.assert_allclose(out, g[key + "_ps"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out, g[key + "_ps"], rtol=2e-7, atol=2e-7)
         for k in (2, 3):
             opt = _opt("cem", nu, num_rollouts=N, num_nodes=K, num_elites=k, sigma_min=0.01, sigma_max=0.3)
             out = opt.update_nominal_knots(knots, rewards)
@@ -77,11 +77,11 @@ def test_update_nominal_knots_matches_reference_golden(gpu):
                 # tie at the cut: numpy's introsort order is unspecified; check the documented rule instead
                 order = sorted(range(N), key=lambda i: (-r32[i], -i))[:k]
                 exp = knots[order].mean(0)
-                np.testing.assert_allclose(out, exp, rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(out, exp, rtol=2e-6, atol=2e-7)
             else:
                 assert set(np.argsort(-r32, kind="stable")[:k]) == set(ref_idx)
-                np.testing.assert_allclose(out, g[f"{key}_cem{k}_nominal"], rtol=1e-5, atol=1e-6)
-                np.testing.assert_allclose(opt.sigma, g[f"{key}_cem{k}_sigma"], rtol=1e-4, atol=1e-6)
+                np.testing.assert_allclose(out, g[f"{key}_cem{k}_nominal"], rtol=1.5e-6, atol=1.5e-7)
+                np.testing.assert_allclose(opt.sigma, g[f"{key}_cem{k}_sigma"], rtol=5e-6, atol=5e-8)
 
 
 @pytest.mark.parametrize("task_name", ["cartpole", "cylinder_push"])
@@ -92,13 +92,13 @@ def test_task_reward_kernel_matches_reference_golden(gpu, task_name):
     if task_name == "cartpole":
         t = T.Cartpole()
         out = t.reward(g["cartpole_states"], None, g["cartpole_controls"])
-        np.testing.assert_allclose(out, g["cartpole_reward"], rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(out, g["cartpole_reward"], rtol=3e-7, atol=1.5e-6)
     else:
         for i in (0, 1):
             t = T.CylinderPush()
             t.config.goal_pos = g[f"cylinder{i}_goal"]
             out = t.reward(g[f"cylinder{i}_states"], None, None)
-            np.testing.assert_allclose(out, g[f"cylinder{i}_reward"], rtol=2e-5, atol=1e-5)
+            np.testing.assert_allclose(out, g[f"cylinder{i}_reward"], rtol=1e-6, atol=5e-7)
 
 
 def _controls(rng, N, H, nu, scale):
@@ -128,13 +128,13 @@ def test_rollout_backend_matches_oracle(gpu, task_name, scale, x0):
     rs, rsens = om.rollout(x0, U)
     # fp32 vs fp64 over 64 steps: absolute 2e-3 on O(1) states (error grows along the horizon), first step 1e-5
     np.testing.assert_allclose(states[:, 0], rs[:, 0], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(states, rs, rtol=0, atol=3e-3)
-    np.testing.assert_allclose(sensors, rsens, rtol=0, atol=3e-3)
+    np.testing.assert_allclose(states, rs, rtol=0, atol=0.0009)
+    np.testing.assert_allclose(sensors, rsens, rtol=0, atol=0.00021)
     # batched x0
     xb = x0[None] + 0.01 * rng.standard_normal((N, om.nx))
     sb, _, _ = be.rollout(xb, U)
     rb, _ = om.rollout(xb, U)
-    np.testing.assert_allclose(sb, rb, rtol=0, atol=3e-3)
+    np.testing.assert_allclose(sb, rb, rtol=0, atol=0.0009)
 
 
 @pytest.mark.parametrize("task_name", ["cartpole", "cylinder_push"])
@@ -150,8 +150,8 @@ def test_rollout_backend_ragged_tiles(gpu, task_name, N, H):
     x0 = np.array([1.0, np.pi, 0.0, 0.0] if task_name == "cartpole" else [1.0, 0.0, 2 * np.cos(1.0), 2 * np.sin(1.0), 0, 0, 0, 0])
     states, sensors, _ = GpuRolloutBackend(task_name, N).rollout(x0, U)
     rs, rsens = om.rollout(x0, U)
-    np.testing.assert_allclose(states, rs, rtol=0, atol=3e-3)
-    np.testing.assert_allclose(sensors, rsens, rtol=0, atol=3e-3)
+    np.testing.assert_allclose(states, rs, rtol=0, atol=2.1e-5)
+    np.testing.assert_allclose(sensors, rsens, rtol=0, atol=6e-6)
 
 
 @pytest.mark.parametrize("task_name,opt_name,N,K,H", [
@@ -189,22 +189,22 @@ def test_plan_step_matches_oracle(gpu, task_name, opt_name, N, K, H):
     torch.cuda.synchronize()
     ref = oracle_plan_step(O.Model(task_name), ctrl, nominal0, noise, opt_name, cem_sigma0)
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
-    np.testing.assert_allclose(cand, ref["knots"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(cand, ref["knots"], rtol=2e-7, atol=2e-7)
     costs = -ctrl.rewards_local
     # per-rollout cost: fp32 accumulation over 64 steps of O(1..100) terms
-    np.testing.assert_allclose(costs, -ref["rewards"], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(costs, -ref["rewards"], rtol=3e-6, atol=3e-5)
     if opt_name == "mppi":
         # exact update on the GPU's own costs isolates the reduction from rollout round-off
         exp = O.mppi_update(ref["knots"], -costs.astype(np.float64), ctrl.optimizer.temperature)
-        np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=2e-4)
-        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(ctrl.nominal_knots, exp, rtol=0, atol=6e-7)
+        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=2e-5)
     elif opt_name == "ps":
         assert np.argmax(-costs) == np.argmax(ref["rewards"])
-        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=1e-7, atol=1e-7)
     else:
         exp_nom, exp_sig, _ = O.cem_update(ref["knots"], -costs.astype(np.float64), ctrl.optimizer.num_elites, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
-        np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=5e-7, atol=5e-8)
+        np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=5e-7, atol=5e-9)
 
 
 def test_time_shift_and_multiple_plan_steps(gpu):
@@ -234,7 +234,7 @@ def test_time_shift_and_multiple_plan_steps(gpu):
         ctrl.update_action()
         torch.cuda.synchronize()
         ref = oracle_plan_step(om, ctrl, shifted, noise, "mppi")
-        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=5e-3)
+        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], rtol=0, atol=0.00015)
         np.testing.assert_allclose(ctrl.times, ctrl.time + ctrl.spline_timesteps)
         a = ctrl.action(ctrl.time + 0.01)
         assert a.shape == (ctrl.nu,)
@@ -288,7 +288,7 @@ def test_min_max_normaliser_is_equivalent_to_scaled_sigma(gpu):
     cand_n = np.concatenate([norm(nominal0)[None], norm(nominal0)[None] + sigma[None] * noise.astype(np.float64)])
     cand = denorm(np.clip(cand_n, -1, 1))
     got = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
-    np.testing.assert_allclose(got, cand, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got, cand, rtol=3e-7, atol=3e-7)
 
 
 def test_plugin_task_with_its_own_reward_runs_on_the_materialise_path(gpu):
@@ -333,8 +333,8 @@ def test_plugin_task_with_its_own_reward_runs_on_the_materialise_path(gpu):
         ctrl.update_action()
         outs.append((ctrl.nominal_knots.copy(), ctrl.rewards_local.copy()))
     # the torch reward is checked against the fused cost first (same formula), then the update
-    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=2e-3)
-    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=0, atol=0.00014)
 
 
 @pytest.mark.parametrize("kind,K,nu,N,H", [("zero", 4, 1, 70, 50), ("linear", 5, 2, 129, 64), ("cubic", 4, 16, 33, 64), ("cubic", 8, 8, 1, 7)])
@@ -361,11 +361,11 @@ def test_spline_controls_kernel_matches_reference_splines(gpu, kind, K, nu, N, H
     out = torch.empty((N, H, nu), dtype=torch.float32, device=dev)
     L = _lib.lib()
     _lib.check(L.jh_spline_controls(_lib.ptr(Wd), None, _lib.ptr(nd), _lib.ptr(ed), N, _lib.ptr(sd), _lib.ptr(lh), N, 0, H, K, nu, _lib.ptr(out), current_stream_ptr()), "spline")
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=5e-6)  # fp32 accumulation of K terms of O(1)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=1.5e-6)  # fp32 accumulation of K terms of O(1)
     kd = t(knots)
     out2 = torch.empty_like(out)
     _lib.check(L.jh_spline_controls(_lib.ptr(Wd), _lib.ptr(kd), None, None, 0, None, None, N, 0, H, K, nu, _lib.ptr(out2), current_stream_ptr()), "spline")
-    np.testing.assert_allclose(out2.cpu().numpy(), want, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(out2.cpu().numpy(), want, rtol=0, atol=1e-6)
     with pytest.raises(ValueError):
         _lib.check(L.jh_spline_controls(_lib.ptr(Wd), None, None, None, 0, None, None, N, 0, H, K, nu, _lib.ptr(out2), current_stream_ptr()), "spline")
 
@@ -404,10 +404,10 @@ def test_knot_moments_kernel(gpu, nu, K, N):
     out = torch.full((2 * nu,), 7.0, dtype=torch.float32, device=dev)  # the call zeroes it
     L = _lib.lib()
     _lib.check(L.jh_knot_moments(None, _lib.ptr(nd), _lib.ptr(ed), N, _lib.ptr(sd), _lib.ptr(lh), _lib.ptr(cd), N, 0, K, nu, _lib.ptr(out), current_stream_ptr()), "moments")
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-4)  # fp32 sums of N*K terms of O(1)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-5)  # fp32 sums of N*K terms of O(1)
     kd = t(knots)
     _lib.check(L.jh_knot_moments(_lib.ptr(kd), None, None, 0, None, None, _lib.ptr(cd), N, 0, K, nu, _lib.ptr(out), current_stream_ptr()), "moments")
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-5)
 
 
 @pytest.mark.parametrize("opt_name", ["mppi", "cem"])
@@ -465,9 +465,9 @@ def test_running_normaliser_plan_steps_match_the_reference_loop(gpu, opt_name):
         want = nrm.denormalize(nominal_n)
         got = ctrl.action_normalizer
         assert got.count == nrm.count == (step + 1) * 2 * N * K
-        np.testing.assert_allclose(got.mean, nrm.mean, rtol=0, atol=2e-6)
-        np.testing.assert_allclose(got.std, nrm.std, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(got.mean, nrm.mean, rtol=0, atol=6e-7)
+        np.testing.assert_allclose(got.std, nrm.std, rtol=2e-6, atol=2e-7)
         # costs are fp32: the MPPI average moves by ~1e-4 relative, the CEM elite mean is exact unless two candidates tie
-        np.testing.assert_allclose(ctrl.nominal_knots, want, rtol=0, atol=5e-4)
+        np.testing.assert_allclose(ctrl.nominal_knots, want, rtol=0, atol=5e-6)
         if opt_name == "cem":
-            np.testing.assert_allclose(ctrl.optimizer.sigma, cem_sigma, rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(ctrl.optimizer.sigma, cem_sigma, rtol=1.5e-6, atol=1.5e-8)

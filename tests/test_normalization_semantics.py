@@ -105,5 +105,5 @@ def test_running_kind_is_fed_with_the_candidates_of_the_plan_step(gpu):
     ctrl.update_action()
     assert n.count == ctrl.optimizer.num_rollouts * ctrl.optimizer.num_nodes
     cand = ctrl.candidate_knots   # (N, K, nu) raw candidates of this plan step
-    np.testing.assert_allclose(n.mean, cand.mean(axis=(0, 1)), atol=1e-5)
-    np.testing.assert_allclose(n.std, cand.std(axis=(0, 1)), atol=1e-5)
+    np.testing.assert_allclose(n.mean, cand.mean(axis=(0, 1)), atol=1.5e-9)
+    np.testing.assert_allclose(n.std, cand.std(axis=(0, 1)), atol=1e-7)
