@@ -273,6 +273,9 @@ typedef struct jh_tree jh_tree;
 int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out);
 void jh_tree_destroy(jh_tree* t);
 int jh_tree_stats(jh_tree* t, int* out4, int reset);
+/* The robot against itself (judo/models/xml/spot_primitive/contact.xml:4-14: every robot geom pair MuJoCo's static filters and the 11 <exclude> body pairs leave, listed
+ * in the model image): on by default when the image lists pairs, as MuJoCo collides them; on = 0: the ground contacts only (rounds 1-4). */
+int jh_tree_set_self_collision(jh_tree* t, int on);
 int jh_tree_dims(const jh_tree* t, int* out4 /* nq, nv, joints (= controls), nsensordata */);
 int jh_tree_substeps(const jh_tree* t, const float* state_in, const float* ctrl, float* warmstart, int N, int substeps, float* state_out, float* sensors_out,
                      void* stream);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "jh_tree_destroy": (None, [C.c_void_p]),
     "jh_tree_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "jh_tree_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "jh_tree_set_self_collision": (C.c_int, [C.c_void_p, C.c_int]),
     "jh_tree_substeps": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p]),
     "jh_policy_rollout_scratch_floats": (C.c_size_t, [C.c_int]),
     "jh_policy_rollout": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, f32p, f32p, C.POINTER(C.c_int), C.c_void_p]),

@@ -14,6 +14,13 @@
 // all run through tree_cholesky_solve: chains eliminated before the base (no fill-in), the small diagonal blocks factorised redundantly in registers,
 // three LDS exchanges per solve.  Contacts: sphere / capsule / box against the plane (mjc_PlaneSphere / PlaneCapsule / PlaneBox), pyramidal cones,
 // parameters mixed on the host; the contact Jacobian is compact (base + the contact's chain).  Sensors (site positions / frame axes) in the last step.
+//
+// Round 5: the robot against ITSELF (judo/models/xml/spot_primitive/contact.xml:4-14 excludes 11 body pairs; MuJoCo's static filters leave 287 geom pairs:
+// capsule-capsule, box-capsule, sphere-capsule, box-sphere, sphere-sphere, box-box), template parameter SELF.  A pair between two links of one chain, or between a
+// link and the base, still moves with the base and ONE chain: the compact row holds the difference of the two sides' columns (the base columns cancel).  A pair
+// between two different chains (leg against leg, arm against leg) needs a second chain block (J2, at most NX2 such contacts per rollout and step) and couples the two
+// chains in the Hessian: the fill-in-free tree factorisation does not apply, and the rollouts that have such a contact in a step take a dense 25 x 25 Cholesky
+// (dense_cholesky_solve: one row per lane in registers, pivot rows broadcast through LDS) for that step's Newton systems.
 #include "jh_coop.h"
 
 #include <vector>
@@ -36,7 +43,9 @@ enum { TF_DT = 0, TF_IMPRATIO, TF_TOL, TF_MAXITER, TF_LSTOL, TF_GRAV, TF_PLANE_P
 enum { JF_LPOS = 0, JF_LR = 3, JF_AXIS = 12, JF_MASS = 15, JF_IPOS = 16, JF_IR = 19, JF_INERTIA = 28, JF_DAMP = 31, JF_ARM, JF_FL, JF_FB, JF_FD, JF_INVW, JF_LIMITED, JF_LO, JF_HI,
        JF_LK, JF_LB, JF_SOLIMP = 42, JF_KP = 47, JF_KV, JF_CLIM, JF_CLO, JF_CHI, JF_FLIM, JF_FLO, JF_FHI };
 // geom floats
-enum { GF4_SIZE = 0, GF4_POS = 3, GF4_R = 6, GF4_MU = 15, GF4_K, GF4_B, GF4_SOLIMP = 18, GF4_TRAN = 23 };
+enum { GF4_SIZE = 0, GF4_POS = 3, GF4_R = 6, GF4_MU = 15, GF4_K, GF4_B, GF4_SOLIMP = 18, GF4_TRAN = 23, GF4_RBOUND = 24, GF4_MUOWN = 25 };
+// MU, K, B, SOLIMP: mixed with the plane (a geom's plane contacts); robot-robot pairs: max of the two MUOWN, the sum of the two TRAN, and K / B / SOLIMP as stored (tree_model.py
+// checks that every robot geom carries the same solref / solimp / priority, so the mixed values are the stored ones)
 
 // Chain layout the kernel is instantiated for: four legs of three hinges and one arm of seven, contiguous in the dof order (checked by
 // jh_tree_create).  With the chains eliminated before the base, the Cholesky factor of the inertia and of every Newton Hessian has no fill-in:
@@ -46,8 +55,11 @@ constexpr int NCH = 5;
 __host__ __device__ constexpr int CS(int c) { return c < 4 ? 3 * c : 12; }
 __host__ __device__ constexpr int CL(int c) { return c < 4 ? 3 : 7; }
 constexpr int SF_MAX = 2048, SI_MAX = 160, LBW = 28;
+constexpr int NX2 = 8;       // contacts between two different chains a rollout can hold per step (their second chain block lives in RS4::J2)
+constexpr int MAXHIT4 = 64;  // robot-robot geom pairs that survive the broad phase, per rollout and step
 
-struct __attribute__((aligned(16))) RS4 {  // per-rollout shared state; positions are relative to the base origin
+template <bool SELF>
+struct __attribute__((aligned(16))) RS4T {  // per-rollout shared state; positions are relative to the base origin
   float vec[3][G];                        // broadcast vectors (read as float4)
   float Lb[7][LBW];                       // base rows (6 = the rhs) pushed through the chain factors: [0..18] chain columns
   float LbT[NJ][8];                       // the same, transposed: per joint the six base-row entries and the rhs entry
@@ -61,9 +73,26 @@ struct __attribute__((aligned(16))) RS4 {  // per-rollout shared state; position
   float qd[G];
   float raw[NCP][RAW_F];                  // pos3 (relative), dist, geom | chain, tangent hint 3
   float fW[NCP][12];                      // contact frame (9) while the rows are built; then force [0..2] and the 3x3 weight [4..9] of the current Newton iterate
-  union { float M[NVT][NVT]; float J[NCP][JW]; };  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 32*44)
-  int ncon;
+  union {
+    float M[NVT][NVT]; float J[NCP][JW];  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 32*44)
+    struct { float gc[G][4]; int hits[MAXHIT4]; } col;  // robot-robot broad phase (between the inertia rows and the Jacobian): geom centres + bounding radii, surviving pairs
+  };
+  float J2[SELF ? NX2 : 1][24];              // second chain block (7 x 3, padded) of the contacts between two chains
+  int cinfo[SELF ? NCP : 1];                 // per contact: chain / depth of both sides, cross index (decoded by cinfo_* below)
+  int xc[SELF ? NX2 : 1];                    // contact index of cross contact x
+  int ncon, nx2;
 };
+using RS4 = RS4T<false>;
+// cinfo: bits 0-2 side B's chain (0 = the base body, 1 + chain otherwise), 3-5 its depth in the chain, 6-8 / 9-11 the same for side A, 12 side A is a robot geom (a
+// robot-robot contact; else the plane), 13-16 cross index + 1 (0: both sides move with the base and at most one chain), 17 dead (a cross contact above NX2: dropped)
+__device__ __forceinline__ int ci_chB(int ci) { return ci & 7; }
+__device__ __forceinline__ int ci_depB(int ci) { return (ci >> 3) & 7; }
+__device__ __forceinline__ int ci_chA(int ci) { return (ci >> 6) & 7; }
+__device__ __forceinline__ int ci_depA(int ci) { return (ci >> 9) & 7; }
+__device__ __forceinline__ bool ci_self(int ci) { return (ci >> 12) & 1; }
+__device__ __forceinline__ int ci_x(int ci) { return (ci >> 13) & 15; }
+__device__ __forceinline__ int ci_P(int ci) { return ci_chB(ci) > 0 ? ci_chB(ci) : (ci_self(ci) ? ci_chA(ci) : 0); }                                   // primary chain (1 + id), 0 = none
+__device__ __forceinline__ int ci_Q(int ci) { return (ci_self(ci) && ci_chA(ci) > 0 && ci_chB(ci) > 0 && ci_chA(ci) != ci_chB(ci)) ? ci_chA(ci) : 0; }  // second chain of a cross contact
 
 // Sum over the 32 lanes (two DPP rows) of a rollout, bit-identical in every lane.  The row exchange is gfx950's v_permlane16_swap: with both
 // operands = v it leaves (row0, row0, row2, row2) in one and (row1, row1, row3, row3) in the other -- a VALU op, no trip through the LDS crossbar.
@@ -197,7 +226,8 @@ __device__ __forceinline__ void load_row(float* row, const float* fullrow, const
 //   2. base lanes publish those entries, take the Schur complement against the earlier base rows and publish the reduced 6 x 6 system + rhs;
 //   3. every lane factorises the reduced system and solves it (base solution in every lane); every joint lane back-substitutes its own chain.
 // Returns the lane's own entry of x; xb = the six base entries.
-__device__ __forceinline__ float tree_cholesky_solve(float* row, RS4& S, const Role& R, int k, float* xb PA_PARAM) {
+template <class RS>
+__device__ __forceinline__ float tree_cholesky_solve(float* row, RS& S, const Role& R, int k, float* xb PA_PARAM) {
   PHS_DECL
   if (R.isjoint) {
 #pragma unroll
@@ -294,6 +324,62 @@ __device__ __forceinline__ float tree_cholesky_solve(float* row, RS4& S, const R
   return x_own;
 }
 
+// The same system when contacts couple two chains (robot self-collision: leg against leg, arm against leg): the matrix is no longer tree-structured, so it is
+// factorised densely.  Every dof lane holds its full symmetric row (26 registers, the layout above; the accumulation of J' W J fills every block a contact touches),
+// the right-hand-side lane its vector in the same layout.  Right-looking Cholesky in the column order of that layout (joints, then base): the owner of column p scales
+// its row by 1 / sqrt(pivot) and publishes it (26 floats, two alternating LDS vectors: one barrier per pivot), every later row -- and the right-hand side, which so
+// becomes y = L^-1 b -- subtracts its multiple.  The owner keeps the scaled row: it IS column p of L, which the back substitution L' x = y needs row-wise in
+// exactly that lane.  Entries in columns already eliminated turn into garbage and are never read.  ~25 x (26 multiply-adds + 7 broadcast reads) forward and as many
+// backward: three to four times the tree solve, paid only by the wave-steps in which a rollout has such a contact.
+template <class RS>
+__device__ __forceinline__ float dense_cholesky_solve(float* row, RS& S, const Role& R, int k, float* xb) {
+  const int l = threadIdx.x & 31;
+  const bool isbase = l < 6, isrhs = R.bl == 6;
+  const int mycol = R.isjoint ? k : (isbase ? NJ + l : 99);  // own column in the row layout (99: not a dof lane)
+  float myr = 1.f;
+#pragma unroll
+  for (int p = 0; p < NVT; p++) {
+    float* u = S.vec[p & 1];
+    if (mycol == p) {
+      const float r = __frsqrt_rn(fmaxf(row[p], 1e-30f));
+      myr = r;
+#pragma unroll
+      for (int j = 0; j < NVT; j++) { row[j] *= r; u[j] = row[j]; }
+      u[NVT] = r;
+    }
+    __syncthreads();
+    if ((mycol > p && mycol < 99) || isrhs) {
+      const float m = row[p] * u[NVT];
+#pragma unroll
+      for (int j = 0; j < NVT; j++) row[j] = fmaf(-m, u[j], row[j]);
+      if (isrhs) row[p] = m;  // y_p
+    }
+  }
+  __syncthreads();
+  float* xv = S.vec[2];  // y, overwritten from the last column backwards by x
+  if (isrhs) {
+#pragma unroll
+    for (int j = 0; j < NVT; j++) xv[j] = row[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = NVT - 1; p >= 0; p--) {
+    if (mycol == p) {
+      float sx = xv[p];
+#pragma unroll
+      for (int j = p + 1; j < NVT; j++) sx = fmaf(-row[j], xv[j], sx);
+      xv[p] = sx * myr;
+    }
+    __syncthreads();
+  }
+  float x_own = 0.f;
+#pragma unroll
+  for (int b = 0; b < 6; b++) xb[b] = xv[NJ + b];
+  if (mycol < NVT) x_own = xv[mycol];
+  __syncthreads();
+  return x_own;
+}
+
 // contact-frame 3-vector J_c v for a dof vector v in LDS (dof order); cs = first joint of the contact's chain
 __device__ __forceinline__ void jac_mul(float* o, const float* Jc, const float* v, int cs) {
   o[0] = o[1] = o[2] = 0.f;
@@ -302,6 +388,13 @@ __device__ __forceinline__ void jac_mul(float* o, const float* Jc, const float* 
   const float* vc = v + 6 + cs;
 #pragma unroll
   for (int m = 0; m < 7; m++) { const float w = vc[m]; o[0] = fmaf(Jc[JC + 3 * m], w, o[0]); o[1] = fmaf(Jc[JC + 3 * m + 1], w, o[1]); o[2] = fmaf(Jc[JC + 3 * m + 2], w, o[2]); }
+}
+
+// the second chain block of a contact between two chains (7 x 3 in RS4::J2), added to o
+__device__ __forceinline__ void jac_mul2(float* o, const float* J2x, const float* v, int csq) {
+  const float* vc = v + 6 + csq;
+#pragma unroll
+  for (int m = 0; m < 7; m++) { const float w = vc[m]; o[0] = fmaf(J2x[3 * m], w, o[0]); o[1] = fmaf(J2x[3 * m + 1], w, o[1]); o[2] = fmaf(J2x[3 * m + 2], w, o[2]); }
 }
 
 // dot of a register row (dof order) with a broadcast LDS vector
@@ -313,14 +406,16 @@ __device__ __forceinline__ float dot_row(const float* Mrow, const float* v) {
 }
 
 
+template <bool SELF>
 __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ gF, const int* __restrict__ gI, int nF, int nI, const float* state_in, int ld_in,
                                                     const float* __restrict__ ctrl, float* __restrict__ warm, int N, int substeps, float* state_out, int ld_out,
                                                     float* __restrict__ sensors_out, int ld_sens, int* __restrict__ stats, int dshift) {
-  __shared__ RS4 sRS[RPW];
+  using RS = RS4T<SELF>;
+  __shared__ RS sRS[RPW];
   __shared__ __attribute__((aligned(16))) float sF[SF_MAX];  // the model image, shared by the rollouts of the wave
   __shared__ int sI[SI_MAX];
   const int lane = threadIdx.x, l = lane & 31, r = lane >> 5;
-  RS4& S = sRS[r];
+  RS& S = sRS[r];
   for (int i = lane; i < nF && i < SF_MAX; i += WAVE) sF[i] = gF[i];  // (the sensor records at the end of the image are read from global memory, once per launch)
   for (int i = lane; i < nI && i < SI_MAX; i += WAVE) sI[i] = gI[i];
   __syncthreads();
@@ -329,6 +424,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
   const bool live = n < N && (r & ((1 << dshift) - 1)) == 0;
   const int nc = n < N ? n : N - 1;
   const int nj = NJ, ng = sI[1];
+  const int npair = SELF ? sI[6] : 0, oPair = sI[7];  // robot-robot geom pairs (g1 | g2 << 8, g1 < g2), read from the global image
   const bool isbase = l < 6, isjoint = l >= 6 && l < 6 + nj, hasdof = isbase || isjoint, isbody = l == 0 || isjoint;
   const int k = isjoint ? l - 6 : 0;                   // own joint
   const int bidx = isjoint ? 1 + k : 0;                // own body
@@ -378,7 +474,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
 #pragma unroll
       for (int i = 0; i < 6; i++) if (i == l) myqd = vb[i];
       if (hasdof) S.qd[l] = myqd;
-      if (l == 0) S.ncon = 0;
+      if (l == 0) { S.ncon = 0; S.nx2 = 0; }
     }
     __syncthreads();
     // ================================================================ kinematics (positions relative to the base origin)
@@ -560,7 +656,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
     if (l < ng) {
       const float* gf = sF + oGF + l * TG_F; const int owner = sI[oGI + l * TG_I], gtype = sI[oGI + l * TG_I + 1];
       const int gb = owner < 0 ? 0 : 1 + owner;
-      const int och = owner < 0 ? 0 : 1 + (sI[TH_I + owner * TD_I + 1] < 12 ? sI[TH_I + owner * TD_I + 1] / 3 : 4);  // 0: base geom, 1 + chain otherwise
       float bR[9], gp[3], lp[3] = {gf[GF4_POS], gf[GF4_POS + 1], gf[GF4_POS + 2]};
       for (int i = 0; i < 9; i++) bR[i] = S.xR[gb][i];
       mulMV(gp, bR, lp); for (int i = 0; i < 3; i++) gp[i] += S.xpos[gb][i];
@@ -569,7 +664,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         const int i = atomicAdd(&S.ncon, 1);
         if (i >= NCP) { if (stats) atomicAdd(stats, 1); return; }
         float* e = S.raw[i];
-        e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = dist; e[4] = __int_as_float(l | (och << 8)); e[5] = tng[0]; e[6] = tng[1]; e[7] = tng[2];
+        e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = dist; e[4] = __int_as_float(l); e[5] = tng[0]; e[6] = tng[1]; e[7] = tng[2];  // [4]: geom B | (geom A + 1) << 8, A = the plane: 0
       };
       const float zero3[3] = {0.f, 0.f, 0.f};
       float lr[9], gR[9];
@@ -599,41 +694,196 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         }
       }
     }
+    if constexpr (SELF) {
+      // ================================================================ the robot against itself: bounding spheres of the 287 pairs, survivors one per lane
+      auto geom_pose = [&](int g, float* gp, float* gR) __attribute__((always_inline)) {
+        const float* gf = sF + oGF + g * TG_F; const int owner = sI[oGI + g * TG_I]; const int gb = owner < 0 ? 0 : 1 + owner;
+        float bR[9]; for (int i = 0; i < 9; i++) bR[i] = S.xR[gb][i];
+        mulMV(gp, bR, gf + GF4_POS); for (int i = 0; i < 3; i++) gp[i] += S.xpos[gb][i];
+        mulMM(gR, bR, gf + GF4_R);
+      };
+      if (l < ng) {
+        float gp[3], gR[9]; geom_pose(l, gp, gR);
+        S.col.gc[l][0] = gp[0]; S.col.gc[l][1] = gp[1]; S.col.gc[l][2] = gp[2]; S.col.gc[l][3] = sF[oGF + l * TG_F + GF4_RBOUND];
+      }
+      __syncthreads();
+      int nh = 0;
+      for (int base = 0; base < npair; base += G) {
+        const int pi = base + l;
+        bool hit = false; int pk = 0;
+        if (pi < npair) {
+          pk = gI[oPair + pi];
+          const int g1 = pk & 255, g2 = pk >> 8;
+          const float* c1 = S.col.gc[g1]; const float* c2 = S.col.gc[g2];
+          const float d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}, rs = c1[3] + c2[3];
+          hit = dot3(d, d) <= rs * rs;  // (mj_collideGeoms' bounding-sphere filter; conservative, like the box cull below: neither changes a contact)
+          // a box against the other geom's bounding sphere: the body box's own sphere (0.44 m) holds most of the robot
+#pragma unroll
+          for (int sd = 0; sd < 2; sd++) {
+            const int gb_ = sd == 0 ? g1 : g2; const float* co = sd == 0 ? c2 : c1;
+            if (hit && sI[oGI + gb_ * TG_I + 1] == 6) {
+              float bp[3], bRm[9]; geom_pose(gb_, bp, bRm);
+              const float dw[3] = {co[0] - bp[0], co[1] - bp[1], co[2] - bp[2]}; float dl[3]; mulMTV(dl, bRm, dw);
+              const float* hs = sF + oGF + gb_ * TG_F + GF4_SIZE;
+              const float ex = fmaxf(fabsf(dl[0]) - hs[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hs[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hs[2], 0.f);
+              hit = ex * ex + ey * ey + ez * ez <= co[3] * co[3];
+            }
+          }
+        }
+        const unsigned m32 = (unsigned)(__ballot(hit) >> (32 * r));
+        const int pos = nh + __popc(m32 & ((1u << l) - 1u));
+        if (hit && pos < MAXHIT4) S.col.hits[pos] = pk;
+        nh += __popc(m32);
+      }
+      if (nh > MAXHIT4) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT4); nh = MAXHIT4; }  // (candidate pairs lost: counted with the dropped contacts)
+      __syncthreads();
+      // narrow phase (MuJoCo's primitives, restated in oracle/jo_engine.c collide_geoms): the normal points from geom 1 to geom 2 of the pair
+      struct SelfSink {
+        RS* S; int* stats; int pk; bool flip;
+        __device__ __forceinline__ void push(const float* pos, const float* n, float dist) {
+          const int i = atomicAdd(&S->ncon, 1);
+          if (i >= NCP) { if (stats) atomicAdd(stats, 1); return; }
+          float* e = S->raw[i];
+          e[0] = pos[0]; e[1] = pos[1]; e[2] = pos[2]; e[3] = dist; e[4] = __int_as_float((pk >> 8) | (((pk & 255) + 1) << 8));
+          e[5] = flip ? -n[0] : n[0]; e[6] = flip ? -n[1] : n[1]; e[7] = flip ? -n[2] : n[2];
+        }
+      };
+      for (int base = 0; __any(base < nh); base += G) {
+        const int idx = base + l;
+        if (idx < nh) {
+          const int pk = S.col.hits[idx], g1 = pk & 255, g2 = pk >> 8;
+          const int t1 = sI[oGI + g1 * TG_I + 1], t2 = sI[oGI + g2 * TG_I + 1];
+          const float* f1 = sF + oGF + g1 * TG_F; const float* f2 = sF + oGF + g2 * TG_F;
+          float p1[3], R1[9], p2[3], R2[9]; geom_pose(g1, p1, R1); geom_pose(g2, p2, R2);
+          SelfSink sk{&S, live ? stats : nullptr, pk, false};
+          auto sphere_sphere = [&](const float* ca, float ra, const float* cb, float rb) __attribute__((always_inline)) {
+            const float d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]}; const float ln = sqrtf(dot3(d, d)), dist = ln - ra - rb;
+            if (dist >= 0.f || ln < 1e-12f) return;
+            const float n3[3] = {d[0] / ln, d[1] / ln, d[2] / ln}, mm = ra + 0.5f * dist;
+            const float ps[3] = {ca[0] + mm * n3[0], ca[1] + mm * n3[1], ca[2] + mm * n3[2]};
+            sk.push(ps, n3, dist);
+          };
+          auto sphere_capsule = [&](const float* ps, float rs_, const float* pc, const float* Rc, const float* sc) __attribute__((always_inline)) {  // normal: sphere -> capsule
+            float a[3]; col3(a, Rc, 2);
+            const float d[3] = {ps[0] - pc[0], ps[1] - pc[1], ps[2] - pc[2]};
+            const float x = jh_clampf(dot3(a, d), -sc[1], sc[1]);
+            const float v[3] = {pc[0] + a[0] * x, pc[1] + a[1] * x, pc[2] + a[2] * x};
+            sphere_sphere(ps, rs_, v, sc[0]);
+          };
+          if (t1 == 6 && t2 == 6) collide_box_box(sk, p1, R1, f1 + GF4_SIZE, p2, R2, f2 + GF4_SIZE);
+          else if (t1 == 6 && t2 == 2) collide_box_sphere(sk, p1, R1, f1 + GF4_SIZE, p2, f2[GF4_SIZE]);
+          else if (t1 == 2 && t2 == 6) { sk.flip = true; collide_box_sphere(sk, p2, R2, f2 + GF4_SIZE, p1, f1[GF4_SIZE]); }
+          else if (t1 == 6 && t2 == 3) collide_box_capsule(sk, p1, R1, f1 + GF4_SIZE, p2, R2, f2[GF4_SIZE], f2[GF4_SIZE + 1]);
+          else if (t1 == 3 && t2 == 6) { sk.flip = true; collide_box_capsule(sk, p2, R2, f2 + GF4_SIZE, p1, R1, f1[GF4_SIZE], f1[GF4_SIZE + 1]); }
+          else if (t1 == 2 && t2 == 2) sphere_sphere(p1, f1[GF4_SIZE], p2, f2[GF4_SIZE]);
+          else if (t1 == 2 && t2 == 3) sphere_capsule(p1, f1[GF4_SIZE], p2, R2, f2 + GF4_SIZE);
+          else if (t1 == 3 && t2 == 2) { sk.flip = true; sphere_capsule(p2, f2[GF4_SIZE], p1, R1, f1 + GF4_SIZE); }
+          else if (t1 == 3 && t2 == 3) {  // mjc_CapsuleCapsule: closest points of the two axis segments, then sphere against sphere
+            float a1[3], a2[3]; col3(a1, R1, 2); col3(a2, R2, 2);
+            const float r1_ = f1[GF4_SIZE], r2_ = f2[GF4_SIZE];
+            for (int i = 0; i < 3; i++) { a1[i] *= f1[GF4_SIZE + 1]; a2[i] *= f2[GF4_SIZE + 1]; }
+            const float dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+            const float ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+            const float det = ma * mc - mb * mb;
+            if (fabsf(det) >= 1e-6f * ma * mc) {  // (MuJoCo: |det| >= mjMINVAL in fp64; in fp32 the determinant of two axes less than ~1e-3 rad apart is rounding noise)
+              float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+              if (x1 > 1.f) { x1 = 1.f; x2 = (v - mb) / mc; } else if (x1 < -1.f) { x1 = -1.f; x2 = (v + mb) / mc; }
+              if (x2 > 1.f) { x2 = 1.f; x1 = jh_clampf((u - mb) / ma, -1.f, 1.f); }
+              else if (x2 < -1.f) { x2 = -1.f; x1 = jh_clampf((u + mb) / ma, -1.f, 1.f); }
+              const float v1[3] = {p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p1[2] + a1[2] * x1}, v2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
+              sphere_sphere(v1, r1_, v2, r2_);
+            } else {  // parallel axes: the ends of capsule 1 against segment 2, then the ends of capsule 2 against segment 1, at most two contacts
+              int nfound = 0;
+              for (int e = 0; e < 4; e++) {
+                float x1, x2;
+                if (e < 2) { x1 = e == 0 ? 1.f : -1.f; x2 = jh_clampf((v - x1 * mb) / mc, -1.f, 1.f); }
+                else { x2 = e == 2 ? 1.f : -1.f; x1 = jh_clampf((u - x2 * mb) / ma, -1.f, 1.f); }
+                const float v1[3] = {p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p1[2] + a1[2] * x1}, v2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
+                const float d[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]}; const float ln = sqrtf(dot3(d, d));
+                if (nfound < 2 && ln - r1_ - r2_ < 0.f && ln >= 1e-12f) { sphere_sphere(v1, r1_, v2, r2_); nfound++; }
+              }
+            }
+          }
+        }
+      }
+    }
     __syncthreads();
     // ================================================================ constraint rows
     const int ncon = S.ncon < NCP ? S.ncon : NCP;
     Slot4 sl;
     sl.valid = l < ncon; sl.D = 0.f; sl.mu = 0.f;
-    int my_cs = 0;  // first joint of the own contact's chain
-    if (sl.valid) { const int och = __float_as_int(S.raw[l][4]) >> 8; my_cs = och == 0 ? 0 : (och <= 4 ? 3 * (och - 1) : CS(4)); }
     for (int w = 0; w < 3; w++) sl.aref[w] = sl.jar[w] = sl.jp[w] = 0.f;
-    if (sl.valid) {  // contact frame: plane normal (from the plane, geom 1, to the robot geom), second axis along a capsule's axis
-      float fr[9] = {pln[0], pln[1], pln[2], 0, 0, 0, 0, 0, 0};
-      make_frame(fr);
+    // sides of the own contact: B = the robot geom of a plane contact / geom 2 of a robot-robot pair, A = the plane / geom 1
+    int my_ci = 0;
+    {
+      bool cross = false;
+      if (sl.valid) {
+        const int pk = __float_as_int(S.raw[l][4]), gB = pk & 255, gA1 = (pk >> 8) & 255;
+        auto side = [&](int g, int& ch, int& dep) __attribute__((always_inline)) {
+          const int owner = sI[oGI + g * TG_I];
+          if (owner < 0) { ch = 0; dep = 0; } else { const int cs_ = sI[TH_I + owner * TD_I + 1]; ch = 1 + (cs_ < 12 ? cs_ / 3 : 4); dep = sI[TH_I + owner * TD_I + 2]; }
+        };
+        int chB, depB, chA = 0, depA = 0; side(gB, chB, depB);
+        const bool selfc = SELF && gA1 != 0;
+        if (selfc) side(gA1 - 1, chA, depA);
+        my_ci = chB | (depB << 3) | (chA << 6) | (depA << 9) | ((selfc ? 1 : 0) << 12);
+        cross = ci_Q(my_ci) != 0;
+      }
+      if constexpr (SELF) {
+        const unsigned xm = (unsigned)(__ballot(cross) >> (32 * r));
+        if (cross) {
+          const int x = __popc(xm & ((1u << l) - 1u));
+          if (x < NX2) { my_ci |= (x + 1) << 13; S.xc[x] = l; }
+          else { my_ci |= 1 << 17; sl.valid = false; if (live && stats) atomicAdd(stats, 1); }  // (above the capacity for contacts between two chains: dropped and counted)
+        }
+        if (l == 0) S.nx2 = min((int)__popc(xm), NX2);
+        if (l < ncon) S.cinfo[l] = my_ci;
+      }
+    }
+    const int my_P = ci_P(my_ci), my_Q = ci_Q(my_ci);
+    const int my_cs = my_P == 0 ? 0 : (my_P <= 4 ? 3 * (my_P - 1) : CS(4));   // first joint of the own contact's (primary) chain
+    const int my_csq = my_Q == 0 ? 0 : (my_Q <= 4 ? 3 * (my_Q - 1) : CS(4));  // ... of its second chain (contacts between two chains)
+    const int my_x = ci_x(my_ci) > 0 ? ci_x(my_ci) - 1 : 0;
+    if (l < ncon) {  // contact frame.  Plane contacts: plane normal (from the plane, geom 1, to the robot geom), second axis along a capsule's axis; robot-robot: the narrow phase's normal
       const float* e = S.raw[l];
-      float y[3] = {e[5], e[6], e[7]};
-      const float dp = dot3(fr, y); y[0] -= fr[0] * dp; y[1] -= fr[1] * dp; y[2] -= fr[2] * dp;
-      const float nn = sqrtf(dot3(y, y));
-      if (nn > 0.5e-3f) { for (int i = 0; i < 3; i++) fr[3 + i] = y[i] / nn; cross3(fr + 6, fr, fr + 3); }
+      float fr[9] = {pln[0], pln[1], pln[2], 0, 0, 0, 0, 0, 0};
+      if (SELF && ci_self(my_ci)) { fr[0] = e[5]; fr[1] = e[6]; fr[2] = e[7]; }
+      make_frame(fr);
+      if (!(SELF && ci_self(my_ci))) {
+        float y[3] = {e[5], e[6], e[7]};
+        const float dp = dot3(fr, y); y[0] -= fr[0] * dp; y[1] -= fr[1] * dp; y[2] -= fr[2] * dp;
+        const float nn = sqrtf(dot3(y, y));
+        if (nn > 0.5e-3f) { for (int i = 0; i < 3; i++) fr[3 + i] = y[i] / nn; cross3(fr + 6, fr, fr + 3); }
+      }
       for (int w = 0; w < 9; w++) S.fW[l][w] = fr[w];
     }
     __syncthreads();
-    for (int c = 0; c < ncon; c++) {  // Jacobian: every dof lane its own column (robot side only: the plane is static); the spare lanes clear the padding
+    const int nx2 = SELF ? S.nx2 : 0;
+    for (int c = 0; c < ncon; c++) {  // Jacobian: every dof lane its own column, side B minus side A (the plane is static); the spare lanes clear the padding
       const float* e = S.raw[c];
-      const int och = __float_as_int(e[4]) >> 8, odepth = och == 0 ? -1 : sI[TH_I + sI[oGI + (__float_as_int(e[4]) & 255) * TG_I] * TD_I + 2];
-      if (isbase || (isjoint && och == 1 + R.cid)) {
-        const float pos[3] = {e[0], e[1], e[2]};
-        float col[3] = {0.f, 0.f, 0.f};
-        if (isbase || cdepth <= odepth) {
-          float v[3]; cross3(v, Sown, pos); for (int i = 0; i < 3; i++) v[i] += Sown[3 + i];
-          const float* fr = S.fW[c];
-          col[0] = dot3(fr, v); col[1] = dot3(fr + 3, v); col[2] = dot3(fr + 6, v);
+      int ci;
+      if constexpr (SELF) ci = S.cinfo[c];
+      else { const int owner = sI[oGI + (__float_as_int(e[4]) & 255) * TG_I]; ci = owner < 0 ? 0 : ((1 + (sI[TH_I + owner * TD_I + 1] < 12 ? sI[TH_I + owner * TD_I + 1] / 3 : 4)) | (sI[TH_I + owner * TD_I + 2] << 3)); }
+      const int P = ci_P(ci), Q = SELF ? ci_Q(ci) : 0, xq = ci_x(ci) > 0 ? ci_x(ci) - 1 : 0;
+      const bool dead = SELF && ((ci >> 17) & 1);
+      const bool inP = isjoint && P == 1 + R.cid, inQ = SELF && isjoint && Q == 1 + R.cid && !dead;
+      if (isbase || inP || inQ) {
+        float sgn = 0.f;
+        if (isbase) sgn = ci_self(ci) ? 0.f : 1.f;  // (both sides of a robot-robot contact ride on the base: its columns cancel)
+        else {
+          if (ci_chB(ci) == 1 + R.cid && cdepth <= ci_depB(ci)) sgn += 1.f;
+          if (ci_self(ci) && ci_chA(ci) == 1 + R.cid && cdepth <= ci_depA(ci)) sgn -= 1.f;
         }
-        float* o = S.J[c] + (isbase ? 3 * l : JC + 3 * cdepth);
+        const float pos[3] = {e[0], e[1], e[2]};
+        float v[3]; cross3(v, Sown, pos); for (int i = 0; i < 3; i++) v[i] += Sown[3 + i];
+        const float* fr = S.fW[c];
+        const float col[3] = {sgn * dot3(fr, v), sgn * dot3(fr + 3, v), sgn * dot3(fr + 6, v)};
+        float* o = isbase ? S.J[c] + 3 * l : (inP ? S.J[c] + JC + 3 * cdepth : S.J2[xq] + 3 * cdepth);
         o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
-      } else if (l >= NVT) {  // positions the contact's chain does not have (legs: 3..6; base geoms: all)
-        const int m = l - NVT, len = och == 0 ? 0 : (och < 5 ? 3 : 7);
+      } else if (l >= NVT) {  // positions the contact's chain(s) do not have (legs: 3..6; a contact on the base alone: all)
+        const int m = l - NVT, len = P == 0 ? 0 : (P < 5 ? 3 : 7);
         if (m >= len) { float* o = S.J[c] + JC + 3 * m; o[0] = o[1] = o[2] = 0.f; }
+        if (SELF && Q != 0 && !dead && m >= (Q < 5 ? 3 : 7)) { float* o = S.J2[xq] + 3 * m; o[0] = o[1] = o[2] = 0.f; }
       }
     }
     __syncthreads();
@@ -641,12 +891,18 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       const float* e = S.raw[l]; const float dist = e[3]; const int gid = __float_as_int(e[4]) & 255;
       const float* gf = sF + oGF + gid * TG_F;
       float si[5]; for (int w = 0; w < 5; w++) si[w] = gf[GF4_SOLIMP + w];
-      const float mu = gf[GF4_MU], imp = impedance(si, dist);
-      const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * gf[GF4_TRAN] * (1.f + mu * mu));
+      float mu = gf[GF4_MU], tran = gf[GF4_TRAN];
+      if (SELF && ci_self(my_ci)) {  // robot against robot: mj_contactParam with equal priorities -- the larger friction; the two bodies' inverse weights
+        const float* ga = sF + oGF + (((__float_as_int(e[4]) >> 8) & 255) - 1) * TG_F;
+        mu = fmaxf(gf[GF4_MUOWN], ga[GF4_MUOWN]); tran = gf[GF4_TRAN] + ga[GF4_TRAN];
+      }
+      const float imp = impedance(si, dist);
+      const float R0 = fmaxf(1e-15f, (1.f - imp) / imp * tran * (1.f + mu * mu));
       const float Rpy = fmaxf(1e-15f, 2.f * (mu * mu / fmaxf(1e-15f, impratio)) * R0);
       sl.D = 1.f / Rpy; sl.mu = mu;
       float vel[3];
       jac_mul(vel, S.J[l], S.qd, my_cs);
+      if (SELF && my_Q != 0) jac_mul2(vel, S.J2[my_x], S.qd, my_csq);
       sl.aref[0] = -gf[GF4_B] * vel[0] - gf[GF4_K] * imp * dist; sl.aref[1] = -gf[GF4_B] * vel[1]; sl.aref[2] = -gf[GF4_B] * vel[2];
     }
     DofRows4 dr;
@@ -662,7 +918,17 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
     // ================================================================ Newton solver (tree-structured Hessian, one row per lane)
     float a_own = a0_own;
     unsigned involved = 0;  // bit c: contact c moves with this lane's dof (base lanes: every contact; joint lanes: contacts on their chain)
-    if (hasdof) for (int c = 0; c < ncon; c++) involved |= (isbase || (__float_as_int(S.raw[c][4]) >> 8) == 1 + R.cid) ? (1u << c) : 0u;
+    if (hasdof) for (int c = 0; c < ncon; c++) {
+      int P;
+      if constexpr (SELF) P = ci_P(S.cinfo[c]);
+      else { const int owner = sI[oGI + (__float_as_int(S.raw[c][4]) & 255) * TG_I]; P = owner < 0 ? 0 : 1 + (sI[TH_I + owner * TD_I + 1] < 12 ? sI[TH_I + owner * TD_I + 1] / 3 : 4); }
+      involved |= (isbase || P == 1 + R.cid) ? (1u << c) : 0u;
+    }
+    // contacts between two chains (SELF): which of them have this lane's chain as their second chain, and the wave-uniform question whether a rollout has any
+    unsigned involved2 = 0;
+    if constexpr (SELF) { if (isjoint) for (int x = 0; x < nx2; x++) involved2 |= ci_Q(S.cinfo[S.xc[x]]) == 1 + R.cid ? (1u << x) : 0u; }
+    const bool dense_step = SELF && __any(nx2 > 0);
+    const int cd3 = 3 * (cdepth < 0 ? 0 : cdepth);
     const int own_col = isbase ? 3 * l : JC + 3 * (cdepth < 0 ? 0 : cdepth);  // own column in a compact Jacobian row
     const float iMd = 1.f / Md_own;
     const float snorm = gsum32(hasdof ? fs_own * fs_own * iMd : 0.f);
@@ -672,13 +938,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (hasdof) { S.vec[0][l] = qws; S.vec[1][l] = a0_own; S.vec[2][l] = qws - a0_own; }
       __syncthreads();
       float jar_ws[3] = {0.f, 0.f, 0.f};
-      if (sl.valid) { float o[3]; jac_mul(o, S.J[l], S.vec[0], my_cs); for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
+      if (sl.valid) { float o[3]; jac_mul(o, S.J[l], S.vec[0], my_cs); if (SELF && my_Q != 0) jac_mul2(o, S.J2[my_x], S.vec[0], my_csq); for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
       dr.jf = qws - dr.faref; dr.jl = dr.lims * qws - dr.laref;
       const float mdw = dot_row(Mrow, S.vec[2]);
       const float cost_ws = gsum32(lane_cost4(sl, dr) + (hasdof ? 0.5f * (qws - a0_own) * mdw : 0.f));
       for (int w = 0; w < 3; w++) jar_ws[w] = sl.jar[w];
       const float jf_ws = dr.jf, jl_ws = dr.jl;
-      if (sl.valid) { float o[3]; jac_mul(o, S.J[l], S.vec[1], my_cs); for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
+      if (sl.valid) { float o[3]; jac_mul(o, S.J[l], S.vec[1], my_cs); if (SELF && my_Q != 0) jac_mul2(o, S.J2[my_x], S.vec[1], my_csq); for (int w = 0; w < 3; w++) sl.jar[w] = o[w] - sl.aref[w]; }
       dr.jf = a0_own - dr.faref; dr.jl = dr.lims * a0_own - dr.laref;
       const float cost_0 = gsum32(lane_cost4(sl, dr));
       if (cost_ws < cost_0) { a_own = qws; for (int w = 0; w < 3; w++) sl.jar[w] = jar_ws[w]; dr.jf = jf_ws; dr.jl = jl_ws; }
@@ -690,7 +956,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         // ---- (1) gradient row
         const float da_own = a_own - a0_own;
         if (hasdof) S.vec[0][l] = da_own;
-        if (sl.valid) { float f[3], Wm[6]; pyramid_eval(sl.jar, sl.D, sl.mu, f, Wm); float* o = S.fW[l]; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[4 + w] = Wm[w]; }
+        if (l < ncon) {  // (a dropped contact -- above the capacity for contacts between two chains -- keeps its row with zero force and weight)
+          float f[3] = {0.f, 0.f, 0.f}, Wm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (sl.valid) pyramid_eval(sl.jar, sl.D, sl.mu, f, Wm);
+          float* o = S.fW[l]; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; for (int w = 0; w < 6; w++) o[4 + w] = Wm[w];
+        }
         __syncthreads();
         float g_own = dot_row(Mrow, S.vec[0]), hd = 0.f;
         if (dr.fl > 0.f) {
@@ -702,6 +972,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           const float* jc = S.J[c] + own_col; const float* fc = S.fW[c];
           const float on = (involved >> c) & 1u ? 1.f : 0.f;
           g_own -= on * (jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]);
+        }
+        if constexpr (SELF) {
+          for (int x = 0; x < nx2; x++) {  // second chain block of the contacts between two chains
+            const float* jc = S.J2[x] + cd3; const float* fc = S.fW[S.xc[x]];
+            const float on = (involved2 >> x) & 1u ? 1.f : 0.f;
+            g_own -= on * (jc[0] * fc[0] + jc[1] * fc[1] + jc[2] * fc[2]);
+          }
         }
         // ---- (2) convergence; leave before any Hessian work once both rollouts of the wave are done
         const float gn = gsum32(hasdof ? g_own * g_own * iMd : 0.f);
@@ -724,7 +1001,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           for (int m = 0; m < 7; m++) dch[m] = Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2;
 #pragma unroll
           for (int m = 0; m < 6; m++) dba[m] = Jc[3 * m] * G0 + Jc[3 * m + 1] * G1 + Jc[3 * m + 2] * G2;
-          const int och = __float_as_int(S.raw[c][4]) >> 8;  // 0: the geom sits on the base (its chain part is zero), else 1 + chain
+          int och;  // 0: both sides sit on the base (the chain part is zero), else 1 + the contact's (primary) chain
+          if constexpr (SELF) och = ci_P(S.cinfo[c]);
+          else { const int owner = sI[oGI + (__float_as_int(S.raw[c][4]) & 255) * TG_I]; och = owner < 0 ? 0 : 1 + (sI[TH_I + owner * TD_I + 1] < 12 ? sI[TH_I + owner * TD_I + 1] / 3 : 4); }
 #pragma unroll
           for (int ch = 0; ch < NCH; ch++) {
             const float sel = och == 1 + ch ? 1.f : 0.f;
@@ -734,10 +1013,35 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
 #pragma unroll
           for (int m = 0; m < 6; m++) row[NJ + m] += dba[m];
         }
+        if constexpr (SELF) {
+          // contacts between two chains P and Q: a lane of P (or of the base) has its own column in J and took the P block and the base block above -- it still needs the Q
+          // block; a lane of Q has its own column in J2 and takes all three.  Same J' W J, the row of every dof the contact moves complete and symmetric.
+          for (int x = 0; x < nx2; x++) {
+            const int c = S.xc[x], ci = S.cinfo[c], P = ci_P(ci), Q = ci_Q(ci);
+            const float* fc = S.fW[c]; const float* Jc = S.J[c]; const float* Jq = S.J2[x];
+            const float onP = (involved >> c) & 1u ? 1.f : 0.f, onQ = (involved2 >> x) & 1u ? 1.f : 0.f;
+            const float j0 = onP * Jc[own_col] + onQ * Jq[cd3], j1 = onP * Jc[own_col + 1] + onQ * Jq[cd3 + 1], j2 = onP * Jc[own_col + 2] + onQ * Jq[cd3 + 2];
+            const float G0 = fc[4] * j0 + fc[5] * j1 + fc[7] * j2, G1 = fc[5] * j0 + fc[6] * j1 + fc[8] * j2, G2 = fc[7] * j0 + fc[8] * j1 + fc[9] * j2;
+            float dq[7], dch[7], dba[6];
+#pragma unroll
+            for (int m = 0; m < 7; m++) { dq[m] = Jq[3 * m] * G0 + Jq[3 * m + 1] * G1 + Jq[3 * m + 2] * G2; dch[m] = onQ * (Jc[JC + 3 * m] * G0 + Jc[JC + 3 * m + 1] * G1 + Jc[JC + 3 * m + 2] * G2); }
+#pragma unroll
+            for (int m = 0; m < 6; m++) dba[m] = onQ * (Jc[3 * m] * G0 + Jc[3 * m + 1] * G1 + Jc[3 * m + 2] * G2);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+              const float selq = Q == 1 + ch ? 1.f : 0.f, selp = P == 1 + ch ? 1.f : 0.f;
+#pragma unroll
+              for (int m = 0; m < CL(ch); m++) row[CS(ch) + m] = fmaf(selq, dq[m], fmaf(selp, dch[m], row[CS(ch) + m]));
+            }
+#pragma unroll
+            for (int m = 0; m < 6; m++) row[NJ + m] += dba[m];
+          }
+        }
         PH(6)
         // ---- (4) factorise and solve; the direction goes back through LDS
         float xb[6];
-        const float p_own = tree_cholesky_solve(row, S, R, k, xb PA_ARG);
+        // (a rollout with a contact between two chains has no tree-structured Hessian: the wave then factorises densely -- valid for its other rollout too)
+        const float p_own = dense_step ? dense_cholesky_solve(row, S, R, k, xb) : tree_cholesky_solve(row, S, R, k, xb PA_ARG);
         if (hasdof) S.vec[2][l] = p_own;
         __syncthreads();
         PH(7)
@@ -745,7 +1049,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         const float Mp_own = dot_row(Mrow, S.vec[2]);
         const float pMp = gsum32(hasdof ? p_own * Mp_own : 0.f), pMd = gsum32(hasdof ? Mp_own * da_own : 0.f), gp = gsum32(hasdof ? g_own * p_own : 0.f);
         if (act && !(gp < 0.f)) act = false;
-        if (sl.valid) jac_mul(sl.jp, S.J[l], S.vec[2], my_cs);
+        if (sl.valid) { jac_mul(sl.jp, S.J[l], S.vec[2], my_cs); if (SELF && my_Q != 0) jac_mul2(sl.jp, S.J2[my_x], S.vec[2], my_csq); }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
         float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
         for (int ls = 0; ls < 12 && __any(lsact); ls++) {
@@ -821,7 +1125,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
 
 }  // namespace
 
-struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni, ns; std::vector<hipEvent_t> events; };
+struct jh_tree { float* d_f; int* d_i; int* d_stats; int nj, ng, nq, nv, nf, ni, ns, npair, self_collision; std::vector<hipEvent_t> events; };
 
 extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(blob && out && nbytes >= 16, "tree_create: null or short blob");
@@ -833,8 +1137,13 @@ extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(ii[0] == NJ && ii[2] == NQ && ii[3] == NVT && ii[1] <= G - 1, "tree_create: the kernel is instantiated for a free base + 19 hinges (got %d joints, nq %d, nv %d, %d geoms)", ii[0], ii[2], ii[3], ii[1]);
   JH_REQUIRE((size_t)(TH_F + ii[0] * TD_F + ii[1] * TG_F) <= (size_t)SF_MAX && (size_t)(TH_I + ii[0] * TD_I + ii[1] * TG_I) <= (size_t)SI_MAX,
              "tree_create: model image too large for the kernel's LDS copy");
-  JH_REQUIRE(ii[4] >= 0 && ii[4] <= G && nf == (size_t)(TH_F + ii[0] * TD_F + ii[1] * TG_F + ii[4] * TS_F) && ni == (size_t)(TH_I + ii[0] * TD_I + ii[1] * TG_I + ii[4] * TS_I),
+  JH_REQUIRE(ii[4] >= 0 && ii[4] <= G && ii[6] >= 0 && nf == (size_t)(TH_F + ii[0] * TD_F + ii[1] * TG_F + ii[4] * TS_F) &&
+             ni == (size_t)(TH_I + ii[0] * TD_I + ii[1] * TG_I + ii[4] * TS_I + ii[6]) && (ii[6] == 0 || ii[7] == TH_I + ii[0] * TD_I + ii[1] * TG_I + ii[4] * TS_I),
              "tree_create: image sizes do not match the counts in its header (or more than 32 sensors)");
+  for (int p = 0; p < ii[6]; p++) {  // robot-robot geom pairs: g1 | g2 << 8 with g1 < g2 < number of geoms
+    const int pk = ii[ii[7] + p], g1 = pk & 255, g2 = pk >> 8;
+    JH_REQUIRE(g1 < g2 && g2 < ii[1], "tree_create: bad geom pair %d (%d, %d)", p, g1, g2);
+  }
   for (int c = 0; c < NCH; c++)
     for (int m = 0; m < CL(c); m++) {
       const int* jr = ii + TH_I + (CS(c) + m) * TD_I;
@@ -843,6 +1152,7 @@ extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   jh_tree* t = new jh_tree();
   t->nf = (int)nf; t->ni = (int)ni; t->ns = ii[5];
   t->nj = ii[0]; t->ng = ii[1]; t->nq = ii[2]; t->nv = ii[3];
+  t->npair = ii[6]; t->self_collision = ii[6] > 0 ? 1 : 0;  // the robot collides with itself when the image lists pairs, as MuJoCo does (jh_tree_set_self_collision)
   JH_HIP(hipMalloc(&t->d_f, 4 * nf)); JH_HIP(hipMalloc(&t->d_i, 4 * ni)); JH_HIP(hipMalloc(&t->d_stats, 64 * sizeof(int)));
   JH_HIP(hipMemcpy(t->d_f, f, 4 * nf, hipMemcpyHostToDevice)); JH_HIP(hipMemcpy(t->d_i, ii, 4 * ni, hipMemcpyHostToDevice));
   JH_HIP(hipMemset(t->d_stats, 0, 64 * sizeof(int)));
@@ -876,6 +1186,13 @@ extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
   return JH_OK;
 }
 
+extern "C" int jh_tree_set_self_collision(jh_tree* t, int on) {
+  JH_REQUIRE(t, "tree_set_self_collision: null pointer");
+  JH_REQUIRE(!on || t->npair > 0, "tree_set_self_collision: the model image lists no robot-robot geom pairs");
+  t->self_collision = on ? 1 : 0;
+  return JH_OK;
+}
+
 extern "C" int jh_tree_dims(const jh_tree* t, int* out4) {
   JH_REQUIRE(t && out4, "tree_dims: null pointer");
   out4[0] = t->nq; out4[1] = t->nv; out4[2] = t->nj; out4[3] = t->ns;
@@ -887,8 +1204,12 @@ extern "C" int jh_tree_substeps(const jh_tree* t, const float* state_in, const f
   JH_REQUIRE(t && state_in && ctrl && state_out, "tree_substeps: null pointer");
   JH_REQUIRE(N > 0 && substeps > 0, "tree_substeps: need at least one rollout and one step");
   const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
-  hipLaunchKernelGGL(k_tree_v4, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
-                     sensors_out, t->ns, t->d_stats, dshift);
+  if (t->self_collision)
+    hipLaunchKernelGGL(k_tree_v4<true>, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
+                       sensors_out, t->ns, t->d_stats, dshift);
+  else
+    hipLaunchKernelGGL(k_tree_v4<false>, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, (hipStream_t)stream, t->d_f, t->d_i, t->nf, t->ni, state_in, NX, ctrl, warmstart, N, substeps, state_out, NX,
+                       sensors_out, t->ns, t->d_stats, dshift);
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
@@ -930,8 +1251,12 @@ extern "C" int jh_policy_rollout(const jh_policy* p, jh_tree* t, const float* x0
     if (rc != JH_OK) return rc;
     if (reset_warmstart) JH_HIP(hipMemsetAsync(warmstart, 0, (size_t)N * NVT * sizeof(float), st));
     const int dshift = jh_latency_shift(N, RPW), per_wave = RPW >> dshift;
-    hipLaunchKernelGGL(k_tree_v4, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
-                       sensors ? sensors + (size_t)i * t->ns : nullptr, T * t->ns, t->d_stats, dshift);
+    if (t->self_collision)
+      hipLaunchKernelGGL(k_tree_v4<true>, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
+                         sensors ? sensors + (size_t)i * t->ns : nullptr, T * t->ns, t->d_stats, dshift);
+    else
+      hipLaunchKernelGGL(k_tree_v4<false>, dim3((N + per_wave - 1) / per_wave), dim3(WAVE), 0, st, t->d_f, t->d_i, t->nf, t->ni, xin, ld, control, warmstart, N, substeps, states + (size_t)i * NX, T * NX,
+                         sensors ? sensors + (size_t)i * t->ns : nullptr, T * t->ns, t->d_stats, dshift);
     if (deadline) JH_HIP(hipEventRecord(t->events[i + 1], st));
   }
   JH_HIP(hipGetLastError());

@@ -96,7 +96,8 @@ class SpotTreeEngine:
 
     NQ, NV, NU = 26, 25, 19
 
-    def __init__(self, desc: dict | None = None, device: torch.device | None = None) -> None:
+    def __init__(self, desc: dict | None = None, device: torch.device | None = None, self_collision: bool = True) -> None:
+        """self_collision: the robot's own geom pairs collide, as in the reference's model (spot_primitive/contact.xml); False = the ground contacts only."""
         self.device = device or require_gpu()
         self.desc = desc if desc is not None else load_description("spot")
         blob = pack_tree_blob(self.desc)
@@ -109,6 +110,8 @@ class SpotTreeEngine:
         dims = (C.c_int * 4)()
         _lib.check(_lib.lib().jh_tree_dims(self.handle, dims), "jh_tree_dims")
         self.nsensordata = int(dims[3])
+        self.self_collision = bool(self_collision)
+        _lib.check(_lib.lib().jh_tree_set_self_collision(self.handle, int(self.self_collision)), "jh_tree_set_self_collision")
 
     def substeps(self, states: torch.Tensor, ctrl: torch.Tensor, warmstart: torch.Tensor | None, n: int, out: torch.Tensor | None = None,
                  sensors: torch.Tensor | None = None) -> torch.Tensor:

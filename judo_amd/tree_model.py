@@ -2,9 +2,11 @@
 
 Structure accepted (the Spot model, judo/models/xml/spot_primitive/robot.xml): one free base body; serial chains of hinge joints hanging
 off the base (4 legs x 3, one arm x 7), one body per joint, joint anchors at the body origins; position servos with ctrl and force
-ranges; friction loss and limits on every joint; sphere / capsule / box collision geoms against ONE static plane (robot self-collision
-pairs are not generated this round, as in the oracle); pyramidal cones.  Contact parameters are mixed on the host: the plane has the
-higher priority in the shipped model, so its friction / solref / solimp apply (mj_contactParam).
+ranges; friction loss and limits on every joint; sphere / capsule / box collision geoms against ONE static plane and against each other -- the
+robot-robot geom pairs MuJoCo's static filters leave (same body, parent-child, the <exclude> pairs of spot_primitive/contact.xml:4-14; 287 for Spot) are
+listed in the image; pyramidal cones.  Contact parameters are mixed on the host: the plane has the higher priority in the shipped model, so its
+friction / solref / solimp apply to plane contacts (mj_contactParam); the robot geoms all carry the same solref / solimp / priority (checked), so a
+robot-robot pair takes the larger of the two frictions and the stored solref / solimp.
 
 Float image F / int image I (little-endian fp32 / int32), see the enums at the top of jh_engine_v4.hip.
 """
@@ -59,6 +61,26 @@ def tree_structure(desc: dict) -> dict:
     return dict(layout=lay, base=base, hinges=hinges, body_of=body_of, info=info)
 
 
+def robot_pairs(desc: dict, robot_geoms: list) -> list[tuple[int, int]]:
+    """Robot-robot geom pairs (indices into `robot_geoms`, g1 < g2) after MuJoCo's static filters: not on the same body, not parent and child, not excluded."""
+    bodies, geoms = desc["bodies"], desc["geoms"]
+    excl = {tuple(sorted(e)) for e in desc.get("excludes", [])}
+    pairs = []
+    for i, ga in enumerate(robot_geoms):
+        for j in range(i + 1, len(robot_geoms)):
+            gb = robot_geoms[j]
+            b1, b2 = ga["body"], gb["body"]
+            if b1 == b2 or tuple(sorted((b1, b2))) in excl or bodies[b1]["parent"] == b2 or bodies[b2]["parent"] == b1:
+                continue
+            pairs.append((i, j))
+    return pairs
+
+
+def bounding_radius(g: dict) -> float:
+    size = list(g["size"]) + [0, 0, 0]
+    return {"sphere": size[0], "capsule": size[0] + size[1], "box": float(np.linalg.norm(size[:3]))}[g["type"]]
+
+
 def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
     st = tree_structure(desc)
     lay, base, hinges, body_of, info = st["layout"], st["base"], st["hinges"], st["body_of"], st["info"]
@@ -82,8 +104,16 @@ def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
         raise NotImplementedError("tree kernel: at most one unit-gear position servo per joint")
 
     sensors = desc.get("sensors", [])
+    pairs = robot_pairs(desc, robot_geoms)
+    if pairs:
+        ref = robot_geoms[0]
+        for g in robot_geoms:  # one set of mixing inputs for every robot-robot pair (see the module docstring)
+            if list(g["solref"]) != list(ref["solref"]) or list(g["solimp"]) != list(ref["solimp"]) or g.get("priority", 0) != ref.get("priority", 0) or g.get("solmix", 1.0) != ref.get("solmix", 1.0):
+                raise NotImplementedError("tree kernel: robot geoms with different solref / solimp / priority / solmix")
+        if np.abs(bodyw[plane["body"]]).max() != 0:
+            raise NotImplementedError("tree kernel: the plane must sit on a static body (zero inverse weight)")
     F = np.zeros(TH_F + nj * TD_F + len(robot_geoms) * TG_F + len(sensors) * TS_F, dtype=np.float32)
-    I = np.zeros(TH_I + nj * TD_I + len(robot_geoms) * TG_I + len(sensors) * TS_I, dtype=np.int32)
+    I = np.zeros(TH_I + nj * TD_I + len(robot_geoms) * TG_I + len(sensors) * TS_I + len(pairs), dtype=np.int32)
     bb = bodies[base]
     F[0:8] = [o["timestep"], o["impratio"], SOLVER_TOL, SOLVER_MAX_ITER, SOLVER_LS_TOL, *o["gravity"]]
     F[8:14] = [*ppos, *Rp[:, 2]]                       # plane point, plane normal
@@ -150,6 +180,12 @@ def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
         f[16:18] = [cK, cB]
         f[18:23] = clamp_solimp(solimp)
         f[23] = bodyw[gb][0] + bodyw[plane["body"]][0]   # diagApprox: translational inverse weights of both bodies
+        f[24] = bounding_radius(g)                       # mj_collideGeoms' bounding-sphere filter of the robot-robot pairs
+        f[25] = max(1e-5, g["friction"][0])              # the geom's own friction (robot-robot: the larger of the two)
+        if pairs:  # a robot-robot pair mixes two equal sets: solref / solimp as stored require the plane's to equal the robot's own, or the plane not to win
+            own_k, own_b = solref_to_kb(g["solref"], g["solimp"], o["timestep"])
+            if not (np.isclose(own_k, cK) and np.isclose(own_b, cB) and np.allclose(clamp_solimp(g["solimp"]), clamp_solimp(solimp))):
+                raise NotImplementedError("tree kernel: robot-robot pairs need the robot geoms' own solref / solimp to equal the plane-mixed ones")
         I[og_i + gi * TG_I: og_i + (gi + 1) * TG_I] = [owner, GTYPE[g["type"]]]
     # sensors: site positions (optionally in the frame of a world-fixed reference site) and site frame axes, as the Spot models declare them
     os_f, os_i = og_f + len(robot_geoms) * TG_F, og_i + len(robot_geoms) * TG_I
@@ -190,6 +226,10 @@ def pack_tree_model(desc: dict) -> tuple[np.ndarray, np.ndarray]:
         I[os_i + k * TS_I: os_i + (k + 1) * TS_I] = [kind, owner, sn["adr"], has_ref]
         nsd += 3
     I[4:6] = [len(sensors), nsd]
+    op = os_i + len(sensors) * TS_I
+    I[6:8] = [len(pairs), op]
+    for k, (a, b) in enumerate(pairs):
+        I[op + k] = a | (b << 8)
     return F, I
 
 

@@ -26,7 +26,8 @@ def spot(gpu):
     from judo_amd.policy import SpotTreeEngine
     from oracle import policy as P
 
-    return P, P.spot_model(), SpotTreeEngine()
+    # both sides model the robot's own contact pairs, as the reference's model does (spot_primitive/contact.xml; the engine's default since round 5)
+    return P, P.spot_model(self_collision=True), SpotTreeEngine()
 
 
 def _oracle_steps(om, X, U, k, with_sensors=False):
@@ -95,6 +96,89 @@ def test_tree_substeps_match_oracle(spot, case):
     np.testing.assert_allclose(sens.cpu().numpy(), sref, rtol=0, atol=1.5e-6)
     with pytest.raises(ValueError):
         eng.substeps(xs, us, None, 1, sensors=sens[:, :47].contiguous())
+
+
+def _self_collision_states(P, om, n_want, seed):
+    """States in the air (no ground contact) whose random joint configuration makes the robot touch itself, classified by what the contacts couple: the base and one
+    chain (arm or leg against the body), one chain with itself (forearm against shoulder), two different chains (leg against leg, arm against leg)."""
+    from judo_amd.models import load_description
+    from judo_amd.tree_model import tree_structure
+
+    desc = load_description("spot")
+    st = tree_structure(desc)
+    gs, hinges = desc["geoms"], [j for j in desc["joints"] if j["type"] != "free"]
+    lo = np.array([j["range"][0] for j in hinges]) + 0.02
+    hi = np.array([j["range"][1] for j in hinges]) - 0.02
+
+    def chain(g):
+        b = gs[g]["body"]
+        if b not in st["body_of"]:
+            return 0
+        c0 = st["info"][st["body_of"][b]]["start"]
+        return 1 + (c0 // 3 if c0 < 12 else 4)
+
+    rng = np.random.default_rng(seed)
+    x0 = P.spot_reset_state()
+    out = {"base": [], "same": [], "legleg": [], "armleg": []}
+    for _ in range(6000):
+        if all(len(v) >= n_want for v in out.values()):
+            break
+        x = x0.copy()
+        x[2] = 1.0
+        x[7:26] = np.clip(x0[7:26] + rng.standard_normal(19) * rng.choice([0.3, 0.8, 1.5]), lo, hi)
+        x[26:] = rng.standard_normal(25) * 0.2
+        f = om.forward(x[:26], x[26:], x[7:26])
+        if f["ncon"] == 0 or f["ncon"] > 12 or f["contacts"][:, 0].min() < -0.02:
+            continue  # (deep interpenetration of a random pose: stiff, and nothing a rollout visits)
+        kinds = set()
+        for c in f["contacts"]:
+            c1, c2 = chain(int(c[13])), chain(int(c[14]))
+            kinds.add("base" if 0 in (c1, c2) else ("same" if c1 == c2 else ("armleg" if 5 in (c1, c2) else "legleg")))
+        for k in kinds:
+            if len(out[k]) < n_want:
+                out[k].append(x)
+    return out
+
+
+def test_robot_self_collision_matches_oracle(spot):
+    """The robot against itself (spot_primitive/contact.xml:4-14; System::rollout's mj_step, system_class.cpp:286-330): states whose contacts couple the base with a chain,
+    a chain with itself and -- the case that breaks the tree structure of the Hessian (dense factorisation in the kernel) -- two different chains, against the oracle
+    with the same 287 robot-robot pairs: one step, then several."""
+    import torch
+
+    P, om, eng = spot
+    assert eng.self_collision
+    groups = _self_collision_states(P, om, 6, seed=5)
+    assert all(len(v) >= 4 for v in groups.values()), {k: len(v) for k, v in groups.items()}
+    for kind, xs in groups.items():
+        X = np.stack(xs)
+        U = X[:, 7:26].copy()
+        xt = torch.as_tensor(X, dtype=torch.float32, device="cuda")
+        ut = torch.as_tensor(U, dtype=torch.float32, device="cuda")
+        eng.stats()
+        for k in (1, 3):
+            warm = torch.zeros((len(X), 25), dtype=torch.float32, device="cuda")
+            got = eng.substeps(xt, ut, warm, k).cpu().numpy()
+            ref = _oracle_steps(om, X, U, k)
+            assert np.isfinite(got).all()
+            e = np.abs(got - ref)
+            # velocities after a step through stiff robot-robot contacts (fp32 against fp64); positions follow with the time step
+            assert bounded(f"self-collision {kind}, {k} steps: joint velocity error, max", e[:, 32:].max(), 5e-2)
+            assert bounded(f"self-collision {kind}, {k} steps: base velocity error, max", e[:, 26:32].max(), 2e-2)
+            assert bounded(f"self-collision {kind}, {k} steps: position error, max", e[:, :26].max(), 1e-3)
+            assert bounded(f"self-collision {kind}, {k} steps: joint velocity error, median", np.median(e[:, 32:]), 1e-4)
+        st = eng.stats()
+        assert st["contacts_dropped"] == 0 and st["steps_at_cap"] <= 1, (kind, st)
+    # the contacts matter: without them the same states move differently (the test above is not vacuous)
+    from judo_amd.policy import SpotTreeEngine
+
+    eng0 = SpotTreeEngine(self_collision=False)
+    X = np.stack(groups["legleg"])
+    xt = torch.as_tensor(X, dtype=torch.float32, device="cuda")
+    ut = torch.as_tensor(X[:, 7:26].copy(), dtype=torch.float32, device="cuda")
+    a = eng.substeps(xt, ut, None, 1).cpu().numpy()
+    b = eng0.substeps(xt, ut, None, 1).cpu().numpy()
+    assert np.abs(a[:, 32:] - b[:, 32:]).max() > 0.05
 
 
 def test_policy_rollout_backend_matches_oracle(spot):

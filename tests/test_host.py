@@ -394,8 +394,17 @@ def test_tree_model_image():
     assert (nj, ng, int(I[2]), int(I[3])) == (19, 27, 26, 25)
     nsen, nsd = int(I[4]), int(I[5])
     assert (nsen, nsd) == (16, 48)
-    assert F.size == TH_F + nj * TD_F + ng * TG_F + nsen * TS_F and I.size == TH_I + nj * TD_I + ng * TG_I + nsen * TS_I and F.dtype == np.float32 and I.dtype == np.int32
-    srec = I[TH_I + nj * TD_I + ng * TG_I :].reshape(nsen, TS_I)
+    npair, opair = int(I[6]), int(I[7])
+    assert F.size == TH_F + nj * TD_F + ng * TG_F + nsen * TS_F and I.size == TH_I + nj * TD_I + ng * TG_I + nsen * TS_I + npair and F.dtype == np.float32 and I.dtype == np.int32
+    # the robot against itself: the 287 geom pairs MuJoCo's static filters and the 11 excludes of spot_primitive/contact.xml leave, g1 | g2 << 8 with g1 < g2, behind the sensor records
+    assert npair == 287 and opair == TH_I + nj * TD_I + ng * TG_I + nsen * TS_I
+    pk = I[opair : opair + npair]
+    assert ((pk & 255) < (pk >> 8)).all() and (pk >> 8).max() < ng and len(set(pk.tolist())) == npair
+    from oracle import oracle as O
+    plane = next(i for i, g in enumerate(desc["geoms"]) if g["type"] == "plane")
+    assert plane == ng  # (robot geom indices = the description's: the plane comes last)
+    assert {(int(p) & 255, int(p) >> 8) for p in pk} == {p for p in O.collision_pairs(desc, scope="all") if plane not in p}
+    srec = I[TH_I + nj * TD_I + ng * TG_I : opair].reshape(nsen, TS_I)
     assert list(srec[:, 2]) == list(range(0, 48, 3)) and set(srec[:, 0]) == {0, 1, 2, 3} and srec[0, 3] == 1 and (srec[2:4, 1] == -2).all()   # object axes sit on a world-fixed site
     assert abs(F[0] - 0.01) < 1e-9 and np.allclose(F[11:14], [0, 0, 1]) and np.allclose(F[5:8], [0, 0, -9.81])
     M, _ = models.mass_matrix(desc, models.qpos0(desc))
