@@ -40,7 +40,7 @@ WORKLOADS = {
     "spot_navigate": ("mppi", 65536, 100),
 }
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = "r04_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"
 
 
 def usable_cpus() -> int:

@@ -163,10 +163,10 @@ def test_robot_self_collision_matches_oracle(spot):
             assert np.isfinite(got).all()
             e = np.abs(got - ref)
             # velocities after a step through stiff robot-robot contacts (fp32 against fp64); positions follow with the time step
-            assert bounded(f"self-collision {kind}, {k} steps: joint velocity error, max", e[:, 32:].max(), 5e-2)
-            assert bounded(f"self-collision {kind}, {k} steps: base velocity error, max", e[:, 26:32].max(), 2e-2)
-            assert bounded(f"self-collision {kind}, {k} steps: position error, max", e[:, :26].max(), 1e-3)
-            assert bounded(f"self-collision {kind}, {k} steps: joint velocity error, median", np.median(e[:, 32:]), 1e-4)
+            assert bounded(f"self-collision {kind}, {k} steps: joint velocity error, max", e[:, 32:].max(), 2.5e-4)  # observed <= 5.0e-5 over the four kinds
+            assert bounded(f"self-collision {kind}, {k} steps: base velocity error, max", e[:, 26:32].max(), 2.5e-5)  # observed <= 4.8e-6
+            assert bounded(f"self-collision {kind}, {k} steps: position error, max", e[:, :26].max(), 6e-6)  # observed <= 1.2e-6
+            assert bounded(f"self-collision {kind}, {k} steps: joint velocity error, median", np.median(e[:, 32:]), 1e-6)  # observed <= 1.7e-7
         st = eng.stats()
         assert st["contacts_dropped"] == 0 and st["steps_at_cap"] <= 1, (kind, st)
     # the contacts matter: without them the same states move differently (the test above is not vacuous)
@@ -351,7 +351,11 @@ def test_tree_kernel_survives_falls(spot):
     got = xs.cpu().numpy()
     st = eng.stats()
     assert np.isfinite(got).all()
-    assert got[:, 2].min() > 0.02 and bounded("got[:, 2].max()", got[:, 2].max(), 3.0)  # nothing tunnels through the plane, nothing is shot into the sky
+    # nothing tunnels through the plane, nothing is shot into the sky -- except by its own doing: the random joint offsets start a fifth of the robots with the arm 5-10 cm INSIDE the
+    # body (robot-robot pairs collide since round 5), and the oracle launches those just the same (two of the 512 above 3 m)
+    deep = np.array([(lambda f: f["ncon"] > 0 and any(c[13] != 27 and c[14] != 27 and c[0] < -0.05 for c in f["contacts"]))(om.forward(x[:26], x[26:], P.DEFAULT_JOINT_POS)) for x in X])
+    assert 0 < deep.sum() < N // 4  # (95 of 512)
+    assert got[:, 2].min() > 0.02 and bounded("got[~deep, 2].max()", got[~deep, 2].max(), 3.0)
     assert bounded("np.abs(got[:, 26:]).max()", np.abs(got[:, 26:]).max(), 50.0)
     assert st["steps"] == N * 100 and st["contacts_dropped"] < 0.01 * st["steps"], st
     # one of them against the oracle for a few steps (a tumbling robot is chaotic: short horizon, loose tolerance)
