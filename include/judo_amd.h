@@ -65,23 +65,7 @@ int jh_model_dims(const jh_model* m, int* dims /* HOST */);
  * the LDS pool holds), out[7] reserved (0).  The counters are 32-bit and wrap: reset them at least every ~10^9 rollout-steps.  HOST pointer. */
 int jh_model_stats(jh_model* m, int* out /* HOST, 8 ints */, int reset);
 
-/* Articulated-body engine kernel generation for this model: 3 (default, the only one in this library) = cooperative kernel on a register diet, two waves per
- * SIMD (leap_cube: hand self-collision, jh_engine_v5.hip; fr3_pick: matrix-free contact Jacobian, jh_engine_v6.hip); 2 = the cooperative kernels of round 1 / 2,
- * one wave per SIMD; 1 = one lane per rollout, an independent second implementation -- both only after jh_register_xcheck (test builds).  "leap_cube" is the model family: leap_cube, leap_cube_down
- * and caltech_leap_cube (the last one only on generation 3: its sensor layout and static-geometry groups exist there alone). */
-int jh_model_set_kernel(jh_model* m, int generation);
-
-/* Kernel generations 1 and 2 are cross-check implementations for the parity tests and are NOT part of this library: they live in the test-only
- * libjudo_amd_xcheck.so (built next to the tests), which hands its launchers to this library when it is loaded.  Until then jh_model_set_kernel(m, 1 | 2)
- * returns JH_ERR_UNSUPPORTED.  `generation` is passed through to the launchers; `max_knots` is the LDS staging limit of the one-lane kernel. */
-typedef struct jh_xcheck_launchers {
-  int (*rollout_cost)(const jh_model* m, int generation, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W,
-                      const float* ctrl_lo_hi, const float* task_params, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, void* stream);
-  int (*rollout_materialize)(const jh_model* m, int generation, const float* x0, int x0_batched, const float* controls, int N, int H, float* states, float* sensors,
-                             void* stream);
-  int (*max_knots)(const jh_model* m, int H);
-} jh_xcheck_launchers;
-int jh_register_xcheck(const jh_xcheck_launchers* launchers);
+/* (The cross-check kernel generations of the parity tests and their registration hook are NOT part of this interface: include/judo_amd_xcheck.h.) */
 
 /* leap_cube on kernel generation 3: model the hand's own contacts (every finger-finger / finger-palm geom pair MuJoCo's filters leave: same welded body,
  * parent-child, the 18 <exclude> pairs of leap_components/params_and_default.xml:76-101) next to the cube's -- the default, MuJoCo collides them -- or,

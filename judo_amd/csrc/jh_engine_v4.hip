@@ -57,6 +57,7 @@ __host__ __device__ constexpr int CL(int c) { return c < 4 ? 3 : 7; }
 constexpr int SF_MAX = 2048, SI_MAX = 160, LBW = 28;
 constexpr int NX2 = 8;       // contacts between two different chains a rollout can hold per step (their second chain block lives in RS4::J2)
 constexpr int MAXHIT4 = 64;  // robot-robot geom pairs that survive the broad phase, per rollout and step
+constexpr int MAXPP = 9;     // robot-robot geom pairs per lane (32 lanes: 288 pairs; Spot has 287): the lane's share of the pair list is read once per launch and kept in registers
 
 template <bool SELF>
 struct __attribute__((aligned(16))) RS4T {  // per-rollout shared state; positions are relative to the base origin
@@ -75,7 +76,7 @@ struct __attribute__((aligned(16))) RS4T {  // per-rollout shared state; positio
   float fW[NCP][12];                      // contact frame (9) while the rows are built; then force [0..2] and the 3x3 weight [4..9] of the current Newton iterate
   union {
     float M[NVT][NVT]; float J[NCP][JW];  // the inertia lives in LDS only until every lane has its row in registers (25*25 < 32*44)
-    struct { float gc[G][4]; int hits[MAXHIT4]; } col;  // robot-robot broad phase (between the inertia rows and the Jacobian): geom centres + bounding radii, surviving pairs
+    struct { float gc[G][4]; float bx[G][12]; int hits[MAXHIT4]; } col;  // robot-robot broad phase (between the inertia rows and the Jacobian): geom centres + bounding radii, world poses of the box geoms (rotation 9, centre 3), surviving pairs
   };
   float J2[SELF ? NX2 : 1][24];              // second chain block (7 x 3, padded) of the contacts between two chains
   int cinfo[SELF ? NCP : 1];                 // per contact: chain / depth of both sides, cross index (decoded by cinfo_* below)
@@ -457,6 +458,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
   }
   const float u = hasact ? ctrl[(size_t)nc * NJ + k] : 0.f;
   int n_iters = 0, n_maxed = 0;
+  int pkr[MAXPP];  // this lane's robot-robot pairs (pair 32 i + l), -1 beyond the list: nine L2 round trips per LAUNCH instead of nine per step
+#pragma unroll
+  for (int i = 0; i < MAXPP; i++) pkr[i] = (SELF && 32 * i + l < npair) ? gI[oPair + 32 * i + l] : -1;
   PH_DECL
 
   for (int step = 0; step < substeps; step++) {
@@ -695,6 +699,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       }
     }
     if constexpr (SELF) {
+      PH(3)
       // ================================================================ the robot against itself: bounding spheres of the 287 pairs, survivors one per lane
       auto geom_pose = [&](int g, float* gp, float* gR) __attribute__((always_inline)) {
         const float* gf = sF + oGF + g * TG_F; const int owner = sI[oGI + g * TG_I]; const int gb = owner < 0 ? 0 : 1 + owner;
@@ -705,14 +710,15 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (l < ng) {
         float gp[3], gR[9]; geom_pose(l, gp, gR);
         S.col.gc[l][0] = gp[0]; S.col.gc[l][1] = gp[1]; S.col.gc[l][2] = gp[2]; S.col.gc[l][3] = sF[oGF + l * TG_F + GF4_RBOUND];
+        if (sI[oGI + l * TG_I + 1] == 6) { for (int i = 0; i < 9; i++) S.col.bx[l][i] = gR[i]; }  // (a box's pose once per step, not once per pair that names it)
       }
       __syncthreads();
       int nh = 0;
-      for (int base = 0; base < npair; base += G) {
-        const int pi = base + l;
-        bool hit = false; int pk = 0;
-        if (pi < npair) {
-          pk = gI[oPair + pi];
+#pragma unroll
+      for (int ip = 0; ip < MAXPP; ip++) {
+        if (32 * ip >= npair) break;
+        bool hit = false; const int pk = pkr[ip];
+        if (pk >= 0) {
           const int g1 = pk & 255, g2 = pk >> 8;
           const float* c1 = S.col.gc[g1]; const float* c2 = S.col.gc[g2];
           const float d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}, rs = c1[3] + c2[3];
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           for (int sd = 0; sd < 2; sd++) {
             const int gb_ = sd == 0 ? g1 : g2; const float* co = sd == 0 ? c2 : c1;
             if (hit && sI[oGI + gb_ * TG_I + 1] == 6) {
-              float bp[3], bRm[9]; geom_pose(gb_, bp, bRm);
+              const float* bp = S.col.gc[gb_]; const float* bRm = S.col.bx[gb_];
               const float dw[3] = {co[0] - bp[0], co[1] - bp[1], co[2] - bp[2]}; float dl[3]; mulMTV(dl, bRm, dw);
               const float* hs = sF + oGF + gb_ * TG_F + GF4_SIZE;
               const float ex = fmaxf(fabsf(dl[0]) - hs[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hs[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hs[2], 0.f);
@@ -737,6 +743,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       }
       if (nh > MAXHIT4) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT4); nh = MAXHIT4; }  // (candidate pairs lost: counted with the dropped contacts)
       __syncthreads();
+      PH(14)
       // narrow phase (MuJoCo's primitives, restated in oracle/jo_engine.c collide_geoms): the normal points from geom 1 to geom 2 of the pair
       struct SelfSink {
         RS* S; int* stats; int pk; bool flip;
@@ -806,6 +813,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           }
         }
       }
+      PH(15)
     }
     __syncthreads();
     // ================================================================ constraint rows
@@ -1140,6 +1148,7 @@ extern "C" int jh_tree_create(const void* blob, size_t nbytes, jh_tree** out) {
   JH_REQUIRE(ii[4] >= 0 && ii[4] <= G && ii[6] >= 0 && nf == (size_t)(TH_F + ii[0] * TD_F + ii[1] * TG_F + ii[4] * TS_F) &&
              ni == (size_t)(TH_I + ii[0] * TD_I + ii[1] * TG_I + ii[4] * TS_I + ii[6]) && (ii[6] == 0 || ii[7] == TH_I + ii[0] * TD_I + ii[1] * TG_I + ii[4] * TS_I),
              "tree_create: image sizes do not match the counts in its header (or more than 32 sensors)");
+  JH_REQUIRE(ii[6] <= MAXPP * G, "tree_create: %d robot-robot geom pairs, the kernel holds %d", ii[6], MAXPP * G);
   for (int p = 0; p < ii[6]; p++) {  // robot-robot geom pairs: g1 | g2 << 8 with g1 < g2 < number of geoms
     const int pk = ii[ii[7] + p], g1 = pk & 255, g2 = pk >> 8;
     JH_REQUIRE(g1 < g2 && g2 < ii[1], "tree_create: bad geom pair %d (%d, %d)", p, g1, g2);
@@ -1176,10 +1185,12 @@ extern "C" int jh_tree_stats(jh_tree* t, int* out4, int reset) {
     unsigned long long ph[16]; double tot = 0;
     JH_HIP(hipMemcpy(ph, t->d_stats + 8, sizeof(ph), hipMemcpyDeviceToHost));
     for (int i = 0; i < 10; i++) tot += (double)ph[i];
+    tot += (double)ph[14] + (double)ph[15];
     const char* nm[10] = {"kinematics", "inertia+bias", "a0 solve", "collision+rows", "warm/step", "gradient", "hessian", "factor", "linesearch", "integrate"};
     for (int i = 0; i < 10; i++) fprintf(stderr, "  phase %-15s %6.2f%%  %.0f cycles/step/wave\n", nm[i], 100.0 * ph[i] / (tot > 0 ? tot : 1), out4[3] ? 2.0 * ph[i] / out4[3] : 0.0);
     const char* sn[4] = {"chain blocks", "base rows+schur", "reduced system", "chain backsub"};
     for (int i = 0; i < 4; i++) fprintf(stderr, "    solve: %-15s %.0f cycles/step/wave\n", sn[i], out4[3] ? 2.0 * ph[10 + i] / out4[3] : 0.0);
+    fprintf(stderr, "    robot-robot broad phase %.0f, narrow phase %.0f cycles/step/wave (inside collision+rows)\n", out4[3] ? 2.0 * ph[14] / out4[3] : 0.0, out4[3] ? 2.0 * ph[15] / out4[3] : 0.0);
   }
 #endif
   if (reset) JH_HIP(hipMemset(t->d_stats, 0, 64 * sizeof(int)));

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "judo_amd.h"
+#include "judo_amd_xcheck.h"  // (the test-build hooks: the cross-check kernel generations register through them)
 
 #define JH_BLOB_MAGIC 0x314D484Au /* "JHM1" */
 #define JH_BLOB_VERSION 1u

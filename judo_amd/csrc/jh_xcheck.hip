@@ -3,7 +3,7 @@
 // Generation 1 (jh_engine.hip: one lane per rollout, model-generic, the independent second GPU implementation of the articulated step) and generation 2
 // (jh_engine_v2.hip / jh_engine_v3.hip: the cooperative kernels of rounds 1 and 2, one wave per SIMD) are what the parity tests compare the shipped kernels
 // with; the product library does not contain them.  Loading this library and calling jh_xcheck_register() installs their launchers
-// through jh_register_xcheck (include/judo_amd.h).
+// through jh_register_xcheck (include/judo_amd_xcheck.h).
 #include "jh_internal.h"
 
 static int xc_cost(const jh_model* m, int gen, const float* x0, const float* nominal, const float* noise, int ldn, const float* sigma, const float* W, const float* lohi,

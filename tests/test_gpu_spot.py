@@ -18,7 +18,7 @@ SL = dict(pos=slice(0, 3), quat=slice(3, 7), q=slice(7, 26), vlin=slice(26, 29),
 def _check(got, ref, scale=1.0):
     for name, sl in SL.items():
         err = np.abs(got[..., sl] - ref[..., sl]).max()
-        assert err <= TOL[name] * scale, f"{name}: {err:.3e} > {TOL[name] * scale:.1e}"
+        assert bounded(f"spot state error / scale: {name}", err / scale, TOL[name]), f"{name}: {err:.3e} > {TOL[name] * scale:.1e}"
 
 
 @pytest.fixture(scope="module")

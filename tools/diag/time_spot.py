@@ -9,6 +9,9 @@ from judo_amd.policy import PolicyRolloutBackend
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 be = PolicyRolloutBackend(N)
+if os.environ.get("SELF") == "0":  # the ground contacts only (rounds 1-4), for A/B
+    from judo_amd import _lib
+    _lib.check(_lib.lib().jh_tree_set_self_collision(be.engine.handle, 0), "jh_tree_set_self_collision")
 x0 = np.concatenate([[0, 0, ST.STANDING_HEIGHT, 1, 0, 0, 0], ST.LEGS_STANDING_POS_RL, ST.ARM_STOWED_POS, np.zeros(25)])
 DEFAULT_POLICY_COMMAND = np.concatenate([[0, 0, 0], ST.ARM_STOWED_POS, np.zeros(12), [0, 0, ST.STANDING_HEIGHT]])
 DEFAULT_JOINT_POS = np.array([0.12, 0.5, -1, -0.12, 0.5, -1, 0.12, 0.5, -1, -0.12, 0.5, -1, 0, -0.9, 1.8, 0, -0.9, 0, -1.54])
