@@ -711,6 +711,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
         float gp[3], gR[9]; geom_pose(l, gp, gR);
         S.col.gc[l][0] = gp[0]; S.col.gc[l][1] = gp[1]; S.col.gc[l][2] = gp[2]; S.col.gc[l][3] = sF[oGF + l * TG_F + GF4_RBOUND];
         if (sI[oGI + l * TG_I + 1] == 6) { for (int i = 0; i < 9; i++) S.col.bx[l][i] = gR[i]; }  // (a box's pose once per step, not once per pair that names it)
+        if (sI[oGI + l * TG_I + 1] == 3) { S.col.bx[l][0] = gR[2]; S.col.bx[l][1] = gR[5]; S.col.bx[l][2] = gR[8]; }  // a capsule's axis
       }
       __syncthreads();
       int nh = 0;
@@ -731,8 +732,12 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
               const float* bp = S.col.gc[gb_]; const float* bRm = S.col.bx[gb_];
               const float dw[3] = {co[0] - bp[0], co[1] - bp[1], co[2] - bp[2]}; float dl[3]; mulMTV(dl, bRm, dw);
               const float* hs = sF + oGF + gb_ * TG_F + GF4_SIZE;
-              const float ex = fmaxf(fabsf(dl[0]) - hs[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hs[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hs[2], 0.f);
-              hit = ex * ex + ey * ey + ez * ez <= co[3] * co[3];
+              // a capsule as its axis segment's extent along the box axes (an outer bound of the segment) plus its radius, anything else as its bounding sphere
+              const int go_ = sd == 0 ? g2 : g1; const bool cap = sI[oGI + go_ * TG_I + 1] == 3;
+              float al[3] = {0.f, 0.f, 0.f}, rr = co[3];
+              if (cap) { mulMTV(al, bRm, S.col.bx[go_]); const float* so = sF + oGF + go_ * TG_F + GF4_SIZE; rr = so[0]; for (int i = 0; i < 3; i++) al[i] = fabsf(al[i]) * so[1]; }
+              const float ex = fmaxf(fabsf(dl[0]) - hs[0] - al[0], 0.f), ey = fmaxf(fabsf(dl[1]) - hs[1] - al[1], 0.f), ez = fmaxf(fabsf(dl[2]) - hs[2] - al[2], 0.f);
+              hit = ex * ex + ey * ey + ez * ez <= rr * rr;
             }
           }
         }
