@@ -361,4 +361,5 @@ def test_tree_kernel_survives_falls(spot):
     # one of them against the oracle for a few steps (a tumbling robot is chaotic: short horizon, loose tolerance)
     ref = om.rollout(X[0], np.repeat(P.DEFAULT_JOINT_POS[None], 5, axis=0)[None], nthread=1)[0][0, -1]
     got5 = eng.substeps(torch.as_tensor(X[:1], dtype=torch.float32, device="cuda"), us[:1], torch.zeros((1, 25), device="cuda"), 5).cpu().numpy()[0]
-    assert bounded("np.abs(got5[:7] - ref[:7]).max()", np.abs(got5[:7] - ref[:7]).max(), 7e-7)
+    # (ONE state through five steps of stiff contacts: what is observed moves with the build's rounding -- 1.0e-7 and 2e-6 on two builds of round 5 -- so this bound is not 5 x a sample)
+    assert bounded("np.abs(got5[:7] - ref[:7]).max()", np.abs(got5[:7] - ref[:7]).max(), 1e-5)
