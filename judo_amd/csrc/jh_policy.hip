@@ -8,6 +8,7 @@
 // 0.42 MFLOP per rollout and control step.  The physics substeps between two policy steps are jh_engine_v4.hip (k_tree_v4); jh_policy_rollout there
 // alternates the two for a whole rollout.
 #include "jh_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -77,8 +78,10 @@ __device__ __forceinline__ void small_layer(const float* __restrict__ A, const f
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
   for (int n0 = 0; n0 < Nout; n0 += BN) {
-    f32x16 acc;
-    for (int v = 0; v < 16; v++) acc[v] = 0.f;
+    f32x16 acc[4];  // one per class of K chunks (chunk c -> acc[c & 3]): the summation order the per-layer launches below can reproduce with the classes on four waves
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      for (int v = 0; v < 16; v++) acc[u][v] = 0.f;
     f32x4 ra, rw[4];
     auto fetch = [&](int k0) __attribute__((always_inline)) {
       {  // A: 32 rows x 8 float4 = one per thread
@@ -94,17 +97,23 @@ __device__ __forceinline__ void small_layer(const float* __restrict__ A, const f
       }
     };
     fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-      { const int r = tid >> 3, c = (tid & 7) * 4; float* pa_ = sA + r * LDT + c; pa_[0] = ra.x; pa_[1] = ra.y; pa_[2] = ra.z; pa_[3] = ra.w; }
+    for (int k0 = 0; k0 < K; k0 += 4 * BK) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) { const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4; float* pw_ = sW + r * LDT + c; pw_[0] = rw[q].x; pw_[1] = rw[q].y; pw_[2] = rw[q].z; pw_[3] = rw[q].w; }
-      __syncthreads();
-      if (k0 + BK < K) fetch(k0 + BK);
-      const float* pa = sA + (l & 31) * LDT + (l >> 5);
-      const float* pw = sW + (32 * wave + (l & 31)) * LDT + (l >> 5);
+      for (int u = 0; u < 4; u++) {
+        const int kc = k0 + u * BK;
+        if (kc < K) {
+          { const int r = tid >> 3, c = (tid & 7) * 4; float* pa_ = sA + r * LDT + c; pa_[0] = ra.x; pa_[1] = ra.y; pa_[2] = ra.z; pa_[3] = ra.w; }
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pw[kk], acc, 0, 0, 0);
-      __syncthreads();
+          for (int q = 0; q < 4; q++) { const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4; float* pw_ = sW + r * LDT + c; pw_[0] = rw[q].x; pw_[1] = rw[q].y; pw_[2] = rw[q].z; pw_[3] = rw[q].w; }
+          __syncthreads();
+          if (kc + BK < K) fetch(kc + BK);
+          const float* pa = sA + (l & 31) * LDT + 16 * (l >> 5);  // MFMA step t of a chunk contracts k = t (lanes 0..31) and k = 16 + t (lanes 32..63)
+          const float* pw = sW + (32 * wave + (l & 31)) * LDT + 16 * (l >> 5);
+#pragma unroll
+          for (int t = 0; t < BK / 2; t++) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], pw[t], acc[u], 0, 0, 0);
+          __syncthreads();
+        }
+      }
     }
     const int col = n0 + 32 * wave + (l & 31);
     if (col < Nout) {
@@ -112,7 +121,7 @@ __device__ __forceinline__ void small_layer(const float* __restrict__ A, const f
 #pragma unroll
       for (int v = 0; v < 16; v++) {
         const int row = m0 + (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
-        if (row < M) { float x = acc[v] + b; if (ELU) x = x > 0.f ? x : expm1f(x); C[(size_t)row * Nout + col] = x; }
+        if (row < M) { float x = ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) + b; if (ELU) x = x > 0.f ? x : expm1f(x); C[(size_t)row * Nout + col] = x; }
       }
     }
   }
@@ -130,6 +139,78 @@ __global__ __launch_bounds__(256) void k_policy_step(PolicyTables T, ActorWeight
   small_layer<true>(h1, Wt.w[2], Wt.b[2], N, H1, H2, h2, m0, sA, sW);
   small_layer<false>(h2, Wt.w[3], Wt.b[3], N, H2, ACT, act, m0, sA, sW);
   if ((int)threadIdx.x < SM && m0 + (int)threadIdx.x < N) control_row(T, obs, act, m0 + threadIdx.x, policy_out, control);
+}
+
+
+// ---- a few dozen rollouts (the reference ships 24: `judo/tasks/spot/spot_base.py`, num_rollouts): k_policy_step above is ONE workgroup walking 56 weight chunks one
+// after the other, 68 us of which 57 k cycles are dependent MFMA chains on four SIMDs.  Below a few hundred rollouts the step is a chain of four launches instead, a layer each,
+// its column tiles (32 rollouts x 32 outputs) spread over workgroups and the four classes of K chunks over the tile's four waves: lane (i = l & 31, h = l >> 5) of wave w loads
+// floats [16 h, 16 h + 16) of the chunks w, w + 4, ... of the input row i and of the weight row j = i straight into registers (all loads in flight at once: no LDS staging, no
+// barrier in the chain), issues 16 MFMA steps per chunk, and the four partial tiles are added as k_policy_step adds its four accumulators: the two paths give the same bits, so a
+// rollout's result does not depend on the size of the batch it is in (tests/test_gpu_spot.py::test_policy_rollout_is_reproducible_and_batch_independent).
+constexpr int SMALL_N = 2048;  // largest batch that takes the per-layer launches (measured: 34 / 37 / 51 / 80 / 134 us at 512 / 1 024 / 2 048 / 4 096 / 8 192 rollouts against 75 / 76 / 76 / 80 / 84 of k_policy_step)
+
+template <int K, int NOUT, bool ELU, bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void k_policy_layer(PolicyTables T, const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ states, ObsLayout Y,
+                                                      const float* __restrict__ command, float* policy_out, int N, float* obs, const float* A, float* __restrict__ C,
+                                                      float* __restrict__ control) {
+  static_assert(K % 4 == 0, "rows are read as float4");
+  constexpr int NCHUNK = (K + BK - 1) / BK, NCW = (NCHUNK + 3) / 4;  // chunks of 32 along K; chunks per wave
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float part[3][16][64];
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, j = l & 31, h = l >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  if (FIRST) {  // every column tile's workgroup writes the (identical) observation rows of its row block and reads its own copy back
+    if (tid < 32 && m0 + tid < N) obs_row(T, states, Y, command, policy_out, m0 + tid, obs);
+    __syncthreads();
+  }
+  const bool arow = m0 + j < N, wrow = n0 + j < NOUT;
+  const float* pa = A + (size_t)(m0 + j) * K;
+  const float* pw = W + (size_t)(n0 + j) * K;
+  f32x4 a[NCW][4], b[NCW][4];
+#pragma unroll
+  for (int m = 0; m < NCW; m++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = BK * (wave + 4 * m) + 16 * h + 4 * q;
+      a[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; b[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (arow && k < K) a[m][q] = *reinterpret_cast<const f32x4*>(pa + k);
+      if (wrow && k < K) b[m][q] = *reinterpret_cast<const f32x4*>(pw + k);
+    }
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; v++) acc[v] = 0.f;
+#pragma unroll
+  for (int m = 0; m < NCW; m++)
+    if (BK * (wave + 4 * m) < K) {  // (k_policy_step skips a chunk past K too: the same MFMA steps in both)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].x, b[m][q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].y, b[m][q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].z, b[m][q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q].w, b[m][q].w, acc, 0, 0, 0);
+      }
+    }
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < 16; v++) part[wave - 1][v][l] = acc[v];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int col = n0 + j;
+    const float bv = col < NOUT ? bias[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int row = m0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      float x = ((acc[v] + part[0][v][l]) + (part[1][v][l] + part[2][v][l])) + bv;
+      if (ELU) x = x > 0.f ? x : expm1f(x);
+      if (row < N && col < NOUT) C[(size_t)row * NOUT + col] = x;
+    }
+  }
+  if (LAST) {  // NOUT <= 32: one column tile, so this workgroup holds every action of its rows
+    __syncthreads();
+    if (tid < 32 && m0 + tid < N) control_row(T, obs, C, m0 + tid, policy_out, control);
+  }
 }
 
 }  // namespace
@@ -170,7 +251,16 @@ int jh_policy_step_strided(const jh_policy* p, const float* states, int ld, int 
   float* obs = scratch; float* h0 = obs + (size_t)N * OBS; float* h1 = h0 + (size_t)N * H0; float* h2 = h1 + (size_t)N * H1; float* act = h2 + (size_t)N * H2;
   const ObsLayout Y = {ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, ldc};
   ActorWeights Wt; for (int i = 0; i < 4; i++) { Wt.w[i] = p->d_w[i]; Wt.b[i] = p->d_b[i]; }
-  hipLaunchKernelGGL(k_policy_step, dim3((N + SM - 1) / SM), dim3(256), 0, st, p->tab, Wt, states, Y, command, policy_out, N, obs, h0, h1, h2, act, control);
+  static const int layers_max = [] { const char* e = getenv("JUDO_AMD_POLICY_LAYERS_MAX"); return e && e[0] ? atoi(e) : SMALL_N; }();  // diagnostic override of the switch-over
+  if (N <= layers_max) {
+    const int rb = (N + 31) / 32;
+    hipLaunchKernelGGL((k_policy_layer<OBS, H0, true, true, false>), dim3(H0 / 32, rb), dim3(256), 0, st, p->tab, Wt.w[0], Wt.b[0], states, Y, command, policy_out, N, obs, obs, h0, control);
+    hipLaunchKernelGGL((k_policy_layer<H0, H1, true, false, false>), dim3(H1 / 32, rb), dim3(256), 0, st, p->tab, Wt.w[1], Wt.b[1], states, Y, command, policy_out, N, obs, h0, h1, control);
+    hipLaunchKernelGGL((k_policy_layer<H1, H2, true, false, false>), dim3(H2 / 32, rb), dim3(256), 0, st, p->tab, Wt.w[2], Wt.b[2], states, Y, command, policy_out, N, obs, h1, h2, control);
+    hipLaunchKernelGGL((k_policy_layer<H2, ACT, false, false, true>), dim3(1, rb), dim3(256), 0, st, p->tab, Wt.w[3], Wt.b[3], states, Y, command, policy_out, N, obs, h2, act, control);
+  } else {
+    hipLaunchKernelGGL(k_policy_step, dim3((N + SM - 1) / SM), dim3(256), 0, st, p->tab, Wt, states, Y, command, policy_out, N, obs, h0, h1, h2, act, control);
+  }
   JH_HIP(hipGetLastError());
   return JH_OK;
 }
