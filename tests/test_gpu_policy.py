@@ -24,8 +24,8 @@ def test_policy_step_matches_golden_and_oracle(gpu):
     states = np.concatenate([g["step_qpos"], g["step_qvel"]], axis=1)
     ctrl, out = pol.step(states, g["step_command"], g["step_prev"], lay)
     np.testing.assert_allclose(pol.last_observation.cpu().numpy(), g["step_obs"], rtol=0, atol=2e-6)   # fp32 rotation of O(1) vectors
-    np.testing.assert_allclose(out, g["step_out"], rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(ctrl, g["step_ctrl"], rtol=1.4e-5, atol=7e-6)
+    np.testing.assert_allclose(out, g["step_out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ctrl, g["step_ctrl"], rtol=7e-6, atol=3.5e-6)
     # ragged batch sizes around the 32-row tiles and either side of the switch from per-layer launches to the fused launch (2 048 rollouts), torch tensors in / out:
     Ws, bs = P.load_actor()
     rng = np.random.default_rng(3)
@@ -38,8 +38,8 @@ def test_policy_step_matches_golden_and_oracle(gpu):
         st = torch.as_tensor(np.concatenate([qpos, qvel], 1), dtype=torch.float32, device="cuda")
         c2, o2 = pol.step(st, torch.as_tensor(cmd, dtype=torch.float32, device="cuda"), torch.as_tensor(prev, dtype=torch.float32, device="cuda"), lay)
         assert isinstance(c2, torch.Tensor) and c2.shape == (N, 19) and o2.shape == (N, 12)
-        np.testing.assert_allclose(o2.cpu().numpy(), out_ref, rtol=0.0001, atol=0.0001)
-        np.testing.assert_allclose(c2.cpu().numpy(), ctrl_ref, rtol=3e-5, atol=1.5e-5)
+        np.testing.assert_allclose(o2.cpu().numpy(), out_ref, rtol=5e-5, atol=5e-5)
+        np.testing.assert_allclose(c2.cpu().numpy(), ctrl_ref, rtol=1.5e-5, atol=7.5e-6)
     with pytest.raises(ValueError):
         pol.step(states[:, :-1], g["step_command"], g["step_prev"], lay)
     with pytest.raises(ValueError):

@@ -199,7 +199,7 @@ def test_policy_rollout_backend_matches_oracle(spot):
     for i in range(N):
         ref, sref, o = P.policy_rollout(om, Ws, bs, x0, cmds[i], with_sensors=True)
         _check(states[i], ref, scale=10.0)   # 80 physics steps of a closed loop: fp32 differences feed back through the policy
-        np.testing.assert_allclose(sensors[i], sref, rtol=0, atol=6e-6)
+        np.testing.assert_allclose(sensors[i], sref, rtol=0, atol=2e-6)
         np.testing.assert_allclose(outs[i], o, atol=3.5e-5)
     assert abs(states[1, -1, 0] - 0.27) < 0.08 and abs(states[0, -1, 0]) < 0.02   # it walks forward when told to, stands otherwise
     # the reference keeps its mjData between control steps: carrying the warm start changes the result only at solver-tolerance level
