@@ -46,7 +46,7 @@ __device__ __forceinline__ void obs_row(const PolicyTables& T, const float* __re
   for (int i = 0; i < 12; i++) { o[19 + i] = cmd[10 + i]; o[72 + i] = prev_out[(size_t)n * ACT + i]; }
   for (int i = 0; i < NJ; i++) { o[34 + T.m2o[i]] = qpos[leg_qpos + i] - T.default_pos[i]; o[53 + T.m2o[i]] = qvel[leg_qvel + i]; }
 }
-constexpr int BN = 128, BK = 32, LDT = BK + 1;
+constexpr int SM = 32, BN = 128, BK = 32, LDT = BK + 4;  // row stride 36 floats: 16-byte rows, and eight lanes' float4 of eight consecutive rows cover the 32 banks
 
 __device__ __forceinline__ void control_row(const PolicyTables& T, const float* __restrict__ obs, const float* __restrict__ actions, int n,
                                             float* __restrict__ policy_out, float* __restrict__ control) {
@@ -64,53 +64,74 @@ __device__ __forceinline__ void control_row(const PolicyTables& T, const float* 
 }
 // ---- the whole policy step in ONE launch.  A workgroup (4 waves) takes 32 rollouts through the observation, the four layers and the control mapping.
 // C (32 x Nout) = act(A (32 x K) W^T + b), W (Nout x K) row-major (the ONNX Gemm layout with transB = 1): a layer's column tiles (32 x 128, one 32 x 32 MFMA
-// accumulator per wave) are walked one after the other, K in chunks of 32 staged in LDS with the next chunk's global loads in flight; the activations go through
-// the global scratch (L2-resident).  Operand map of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; result
-// register v of lane l is C[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31].
-// History: one launch per layer with 128 x 128 tiles (2 x 2 accumulators per wave) took 510 us at 65 536 rollouts and ~100 us at the 24 the reference ships (six
-// launches of mostly empty tiles); this kernel takes 380 us and 45 us.
+// accumulator per class of K chunks and wave) are walked one after the other, K in chunks of 32 through two LDS buffers (one barrier per chunk) with two more chunks in flight
+// from global memory in registers; the activations go through the global scratch (L2-resident).  Operand map of v_mfma_f32_32x32x2_f32: lane l supplies
+// A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; result register v of lane l is C[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31].
+// History: one launch per layer with 128 x 128 tiles (2 x 2 accumulators per wave) took 510 us at 65 536 rollouts; this kernel with one accumulator 380 us; with the four
+// accumulators that let the per-layer launches below reproduce its sums 428 us (two waves per SIMD instead of three), with the two-buffer pipeline 414 us = 59 TFLOP/s, 38 % of
+// the f32 MFMA peak: 2 048 workgroups each read all 830 KB of weights, 5.6 TB/s out of the L2.
 struct ActorWeights { const float* w[4]; const float* b[4]; };
-constexpr int SM = 32;
 
 template <bool ELU>
 __device__ __forceinline__ void small_layer(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias, int M, int K, int Nout,
-                                            float* __restrict__ C, int m0, float* sA, float* sW) {
+                                            float* __restrict__ C, int m0, float (*sA)[SM * LDT], float (*sW)[BN * LDT]) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+  const int NC = (K + BK - 1) / BK;  // chunks of 32 along K
   for (int n0 = 0; n0 < Nout; n0 += BN) {
     f32x16 acc[4];  // one per class of K chunks (chunk c -> acc[c & 3]): the summation order the per-layer launches below can reproduce with the classes on four waves
 #pragma unroll
     for (int u = 0; u < 4; u++)
       for (int v = 0; v < 16; v++) acc[u][v] = 0.f;
-    f32x4 ra, rw[4];
-    auto fetch = [&](int k0) __attribute__((always_inline)) {
+    // software pipeline: chunk c is contracted out of LDS buffer c & 1 while chunk c + 1 moves from registers to the other buffer and chunks c + 2, c + 3 are in flight from
+    // global memory (two register stages): one barrier per chunk
+    f32x4 ra[2], rw[2][4];
+    auto fetch = [&](int c, f32x4& fa, f32x4* fw) __attribute__((always_inline)) {
+      const int k = c * BK + (tid & 7) * 4;
       {  // A: 32 rows x 8 float4 = one per thread
-        const int r = tid >> 3, c = (tid & 7) * 4, k = k0 + c;
-        ra = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M && k < K) ra = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
+        const int r = tid >> 3;
+        fa = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M && k < K) fa = *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r) * K + k);
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {  // W: 128 rows x 8 float4 = four per thread
-        const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4, k = k0 + c;
-        rw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n0 + r < Nout && k < K) rw[q] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
+        const int r = (tid + 256 * q) >> 3;
+        fw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n0 + r < Nout && k < K) fw[q] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + k);
       }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += 4 * BK) {
+    auto stage = [&](int buf, const f32x4& fa, const f32x4* fw) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(sA[buf] + (tid >> 3) * LDT + (tid & 7) * 4) = fa;
+#pragma unroll
+      for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4*>(sW[buf] + ((tid + 256 * q) >> 3) * LDT + (tid & 7) * 4) = fw[q];
+    };
+    fetch(0, ra[0], rw[0]);
+    if (1 < NC) fetch(1, ra[1], rw[1]);
+    stage(0, ra[0], rw[0]);
+    if (2 < NC) fetch(2, ra[0], rw[0]);
+    __syncthreads();
+    for (int c0 = 0; c0 < NC; c0 += 4) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int kc = k0 + u * BK;
-        if (kc < K) {
-          { const int r = tid >> 3, c = (tid & 7) * 4; float* pa_ = sA + r * LDT + c; pa_[0] = ra.x; pa_[1] = ra.y; pa_[2] = ra.z; pa_[3] = ra.w; }
+        const int c = c0 + u;
+        if (c < NC) {
+          // MFMA step t of a chunk contracts k = t (lanes 0..31) and k = 16 + t (lanes 32..63): a lane's 16 operands are 64 contiguous bytes of its row
+          const f32x4* pa = reinterpret_cast<const f32x4*>(sA[u & 1] + (l & 31) * LDT + 16 * (l >> 5));
+          const f32x4* pw = reinterpret_cast<const f32x4*>(sW[u & 1] + (32 * wave + (l & 31)) * LDT + 16 * (l >> 5));
+          f32x4 oa[4], ow[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) { const int e = tid + 256 * q, r = e >> 3, c = (e & 7) * 4; float* pw_ = sW + r * LDT + c; pw_[0] = rw[q].x; pw_[1] = rw[q].y; pw_[2] = rw[q].z; pw_[3] = rw[q].w; }
-          __syncthreads();
-          if (kc + BK < K) fetch(kc + BK);
-          const float* pa = sA + (l & 31) * LDT + 16 * (l >> 5);  // MFMA step t of a chunk contracts k = t (lanes 0..31) and k = 16 + t (lanes 32..63)
-          const float* pw = sW + (32 * wave + (l & 31)) * LDT + 16 * (l >> 5);
+          for (int q = 0; q < 4; q++) { oa[q] = pa[q]; ow[q] = pw[q]; }
+          if (c + 1 < NC) {
+            stage((u + 1) & 1, ra[(u + 1) & 1], rw[(u + 1) & 1]);
+            if (c + 3 < NC) fetch(c + 3, ra[(u + 1) & 1], rw[(u + 1) & 1]);
+          }
 #pragma unroll
-          for (int t = 0; t < BK / 2; t++) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], pw[t], acc[u], 0, 0, 0);
+          for (int q = 0; q < 4; q++) {
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[q].x, ow[q].x, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[q].y, ow[q].y, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[q].z, ow[q].z, acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[q].w, ow[q].w, acc[u], 0, 0, 0);
+          }
           __syncthreads();
         }
       }
@@ -130,7 +151,7 @@ __device__ __forceinline__ void small_layer(const float* __restrict__ A, const f
 
 __global__ __launch_bounds__(256) void k_policy_step(PolicyTables T, ActorWeights Wt, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
                                                       float* policy_out, int N, float* obs, float* h0, float* h1, float* h2, float* act, float* __restrict__ control) {
-  __shared__ float sA[SM * LDT], sW[BN * LDT];
+  __shared__ __attribute__((aligned(16))) float sA[2][SM * LDT], sW[2][BN * LDT];
   const int m0 = blockIdx.x * SM;
   if ((int)threadIdx.x < SM && m0 + (int)threadIdx.x < N) obs_row(T, states, Y, command, policy_out, m0 + threadIdx.x, obs);
   __syncthreads();
