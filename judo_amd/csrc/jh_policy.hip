@@ -9,6 +9,7 @@
 // alternates the two for a whole rollout.
 #include "jh_internal.h"
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_policy_step(PolicyTables T, ActorWeight
 
 
 // ---- a few dozen rollouts (the reference ships 24: `judo/tasks/spot/spot_base.py`, num_rollouts): k_policy_step above is ONE workgroup walking 56 weight chunks one
-// after the other, 68 us of which 57 k cycles are dependent MFMA chains on four SIMDs.  Below a few hundred rollouts the step is a chain of four launches instead, a layer each,
+// after the other, 68 us of which 57 k cycles are dependent MFMA chains on four SIMDs.  From ROW_N (below) to SMALL_N rollouts the step is a chain of four launches instead, a layer each,
 // its column tiles (32 rollouts x 32 outputs) spread over workgroups and the four classes of K chunks over the tile's four waves: lane (i = l & 31, h = l >> 5) of wave w loads
 // floats [16 h, 16 h + 16) of the chunks w, w + 4, ... of the input row i and of the weight row j = i straight into registers (all loads in flight at once: no LDS staging, no
 // barrier in the chain), issues 16 MFMA steps per chunk, and the four partial tiles are added as k_policy_step adds its four accumulators: the two paths give the same bits, so a
@@ -234,9 +235,81 @@ __global__ __launch_bounds__(256) void k_policy_layer(PolicyTables T, const floa
   }
 }
 
+
+// ---- a few dozen to a few hundred rollouts (24 in the shipped Spot tasks): even four launches are mostly launch latency (4 x ~4 us of the 29).  Up to ROW_N rollouts the step is ONE launch of
+// one workgroup PER ROLLOUT (16 waves) on the vector ALUs: a thread owns one or two class sums of one output of a layer and evaluates them in k_policy_step's order -- chunk c of
+// 32 goes to class c & 3, inside a chunk the MFMA step t contracts k = t and then k = 16 + t, one fused multiply-add each, which is what v_mfma_f32_32x32x2_f32 does per output --
+// so the bits are those of the other two paths (the batch-independence test crosses all three).  The weights are read from a transposed copy ([k][output]: a wave's loads are
+// contiguous), the layer's input is broadcast out of LDS, the class sums of an output meet in LDS and are added in the same order.
+constexpr int ROW_N = 512;  // 16-17 us up to 256 rollouts (a workgroup per CU), 29 us at 512; the per-layer launches: 29-34 us
+
+template <int K, int NOUT, int NCLS, int U>  // a thread's share of output o: NCLS of the 4 classes from class cls0 on, summed in class order; U chunks per class in flight
+__device__ __forceinline__ float row_dot(const float* __restrict__ Wt, const float* x /* LDS, zero-padded to a multiple of 32 */, int o, int cls0) {
+  constexpr int NC = (K + BK - 1) / BK;
+  float acc[NCLS];
+#pragma unroll
+  for (int a = 0; a < NCLS; a++) acc[a] = 0.f;
+#pragma unroll 1
+  for (int c0 = 0; c0 < NC; c0 += 4 * U) {
+    float w[U][NCLS][BK];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int a = 0; a < NCLS; a++) {
+        const int c = c0 + 4 * u + cls0 + a;
+#pragma unroll
+        for (int q = 0; q < BK; q++) { const int k = c * BK + q; w[u][a][q] = (c < NC && k < K) ? Wt[(size_t)k * NOUT + o] : 0.f; }
+      }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int t = 0; t < BK / 2; t++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int a = 0; a < NCLS; a++) {
+            const int c = c0 + 4 * u + cls0 + a;
+            if (c < NC) acc[a] = __builtin_fmaf(x[c * BK + 16 * h + t], w[u][a][16 * h + t], acc[a]);
+          }
+  }
+  float r = acc[0];
+  if (NCLS == 2) r = acc[0] + acc[1];
+  if (NCLS == 4) r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  return r;
+}
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+constexpr int ROW_T = 1024;  // threads of a rollout's workgroup: (output, class) pairs of the widest layers
+__global__ __launch_bounds__(ROW_T) void k_policy_row(PolicyTables T, ActorWeights Wt /* transposed */, const float* __restrict__ states, ObsLayout Y, const float* __restrict__ command,
+                                                      float* policy_out, int N, float* obs, float* act, float* __restrict__ control) {
+  __shared__ float x0[96], x1[H0], x2[H1], x3[H2], part[ROW_T];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) obs_row(T, states, Y, command, policy_out, n, obs);
+  __syncthreads();
+  if (tid < 96) x0[tid] = tid < OBS ? obs[(size_t)n * OBS + tid] : 0.f;
+  __syncthreads();
+  part[tid] = row_dot<OBS, H0, 2, 1>(Wt.w[0], x0, tid & (H0 - 1), 2 * (tid >> 9));  // 512 outputs x 2 pairs of classes
+  __syncthreads();
+  if (tid < H0) x1[tid] = elu1((part[tid] + part[H0 + tid]) + Wt.b[0][tid]);
+  __syncthreads();
+  part[tid] = row_dot<H0, H1, 1, 2>(Wt.w[1], x1, tid & (H1 - 1), tid >> 8);  // 256 outputs x 4 classes
+  __syncthreads();
+  if (tid < H1) x2[tid] = elu1(((part[tid] + part[H1 + tid]) + (part[2 * H1 + tid] + part[3 * H1 + tid])) + Wt.b[1][tid]);
+  __syncthreads();
+  if (tid < 4 * H2) part[tid] = row_dot<H1, H2, 1, 2>(Wt.w[2], x2, tid & (H2 - 1), tid >> 7);  // 128 outputs x 4 classes
+  __syncthreads();
+  if (tid < H2) x3[tid] = elu1(((part[tid] + part[H2 + tid]) + (part[2 * H2 + tid] + part[3 * H2 + tid])) + Wt.b[2][tid]);
+  __syncthreads();
+  if (tid < 4 * ACT) part[tid] = row_dot<H2, ACT, 1, 1>(Wt.w[3], x3, tid >> 2, tid & 3);  // 12 outputs x 4 classes
+  __syncthreads();
+  if (tid < ACT) act[(size_t)n * ACT + tid] = ((part[4 * tid] + part[4 * tid + 1]) + (part[4 * tid + 2] + part[4 * tid + 3])) + Wt.b[3][tid];
+  __syncthreads();
+  if (tid == 0) control_row(T, obs, act, n, policy_out, control);
+}
+
 }  // namespace
 
-struct jh_policy { float* d_w[4]; float* d_b[4]; PolicyTables tab; };
+struct jh_policy { float* d_w[4]; float* d_wt[4]; float* d_b[4]; PolicyTables tab; };  // d_wt: the weights transposed ([in][out]) for k_policy_row
 
 extern "C" int jh_policy_create(const float* const* weights /* W0..W3, (out,in) row-major */, const float* const* biases, jh_policy** out) {
   JH_REQUIRE(weights && biases && out, "policy_create: null pointer");
@@ -247,6 +320,10 @@ extern "C" int jh_policy_create(const float* const* weights /* W0..W3, (out,in) 
     JH_HIP(hipMalloc(&p->d_w[i], sizeof(float) * dims[i] * dims[i + 1]));
     JH_HIP(hipMalloc(&p->d_b[i], sizeof(float) * dims[i + 1]));
     JH_HIP(hipMemcpy(p->d_w[i], weights[i], sizeof(float) * dims[i] * dims[i + 1], hipMemcpyHostToDevice));
+    std::vector<float> tr((size_t)dims[i] * dims[i + 1]);
+    for (int o = 0; o < dims[i + 1]; o++) for (int k = 0; k < dims[i]; k++) tr[(size_t)k * dims[i + 1] + o] = weights[i][(size_t)o * dims[i] + k];
+    JH_HIP(hipMalloc(&p->d_wt[i], sizeof(float) * tr.size()));
+    JH_HIP(hipMemcpy(p->d_wt[i], tr.data(), sizeof(float) * tr.size(), hipMemcpyHostToDevice));
     JH_HIP(hipMemcpy(p->d_b[i], biases[i], sizeof(float) * dims[i + 1], hipMemcpyHostToDevice));
   }
   const int m2o[NJ] = {1, 6, 11, 2, 7, 12, 3, 8, 13, 4, 9, 14, 0, 5, 10, 15, 16, 17, 18};
@@ -260,7 +337,7 @@ extern "C" int jh_policy_create(const float* const* weights /* W0..W3, (out,in) 
 
 extern "C" void jh_policy_destroy(jh_policy* p) {
   if (!p) return;
-  for (int i = 0; i < 4; i++) { (void)hipFree(p->d_w[i]); (void)hipFree(p->d_b[i]); }
+  for (int i = 0; i < 4; i++) { (void)hipFree(p->d_w[i]); (void)hipFree(p->d_wt[i]); (void)hipFree(p->d_b[i]); }
   delete p;
 }
 
@@ -273,7 +350,11 @@ int jh_policy_step_strided(const jh_policy* p, const float* states, int ld, int 
   const ObsLayout Y = {ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, ldc};
   ActorWeights Wt; for (int i = 0; i < 4; i++) { Wt.w[i] = p->d_w[i]; Wt.b[i] = p->d_b[i]; }
   static const int layers_max = [] { const char* e = getenv("JUDO_AMD_POLICY_LAYERS_MAX"); return e && e[0] ? atoi(e) : SMALL_N; }();  // diagnostic override of the switch-over
-  if (N <= layers_max) {
+  static const int rows_max = [] { const char* e = getenv("JUDO_AMD_POLICY_ROWS_MAX"); return e && e[0] ? atoi(e) : ROW_N; }();
+  if (N <= rows_max) {
+    ActorWeights Wr; for (int i = 0; i < 4; i++) { Wr.w[i] = p->d_wt[i]; Wr.b[i] = p->d_b[i]; }
+    hipLaunchKernelGGL(k_policy_row, dim3(N), dim3(ROW_T), 0, st, p->tab, Wr, states, Y, command, policy_out, N, obs, act, control);
+  } else if (N <= layers_max) {
     const int rb = (N + 31) / 32;
     hipLaunchKernelGGL((k_policy_layer<OBS, H0, true, true, false>), dim3(H0 / 32, rb), dim3(256), 0, st, p->tab, Wt.w[0], Wt.b[0], states, Y, command, policy_out, N, obs, obs, h0, control);
     hipLaunchKernelGGL((k_policy_layer<H0, H1, true, false, false>), dim3(H1 / 32, rb), dim3(256), 0, st, p->tab, Wt.w[1], Wt.b[1], states, Y, command, policy_out, N, obs, h0, h1, control);

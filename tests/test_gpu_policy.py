@@ -26,10 +26,10 @@ def test_policy_step_matches_golden_and_oracle(gpu):
     np.testing.assert_allclose(pol.last_observation.cpu().numpy(), g["step_obs"], rtol=0, atol=2e-6)   # fp32 rotation of O(1) vectors
     np.testing.assert_allclose(out, g["step_out"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ctrl, g["step_ctrl"], rtol=7e-6, atol=3.5e-6)
-    # ragged batch sizes around the 32-row tiles and either side of the switch from per-layer launches to the fused launch (2 048 rollouts), torch tensors in / out:
+    # ragged batch sizes around the 32-row tiles and either side of the switches between the three launch shapes (512 and 2 048 rollouts), torch tensors in / out:
     Ws, bs = P.load_actor()
     rng = np.random.default_rng(3)
-    for N in (1, 127, 129, 1000, 2048, 2049, 5000):
+    for N in (1, 127, 129, 512, 513, 1000, 2048, 2049, 5000):
         qpos = rng.standard_normal((N, nq)) * 0.3
         qpos[:, 3:7] = rng.standard_normal((N, 4)); qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
         qvel, cmd, prev = rng.standard_normal((N, nv)), rng.standard_normal((N, 25)) * 0.3, rng.standard_normal((N, 12))

@@ -252,12 +252,13 @@ def test_policy_rollout_is_reproducible_and_batch_independent(spot):
         else:
             os.environ.pop("JUDO_AMD_LATENCY_SHIFT", None)
     assert np.array_equal(d0, d1) and np.array_equal(d0, a[:n])
-    # the policy step's two paths (four per-layer launches up to 2 048 rollouts, one fused launch above: jh_policy.hip) sum in the same order: the same bits
-    Nb = 2100
-    reps = Nb // n + 1
-    be3 = PolicyRolloutBackend(Nb)
-    e, _, _ = be3.rollout(np.tile(X[:n], (reps, 1))[:Nb], np.tile(cmds[:n], (reps, 1, 1))[:Nb], np.zeros((Nb, 12)))
-    assert np.array_equal(e[:n], d0) and np.array_equal(e[n : 2 * n], d0)
+    # the policy step's three paths (jh_policy.hip: a workgroup per rollout up to 512 rollouts, four per-layer launches up to 2 048, one fused launch above) sum in the
+    # same order: the same bits
+    for Nb in (600, 2100):
+        reps = Nb // n + 1
+        be3 = PolicyRolloutBackend(Nb)
+        e, _, _ = be3.rollout(np.tile(X[:n], (reps, 1))[:Nb], np.tile(cmds[:n], (reps, 1, 1))[:Nb], np.zeros((Nb, 12)))
+        assert np.array_equal(e[:n], d0) and np.array_equal(e[n : 2 * n], d0), Nb
 
 
 def test_spot_navigate_controller_plans_through_the_policy_rollout(spot):
