@@ -16,6 +16,9 @@ __device__ __forceinline__ float dppf(float v) {
 template <int CTRL>
 __device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+// lane N of each DPP row to all 16 lanes of that row (row_newbcast:N, gfx90a and later): one VALU operand modifier, no LDS round trip
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) { return dppf<0x150 + N>(v); }
 
 // The sums must come out bit-identical in every lane of the group (the lanes of a rollout take the same branches on them, e.g. the
 // line-search step).  With -ffp-contract the compiler may fuse the multiply that produced `v` into the first butterfly add,

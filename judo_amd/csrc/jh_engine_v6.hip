@@ -15,7 +15,18 @@
 using namespace jh_eng;
 using namespace jh_coop;
 
+#ifndef JH_V6_DPPCHOL
+#define JH_V6_DPPCHOL 1
+#endif
+#include <type_traits>
+#include <utility>
+
 namespace {
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }  // f(integral_constant<int, 0>) ... f(<N - 1>): compile-time indices for DPP controls
+
 
 constexpr int G = 16, RPW = 4, WAVE = 64;
 constexpr int NA = 9, NCHAIN = 7, NVT = 15, NQ = 16, NU = 8, NS = 14, NX = 31, NMB = 10;
@@ -931,6 +942,33 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) Hrow[j] = S.vec[1][j];
         }
+#if JH_V6_DPPCHOL
+        // ---- (4) Cholesky in registers: lane r holds row r (lane 15: the right-hand side as a sixteenth row); at step k every lane takes lane k's diagonal and the
+        // column-k entries of the rows its own trailing entries meet with row broadcasts (DPP row_newbcast: an operand modifier, no LDS, no barrier).  Entry (r, j) receives
+        // its subtractions in the order k = 0, 1, ... of the left-looking row form this replaces (fifteen publish-to-LDS / barrier / read-back rounds): the same bits.
+        // Entries above the diagonal are never read.
+        static_for<NVT>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const float rinv = __frsqrt_rn(fmaxf(row_bcast<k>(Hrow[k]), 1e-30f));
+          const float lk = Hrow[k] * rinv;
+          Hrow[k] = l == k ? rinv : lk;  // (lane k keeps 1 / L_kk in its diagonal slot: the backward solve takes it from there, no register array of its own)
+          static_for<NVT - 1 - k>([&](auto jc) {
+            constexpr int j = k + 1 + decltype(jc)::value;
+            Hrow[j] = __builtin_fmaf(-lk, row_bcast<j>(lk), Hrow[j]);
+          });
+        });
+        // ---- (5) backward solve, redundantly: every lane gets the whole direction p (row 15 = y, column k of L across the lanes)
+        float p[NVT];
+        static_for<NVT>([&](auto kc) {
+          constexpr int k = NVT - 1 - decltype(kc)::value;
+          float s = row_bcast<15>(Hrow[k]);
+          static_for<NVT - 1 - k>([&](auto jc) {
+            constexpr int j = k + 1 + decltype(jc)::value;
+            s = __builtin_fmaf(-row_bcast<j>(Hrow[k]), p[j], s);
+          });
+          p[k] = s * row_bcast<k>(Hrow[k]);
+        });
+#else
         // ---- (4) left-looking row Cholesky through LDS: at step k lane k finishes and publishes row k, rows below take column k
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
@@ -965,6 +1003,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           for (int j = k + 1; j < NVT; j++) s -= S.Lp[tri(j, k)] * p[j];
           p[k] = s * S.Lp[tri(k, k)];
         }
+#endif
         float p_own = 0.f;
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
