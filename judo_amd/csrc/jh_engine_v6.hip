@@ -18,6 +18,9 @@ using namespace jh_coop;
 #ifndef JH_V6_DPPCHOL
 #define JH_V6_DPPCHOL 1
 #endif
+#ifndef JH_V6_BROADLDS
+#define JH_V6_BROADLDS 1
+#endif
 #include <type_traits>
 #include <utility>
 
@@ -641,18 +644,33 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     }
     __syncthreads();
     PH6(2)
-    // ================================================================ collision: 63 candidate pairs over the lanes, balanced narrow phase
+    // ================================================================ collision: the candidate pairs (78) over the lanes, balanced narrow phase
     {
       int nh = 0;
+#if JH_V6_BROADLDS
+      // every geom's world centre and bounding radius go to LDS once (the storage of the raw contact pool: its last reader was the previous step's slot loading, its next
+      // writer is the narrow phase below), so a pair's first test is two LDS reads instead of a chain of dependent global loads (pair -> geom -> body -> pose) per pair
+      float (*gcen)[4] = reinterpret_cast<float (*)[4]>(&S.raw[0][0]);
+      for (int g = l; g < m.NAG; g += G) {
+        const float* f = gF + m.oAGF + g * GEOM_F;
+        float pc[3]; geom_pose3(S, f, gI[m.oAGI + g * GEOM_I], pc, nullptr, false);
+        gcen[g][0] = pc[0]; gcen[g][1] = pc[1]; gcen[g][2] = pc[2]; gcen[g][3] = f[GF_RBOUND];
+      }
+      __syncthreads();
+#endif
       for (int base = 0; base < m.NPAIR; base += G) {
         const int p = base + l;
         bool hit = false;
         if (p < m.NPAIR) {
           const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
           const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
+#if JH_V6_BROADLDS
+          const float dc[3] = {gcen[g2][0] - gcen[g1][0], gcen[g2][1] - gcen[g1][1], gcen[g2][2] - gcen[g1][2]}, rb2 = gcen[g2][3], rs = gcen[g1][3] + rb2;
+#else
           float p1[3], p2[3];
           geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, nullptr, false); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, nullptr, false);
-          float dc[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, rs = f1[GF_RBOUND] + f2[GF_RBOUND];
+          float dc[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, rb2 = f2[GF_RBOUND], rs = f1[GF_RBOUND] + rb2;
+#endif
           hit = dot3(dc, dc) <= rs * rs;
           if (hit) {  // second level: the bounding sphere of geom 2 against the BOX geom 1 itself (the table's bounding sphere alone contains the whole scene: without
                       // this its twenty pairs reach the narrow phase in every step).  Conservative, so the contacts do not change.
@@ -661,7 +679,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             if (b1 < 0) { for (int k = 0; k < 9; k++) R1[k] = f1[GF_R + k]; } else mulMM(R1, S.xR[b1], f1 + GF_R);
             mulMTV(dl, R1, dc);
             const float ex = fmaxf(fabsf(dl[0]) - f1[GF_SIZE], 0.f), ey = fmaxf(fabsf(dl[1]) - f1[GF_SIZE + 1], 0.f), ez = fmaxf(fabsf(dl[2]) - f1[GF_SIZE + 2], 0.f);
-            hit = ex * ex + ey * ey + ez * ez <= f2[GF_RBOUND] * f2[GF_RBOUND];
+            hit = ex * ex + ey * ey + ez * ez <= rb2 * rb2;
           }
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
@@ -671,6 +689,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       }
       if (nh > MAXHIT) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT); nh = MAXHIT; }  // candidate pairs beyond the list: counted with the dropped contacts
       __syncthreads();
+#ifdef JH_V6_PHASE_BROAD
+      PH6(6)  // (diagnostic: the broad phase lands in the 'tail' slot)
+#endif
       for (int base = 0; __any(base < nh); base += G) {
         const int idx = base + l;
         if (idx < nh) {
@@ -1179,6 +1200,7 @@ bool jh_model_is_fr3(const jh_model* m) {
   }
   const int nag = m->h_i[gi], npair = m->h_i[gi + 1], neq = m->h_i[gi + 2], ngs = m->h_i[gi + 5];
   if (neq > 1 || ngs > G || m->h_i[gi + 4] > 8) return false;
+  if (nag > NCP * RAW_F / 4) return false;  // the geoms' centres live in the raw contact pool's storage during the broad phase (k_fr3_v6)
   for (int s = 0; s < ngs; s++) if (m->h_i[gi + 8 + nag * jh_eng::GEOM_I + npair * 2 + neq * jh_eng::EQ_I + m->h_i[gi + 3] + m->h_i[gi + 4] * 4 + s * 4] == 2) return false;  // no jointpos sensors
   {  // the fused mode's shortcut (fr3_cost_reads_distance, jh_engine_common.h) names the distance sensors by their sensordata address: they must be the model's
      // first FR3_NDIST sensordata entries, distance sensor d at address d (fr3_pick.xml: finger-object x 2, finger-table x 2, object-table)
