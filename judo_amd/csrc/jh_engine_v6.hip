@@ -15,12 +15,6 @@
 using namespace jh_eng;
 using namespace jh_coop;
 
-#ifndef JH_V6_DPPCHOL
-#define JH_V6_DPPCHOL 1
-#endif
-#ifndef JH_V6_BROADLDS
-#define JH_V6_BROADLDS 1
-#endif
 #include <type_traits>
 #include <utility>
 
@@ -61,6 +55,9 @@ constexpr int NFS = JH_V6_NFS, NFF = NFS * G;  // finger-finger contacts: kept i
 // tools/diag/profile_fr3_phases.py) is bound by its fifteen LDS exchanges, not by the dependent chains of the left-looking form; with per-lane masks on the updates it was 13 %
 // slower.  A two-column block form (eight exchanges instead of fifteen, both columns of L formed redundantly by every row): correct and 2.8 % slower (8.72 against
 // 8.48 ms) -- the exchanges do not bound the factorisation either; what is left is its 15-step dependent structure on one wave.
+// Round 5 (the git history has the LDS row form as JH_V6_DPPCHOL=0): that conclusion was wrong about the cause.  The factorisation in registers with DPP row broadcasts (step (4) of
+// the Newton iteration: no LDS, no barrier, the same subtraction order and so the same bits) took the kernel from 8.26 to 7.68 ms on the recorded inputs: what the LDS
+// variants had in common was the publish / wait / read-back round trip per pivot, whichever way the updates were arranged around it.
 #ifndef JH_V6_NS1
 #define JH_V6_NS1 1  // among the wave-steps without a finger-finger contact, those with at most 16 general contacts per rollout take a one-slot copy: 8.98 -> 8.79 ms
 #endif
@@ -84,10 +81,7 @@ struct __attribute__((aligned(16))) RS6 {  // per-rollout shared state
   float vec[3][16];
   union {                                       // the raw contact pool is dead once the slots are loaded; the Newton matrices then reuse its storage
     float raw[NCP][RAW_F];                      // pos3, normal3, dist, pair
-    struct {
-      float H[NVT * (NVT + 1) / 2];             // dof-space Hessian, packed lower triangle
-      float Lp[16 * 17 / 2];                    // Cholesky rows, packed (row 15 = transformed right-hand side); diagonal holds 1/L_kk
-    };
+    float H[NVT * (NVT + 1) / 2];               // dof-space Hessian, packed lower triangle
   };
   float ffraw[NFF][FF_F];                       // finger-finger contacts between narrow phase and slots: normal3, dist, pair
   float g[16];                                  // gradient (own rows + contact forces by float atomics)
@@ -647,7 +641,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     // ================================================================ collision: the candidate pairs (78) over the lanes, balanced narrow phase
     {
       int nh = 0;
-#if JH_V6_BROADLDS
       // every geom's world centre and bounding radius go to LDS once (the storage of the raw contact pool: its last reader was the previous step's slot loading, its next
       // writer is the narrow phase below), so a pair's first test is two LDS reads instead of a chain of dependent global loads (pair -> geom -> body -> pose) per pair
       float (*gcen)[4] = reinterpret_cast<float (*)[4]>(&S.raw[0][0]);
@@ -657,20 +650,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         gcen[g][0] = pc[0]; gcen[g][1] = pc[1]; gcen[g][2] = pc[2]; gcen[g][3] = f[GF_RBOUND];
       }
       __syncthreads();
-#endif
       for (int base = 0; base < m.NPAIR; base += G) {
         const int p = base + l;
         bool hit = false;
         if (p < m.NPAIR) {
           const int g1 = gI[m.oPairI + 2 * p], g2 = gI[m.oPairI + 2 * p + 1];
           const float* f1 = gF + m.oAGF + g1 * GEOM_F; const float* f2 = gF + m.oAGF + g2 * GEOM_F;
-#if JH_V6_BROADLDS
           const float dc[3] = {gcen[g2][0] - gcen[g1][0], gcen[g2][1] - gcen[g1][1], gcen[g2][2] - gcen[g1][2]}, rb2 = gcen[g2][3], rs = gcen[g1][3] + rb2;
-#else
-          float p1[3], p2[3];
-          geom_pose3(S, f1, gI[m.oAGI + g1 * GEOM_I], p1, nullptr, false); geom_pose3(S, f2, gI[m.oAGI + g2 * GEOM_I], p2, nullptr, false);
-          float dc[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, rb2 = f2[GF_RBOUND], rs = f1[GF_RBOUND] + rb2;
-#endif
           hit = dot3(dc, dc) <= rs * rs;
           if (hit) {  // second level: the bounding sphere of geom 2 against the BOX geom 1 itself (the table's bounding sphere alone contains the whole scene: without
                       // this its twenty pairs reach the narrow phase in every step).  Conservative, so the contacts do not change.
@@ -963,7 +949,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
 #pragma unroll
           for (int j = 0; j < NVT; j++) Hrow[j] = S.vec[1][j];
         }
-#if JH_V6_DPPCHOL
         // ---- (4) Cholesky in registers: lane r holds row r (lane 15: the right-hand side as a sixteenth row); at step k every lane takes lane k's diagonal and the
         // column-k entries of the rows its own trailing entries meet with row broadcasts (DPP row_newbcast: an operand modifier, no LDS, no barrier).  Entry (r, j) receives
         // its subtractions in the order k = 0, 1, ... of the left-looking row form this replaces (fifteen publish-to-LDS / barrier / read-back rounds): the same bits.
@@ -989,42 +974,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           });
           p[k] = s * row_bcast<k>(Hrow[k]);
         });
-#else
-        // ---- (4) left-looking row Cholesky through LDS: at step k lane k finishes and publishes row k, rows below take column k
-#pragma unroll
-        for (int k = 0; k < NVT; k++) {
-          if (l == k) {
-            float d = Hrow[k];
-#pragma unroll
-            for (int j = 0; j < k; j++) d -= Hrow[j] * Hrow[j];
-            const float rinv = __frsqrt_rn(fmaxf(d, 1e-30f));
-#pragma unroll
-            for (int j = 0; j < k; j++) S.Lp[tri(k, j)] = Hrow[j];
-            S.Lp[tri(k, k)] = rinv;
-          }
-          __syncthreads();
-          if (l > k) {
-            float s = Hrow[k];
-#pragma unroll
-            for (int j = 0; j < k; j++) s -= Hrow[j] * S.Lp[tri(k, j)];
-            Hrow[k] = s * S.Lp[tri(k, k)];
-          }
-        }
-        if (l == 15) {
-#pragma unroll
-          for (int j = 0; j < NVT; j++) S.Lp[tri(15, j)] = Hrow[j];
-        }
-        __syncthreads();
-        // ---- (5) backward solve, redundantly: every lane gets the whole direction p
-        float p[NVT];
-#pragma unroll
-        for (int k = NVT - 1; k >= 0; k--) {
-          float s = S.Lp[tri(15, k)];
-#pragma unroll
-          for (int j = k + 1; j < NVT; j++) s -= S.Lp[tri(j, k)] * p[j];
-          p[k] = s * S.Lp[tri(k, k)];
-        }
-#endif
         float p_own = 0.f;
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) p_own = p[j];
