@@ -788,6 +788,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
     float sff = 0.f;  // sff = a13 + a14 of the current iterate: all a finger-finger contact sees of it
     const float iMd = 1.f / Md_own;
     const float snorm = gsum(hasdof ? fs_own * fs_own * iMd : 0.f);
+    // does any general contact of the wave touch the arm?  Only those scatter into the arm's gradient rows and Hessian rows (LDS float atomics); a wave-step whose contacts all
+    // lie between the free box and the static geometry keeps both in registers (the box's entries are row sums) and skips the publish / barrier / read-back of either.
+    bool armc = false;
+#pragma unroll
+    for (int k = 0; k < NS; k++) armc = armc || (sl[k].sa > -2 && (sl[k].sa >= 1 || sl[k].sb >= 1));
+    const bool arm_any = __any(armc);
     iters_this = 0;
     {
       // ---- warm start: the better of last step's acceleration and the unconstrained one
@@ -865,8 +871,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
           if (l == 13 || l == 14) g_own += ffg;
         }
         // the general contacts' -J'f: the owner lane of a contact adds its force to the rows of the dofs it acts on (float atomics, matrix-free columns)
-        if (hasdof) S.g[l] = g_own;
-        __syncthreads();
+        if (arm_any) {
+          if (hasdof) S.g[l] = g_own;
+          __syncthreads();
+        }
         float gcp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (act) {
 #pragma unroll
@@ -879,8 +887,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             body_force(S, t.sb, t.pos, Fw, 1.f, gcp);
           }
         }
-        __syncthreads();
-        if (hasdof) g_own = S.g[l];
+        if (arm_any) {
+          __syncthreads();
+          if (hasdof) g_own = S.g[l];
+        }
 #pragma unroll
         for (int q = 0; q < 6; q++) { const float v = gsum(gcp[q]); if (l == q) g_own += v; }
         // ---- (2) convergence on the scaled gradient; leave before any Hessian work once every rollout of the wave is done
@@ -900,7 +910,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         if (act) iters_this++;
         // ---- (3) Hessian row r (columns 0..r): M + dof rows + equality + sum_c J_c[:,r]' W_c J_c[:,0..r]; lane 15 holds -g
         PH6(5)
-        if (hasdof) S.vec[1][l] = -g_own;
         float Hrow[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) Hrow[j] = 0.f;
@@ -917,11 +926,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         if (l == 13) Hrow[13] += ffh;
         if (l == 14) { Hrow[13] += ffh; Hrow[14] += ffh; }
         // the rows go to LDS, the general contacts add J'WJ there (float atomics, matrix-free columns), the lanes take their rows back
-        if (hasdof && act) {
+        if (arm_any) {
+          if (hasdof && act) {
 #pragma unroll
-          for (int j = 0; j < NVT; j++) if (j <= l) S.H[tri(l, j)] = Hrow[j];
+            for (int j = 0; j < NVT; j++) if (j <= l) S.H[tri(l, j)] = Hrow[j];
+          }
+          __syncthreads();
         }
-        __syncthreads();
         float hcp[21];
 #pragma unroll
         for (int e = 0; e < 21; e++) hcp[e] = 0.f;
@@ -933,10 +944,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             slot_assemble(S, sl[k], Wm, hcp);
           }
         }
-        __syncthreads();
-        if (hasdof && act) {
+        if (arm_any) {
+          __syncthreads();
+          if (hasdof && act) {
 #pragma unroll
-          for (int j = 0; j < NVT; j++) if (j <= l) Hrow[j] = S.H[tri(l, j)];
+            for (int j = 0; j < NVT; j++) if (j <= l) Hrow[j] = S.H[tri(l, j)];
+          }
         }
 #pragma unroll
         for (int q = 0; q < 6; q++)
@@ -945,10 +958,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         PH6(7)  // (the Hessian assembly alone; the rest of the solve stays in slot 5)
 #pragma unroll
         for (int j = 0; j < NVT; j++) if (j == l) hdiag = Hrow[j];
-        if (l == 15) {
-#pragma unroll
-          for (int j = 0; j < NVT; j++) Hrow[j] = S.vec[1][j];
-        }
+        static_for<NVT>([&](auto jc) {  // the right-hand side -g as a sixteenth row in lane 15 (dof j is lane j's)
+          constexpr int j = decltype(jc)::value;
+          const float gj = row_bcast<j>(-g_own);
+          if (l == 15) Hrow[j] = gj;
+        });
         // ---- (4) Cholesky in registers: lane r holds row r (lane 15: the right-hand side as a sixteenth row); at step k every lane takes lane k's diagonal and the
         // column-k entries of the rows its own trailing entries meet with row broadcasts (DPP row_newbcast: an operand modifier, no LDS, no barrier).  Entry (r, j) receives
         // its subtractions in the order k = 0, 1, ... of the left-looking row form this replaces (fifteen publish-to-LDS / barrier / read-back rounds): the same bits.
