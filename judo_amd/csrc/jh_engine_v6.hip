@@ -321,6 +321,31 @@ __device__ __forceinline__ void chol_solve(float* L, float* x) {
     x[i] = s * inv[i]; }
 }
 
+// The arm's 9 x 9 system with its rows spread over the arm's lanes (lane 6 + a holds row a, entries b <= a; lane 15 the right-hand side as a tenth row): right-looking
+// Cholesky and both triangular solves with DPP row broadcasts, every entry receiving its subtractions in the order of chol_solve<9> (the same bits); every lane gets x.
+// Replaces the factorisation every lane did redundantly on its own copy of the 45 entries.
+__device__ __forceinline__ void arm_chol_solve(float* R, float* x, int l) {
+  static_for<NA>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const float rinv = __frsqrt_rn(fmaxf(row_bcast<6 + k>(R[k]), 1e-30f));
+    const float lk = R[k] * rinv;
+    R[k] = l == 6 + k ? rinv : lk;
+    static_for<NA - 1 - k>([&](auto jc) {
+      constexpr int j = k + 1 + decltype(jc)::value;
+      R[j] = __builtin_fmaf(-lk, row_bcast<6 + j>(lk), R[j]);
+    });
+  });
+  static_for<NA>([&](auto kc) {
+    constexpr int k = NA - 1 - decltype(kc)::value;
+    float s = row_bcast<15>(R[k]);
+    static_for<NA - 1 - k>([&](auto jc) {
+      constexpr int j = k + 1 + decltype(jc)::value;
+      s = __builtin_fmaf(-row_bcast<6 + j>(R[k]), x[j], s);
+    });
+    x[k] = s * row_bcast<6 + k>(R[k]);
+  });
+}
+
 __device__ __forceinline__ void rodrigues(float* Rq, const float* al, float sn, float cs) {
   float t = 1.f - cs, x = al[0], y = al[1], z = al[2];
   Rq[0] = t * x * x + cs; Rq[1] = t * x * y - sn * z; Rq[2] = t * x * z + sn * y;
@@ -615,12 +640,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       float fa = hasact ? af[AF_KP] * (cc - q) - af[AF_KV] * qd : 0.f;
       if (df[DF_FRCLIM] * en != 0.f) fa = jh_clampf(fa, df[DF_FRCLO], df[DF_FRCHI]);
       fs_own = -df[DF_DAMP] * en * qd - bown + fa;
-      if (isarm) S.vec[0][ai] = fs_own;
       __syncthreads();
       float x9[NA];
-#pragma unroll
-      for (int a = 0; a < NA; a++) x9[a] = S.vec[0][a];
-      chol_solve<NA>(Lm, x9);
+      {
+        float R9[NA];
+        static_for<NA>([&](auto bc) { constexpr int b = decltype(bc)::value; const float fb = row_bcast<6 + b>(fs_own); R9[b] = l == 15 ? fb : S.M[ai][b]; });
+        arm_chol_solve(R9, x9, l);
+      }
       a0_own = 0.f;
 #pragma unroll
       for (int a = 0; a < NA; a++) if (a == ai) a0_own = x9[a];
@@ -1075,15 +1101,19 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
       if (isarm) { for (int a = 0; a < NA; a++) rhs_own += S.M[ai][a] * S.vec[0][6 + a]; } else if (iscube) rhs_own += Md_own * da_own;
       if (hasdof) S.vec[1][l] = rhs_own;
       __syncthreads();
-      float Lm[45], x9[NA];
-#pragma unroll
-      for (int a = 0; a < NA; a++) {
-#pragma unroll
-        for (int b = 0; b <= a; b++) Lm[tri(a, b)] = S.M[a][b];
-        Lm[tri(a, a)] += h * (gF[m.oDofF + (6 + a) * DOF_F + DF_DAMP] + gF[m.oDofF + (6 + a) * DOF_F + DF_KV]);
-        x9[a] = S.vec[1][6 + a];
+      float x9[NA];
+      {
+        float R9[NA];
+        const float dh = h * (gF[m.oDofF + (6 + ai) * DOF_F + DF_DAMP] + gF[m.oDofF + (6 + ai) * DOF_F + DF_KV]);
+        static_for<NA>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          const float rb = row_bcast<6 + b>(rhs_own);
+          float v = S.M[ai][b];
+          if (b == ai) v += dh;
+          R9[b] = l == 15 ? rb : v;
+        });
+        arm_chol_solve(R9, x9, l);
       }
-      chol_solve<NA>(Lm, x9);
       float qacc = 0.f;
 #pragma unroll
       for (int a = 0; a < NA; a++) if (a == ai) qacc = x9[a];
