@@ -120,7 +120,7 @@ def cpu_baseline_policy(ctrl, seconds_target: float = 15.0) -> dict:
     """The oracle's policy rollout (numpy actor + fp64 engine, one thread: `oracle.policy.policy_rollout` is a per-rollout Python loop) on a bounded sample."""
     from oracle import policy as P
 
-    om = P.spot_model()
+    om = P.spot_model(self_collision=True)  # the same model the kernel steps by default: the robot's own 287 contact pairs besides the ground
     Ws, bs = P.load_actor()
     H = ctrl.num_timesteps
     rng = np.random.default_rng(0)

@@ -330,7 +330,7 @@ __device__ __forceinline__ float tree_cholesky_solve(float* row, RS& S, const Ro
 // the right-hand-side lane its vector in the same layout.  Right-looking Cholesky in the column order of that layout (joints, then base): the owner of column p scales
 // its row by 1 / sqrt(pivot) and publishes it (26 floats, two alternating LDS vectors: one barrier per pivot), every later row -- and the right-hand side, which so
 // becomes y = L^-1 b -- subtracts its multiple.  The owner keeps the scaled row: it IS column p of L, which the back substitution L' x = y needs row-wise in
-// exactly that lane.  Entries in columns already eliminated turn into garbage and are never read.  ~25 x (26 multiply-adds + 7 broadcast reads) forward and as many
+// exactly that lane.  Columns already eliminated are left alone (a later row's entries there are dead; the right-hand side's hold the finished y_j).  ~25 x (26 multiply-adds + 7 broadcast reads) forward and as many
 // backward: three to four times the tree solve, paid only by the wave-steps in which a rollout has such a contact.
 template <class RS>
 __device__ __forceinline__ float dense_cholesky_solve(float* row, RS& S, const Role& R, int k, float* xb) {
@@ -345,14 +345,14 @@ __device__ __forceinline__ float dense_cholesky_solve(float* row, RS& S, const R
       const float r = __frsqrt_rn(fmaxf(row[p], 1e-30f));
       myr = r;
 #pragma unroll
-      for (int j = 0; j < NVT; j++) { row[j] *= r; u[j] = row[j]; }
+      for (int j = p; j < NVT; j++) { row[j] *= r; u[j] = row[j]; }
       u[NVT] = r;
     }
     __syncthreads();
     if ((mycol > p && mycol < 99) || isrhs) {
       const float m = row[p] * u[NVT];
 #pragma unroll
-      for (int j = 0; j < NVT; j++) row[j] = fmaf(-m, u[j], row[j]);
+      for (int j = p; j < NVT; j++) row[j] = fmaf(-m, u[j], row[j]);  // columns j < p are finished: a later row's entries there are dead, the right-hand side's hold y_j
       if (isrhs) row[p] = m;  // y_p
     }
   }

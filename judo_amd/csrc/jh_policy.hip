@@ -33,11 +33,11 @@ struct ObsLayout { int ld, nq, base_qpos, base_qvel, leg_qpos, leg_qvel, ldc; };
 
 // one thread per rollout; the row is written as 84 consecutive floats
 __device__ __forceinline__ void obs_row(const PolicyTables& T, const float* __restrict__ states, const ObsLayout& Y, const float* __restrict__ command,
-                                        const float* __restrict__ prev_out, int n, float* __restrict__ obs) {
+                                        const float* __restrict__ prev_out, int n, float* __restrict__ obs, int orow = -1 /* row of `obs` to write; default: n */) {
   const int ld = Y.ld, nq = Y.nq, base_qpos = Y.base_qpos, base_qvel = Y.base_qvel, leg_qpos = Y.leg_qpos, leg_qvel = Y.leg_qvel, ldc = Y.ldc;
   const float* qpos = states + (size_t)n * ld; const float* qvel = qpos + nq;
   const float* cmd = command + (size_t)n * ldc;
-  float* o = obs + (size_t)n * OBS;
+  float* o = obs + (size_t)(orow < 0 ? n : orow) * OBS;
   const float inv[4] = {qpos[base_qpos + 3], -qpos[base_qpos + 4], -qpos[base_qpos + 5], -qpos[base_qpos + 6]};
   const float lv[3] = {qvel[base_qvel], qvel[base_qvel + 1], qvel[base_qvel + 2]}, g0[3] = {0.f, 0.f, -1.f};
   float lin[3], grav[3];
@@ -182,12 +182,17 @@ __global__ __launch_bounds__(256) void k_policy_layer(PolicyTables T, const floa
   __shared__ float part[3][16][64];
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, j = l & 31, h = l >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  if (FIRST) {  // every column tile's workgroup writes the (identical) observation rows of its row block and reads its own copy back
-    if (tid < 32 && m0 + tid < N) obs_row(T, states, Y, command, policy_out, m0 + tid, obs);
+  __shared__ __attribute__((aligned(16))) float sobs[FIRST ? 32 * OBS : 4];
+  if (FIRST) {  // every column tile's workgroup builds the observation rows of its row block in its own LDS and contracts out of that copy; the global rows (which the
+                // LAST layer's control mapping reads, launches later) are written by the first column tile alone: no workgroup reads what another one writes
+    if (tid < 32 && m0 + tid < N) obs_row(T, states, Y, command, policy_out, m0 + tid, sobs, tid);
     __syncthreads();
+    if (blockIdx.x == 0)
+      for (int e = tid; e < 32 * OBS; e += 256)
+        if (m0 + e / OBS < N) obs[(size_t)m0 * OBS + e] = sobs[e];
   }
   const bool arow = m0 + j < N, wrow = n0 + j < NOUT;
-  const float* pa = A + (size_t)(m0 + j) * K;
+  const float* pa = FIRST ? sobs + j * K : A + (size_t)(m0 + j) * K;
   const float* pw = W + (size_t)(n0 + j) * K;
   f32x4 a[NCW][4], b[NCW][4];
 #pragma unroll

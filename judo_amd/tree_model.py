@@ -62,7 +62,9 @@ def tree_structure(desc: dict) -> dict:
 
 
 def robot_pairs(desc: dict, robot_geoms: list) -> list[tuple[int, int]]:
-    """Robot-robot geom pairs (indices into `robot_geoms`, g1 < g2) after MuJoCo's static filters: not on the same body, not parent and child, not excluded."""
+    """Robot-robot geom pairs (indices into `robot_geoms`, g1 < g2) after MuJoCo's static filters: not on the same body, not parent and child, not excluded.
+    The contype / conaffinity test passes for every pair by construction: `tools/compile_mjcf.py` refuses a collision geom whose masks are not 1 / 1, and
+    `tree_structure` above has one joint per body (no welded bodies: body == weld id)."""
     bodies, geoms = desc["bodies"], desc["geoms"]
     excl = {tuple(sorted(e)) for e in desc.get("excludes", [])}
     pairs = []

@@ -77,8 +77,8 @@ DEFAULT_POLICY_COMMAND = np.concatenate([[0, 0, 0], ARM_STOWED_POS, np.zeros(12)
 def spot_model(self_collision: bool = False):
     """The Spot model (judo/models/xml/spot_primitive/robot.xml) in the oracle engine.  Default scope (what jh_engine_v4.hip models): robot geoms against the
     ground plane (sphere / capsule / box vs plane).  `self_collision=True` adds the robot's own pairs after MuJoCo's static filters and the 11 excludes of
-    `spot_primitive/contact.xml:4-14` (capsule-capsule, sphere-capsule, box-capsule, box-box, box-sphere, sphere-sphere): the oracle half of that feature --
-    no kernel models them yet.  The model's sensors (relative frame positions, frame axes) are not evaluated."""
+    `spot_primitive/contact.xml:4-14` (capsule-capsule, sphere-capsule, box-capsule, box-box, box-sphere, sphere-sphere): what `k_tree_v4<true>`
+    (jh_engine_v4.hip, the kernel's default since round 5) models and `tests/test_gpu_spot.py::test_robot_self_collision_matches_oracle` compares.  The model's sensors (relative frame positions, frame axes) are not evaluated."""
     from oracle import oracle as O
 
     desc = O.load_description("spot")

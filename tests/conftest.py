@@ -65,7 +65,7 @@ def _record_allclose_calls() -> None:
                 record_margin("allclose", site=f"{os.path.basename(fr.filename)}:{fr.lineno}", used=float(np.nanmax(used)), max_abs=float(np.nanmax(np.abs(x - y))), rtol=float(rtol), atol=float(atol))
         except Exception:
             pass
-        return orig(actual, desired, rtol=rtol, atol=atol, *a, **k)
+        return orig(actual, desired, rtol, atol, *a, **k)
 
     wrapped._judo_recorded = True
     np.testing.assert_allclose = wrapped

@@ -60,8 +60,9 @@ def test_min_max_normaliser_is_an_affine_sigma_scale():
     g = np.load(os.path.join(GOLDEN, "normalizer.npz"))
     lo, hi, x = g["minmax_lo"], g["minmax_hi"], g["minmax_x"]
     finite = np.isfinite(lo) & np.isfinite(hi)
-    scale = np.where(finite, (hi - lo) / 2, 1.0)
-    off = np.where(finite, (hi + lo) / 2, 0.0)
+    lo_f, hi_f = np.where(finite, lo, -1.0), np.where(finite, hi, 1.0)  # (+inf) + (-inf) is a RuntimeWarning even under np.where: mask first
+    scale = np.where(finite, (hi_f - lo_f) / 2, 1.0)
+    off = np.where(finite, (hi_f + lo_f) / 2, 0.0)
     np.testing.assert_allclose((x - off) / scale, g["minmax_norm"], atol=1e-12)
     np.testing.assert_allclose(x * scale + off, g["minmax_denorm"], atol=1e-12)
 

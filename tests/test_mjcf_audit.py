@@ -34,6 +34,7 @@ def test_every_non_visual_attribute_of_the_shipped_mjcf_is_read_by_the_compiler(
     ("spot_primitive/robot.xml", "option", "density", "1000"),
     ("spot_primitive/robot.xml", "body", "gravcomp", "1"),
     ("leap_cube.xml", "body", "zaxis", "0 0 1"),
+    ("spot_primitive/robot.xml", "geom", "contype", "2"),  # mixed collision masks: the pair lists apply MuJoCo's body-level filters only
 ])
 def test_a_value_the_engines_do_not_model_is_refused(monkeypatch, xml_name, tag, attr, value):
     C = _load(os.path.join(ROOT, "tools", "compile_mjcf.py"), "compile_mjcf_audit")

@@ -370,6 +370,11 @@ def compile_model(xml_name: str, task: str) -> dict:
             for g in geoms_here:
                 if g["contype"] == 0 and g["conaffinity"] == 0:
                     continue  # visual-only
+                if (g["contype"], g["conaffinity"]) != (1, 1):
+                    # the runtime's pair lists (judo_amd/engine_model.py, judo_amd/tree_model.py::robot_pairs, oracle/oracle.py::collision_pairs) apply MuJoCo's body-level
+                    # filters only: with every collision geom at contype = conaffinity = 1 the mask test (ct1 & ca2) || (ct2 & ca1) passes for every pair, which is the
+                    # case in all shipped models; anything else would silently produce extra pairs
+                    raise NotImplementedError(f"geom {g['name']}: contype / conaffinity {g['contype']} / {g['conaffinity']}: only 1 / 1 (collides) and 0 / 0 (visual) are modelled")
                 parts = [g]
                 if g["type"] == "mesh":
                     subs = MESH_SUBSTITUTES.get(g["mesh"])
