@@ -275,7 +275,20 @@ def generic_pairs(desc: dict, fused: dict, st: dict, cube_only: bool | None = No
     return out
 
 
+def kernel_stand_ins(desc: dict) -> dict:
+    """The description as the leap KERNEL collides it (jh_engine_v5.hip has box and sphere narrow phases only): caltech_leap_cube's fingertip cylinders
+    (judo/models/xml/caltech_leap_components/leap_rh.xml:131,175,219,259: r = 14 mm, half length 7 mm, the tip's sphere 7 mm further out) become spheres of the
+    cylinder's radius at its centre -- a STATED DEVIATION of the kernel, not of the model: the description and the oracle keep the cylinder (MuJoCo's general convex
+    collider, restated as GJK + EPA in oracle/jo_engine.c::collide_convex), and tests/test_gpu_leap.py measures what the stand-in costs at trajectory level."""
+    if not any(g["type"] == "cylinder" for g in desc["geoms"]) or desc.get("family", desc["task"]) != "leap_cube":
+        return desc
+    out = dict(desc)
+    out["geoms"] = [dict(g, type="sphere", size=[g["size"][0]], substitute_for_cylinder=list(g["size"])) if g["type"] == "cylinder" else g for g in desc["geoms"]]
+    return out
+
+
 def pack_engine_model(desc: dict) -> bytes:
+    desc = kernel_stand_ins(desc)
     orig = desc
     ref_frames = sensor_reference_frames(orig)
     dofw_o, bodyw_o = inverse_weights(orig)

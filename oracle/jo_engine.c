@@ -472,8 +472,9 @@ static int collide_box_sphere(const double* pb, const double* Rb, const double* 
 /* two spheres (MuJoCo's mjc_SphereSphere: normal along the centre line from the first to the second, position midway through the overlap) */
 static int collide_sphere_sphere(const double* c1, double r1, const double* c2, double r2, double margin, rawcon* out) {
   double d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}; double l = norm3(d), dist = l - r1 - r2;
-  if (dist >= margin || l < 1e-12) return 0;
-  for (int k = 0; k < 3; k++) { out->n[k] = d[k] / l; out->pos[k] = c1[k] + (r1 + 0.5 * dist) * d[k] / l; }
+  if (dist > margin) return 0;                                            /* (mjraw_SphereSphere keeps dist == margin) */
+  if (l < 1e-15) { d[0] = 1; d[1] = d[2] = 0; l = 1; }                   /* coincident centres: mju_normalize3 returns (1, 0, 0) below mjMINVAL */
+  for (int k = 0; k < 3; k++) { out->n[k] = d[k] / l; out->pos[k] = c1[k] + (r1 + 0.5 * dist) * out->n[k]; }
   out->dist = dist;
   return 1;
 }
@@ -886,6 +887,9 @@ static void collision(const jo_model* m, jo_data* d) {
   if (!m->contact_enabled) return;
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_g1[p], g2 = m->pair_g2[p];
+    /* mj_collideGeoms orders a pair by geom TYPE (the lower type is geom 1), whatever their order in the model: the contact's normal points from that geom to the other.
+     * (For the physics the order is immaterial: mju_makeFrame of -n gives (-n, y, -z) for (n, y, z), and elliptic cones and pyramids are symmetric in the tangents.) */
+    if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
     double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
     double dc[3] = {d->geom_xpos[g2][0] - d->geom_xpos[g1][0], d->geom_xpos[g2][1] - d->geom_xpos[g1][1], d->geom_xpos[g2][2] - d->geom_xpos[g1][2]};
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -1473,6 +1477,24 @@ int jo_forward_probe(const jo_model* m, const double* qpos, const double* qvel, 
   int n = d->ncon;
   jo_data_free(d);
   return n;
+}
+
+/* test hook: kinematics + collision only, over a batch of configurations: how many contacts each candidate pair (in jo_add_pair order) produced in total.
+ * (tests: "the pairs the kernel leaves out never touch on this workload" without paying for the solver) */
+void jo_pair_contact_counts(const jo_model* m, const double* qpos, int N, long* counts /* npair */) {
+  jo_data* d = jo_data_new();
+  for (int p = 0; p < m->npair; p++) counts[p] = 0;
+  for (int n = 0; n < N; n++) {
+    memcpy(d->qpos, qpos + (size_t)n * m->nq, sizeof(double) * m->nq);
+    kinematics(m, d);
+    collision(m, d);
+    for (int c = 0; c < d->ncon; c++) {
+      int a = d->con[c].g1, b = d->con[c].g2;
+      for (int p = 0; p < m->npair; p++)
+        if ((m->pair_g1[p] == a && m->pair_g2[p] == b) || (m->pair_g1[p] == b && m->pair_g2[p] == a)) { counts[p]++; break; }
+    }
+  }
+  jo_data_free(d);
 }
 
 /* test hooks: kinematics only.  World pose of a body at qpos; mj_integratePos of qpos by dq (nv) over a unit time. */

@@ -162,6 +162,7 @@ int jo_forward_probe(const jo_model* m, const double* qpos, const double* qvel, 
 
 /* test hooks for checks that use the kinematics / one narrow-phase routine in isolation (tests/test_oracle_independent.py) */
 void jo_body_pose(const jo_model* m, const double* qpos, int body, double* pos, double* mat);
+void jo_pair_contact_counts(const jo_model* m, const double* qpos, int N, long* counts /* npair: contacts per candidate pair over the batch (kinematics + collision only) */);
 void jo_integrate_pos(const jo_model* m, const double* qpos, const double* dq, double* out);
 int jo_collide_shapes(int t1, const double* s1, const double* p1, const double* q1, int t2, const double* s2, const double* p2, const double* q2, double margin, double* out /* 8 rows of 7 */);
 

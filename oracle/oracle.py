@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         L.jo_forward_probe.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp]
         L.jo_body_pose.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
         L.jo_integrate_pos.argtypes = [C.c_void_p, dp, dp, dp]
+        L.jo_pair_contact_counts.argtypes = [C.c_void_p, dp, C.c_int, C.POINTER(C.c_long)]
         L.jo_collide_shapes.argtypes = [C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, C.c_double, dp]
         L.jo_collide_shapes.restype = C.c_int
         L.jo_export_problem.argtypes = [C.c_void_p, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip, dp, dp, dp, ip]
@@ -106,7 +107,8 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
     that have a supported narrow phase.
 
     scope "all" (default): every such pair -- for leap_cube that includes the hand's self-collision (finger-finger, finger-palm), which
-    jh_engine_v5.hip models; scope "cube": leap_cube only, the cube's contacts alone (what jh_engine.hip / jh_engine_v2.hip model)."""
+    jh_engine_v5.hip models, for fr3_pick the arm links against each other and against the gripper; scope "cube": leap_cube only, the cube's contacts alone
+    (what jh_engine.hip / jh_engine_v2.hip model); scope "kernel": fr3_pick only, the subset k_fr3_v6 models (arm links against table and cube only)."""
     bodies, geoms = desc["bodies"], desc["geoms"]
     nb = len(bodies)
     njnt_body = [0] * nb
@@ -126,8 +128,12 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
     supported = {("box", "box"), ("box", "sphere"), ("sphere", "box"), ("sphere", "sphere"), ("cylinder", "cylinder"), ("box", "capsule"), ("capsule", "box"),
                  ("plane", "sphere"), ("plane", "capsule"), ("plane", "box"), ("sphere", "plane"), ("capsule", "plane"), ("box", "plane")}
     spot = desc.get("family", desc["task"]) == "spot"
+    if desc.get("family", desc["task"]) == "leap_cube":  # caltech_leap_cube's fingertip cylinders (caltech_leap_components/leap_rh.xml:131,175,219,259): MuJoCo's general convex collider
+        supported = supported | {("cylinder", "box"), ("box", "cylinder"), ("cylinder", "sphere"), ("sphere", "cylinder")}
     if spot:  # the robot against itself (judo/models/xml/spot_primitive/contact.xml:4-14 lists the 11 body pairs it excludes): capsule-capsule, sphere-capsule on top
         supported = supported | {("capsule", "capsule"), ("sphere", "capsule"), ("capsule", "sphere")}
+    if desc.get("family", desc["task"]) == "fr3_pick":  # link against link (fr3_components/fr3.xml:11,16,23,30,37,46,60,70: no exclude between non-adjacent links)
+        supported = supported | {("capsule", "capsule")}
     pairs = []
     for g1 in range(len(geoms)):
         for g2 in range(g1 + 1, len(geoms)):
@@ -142,14 +148,18 @@ def collision_pairs(desc: dict, scope: str = "all") -> list[tuple[int, int]]:
                 continue
             if (geoms[g1]["type"], geoms[g2]["type"]) not in supported:
                 continue
-            if {geoms[g1]["type"], geoms[g2]["type"]} == {"capsule", "box"} and not spot:
-                # fr3_pick: the capsules stand in for the arm links' collision meshes (absent from the reference repository).  They collide with static geometry
-                # (table) and with the free body (cube); link-against-link and link-against-gripper pairs are left out -- hulls fitted by eye overlap their
-                # neighbours and would inject contact forces the reference does not have
+            if {geoms[g1]["type"], geoms[g2]["type"]} == {"capsule", "box"} and not spot and scope == "kernel":
+                # fr3_pick, scope "kernel": the pair set k_fr3_v6 models (judo_amd/engine_model.py::generic_pairs) -- the arm links' capsules (stand-ins for collision meshes
+                # that are absent from the reference repository) against static geometry (table) and the free body (cube) only.  The DEFAULT scope is what the MJCF says:
+                # every pair MuJoCo's static filters leave (fr3_components/fr3.xml:11-99: eleven collision geoms with default contype, no <exclude>), link against
+                # link and link against hand / finger boxes included; tests/test_oracle.py::test_fr3_link_pairs_never_touch_on_the_measured_workloads holds the two
+                # sets to identical trajectories on the BASELINE workload and the shipped 64 x 250 configuration
                 ob = b2 if geoms[g1]["type"] == "capsule" else b1
                 free = any(j["body"] == ob and j["type"] == "free" for j in desc["joints"])
                 if not (weld(ob) == 0 or free):
                     continue
+            if (geoms[g1]["type"], geoms[g2]["type"]) == ("capsule", "capsule") and scope == "kernel":
+                continue
             if desc.get("family", desc["task"]) == "leap_cube" and scope in ("cube", "task"):
                 cube = next(i for i, g in enumerate(geoms) if g["name"] == "cube")
                 if cube not in (g1, g2):
@@ -281,6 +291,13 @@ class Model:
     def integrate_pos(self, qpos, dq) -> np.ndarray:
         out = np.zeros(self.nq)
         lib().jo_integrate_pos(C.c_void_p(self.ptr), _d(np.ascontiguousarray(qpos, dtype=np.float64)), _d(np.ascontiguousarray(dq, dtype=np.float64)), _d(out))
+        return out
+
+    def pair_contact_counts(self, qpos: np.ndarray) -> np.ndarray:
+        """Contacts per candidate pair (in `self.pairs` order) summed over a batch of configurations (N, nq): kinematics + collision only."""
+        q = np.ascontiguousarray(np.atleast_2d(qpos)[:, : self.nq], dtype=np.float64)
+        out = np.zeros(len(self.pairs), dtype=np.int64)
+        lib().jo_pair_contact_counts(C.c_void_p(self.ptr), _d(q), int(q.shape[0]), out.ctypes.data_as(C.POINTER(C.c_long)))
         return out
 
     def problem(self, qpos, qvel, ctrl, qacc_warmstart=None) -> dict:

@@ -130,8 +130,18 @@ def test_fr3_closed_empty_gripper_keeps_every_pad_contact(gpu):
     assert bounded("np.median(e[ok])", np.median(e[ok]), 5e-9) and bounded("e[:, :, 14:16][ok].max()", e[:, :, 14:16][ok].max(), 5e-6) and bounded("np.percentile(e[:, :, 16 + 13 :][ok], 99)", np.percentile(e[:, :, 16 + 13 :][ok], 99), 7e-5), (np.median(e[ok]), e[:, :, 14:16][ok].max(), np.percentile(e[:, :, 16 + 13 :][ok], 99))
 
 
-@pytest.mark.parametrize("phase", [0, 1, 2, 3])
-def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
+@pytest.mark.parametrize("phase,seed", [(0, 22), (1, 19), (2, 12), (3, 17)])
+def test_fr3_plan_step_cem_matches_oracle(gpu, phase, seed):
+    """One CEM plan step per phase against the oracle, cost by cost and then the refit.
+
+    Where the cost error sits (tools/diag/fr3_cost_terms.py evaluates FR3Pick.reward's terms, judo/tasks/fr3_pick.py:225-311, on the kernel's and the oracle's states): NOT in
+    the discrete finger-touch count (no flag differs in 4 x 10 240 rollout-steps; the fingers are 0.4 m above the table) but in the finger joint positions -- `gripper-open^2` and,
+    in HOMING, the home-pose norm -- of the rollouts whose sampled gripper command shuts the fingers: the two pad stacks slam into each other at up to 0.95 m/s and end up
+    millimetres inside one another, the regime in which the fp64 oracle's own answer moves by metres per second squared when its inputs are rounded to fp32
+    (test_fr3_finger_pads_... above).  So the rollouts are split on the ORACLE's trajectory: `slam` = the stacks overlap by more than 0.5 mm at some step (55-60 % of a CEM
+    sample at sigma 0.155-0.3), where the cost is held to 5 x the observed 95th percentile / maximum (9.4e-3 / 4.6e-2 over 24 seeds, profiles/r06_fr3_cost_terms.txt),
+    and the rest, where it is held to 5 x the observed 1.0e-4 / 1.7e-4.  The seeds are those whose third and fourth best oracle rewards lie further apart than 20 x the
+    elites' cost error (asserted): the CEM refit is then compared with the ORACLE's nominal unconditionally (tools/diag/fr3_elite_gap_seeds.py lists gaps per seed)."""
     import torch
 
     from judo_amd.controller import make_controller
@@ -140,7 +150,7 @@ def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
     from tests.harness import oracle_plan_step
 
     N = 256
-    rng = np.random.default_rng(10 + phase)
+    rng = np.random.default_rng(seed)
     ctrl = make_controller("fr3_pick", "cem")
     ctrl.optimizer.config.num_rollouts = N
     ctrl.controller_cfg.horizon = 40 * ctrl.task.dt
@@ -161,19 +171,26 @@ def test_fr3_plan_step_cem_matches_oracle(gpu, phase):
     ctrl.update_action()
     torch.cuda.synchronize()
     assert ctrl.task.phase == phase == Phase(phase).value
-    ref = oracle_plan_step(O.Model("fr3_pick"), ctrl, nominal0, noise, "cem", sigma0)
+    ref = oracle_plan_step(O.Model("fr3_pick"), ctrl, nominal0, noise, "cem", sigma0)  # the oracle's default model: every pair the MJCF leaves, link against link included
     cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy()
     np.testing.assert_allclose(cand, ref["knots"], rtol=4e-7, atol=4e-7)
     costs = -ctrl.rewards_local
     d = np.abs(costs + ref["rewards"])
-    assert bounded("np.median(d)", np.median(d), 2e-4) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 0.015)  # costs are sums of O(1..40) terms of size O(1..100); observed median 2e-6..5e-5, 95th percentile 2e-3..6e-3
+    slam = (ref["states"][:, :, 14] + ref["states"][:, :, 15]).min(axis=1) < -5e-4
+    assert 0.3 * N < slam.sum() < 0.8 * N
+    assert bounded("cost error, finger stacks apart: median", np.median(d[~slam]), 2e-4) and bounded("cost error, finger stacks apart: p95", np.percentile(d[~slam], 95), 5e-4)
+    assert bounded("cost error, finger stacks apart: max", d[~slam].max(), 1e-3)
+    assert bounded("cost error, finger stacks slammed together: p95", np.percentile(d[slam], 95), 0.05) and bounded("cost error, finger stacks slammed together: max", d[slam].max(), 0.25)
     exp_nom, exp_sig, _ = O.cem_update(ref["knots"], -costs.astype(np.float64), 3, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
     np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=7e-7, atol=7e-8)
     np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=5e-6, atol=5e-8)
-    # the elite set agrees with the oracle's unless two candidates are closer in cost than the fp32 rollout error
-    gap = np.sort(ref["rewards"])[::-1]
-    if gap[2] - gap[3] > 5 * np.percentile(d, 99):
-        np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], atol=7e-7)
+    # the elite set IS the oracle's: the gap between the third and the fourth best reward clears the rollout error of the best four by a factor of 20
+    order = np.argsort(-ref["rewards"])
+    gap = ref["rewards"][order[2]] - ref["rewards"][order[3]]
+    assert gap > 20 * d[order[:4]].max(), (gap, d[order[:4]].max())
+    assert set(np.argsort(costs)[:3]) == set(order[:3])
+    np.testing.assert_allclose(ctrl.nominal_knots, ref["nominal"], atol=7e-7)
+    np.testing.assert_allclose(ctrl.optimizer.sigma, ref["sigma"], rtol=5e-6, atol=5e-8)
 
 
 def test_fr3_full_size_sampled_rollouts_match_oracle(gpu):
@@ -210,7 +227,9 @@ def test_fr3_full_size_sampled_rollouts_match_oracle(gpu):
     np.testing.assert_allclose(cand[idx], ref["knots"], rtol=4e-7, atol=4e-7)
     d = np.abs(costs[idx] + ref["rewards"])
     record_margin("fr3_full_size_sampled", cost_median=np.median(d), cost_p95=np.percentile(d, 95), cost_max=d.max())
-    assert bounded("np.median(d)", np.median(d), 5e-5) and bounded("np.percentile(d, 95)", np.percentile(d, 95), 0.007), (np.median(d), np.percentile(d, 95))
+    slam = (ref["states"][:, :, 14] + ref["states"][:, :, 15]).min(axis=1) < -5e-4  # the finger stacks slammed into each other: see test_fr3_plan_step_cem_matches_oracle
+    assert bounded("full size, finger stacks apart: median", np.median(d[~slam]), 2e-4) and bounded("full size, finger stacks apart: p95", np.percentile(d[~slam], 95), 5e-4)
+    assert bounded("full size, finger stacks slammed together: p95", np.percentile(d[slam], 95), 0.05) and bounded("full size, finger stacks slammed together: max", d[slam].max(), 0.25)
     exp_nom, exp_sig, _ = O.cem_update(cand, -costs, 3, ctrl.optimizer.sigma_min, ctrl.optimizer.sigma_max)
     np.testing.assert_allclose(ctrl.nominal_knots, exp_nom, rtol=3e-7, atol=3e-8)
     np.testing.assert_allclose(ctrl.optimizer.sigma, exp_sig, rtol=5e-7, atol=5e-9)
@@ -256,9 +275,13 @@ def test_fr3_arm_links_collide_with_table_and_cube(gpu):
     from judo_amd.tasks import FR3Pick
     from oracle import oracle as O
 
-    om, task = O.Model("fr3_pick"), FR3Pick()
+    # scope "kernel": the pair subset k_fr3_v6 models.  These poses fold the arm onto the table on purpose -- far outside anything the planner samples -- and the
+    # oracle's default model (every pair the MJCF leaves: link against link, link against gripper) would add contacts the kernel does not have; this test is about the
+    # link-table / link-cube arithmetic.  (How far the default model is from these poses is recorded below; where the kernel actually goes, the left-out pairs never
+    # touch: test_fr3_link_pairs_never_touch_where_the_kernel_goes.)
+    om, task = O.Model("fr3_pick", scope="kernel"), FR3Pick()
     names = [g["name"] for g in om.desc["geoms"]]
-    assert sum("link" in names[b] for a, b in om.pairs) == 15  # table x links 1..7, cube x links 0..7
+    assert sum("link" in names[a] or "link" in names[b] for a, b in om.pairs) == 15  # table x links 1..7, cube x links 0..7
     rng = np.random.default_rng(0)
     N, H = 160, 12
     x0 = np.tile(task.default_state(), (N, 1))
@@ -267,7 +290,7 @@ def test_fr3_arm_links_collide_with_table_and_cube(gpu):
     x0[:, 16:] = 0.2 * rng.standard_normal((N, 15))
     U = np.repeat(x0[:, None, 7:15], H, axis=1)  # hold the pose
     fw = [om.forward(x[:16], x[16:], x[7:15]) for x in x0]
-    link_con = np.array([sum("link" in names[int(r[14])] for r in f["contacts"]) for f in fw])
+    link_con = np.array([sum("link" in names[int(r[13])] or "link" in names[int(r[14])] for r in f["contacts"]) for f in fw])  # (a contact lists the lower geom type first)
     ncon = np.array([f["ncon"] for f in fw])
     assert (link_con > 0).sum() > N // 2 and link_con.max() >= 4
     # (the hand box and the twelve finger boxes come down on the table with the links; generation 1 holds 32 contacts outside the gripper, generation 3 up to 96 --
@@ -351,3 +374,66 @@ def test_fr3_general_contacts_beyond_the_lds_pool(gpu):
     # (a gripper pressed flat onto the table with 60-90 contacts is a stiff, nearly rank-deficient solve: the worst of these states sits at 2e-3 of its velocity scale)
     assert bounded("np.median(e)", np.median(e), 3e-6) and bounded("e.max()", e.max(), 0.005), (np.median(e), e.max())
     np.testing.assert_allclose(g[:, 0, :16], ref[:, 0, :16], atol=5e-5)
+
+
+def test_fr3_link_pairs_never_touch_where_the_kernel_goes(gpu):
+    """The 112 geom pairs the MJCF collides and k_fr3_v6 leaves out (link against link, link against the gripper's boxes: fr3_components/fr3.xml:11-99, no <exclude>) --
+    a stated deviation -- counted on the states the KERNEL's rollouts visit: (a) a 2 048-rollout sample of the BASELINE plan step (32 768 x H 40, CEM, device noise, from
+    QPOS_HOME) and (b) the reference's shipped configuration (64 rollouts x 250 steps, judo/optimizers/overrides.py) in closed loop over 8 plan steps with the kernel as
+    the plant.  Kinematics + the oracle's narrow phase on every visited configuration: no left-out pair produces a contact, so on these workloads the oracle with the
+    kernel's subset IS the oracle with every pair (and the parity tests above compare against the latter)."""
+    import torch
+
+    from judo_amd.controller import make_controller
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from oracle import oracle as O
+
+    full, sub = O.Model("fr3_pick"), O.Model("fr3_pick", scope="kernel")
+    extra = np.array([i for i, p in enumerate(full.pairs) if p not in set(sub.pairs)])
+    assert len(extra) == 112
+
+    def visited_states(ctrl, sample):
+        cand = ctrl.candidate_knots_device.permute(2, 0, 1).cpu().numpy().astype(np.float64)[sample]
+        W = O.spline_weights(ctrl.spline_order, ctrl.spline_timesteps, ctrl.rollout_times)
+        U = O.spline_eval(W, cand)
+        be = GpuRolloutBackend("fr3_pick", len(sample))
+        states, _, _ = be.rollout(ctrl.current_state, U)
+        return np.asarray(states, dtype=np.float64), U
+
+    # (a) BASELINE plan step
+    ctrl = make_controller("fr3_pick", "cem")
+    ctrl.optimizer.config.num_rollouts = 32768
+    ctrl.controller_cfg.horizon = 40 * ctrl.task.dt
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.optimizer.seed(12)
+    ctrl.keep_candidates = True
+    ctrl.update_action()
+    torch.cuda.synchronize()
+    sample = np.sort(np.random.default_rng(3).choice(32768, 2048, replace=False))
+    states, _ = visited_states(ctrl, sample)
+    counts = full.pair_contact_counts(states.reshape(-1, states.shape[-1]))
+    assert counts.sum() > 0 and counts[extra].sum() == 0, [full.pairs[i] for i in extra[counts[extra] > 0]]
+
+    # (b) shipped configuration, closed loop, the kernel as the plant
+    ctrl = make_controller("fr3_pick", "cem")
+    assert ctrl.optimizer.config.num_rollouts == 64 and ctrl.num_timesteps == 250
+    ctrl.reset()
+    ctrl.current_state = ctrl.task.default_state()
+    ctrl.optimizer.seed(5)
+    ctrl.keep_candidates = True
+    plant = GpuRolloutBackend("fr3_pick", 1)
+    nsub = int(round(0.05 / ctrl.task.dt))
+    total = 0
+    for step in range(8):
+        ctrl.time = 0.05 * step
+        ctrl.update_action()
+        torch.cuda.synchronize()
+        states, _ = visited_states(ctrl, np.arange(64))
+        counts = full.pair_contact_counts(states.reshape(-1, states.shape[-1]))
+        total += int(counts.sum())
+        assert counts[extra].sum() == 0, (step, [full.pairs[i] for i in extra[counts[extra] > 0]])
+        u = np.stack([ctrl.action(ctrl.time + k * ctrl.task.dt) for k in range(nsub)])[None]
+        xs, _, _ = plant.rollout(ctrl.current_state, u)
+        ctrl.current_state = np.asarray(xs[0, -1], dtype=np.float64)
+    assert total > 0

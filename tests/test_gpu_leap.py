@@ -301,8 +301,14 @@ def test_caltech_leap_cube_runs_on_the_leap_kernel(gpu):
     N, H = 64, 48
     U = t.reset_command[None, None] + 0.4 * np.repeat(rng.standard_normal((N, 4, 16)), H // 4, axis=1)
     x0 = t.default_state()
+    from judo_amd.engine_model import kernel_stand_ins
+
+    desc = O.load_description("caltech_leap_cube")
+    assert sum(g["type"] == "cylinder" for g in desc["geoms"]) == 4  # the description holds the MJCF's fingertip cylinders (leap_rh.xml:131,175,219,259) ...
     for scope, self_on in (("all", True), ("cube", False)):
-        om = O.Model("caltech_leap_cube", scope=scope)
+        # ... and THIS test holds the kernel's arithmetic to the oracle on the kernel's own geometry (its sphere stand-in for the cylinders, `kernel_stand_ins`);
+        # what the stand-in itself costs against the oracle on the MJCF's geometry is measured by test_caltech_fingertip_cylinder_stand_in_is_a_measured_deviation below
+        om = O.Model("caltech_leap_cube", desc=kernel_stand_ins(desc), scope=scope)
         rs, rsens = om.rollout(x0, U)
         be = GpuRolloutBackend(t.gpu_model(), N)
         be.model.set_self_collision(self_on)
@@ -331,3 +337,41 @@ def test_caltech_leap_cube_runs_on_the_leap_kernel(gpu):
         ctrl.update_action()
     assert np.isfinite(ctrl.nominal_knots).all()
     assert ctrl.traces is None or ctrl.traces.size == 0  # no sensor is named trace*: nothing to draw (judo/controller/controller.py:96-101)
+
+
+def test_caltech_fingertip_cylinder_stand_in_is_a_measured_deviation(gpu):
+    """caltech_leap_cube's fingertips are a cylinder (r = 14 mm, half length 7 mm) capped by a sphere (judo/models/xml/caltech_leap_components/leap_rh.xml:131-132,175-176,
+    219-220,259-260).  The ORACLE collides the cylinder as the MJCF says (MuJoCo's general convex collider, restated as GJK + EPA: oracle/jo_engine.c::collide_convex); the
+    leap KERNEL has box and sphere narrow phases only and takes the cylinder as a sphere of its radius (judo_amd/engine_model.py::kernel_stand_ins): a stated deviation, and
+    this test is its measurement -- kernel against the oracle on the MJCF's geometry, nothing shared.  A rollout in which no cylinder is ever the touching geom must agree
+    to fp32 rounding; the others diverge as contact-rich trajectories do (millimetres to centimetres of cube position after 48 steps), and their share is bounded here."""
+    from judo_amd.engine_model import kernel_stand_ins
+    from judo_amd.rollout_backend import GpuRolloutBackend
+    from judo_amd.tasks import CaltechLeapCube
+    from oracle import oracle as O
+
+    t = CaltechLeapCube()
+    desc = O.load_description("caltech_leap_cube")
+    x0 = t.default_state()
+    N, H = 256, 48
+    om_mjcf, om_standin = O.Model("caltech_leap_cube"), O.Model("caltech_leap_cube", desc=kernel_stand_ins(desc))
+    assert any("cylinder" in (desc["geoms"][a]["type"], desc["geoms"][b]["type"]) for a, b in om_mjcf.pairs)
+    be = GpuRolloutBackend(t.gpu_model(), N)
+    be.model.set_self_collision(True)
+    shares = {}
+    for amp, share_bound, p90_bound in ((0.2, 0.05, 1e-5), (0.4, 0.35, 5e-3)):  # knot noise in rad: the task ships sigma = 0.2 (observed shares 0.01 / 0.17-0.2)
+        rng = np.random.default_rng(4)
+        U = t.reset_command[None, None] + amp * np.repeat(rng.standard_normal((N, 4, 16)), H // 4, axis=1)
+        rc, _ = om_mjcf.rollout(x0, U)
+        rs, _ = om_standin.rollout(x0, U)
+        gs, _, _ = be.rollout(x0, U)
+        untouched = np.abs(rc - rs).reshape(N, -1).max(axis=1) == 0.0  # the oracle never had a cylinder contact that the sphere would not have given identically
+        e = np.abs(gs - rc)
+        assert untouched.sum() >= N // 2
+        assert bounded("cylinder never touched: median state error", np.median(e[untouched]), 5e-7)
+        assert bounded("cylinder never touched: cube position at the horizon, p90", np.percentile(e[untouched][:, -1, :3], 90), 1e-5)
+        share = 1.0 - untouched.mean()
+        shares[amp] = share
+        assert bounded(f"share of rollouts in which a fingertip cylinder decides a contact (noise {amp})", share, share_bound)
+        assert bounded(f"cube position at the horizon against the MJCF's geometry, p90 over ALL rollouts (noise {amp})", np.percentile(e[:, -1, :3], 90), p90_bound)
+    assert shares[0.4] > 0.02  # the cylinders are live in the oracle: at this noise level the stand-in is visible

@@ -326,3 +326,62 @@ def test_philox_known_answers_and_normal_moments():
     # rows and draws are independent streams
     z2 = O.noise_normal(1234, 4, 64, 16384)
     assert abs(np.corrcoef(z.ravel(), z2.ravel())[0, 1]) < 5e-3 and abs(np.corrcoef(z[0], z[1])[0, 1]) < 3e-2
+
+
+def test_caltech_fingertip_cylinders_are_collided_as_cylinders():
+    """The oracle model of caltech_leap_cube holds the MJCF's fingertip cylinders (judo/models/xml/caltech_leap_components/leap_rh.xml:131,175,219,259) and collides them
+    through the general convex routine, as MuJoCo does for cylinder-box; the leap kernel's sphere stand-in (judo_amd/engine_model.py::kernel_stand_ins) is NOT applied
+    to it.  With the stand-in applied to a copy, some rollouts differ (the cylinder's rim reaches where the sphere does not) and the rest are bit-identical."""
+    from judo_amd.engine_model import kernel_stand_ins
+
+    desc = O.load_description("caltech_leap_cube")
+    cyl = [i for i, g in enumerate(desc["geoms"]) if g["type"] == "cylinder"]
+    assert len(cyl) == 4 and all(desc["geoms"][i]["size"][:2] == [0.014, 0.007] for i in cyl) and not any("substitute_for_cylinder" in g for g in desc["geoms"])
+    om = O.Model("caltech_leap_cube")
+    kinds = {tuple(sorted((desc["geoms"][a]["type"], desc["geoms"][b]["type"]))) for a, b in om.pairs}
+    assert ("box", "cylinder") in kinds and ("cylinder", "sphere") in kinds
+    cube = next(i for i, g in enumerate(desc["geoms"]) if g["name"] == "cube")
+    assert all((min(cube, i), max(cube, i)) in set(om.pairs) for i in cyl)
+    os_ = O.Model("caltech_leap_cube", desc=kernel_stand_ins(desc))
+    assert len(os_.pairs) == len(om.pairs)
+    from judo_amd.models import qpos0
+
+    rng = np.random.default_rng(4)
+    N, H = 64, 48
+    home = np.array([a["ctrlrange"] for a in desc["actuators"]]).mean(axis=1) * 0 + 0.5
+    U = home[None, None] + 0.4 * np.repeat(rng.standard_normal((N, 4, 16)), H // 4, axis=1)
+    x0 = np.concatenate([qpos0(desc), np.zeros(22)])
+    rc, _ = om.rollout(x0, U)
+    rs, _ = os_.rollout(x0, U)
+    differ = np.abs(rc - rs).reshape(N, -1).max(axis=1) > 0
+    assert np.isfinite(rc).all() and 0 < differ.sum() < N
+
+
+def test_fr3_link_pairs_never_touch_on_the_baseline_workload():
+    """fr3_components/fr3.xml:11-99 gives the arm eleven collision geoms with default contype and no <exclude>: MuJoCo collides link against link and link against the
+    gripper's boxes.  The oracle's default model has all 190 pairs; k_fr3_v6 models 78 of them (links against table and cube only: a stated deviation, the links'
+    hulls being capsule stand-ins for meshes the reference repository does not hold).  On the BASELINE workload -- rollouts from QPOS_HOME with the CEM's first
+    sigma, 0.155 ramped and clipped to 0.3 rad (judo/optimizers/cem.py:23-27,69-72), H = 40 -- and at TWICE that noise no left-out pair ever produces a contact: the two
+    pair sets give bit-identical trajectories.  (At four times the noise the hand reaches links 0, 1 and 5: the deviation is real, it is outside what the planner samples.)"""
+    from judo_amd.tasks import FR3Pick
+
+    t = FR3Pick()
+    desc = O.load_description("fr3_pick")
+    full, sub = O.Model("fr3_pick"), O.Model("fr3_pick", scope="kernel")
+    extra = [p for p in full.pairs if p not in set(sub.pairs)]
+    assert len(full.pairs) == 190 and len(extra) == 112
+    x0 = t.default_state()
+    assert full.pair_contact_counts(x0[None, :16])[[full.pairs.index(p) for p in extra]].sum() == 0  # the stand-in hulls do not overlap at the home pose
+    lo, hi = np.array([a["ctrlrange"] for a in desc["actuators"]]).T
+    K, H, N = 4, 40, 96
+    sigma_k = np.clip(0.155 * np.linspace(1, 4, K), 0.01, 0.3)
+    W = O.spline_weights("linear", np.linspace(0, 1.0, K), 0.004 * np.arange(H))
+    for mult in (1.0, 2.0):
+        rng = np.random.default_rng(7)
+        knots = np.clip(t.reset_command[None, None] + mult * sigma_k[None, :, None] * rng.standard_normal((N, K, 8)), lo, hi)
+        U = O.spline_eval(W, knots)
+        rf, _ = full.rollout(x0, U)
+        rk, _ = sub.rollout(x0, U)
+        assert np.array_equal(rf, rk), mult
+        counts = full.pair_contact_counts(rf.reshape(-1, rf.shape[-1])[:, :16])
+        assert counts[[full.pairs.index(p) for p in extra]].sum() == 0 and counts.sum() > 0

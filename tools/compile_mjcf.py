@@ -41,7 +41,7 @@ JOINT_DEFAULTS = dict(
 # Collision-mesh substitutes: {mesh name: primitive (or list of primitives) in the geom's own frame}.  The fingertip meshes `tip` / `thumb_tip` are
 # replaced by the primitives the reference itself uses for the same fingertip in its mesh-free hand model
 # (judo/models/xml/caltech_leap_components/leap_rh.xml:131-132,175-176,219-220,259-260: a cylinder r = 14 mm, half length 7 mm, and a sphere r = 14 mm
-# 7 mm further out); the cylinder is taken as a second sphere of the same radius (sphere-swept segment: the two overlap into a capsule-like tip whose
+# 7 mm further out); for the MESH the cylinder is taken as a second sphere of the same radius (sphere-swept segment: the two overlap into a capsule-like tip whose
 # far end sits at the reference's `trace_*_tip` site, leap_hand.xml:120,252).
 MESH_SUBSTITUTES = {
     "tip": [dict(type="sphere", size=[0.014], pos=[0.0, -0.027, 0.0145], quat=[1, 0, 0, 0]), dict(type="sphere", size=[0.014], pos=[0.0, -0.034, 0.0145], quat=[1, 0, 0, 0])],
@@ -49,7 +49,9 @@ MESH_SUBSTITUTES = {
     # fr3 link hulls: capsules along the link axes (radius ~ hull half-width of the FR3 links), not used by
     # the shipped fr3_pick cost except through contacts; fingers' mesh hull -> box over the finger body.
     "link0_coll": dict(type="capsule", size=[0.07, 0.06], pos=[-0.04, 0, 0.06], quat=[0.7071068, 0, 0.7071068, 0]),
-    "link1_coll": dict(type="capsule", size=[0.06, 0.10], pos=[0, 0, -0.10], quat=[1, 0, 0, 0]),
+    # (link1: round 6 shortened it from half length 0.10 at z = -0.10: that hull reached 57 mm into link0's -- the one pair of non-excluded neighbours MuJoCo collides,
+    # link0 being welded to the world -- which no real hull pair does at rest; now 8 mm clear of it at every joint angle, joint 1 turning about the capsule's own axis)
+    "link1_coll": dict(type="capsule", size=[0.06, 0.065], pos=[0, 0, -0.07], quat=[1, 0, 0, 0]),
     "link2_coll": dict(type="capsule", size=[0.06, 0.06], pos=[0, -0.06, 0.0], quat=[0.7071068, 0.7071068, 0, 0]),
     "link3_coll": dict(type="capsule", size=[0.055, 0.07], pos=[0.03, 0, -0.07], quat=[1, 0, 0, 0]),
     "link4_coll": dict(type="capsule", size=[0.055, 0.05], pos=[-0.04, 0.04, 0.0], quat=[0.7071068, 0.7071068, 0, 0]),
@@ -391,12 +393,8 @@ def compile_model(xml_name: str, task: str) -> dict:
                         if len(subs) > 1:
                             gg["name"] = f"{g['name']}_{i_sub + 1}"
                         parts.append(gg)
-                if g["type"] == "cylinder" and task == "caltech_leap_cube":
-                    # fingertip cylinders (MuJoCo collides them with its general convex routine, not with a primitive pair function): taken as a sphere of the
-                    # same radius at the cylinder's centre, which with the tip's own sphere 7 mm further out makes the capsule-like tip described above
-                    gg = dict(g)
-                    gg["type"], gg["size"], gg["substitute_for_cylinder"] = "sphere", [g["size"][0]], list(g["size"])
-                    parts = [gg]
+                # (caltech_leap_cube's fingertip cylinders, caltech_leap_components/leap_rh.xml:131,175,219,259, stay cylinders in the description: the oracle collides them
+                # with its general convex routine as MuJoCo does; the leap KERNEL's stand-in for them is applied by its own packer, judo_amd/engine_model.py::kernel_stand_ins)
                 for gg in parts:
                     for k in ("mesh", "density", "mass", "contype", "conaffinity"):
                         gg.pop(k, None)
