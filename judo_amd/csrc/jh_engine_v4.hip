@@ -749,7 +749,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
       if (nh > MAXHIT4) { if (l == 0 && live && stats) atomicAdd(stats, nh - MAXHIT4); nh = MAXHIT4; }  // (candidate pairs lost: counted with the dropped contacts)
       __syncthreads();
       PH(14)
-      // narrow phase (MuJoCo's primitives, restated in oracle/jo_engine.c collide_geoms): the normal points from geom 1 to geom 2 of the pair
+      // narrow phase, as restated in oracle/jo_engine.c collide_geoms; the normal points from geom 1 to geom 2 of the pair.  MuJoCo's own primitives: capsule-capsule
+      // (mjc_CapsuleCapsule), sphere-capsule, sphere-sphere (mjraw_SphereSphere, incl. its (1,0,0) normal for coincident centres), box-sphere.  NOT MuJoCo's: box-capsule (75 of
+      // the 287 pairs) and box-box (9) go through the build's own jh_coop.h routines -- collide_box_capsule gives up to THREE contacts (both end spheres and the interior
+      // closest point) where mjc_CapsuleBox gives at most two, box-box its own face manifold: stated deviations, shared with the oracle, and therefore
+      // invisible to the parity tests -- no MuJoCo contact set is recorded anywhere in the reference to hold them to.  MuJoCo orders a pair by geom TYPE (sphere < capsule <
+      // box) and points the normal from the lower type; the oracle does that since round 6, this kernel keeps the model's order: mju_makeFrame(-n) = (-n, y, -z) for
+      // (n, y, z) and the pyramid is symmetric in its tangents, so the constraint set is the same either way (the parity test sees only a different row order).
       struct SelfSink {
         RS* S; int* stats; int pk; bool flip;
         __device__ __forceinline__ void push(const float* pos, const float* n, float dist) {
@@ -770,8 +776,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           SelfSink sk{&S, live ? stats : nullptr, pk, false};
           auto sphere_sphere = [&](const float* ca, float ra, const float* cb, float rb) __attribute__((always_inline)) {
             const float d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]}; const float ln = sqrtf(dot3(d, d)), dist = ln - ra - rb;
-            if (dist >= 0.f || ln < 1e-12f) return;
-            const float n3[3] = {d[0] / ln, d[1] / ln, d[2] / ln}, mm = ra + 0.5f * dist;
+            if (dist > 0.f) return;  // (mjraw_SphereSphere keeps dist == margin)
+            const bool same = ln < 1e-12f;  // coincident centres: mju_normalize3 returns (1, 0, 0)
+            const float n3[3] = {same ? 1.f : d[0] / ln, same ? 0.f : d[1] / ln, same ? 0.f : d[2] / ln}, mm = ra + 0.5f * dist;
             const float ps[3] = {ca[0] + mm * n3[0], ca[1] + mm * n3[1], ca[2] + mm * n3[2]};
             sk.push(ps, n3, dist);
           };
