@@ -70,6 +70,13 @@ constexpr int NCH = 4, NLK = 4;
                          // once per step and kept in the part of the contact pool's storage the Newton matrices leave free (768 of 820 bytes), three ds_read_b128 per use instead of
                          // 24 loads + 36 multiply-adds, twice per iteration
 #endif
+#ifndef JH_V5_WORLDROT
+#define JH_V5_WORLDROT 1  // (round 6) the cube's three rotational dofs are solved for in WORLD coordinates (w = R w_body) inside the constraint solver: with the cube's isotropic
+                          // inertia (a cube: leap_cube, leap_cube_down, caltech_leap_cube; checked at model load) the quadratic term is the same in both frames, and the
+                          // rotation columns of a contact become e_q x r -- two non-zeros each -- instead of (R e_q) x r: no read of the cube's rotation matrix, no 3 x 3 product
+                          // anywhere in a Newton iteration (gradient torque, Hessian columns, J p of the line search).  The warm start and the integrated acceleration stay in
+                          // the body frame (MuJoCo's free-joint convention): two 3 x 3 products per STEP.  Same minimiser, different rounding than the body-frame form.
+#endif
 #ifndef JH_V5_C3PAD
 #define JH_V5_C3PAD 278
 #endif
@@ -724,7 +731,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     float a0c_own = 0.f;
     {
       float Icw[3] = {cI[0] * vc[3], cI[1] * vc[4], cI[2] * vc[5]}, gc[3]; cross3(gc, vc + 3, Icw);
+#if JH_V5_WORLDROT
+      (void)gc;  // isotropic inertia: w x (I w) = 0 exactly -- the body-frame expression only carries its own rounding noise
+      a0c_own = l < 3 ? (l == 0 ? grav[0] : (l == 1 ? grav[1] : grav[2])) : 0.f;
+#else
       a0c_own = l < 3 ? (l == 0 ? grav[0] : (l == 1 ? grav[1] : grav[2])) : (l == 3 ? -gc[0] / cI[0] : (l == 4 ? -gc[1] / cI[1] : (l == 5 ? -gc[2] / cI[2] : 0.f)));
+#endif
     }
     WSYNC();
     V5_TICK(0)
@@ -918,6 +930,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       int mx = S.ncon; mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
       if (l == 0 && live) atomicAdd(stats + 64 + min(S.ncon, 63), 1);
       if (lane == 0) atomicAdd(stats + 128 + min(mx, 63), 1);
+      // (round 6) what a quad-per-contact assembly would need: cube contacts by the chain of their finger link (static geometry: any quad); passes = the longest quad's list
+      int cn[5] = {0, 0, 0, 0, 0};
+      const int ncc = S.ncon < NCP ? S.ncon : NCP;
+      for (int i = 0; i < ncc; i++) { const int sd = __float_as_int(S.pool[i][8]), lb_ = sd >> 8; cn[(lb_ > 0 && lb_ < NMB) ? (lb_ - 1) >> 2 : 4]++; }
+      const int cmx = max(max(cn[0], cn[1]), max(cn[2], cn[3])), tot_ = cn[0] + cn[1] + cn[2] + cn[3] + cn[4];
+      int P = max(cmx, (tot_ + 3) >> 2), Pw = P; Pw = max(Pw, __shfl_xor(Pw, 16)); Pw = max(Pw, __shfl_xor(Pw, 32));
+      int cw = cmx; cw = max(cw, __shfl_xor(cw, 16)); cw = max(cw, __shfl_xor(cw, 32));
+      if (l == 0 && live) { atomicAdd(stats + 328 + min(P, 15), 1); atomicAdd(stats + 360 + min(cmx, 11), 1); }
+      if (lane == 0) { atomicAdd(stats + 344 + min(Pw, 15), 1); atomicAdd(stats + 372 + min(cw, 11), 1); }
     }
 #endif
     auto solve_step = [&](auto NS_, auto HC_) __attribute__((always_inline)) -> bool {
@@ -1009,8 +1030,13 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     else {
       // ---- warm start: the better of last step's acceleration (S.ws) and the unconstrained one
       {
-        const float qws = S.ws[6 + l], wsc_own = l < 6 ? S.ws[l] : 0.f;
-        float xl[3] = {S.ws[0], S.ws[1], S.ws[2]}, xr[3] = {S.ws[3], S.ws[4], S.ws[5]}, wa[3]; mulMV(wa, S.xR[0], xr);
+        const float qws = S.ws[6 + l];
+        float xl[3] = {S.ws[0], S.ws[1], S.ws[2]}, xr[3] = {S.ws[3], S.ws[4], S.ws[5]}, wa[3]; mulMV(wa, S.xR[0], xr);  // (S.ws keeps the body-frame acceleration of the last step)
+#if JH_V5_WORLDROT
+        const float wsc_own = l < 3 ? S.ws[l] : (l == 3 ? wa[0] : (l == 4 ? wa[1] : (l == 5 ? wa[2] : 0.f)));
+#else
+        const float wsc_own = l < 6 ? S.ws[l] : 0.f;
+#endif
         float cs = 0.f, jx[3], jar_ws[NS][3];
 #pragma unroll
         for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
@@ -1029,7 +1055,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         const float cost_ws = gsum(cs);
         S.p[6 + l] = a0_own; if (l < 6) S.p[l] = a0c_own;
         WSYNC();
-        float xl0[3] = {S.p[0], S.p[1], S.p[2]}, xr0[3] = {S.p[3], S.p[4], S.p[5]}; mulMV(wa, S.xR[0], xr0);
+        float xl0[3] = {S.p[0], S.p[1], S.p[2]}, xr0[3] = {S.p[3], S.p[4], S.p[5]};
+#if JH_V5_WORLDROT
+        wa[0] = xr0[0]; wa[1] = xr0[1]; wa[2] = xr0[2];
+#else
+        mulMV(wa, S.xR[0], xr0);
+#endif
         cs = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
@@ -1125,15 +1156,38 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             auto Amul = [&](const float* v, float* y) __attribute__((always_inline)) {
               y[0] = A[0] * v[0] + A[1] * v[1] + A[3] * v[2]; y[1] = A[1] * v[0] + A[2] * v[1] + A[4] * v[2]; y[2] = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
             };
+#if !JH_V5_WORLDROT
             float cq[3][3];  // the cube's rotation columns (body axes x arm), up to the sign
+#endif
             if (cube) {
+#if JH_V5_WORLDROT
+              float tb[3]; cross3(tb, t.rc, Fw);  // torque about the cube's origin, world
+#else
               float tq[3], tb[3]; cross3(tq, t.rc, Fw); mulMTV(tb, S.xR[0], tq);
+#endif
               gcp[0] += Fw[0]; gcp[1] += Fw[1]; gcp[2] += Fw[2]; gcp[3] += tb[0]; gcp[4] += tb[1]; gcp[5] += tb[2];
               if (on) {
 #pragma unroll
-                for (int q = 0; q < 3; q++) { float ea[3]; col3(ea, S.xR[0], q); cross3(cq[q], ea, t.rc); }
-#pragma unroll
                 for (int e = 0; e < 6; e++) hcp[e] += A[e];
+#if JH_V5_WORLDROT
+                // rotation columns e_q x r = (0, -rz, ry), (rz, 0, -rx), (-ry, rx, 0): z_q = A (e_q x r) is a combination of two columns of A, and a dot product with
+                // e_p x r has two terms
+                const float rx = t.rc[0], ry = t.rc[1], rz = t.rc[2];
+                const float Ac[3][3] = {{A[0], A[1], A[3]}, {A[1], A[2], A[4]}, {A[3], A[4], A[5]}};  // column k of A (symmetric)
+                float zq[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { zq[0][i] = ry * Ac[2][i] - rz * Ac[1][i]; zq[1][i] = rz * Ac[0][i] - rx * Ac[2][i]; zq[2][i] = rx * Ac[1][i] - ry * Ac[0][i]; }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+#pragma unroll
+                  for (int r2 = 0; r2 < 3; r2++) hcp[tri(3 + q, r2)] += zq[q][r2];
+                }
+                hcp[tri(3, 3)] += ry * zq[0][2] - rz * zq[0][1];
+                hcp[tri(4, 3)] += ry * zq[1][2] - rz * zq[1][1]; hcp[tri(4, 4)] += rz * zq[1][0] - rx * zq[1][2];
+                hcp[tri(5, 3)] += ry * zq[2][2] - rz * zq[2][1]; hcp[tri(5, 4)] += rz * zq[2][0] - rx * zq[2][2]; hcp[tri(5, 5)] += rx * zq[2][1] - ry * zq[2][0];
+#else
+#pragma unroll
+                for (int q = 0; q < 3; q++) { float ea[3]; col3(ea, S.xR[0], q); cross3(cq[q], ea, t.rc); }
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
                   float z[3]; Amul(cq[q], z);
@@ -1142,6 +1196,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
                   for (int r2 = 0; r2 <= q; r2++) hcp[tri(3 + q, 3 + r2)] += dot3(cq[r2], z);
                 }
+#endif
                 hcany = true;
               }
             }
@@ -1168,8 +1223,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                   if (cube) {
 #pragma unroll
                     for (int q = 0; q < 3; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + q], -y[q]);
+#if JH_V5_WORLDROT
+                    atomicAdd(&S.Hcb[ch][u4 * 6 + 3], t.rc[2] * y[1] - t.rc[1] * y[2]);  // -(e_q x r) . y
+                    atomicAdd(&S.Hcb[ch][u4 * 6 + 4], t.rc[0] * y[2] - t.rc[2] * y[0]);
+                    atomicAdd(&S.Hcb[ch][u4 * 6 + 5], t.rc[1] * y[0] - t.rc[0] * y[1]);
+#else
 #pragma unroll
                     for (int q = 0; q < 3; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + 3 + q], -dot3(cq[q], y));
+#endif
                   }
                 }
               }
@@ -1389,7 +1450,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
               n0 = 6;
               for (int q3 = 0; q3 < 3; q3++) {
                 X0[q3][0] = -t.fr[q3]; X0[q3][1] = -t.fr[3 + q3]; X0[q3][2] = -t.fr[6 + q3];
+#if JH_V5_WORLDROT
+                const float ea[3] = {q3 == 0 ? 1.f : 0.f, q3 == 1 ? 1.f : 0.f, q3 == 2 ? 1.f : 0.f}; float c3[3]; cross3(c3, ea, t.rc);
+#else
                 float ea[3], c3[3]; col3(ea, S.xR[0], q3); cross3(c3, ea, t.rc);
+#endif
                 X0[3 + q3][0] = -dot3(t.fr, c3); X0[3 + q3][1] = -dot3(t.fr + 3, c3); X0[3 + q3][2] = -dot3(t.fr + 6, c3);
               }
             } else if (t.la > 0) { o0 = 6 + 4 * ((t.la - 1) >> 2); n0 = 1 + ((t.la - 1) & 3); link_cols(S, t.la, pos, t.fr, -1.f, X0); }
@@ -1491,7 +1556,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         const float gp = gsum(g_own * p_own + gcl * xcl);
         if (act && !(gp < 0.f)) act = false;
         {
+#if JH_V5_WORLDROT
+          const float* wa = xc6 + 3;
+#else
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
+#endif
 #pragma unroll
           for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<HC>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp, V5_C3C(k));
         }
@@ -1621,7 +1690,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #endif
     // ================================================================ implicitfast integration: (M + h diag(d + kv)) qacc = fs + M (a - a0)
     {
+#if JH_V5_WORLDROT
+      S.ws[6 + l] = a_own; if (l < 6) { S.acn[l] = ac_own; if (l < 3) S.ws[l] = ac_own; }  // (rotational part: world here; body frame below)
+#else
       S.ws[6 + l] = a_own; if (l < 6) { S.ws[l] = ac_own; S.acn[l] = ac_own; }
+#endif
 #if JH_V5_PARK
       q = S.pk_q[l]; qd = S.qv[6 + l]; fs_own = S.pk_fs[l];  // (own entries: no other lane wrote them)
 #endif
@@ -1644,7 +1717,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
       for (int k = 0; k < 4; k++) qc[3 + k] = S.pk_cq[k];
       if (!MATERIALIZE) acc = S.pk_acc;
 #endif
+#if JH_V5_WORLDROT
+      {  // the constrained rotational acceleration back in the body frame (MuJoCo's free-joint convention): integrated, and kept as the next step's warm start
+        const float aw[3] = {S.acn[3], S.acn[4], S.acn[5]}; float ab[3]; mulMTV(ab, S.xR[0], aw);
+        for (int k = 0; k < 3; k++) { vc[k] = fmaf(h, S.acn[k], vc[k]); vc[3 + k] = fmaf(h, ab[k], vc[3 + k]); }
+        if (l < 3) S.ws[3 + l] = l == 0 ? ab[0] : (l == 1 ? ab[1] : ab[2]);
+      }
+#else
       for (int k = 0; k < 6; k++) vc[k] = fmaf(h, S.acn[k], vc[k]);  // the cube's inertia is diagonal: its new acceleration is the constrained one itself
+#endif
       for (int k = 0; k < 3; k++) qc[k] = fmaf(h, vc[k], qc[k]);
       float wn = sqrtf(vc[3] * vc[3] + vc[4] * vc[4] + vc[5] * vc[5]), ang = wn * h;
       if (ang > 0.f) {
@@ -1684,7 +1765,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 
 bool model_is_leap(const jh_model* m) {
   return m->kind == JH_TASK_LEAP_CUBE && m->nq == 23 && m->nv == 22 && m->nu == 16 && (m->ns == NS || (m->ns == NS_CALTECH && m->h_i.size() > 18 && m->h_i[18] > 0)) && m->h_i.size() > 17 &&
-         m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG && m->h_i[17] <= MAXBP;
+         m->h_i[0] == 17 && m->h_i[1] == 4 && m->h_i[11] > 0 && m->h_i[5] <= MAXG && m->h_i[12] <= MAXLG && m->h_i[17] <= MAXBP
+#if JH_V5_WORLDROT
+         && m->h_f.size() > (size_t)HF_CINERTIA + 2 && m->h_f[HF_CINERTIA] == m->h_f[HF_CINERTIA + 1] && m->h_f[HF_CINERTIA] == m->h_f[HF_CINERTIA + 2]  // isotropic cube inertia (JH_V5_WORLDROT)
+#endif
+         ;
 }
 
 }  // namespace

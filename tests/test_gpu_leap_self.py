@@ -18,7 +18,15 @@ def _tangled_states(N, seed, frac=0.6, task="leap_cube"):
     from oracle import oracle as O
 
     LEAP_QPOS_HOME = CALTECH_LEAP_QPOS_HOME if task == "caltech_leap_cube" else LEAP_HOME
-    om = O.Model(task)
+    if task == "caltech_leap_cube":
+        # tangled configurations test the KERNEL's arithmetic: the oracle runs on the kernel's geometry (its sphere stand-in for the four fingertip cylinders,
+        # judo_amd/engine_model.py::kernel_stand_ins); what the stand-in costs against the MJCF's cylinders is measured where the planner goes, in
+        # tests/test_gpu_leap.py::test_caltech_fingertip_cylinder_stand_in_is_a_measured_deviation
+        from judo_amd.engine_model import kernel_stand_ins
+
+        om = O.Model(task, desc=kernel_stand_ins(O.load_description(task)))
+    else:
+        om = O.Model(task)
     rng = np.random.default_rng(seed)
     r = np.array([a["ctrlrange"] for a in om.desc["actuators"]])
     q = r[:, 0] + (r[:, 1] - r[:, 0]) * rng.uniform(0.0, 1.0, (N, 16))

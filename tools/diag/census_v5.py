@@ -29,5 +29,6 @@ for i in steps:
 print("ALL", steps)
 a = tot
 for name, lo, hi in (("contacts / rollout-step", 64, 128), ("max contacts of the wave / wave-step", 128, 192), ("Newton iterations / rollout-step", 192, 224), ("Newton iterations / wave-step", 224, 256),
-                     ("line-search evals / rollout iteration", 256, 288), ("line-search evals / wave iteration", 288, 320), ("active rollouts / wave iteration", 320, 328)):
+                     ("line-search evals / rollout iteration", 256, 288), ("line-search evals / wave iteration", 288, 320), ("active rollouts / wave iteration", 320, 328),
+                     ("quad-per-contact passes / rollout-step", 328, 344), ("quad-per-contact passes / wave-step", 344, 360), ("contacts on the busiest chain / rollout-step", 360, 372), ("... / wave-step", 372, 384)):
     h = a[lo:hi]; n = h.sum(); print(f"  {name:42s} mean {(h * np.arange(len(h))).sum() / max(n, 1):6.2f}  cumulative " + " ".join(f"{k}:{v:.3f}" for k, v in enumerate(np.cumsum(h) / max(n, 1)) if k in (0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 32)))
