@@ -138,8 +138,10 @@ __device__ __forceinline__ float cone_eval(const float* jar, const float* D, flo
   float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
   float N = U0, T2 = U1 * U1 + U2 * U2;
   float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
-  if (N >= mu * T || (T <= 0.f && N >= 0.f)) { f[0] = f[1] = f[2] = 0.f; for (int k = 0; k < 6; k++) W[k] = 0.f; return 0.f; }
-  if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+  // (T >= 0 and mu > 0: the degenerate cases T == 0 of MuJoCo's zone tests -- top if N >= 0, bottom if N < 0 -- are the same two comparisons; spelled out as `||` of a second
+  // clause they cost two exec-mask round trips each)
+  if (N >= mu * T) { f[0] = f[1] = f[2] = 0.f; for (int k = 0; k < 6; k++) W[k] = 0.f; return 0.f; }
+  if (mu * N + T <= 0.f) {
     f[0] = -D[0] * jar[0]; f[1] = -D[1] * jar[1]; f[2] = -D[2] * jar[2];
     W[0] = D[0]; W[1] = 0.f; W[2] = D[1]; W[3] = 0.f; W[4] = 0.f; W[5] = D[2];
     return 0.5f * (D[0] * jar[0] * jar[0] + D[1] * jar[1] * jar[1] + D[2] * jar[2] * jar[2]);
@@ -161,8 +163,8 @@ __device__ __forceinline__ float cone_eval(const float* jar, const float* D, flo
 __device__ __forceinline__ void cone_dir(const float* jar, const float* jp, const float* D, float Dm, float mu, float fri, float* d1, float* d2) {
   const float U1 = jar[1] * fri, U2 = jar[2] * fri, N = jar[0] * mu, T2 = U1 * U1 + U2 * U2;
   const float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
-  const bool top = N >= mu * T || (T <= 0.f && N >= 0.f);
-  const bool bottom = mu * N + T <= 0.f || (T <= 0.f && N < 0.f);
+  const bool top = N >= mu * T;             // (T == 0: N >= 0, MuJoCo's degenerate top case)
+  const bool bottom = mu * N + T <= 0.f;    // (T == 0: N <= 0; N == 0 is `top`, which the selects below test first)
   const float b1 = D[0] * jar[0] * jp[0] + D[1] * jar[1] * jp[1] + D[2] * jar[2] * jp[2];
   const float b2 = D[0] * jp[0] * jp[0] + D[1] * jp[1] * jp[1] + D[2] * jp[2] * jp[2];
   const float V0 = jp[0] * mu, V1 = jp[1] * fri, V2 = jp[2] * fri, e = N - mu * T;

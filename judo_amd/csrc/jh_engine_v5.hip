@@ -387,15 +387,16 @@ __device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr,
     const float D[3] = {sl[k].D0, sl[k].D1, sl[k].D1};
     cone_dir(jar, jp, D, sl[k].Dm, sl[k].mu, sl[k].fri, &g1, &g2);
   }
-  if (dr.fl > 0.f) {
-    float D = dr.fD, jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
-    if (x <= -lim) g1 -= fl * jp;
-    else if (x >= lim) g1 += fl * jp;
-    else { g1 += D * x * jp; g2 += D * jp * jp; }
-  }
-  if (dr.lims != 0.f) {
-    float jp = dr.pl, x = fmaf(al, jp, dr.jl);
-    if (x < 0.f) { g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; }
+  {  // the own dof's friction-loss and limit rows, as selects (the same fused multiply-adds as the branches they replace: same bits, a dozen exec-mask instructions fewer per evaluation)
+    const float D = dr.fD, jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
+    const bool has = fl > 0.f, lo_ = x <= -lim, hi_ = x >= lim, mid = has & !lo_ & !hi_;
+    const float t = lo_ ? -fl : (hi_ ? fl : D * x);
+    g1 = has ? fmaf(t, jp, g1) : g1;
+    g2 = mid ? fmaf(D * jp, jp, g2) : g2;
+    const float jl = dr.pl, xl_ = fmaf(al, jl, dr.jl);
+    const bool lim_on = (dr.lims != 0.f) & (xl_ < 0.f);
+    g1 = lim_on ? fmaf(dr.lD * xl_, jl, g1) : g1;
+    g2 = lim_on ? fmaf(dr.lD * jl, jl, g2) : g2;
   }
   *d1 = g1; *d2 = g2;
 }
@@ -1585,7 +1586,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
 #endif
         V5_TICK(10)
-        float lo = 0.f, hi = -1.f, alpha = 1.f, dlo = gp, dhi = 0.f; int side = 0; bool lsact = act;
+        float lo = 0.f, hi = -1.f, alpha = 1.f; bool lsact = act;
 #ifdef JH_V5_CENSUS
         int cen_ls = 0, cen_lsw = 0; const bool cen_act = act;
         if (stats && lane == 0) atomicAdd(stats + 320 + __popcll(__ballot(act && l == 0)), 1);
@@ -1626,19 +1627,17 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           }
           if (lsact) alpha = nx;
 #else
-          if (lsact) {
-            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
-            else {
-              if (d1 < 0.f) { lo = alpha; dlo = d1; if (side < 0) dhi *= 0.5f; side = -1; } else { hi = alpha; dhi = d1; if (side > 0) dlo *= 0.5f; side = 1; }
+          {  // safeguarded Newton step on the slope, as selects (round 6: the nested branches were a dozen exec-mask instructions per evaluation; the same arithmetic)
+            const bool upd = lsact & !(fabsf(d1) <= lstol * fabsf(gp)), neg = d1 < 0.f;
+            lo = (upd & neg) ? alpha : lo; hi = (upd & !neg) ? alpha : hi;
 #if JH_V5_LSRCP
-              float nx = alpha - d1 * __builtin_amdgcn_rcpf(d2);
+            float nx = alpha - d1 * __builtin_amdgcn_rcpf(d2);
 #else
-              float nx = alpha - d1 * __frcp_rn(d2);
+            float nx = alpha - d1 * __frcp_rn(d2);
 #endif
-              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
-              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
-              alpha = nx;
-            }
+            const bool out_lo = nx <= lo, out_hi = nx >= hi;
+            nx = hi < 0.f ? (out_lo ? 2.f * alpha : nx) : ((out_lo | out_hi) ? 0.5f * (lo + hi) : nx);
+            alpha = upd ? nx : alpha; lsact = upd;
           }
 #endif
         }
