@@ -169,9 +169,10 @@ __device__ __forceinline__ void cone_dir(const float* jar, const float* jp, cons
   const float b2 = D[0] * jp[0] * jp[0] + D[1] * jp[1] * jp[1] + D[2] * jp[2] * jp[2];
   const float V0 = jp[0] * mu, V1 = jp[1] * fri, V2 = jp[2] * fri, e = N - mu * T;
   const float Tp = (U1 * V1 + U2 * V2) * iT, Tpp = (V1 * V1 + V2 * V2 - Tp * Tp) * iT, ep = V0 - mu * Tp;
-  const float m1 = Dm * e * ep, m2 = Dm * (ep * ep - e * mu * Tpp);
-  *d1 += top ? 0.f : (bottom ? b1 : m1);
-  *d2 += top ? 0.f : (bottom ? b2 : m2);
+  float m1 = Dm * e * ep, m2 = Dm * (ep * ep - e * mu * Tpp), c1 = b1, c2 = b2;
+  asm volatile("" : "+v"(m1), "+v"(m2), "+v"(c1), "+v"(c2));  // all three zones are evaluated: the selects below stay selects (left to itself the compiler branches around them)
+  *d1 += top ? 0.f : (bottom ? c1 : m1);
+  *d2 += top ? 0.f : (bottom ? c2 : m2);
 }
 
 // pyramidal-cone contact (condim 3): four one-sided rows  jar_n +- mu*jar_t1, jar_n +- mu*jar_t2, all with the same D.

@@ -288,7 +288,8 @@ __device__ __forceinline__ void link_vel(const RS& S, int code, const float* pos
   float c3[NLK][3]; if (c3c) load_c3(c3c, c3); else link_c3(S, ch, pos, c3);
 #pragma unroll
   for (int j = 0; j < NLK; j++) {
-    const float xj = j <= dep ? sign * vec[6 + 4 * ch + j] : 0.f;
+    const float vj = vec[6 + 4 * ch + j];  // (loaded whatever the depth: a valid address, and a conditional load is an exec-mask round trip)
+    const float xj = j <= dep ? sign * vj : 0.f;
     w[0] = fmaf(c3[j][0], xj, w[0]); w[1] = fmaf(c3[j][1], xj, w[1]); w[2] = fmaf(c3[j][2], xj, w[2]);
   }
 #else
@@ -1104,11 +1105,15 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         float g_own = 0.f, hd = 0.f;
 #pragma unroll
         for (int j = 0; j < NLK; j++) g_own += Mrow[j] * quad_get(da_own, j);
-        if (dr.fl > 0.f) {
-          float D = dr.fD, x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
-          if (x <= -lim) g_own -= fl; else if (x >= lim) g_own += fl; else { g_own += D * x; hd += D; }
+        {  // the own dof's friction-loss and limit rows (selects: see lane_rows_dir)
+          const float D = dr.fD, x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
+          const bool has = fl > 0.f, lo_ = x <= -lim, hi_ = x >= lim, mid = has & !lo_ & !hi_;
+          g_own = has ? (lo_ ? g_own - fl : (hi_ ? g_own + fl : fmaf(D, x, g_own))) : g_own;
+          hd = mid ? hd + D : hd;
+          const bool lon = (dr.lims != 0.f) & (dr.jl < 0.f);
+          g_own = lon ? fmaf(dr.lims * dr.lD, dr.jl, g_own) : g_own;
+          hd = lon ? hd + dr.lD : hd;
         }
-        if (dr.lims != 0.f && dr.jl < 0.f) { g_own += dr.lims * dr.lD * dr.jl; hd += dr.lD; }
         if (act) S.g[6 + l] = g_own;
         // One pass over the contacts builds the gradient AND the Hessian of this iterate: the joint columns axis x (pos - anchor), the world force and the cone weights are
         // computed once instead of once per pass.  The pass that finds a rollout converged has then assembled a Hessian nobody reads (one iteration in ten).
@@ -1132,8 +1137,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             float f[3], Wk[6];
             const float D[3] = {t.D0, t.D1, t.D1};
             cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
-            const bool on = aact0 && !(Wk[0] == 0.f && Wk[2] == 0.f && Wk[5] == 0.f);
-            if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f && !on) continue;  // separated contact
+            // separated contact (the cone's top zone: no force, no weights).  Outside the dense-capable copy `aact0` is `act`, true in here, and a contact whose weights
+            // vanish has no force: the test is the weights alone, and `on` a compile-time constant -- three exec-masked regions below merge into straight-line code
+            const bool nz = !((Wk[0] == 0.f) & (Wk[2] == 0.f) & (Wk[5] == 0.f));
+            bool on = true;
+            if constexpr (DENSE) { on = aact0 & nz; if ((f[0] == 0.f) & (f[1] == 0.f) & (f[2] == 0.f) & !on) continue; }
+            else { if (!nz) continue; }
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
             const bool cube = !HC || t.la == CUBE;
@@ -1278,9 +1287,9 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
         g_own = S.g[6 + l];
         const float gn = gsum(g_own * g_own * iMd + gcl * gcl * imck);
-        if (act && gn <= tol * tol * fmaxf(snorm, 1e-12f)) act = false;
+        act = act & !(gn <= tol * tol * fmaxf(snorm, 1e-12f));
         if (!__any(act)) break;
-        if (act) iters_this++;
+        iters_this += act ? 1 : 0;
         n_wave_iters++;
         // ---- (3) Hessian: M + dof rows on the chain diagonals, cube inertia on Hcc, J'WJ of the contacts as atomics into the arrow blocks.  A rollout with a
         // contact between two finger chains has no arrow structure: its Hessian is assembled densely further down (aact = false here)
@@ -1294,7 +1303,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         auto factor_block = [&]() __attribute__((always_inline)) {
           for (int k = 0; k < 10; k++) L[k] = S.Hbb[c][k];
           chol4(L, Linv);
-          for (int j = 0; j < NLK; j++) { Ya[j] = S.Hcb[c][j * 6 + s]; Yb[j] = hasb ? S.Hcb[c][j * 6 + 4 + s] : 0.f; }
+          for (int j = 0; j < NLK; j++) { Ya[j] = S.Hcb[c][j * 6 + s]; const float yb = (&S.Hcb[0][0])[c * 24 + j * 6 + 4 + (s & 1)]; Yb[j] = hasb ? yb : 0.f; }  // (unconditional load, then select)
           fwd4(L, Linv, Ya); fwd4(L, Linv, Yb);
           for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
           fwd4(L, Linv, zb);
@@ -1413,7 +1422,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           bwd4(L, Linv, pc4);
         }
         float p_own = sel4(pc4, s);
-        float xcl = l < 6 ? (l < 4 ? sel4(xc6, l) : (l == 4 ? xc6[4] : xc6[5])) : 0.f;
+        float xcl = l == 0 ? xc6[0] : (l == 1 ? xc6[1] : (l == 2 ? xc6[2] : (l == 3 ? xc6[3] : (l == 4 ? xc6[4] : (l == 5 ? xc6[5] : 0.f)))));
         if (aact) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
         WSYNC();
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
@@ -1636,7 +1645,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             float nx = alpha - d1 * __frcp_rn(d2);
 #endif
             const bool out_lo = nx <= lo, out_hi = nx >= hi;
-            nx = hi < 0.f ? (out_lo ? 2.f * alpha : nx) : ((out_lo | out_hi) ? 0.5f * (lo + hi) : nx);
+            float dbl = 2.f * alpha, mid_ = 0.5f * (lo + hi); asm volatile("" : "+v"(dbl), "+v"(mid_));  // (both computed: selects, not branches)
+            nx = hi < 0.f ? (out_lo ? dbl : nx) : ((out_lo | out_hi) ? mid_ : nx);
             alpha = upd ? nx : alpha; lsact = upd;
           }
 #endif
