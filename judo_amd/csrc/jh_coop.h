@@ -152,30 +152,38 @@ __device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const
   float A[3][3], B[3][3], dv[3], Cm[3][3], AC[3][3], dA[3], dB[3];
   for (int k = 0; k < 3; k++) { col3(A[k], R1, k); col3(B[k], R2, k); dv[k] = p2[k] - p1[k]; }
   for (int i = 0; i < 3; i++) { dA[i] = dot3(dv, A[i]); dB[i] = dot3(dv, B[i]); for (int j = 0; j < 3; j++) { Cm[i][j] = dot3(A[i], B[j]); AC[i][j] = fabsf(Cm[i][j]); } }
-  float best = -1e30f; int btype = -1, bi = 0, bj = 0;
+  // The fifteen separating-axis tests without an exit per axis: one flag, one exit.  (A candidate pair that reaches the narrow phase almost always touches, so the early exits
+  // saved nothing -- and every one of them was an exec-mask round trip and a branch; lanes of a wave sit in different pairs anyway.)  Selects throughout: the same values.
+  float best = -1e30f; int btype = -1, bi = 0, bj = 0; bool sep = false;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
-    float s = fabsf(dA[i]) - (h1[i] + h2[0] * AC[i][0] + h2[1] * AC[i][1] + h2[2] * AC[i][2]);
-    if (s > 0.f) return;
-    if (s > best) { best = s; btype = 0; bi = i; }
+    const float s = fabsf(dA[i]) - (h1[i] + h2[0] * AC[i][0] + h2[1] * AC[i][1] + h2[2] * AC[i][2]);
+    sep = sep | (s > 0.f);
+    const bool up = s > best; best = up ? s : best; btype = up ? 0 : btype; bi = up ? i : bi;
   }
+#pragma unroll
   for (int j = 0; j < 3; j++) {
-    float s = fabsf(dB[j]) - (h2[j] + h1[0] * AC[0][j] + h1[1] * AC[1][j] + h1[2] * AC[2][j]);
-    if (s > 0.f) return;
-    if (s > best) { best = s; btype = 1; bj = j; }
+    const float s = fabsf(dB[j]) - (h2[j] + h1[0] * AC[0][j] + h1[1] * AC[1][j] + h1[2] * AC[2][j]);
+    sep = sep | (s > 0.f);
+    const bool up = s > best; best = up ? s : best; btype = up ? 1 : btype; bj = up ? j : bj;
   }
   float ebest = -1e30f, eL[3] = {0, 0, 0}; int ei = -1, ej = -1;
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       float L[3]; cross3(L, A[i], B[j]);
-      float l2 = dot3(L, L);
-      if (l2 < 1e-12f) continue;
-      float il = rsqrtf(l2); L[0] *= il; L[1] *= il; L[2] *= il;
+      const float l2 = dot3(L, L);
+      const bool okl = !(l2 < 1e-12f);  // (parallel edges: no axis)
+      const float il = rsqrtf(okl ? l2 : 1.f); L[0] *= il; L[1] *= il; L[2] *= il;
       float ra = 0.f, rb = 0.f;
       for (int k = 0; k < 3; k++) { ra += h1[k] * fabsf(dot3(A[k], L)); rb += h2[k] * fabsf(dot3(B[k], L)); }
-      float s = fabsf(dot3(dv, L)) - (ra + rb);
-      if (s > 0.f) return;
-      if (s > ebest) { ebest = s; ei = i; ej = j; eL[0] = L[0]; eL[1] = L[1]; eL[2] = L[2]; }
+      const float s = fabsf(dot3(dv, L)) - (ra + rb);
+      sep = sep | (okl & (s > 0.f));
+      const bool up = okl & (s > ebest);
+      ebest = up ? s : ebest; ei = up ? i : ei; ej = up ? j : ej; eL[0] = up ? L[0] : eL[0]; eL[1] = up ? L[1] : eL[1]; eL[2] = up ? L[2] : eL[2];
     }
+  if (sep) return;
   bool use_edge = ei >= 0 && (best < 0.f ? ebest > best / 1.05f + 1e-12f : ebest > best * 1.05f + 1e-12f);
   if (use_edge) {
     float n[3] = {eL[0], eL[1], eL[2]};
@@ -226,9 +234,9 @@ __device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const
   const float ca = dot3(ci, Ara), cbb = dot3(ci, Arb), cg = dot3(ci, n);
   const float e1a = dot3(e1, Ara), e1b = dot3(e1, Arb), e1g = dot3(e1, n), e2a = dot3(e2, Ara), e2b = dot3(e2, Arb), e2g = dot3(e2, n);
   const float href = pick(hr, ri);
-  auto emit = [&](float al, float be, float ga) __attribute__((always_inline)) {
+  auto emit = [&](bool ok, float al, float be, float ga) __attribute__((always_inline)) {
     float depth = href - ga;
-    if (depth <= 0.f) return;
+    if (!(ok & !(depth <= 0.f))) return;
     float pos[3], nn[3], gm = ga + 0.5f * depth;
     for (int k = 0; k < 3; k++) { pos[k] = pr[k] + al * Ara[k] + be * Arb[k] + gm * n[k]; nn[k] = f0 ? n[k] : -n[k]; }
     sk.push(pos, nn, -depth);
@@ -243,15 +251,16 @@ __device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const
   // coordinate, (c) open.  With (b) open in both, a vertex outside in `a` and exactly on `b = hb` belonged to no set: a closed gripper lost 8 of its 16
   // face-to-face pad contacts that way (found against the oracle's Sutherland-Hodgman clipping, which has no such hole).
 #pragma unroll
-  for (int q = 0; q < 4; q++) if (fabsf(va[q]) <= ha && fabsf(vb[q]) <= hb) emit(va[q], vb[q], vg[q]);   // (a)
+  for (int q = 0; q < 4; q++) emit((fabsf(va[q]) <= ha) & (fabsf(vb[q]) <= hb), va[q], vb[q], vg[q]);   // (a)
 #pragma unroll
   for (int q = 0; q < 4; q++) {                                                                        // (b)
     const int qn = (q + 1) & 3;
     const float da = va[qn] - va[q], db = vb[qn] - vb[q], dg = vg[qn] - vg[q];
 #pragma unroll
     for (int sgn = -1; sgn <= 1; sgn += 2) {
-      if (da != 0.f) { float t = (sgn * ha - va[q]) / da; float bb2 = vb[q] + t * db; if (t > 0.f && t < 1.f && fabsf(bb2) <= hb) emit(sgn * ha, bb2, vg[q] + t * dg); }
-      if (db != 0.f) { float t = (sgn * hb - vb[q]) / db; float aa2 = va[q] + t * da; if (t > 0.f && t < 1.f && fabsf(aa2) <= ha) emit(aa2, sgn * hb, vg[q] + t * dg); }
+      // (one predicate per crossing; with da == 0 the quotient is inf or nan and fails the comparisons by itself, the explicit test keeps the predicate what it was)
+      { const float t = (sgn * ha - va[q]) / da, bb2 = vb[q] + t * db; emit((da != 0.f) & (t > 0.f) & (t < 1.f) & (fabsf(bb2) <= hb), sgn * ha, bb2, vg[q] + t * dg); }
+      { const float t = (sgn * hb - vb[q]) / db, aa2 = va[q] + t * da; emit((db != 0.f) & (t > 0.f) & (t < 1.f) & (fabsf(aa2) <= ha), aa2, sgn * hb, vg[q] + t * dg); }
     }
   }
   const float det = e1a * e2b - e1b * e2a;                                                               // (c)
@@ -261,7 +270,7 @@ __device__ __forceinline__ void collide_box_box(Sink& sk, const float* p1, const
     for (int q = 0; q < 4; q++) {
       const float pa = s1[q] * ha - ca, pb2 = s2[q] * hb - cbb;
       const float t1 = (pa * e2b - pb2 * e2a) * idet, t2 = (e1a * pb2 - e1b * pa) * idet;
-      if (fabsf(t1) < 1.f && fabsf(t2) < 1.f) emit(s1[q] * ha, s2[q] * hb, cg + t1 * e1g + t2 * e2g);
+      emit((fabsf(t1) < 1.f) & (fabsf(t2) < 1.f), s1[q] * ha, s2[q] * hb, cg + t1 * e1g + t2 * e2g);
     }
   }
 }

@@ -169,7 +169,7 @@ __device__ __forceinline__ bool static_code(int b) { return b == 0 || b >= NMB; 
 constexpr int MAXK = JH_V5_MAXK;
 
 // per-lane model constants staged in LDS (index = lane & 15)
-enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_N = JH_V5_LCN };  // (row stride of the LDS table: odd, so that the 16 lanes' rows start in 16 different banks)
+enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_HCC0 = LC_SI + 5, LC_HCC1, LC_N = JH_V5_LCN };  // (LC_HCC0 / 1: what the cube's inertia adds to the packed 6 x 6 block's entries l and 16 + l)  // (row stride of the LDS table: odd, so that the 16 lanes' rows start in 16 different banks)
 
 #ifdef JH_V5_X_DIET  // occupancy experiments on the cube-only instantiations: the arrays only the hand's own contacts use shrink to stubs
 constexpr int RS_NBC = 1, RS_NBPL = 4, RS_NHX = 1, RS_NDH = 4;
@@ -526,6 +526,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     lc[LC_LIMITED] = df[DF_LIMITED]; lc[LC_LO] = df[DF_LO]; lc[LC_HI] = df[DF_HI]; lc[LC_LK] = df[DF_LK]; lc[LC_LB] = df[DF_LB];
     for (int k = 0; k < 5; k++) lc[LC_SI + k] = df[DF_SOLIMP + k];
     lc[LC_KP] = af[AF_KP]; lc[LC_KV] = af[AF_KV]; lc[LC_CLIM] = af[AF_CLIM]; lc[LC_CLO] = af[AF_CLO]; lc[LC_CHI] = af[AF_CHI];
+    // the diagonal of the cube's mass block at its packed positions tri(q, q) = 0, 2, 5, 9, 14, 20: one LDS read per iteration instead of a select chain over scalars that
+    // the register allocator keeps spilled (sixteen v_readlane to get one of them back)
+    lc[LC_HCC0] = (l == 0 || l == 2 || l == 5) ? gF[HF_CMASS] : (l == 9 ? gF[HF_CINERTIA] : (l == 14 ? gF[HF_CINERTIA + 1] : 0.f));
+    lc[LC_HCC1] = l == 4 ? gF[HF_CINERTIA + 2] : 0.f;
   }
   const float* lc = sLane + l * LC_N;
   // Rollout handled by this row of 16 lanes.  A launch too small to fill the GPU (`dshift` > 0, chosen by the launcher) gives a wave 4 >> dshift rollouts instead of four and
@@ -1278,8 +1282,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         gcl = fmaf(mck, dcl, gcl);
         {
           if (aact0) {
-            S.Hcc[l] = h0 + ((l == 0 || l == 2 || l == 5) ? cmass : (l == 9 ? cI[0] : (l == 14 ? cI[1] : 0.f)));
-            if (l < 5) S.Hcc[16 + l] = h1 + (l == 4 ? cI[2] : 0.f);
+            S.Hcc[l] = h0 + lc[LC_HCC0];
+            if (l < 5) S.Hcc[16 + l] = h1 + lc[LC_HCC1];
           }
         }
         WSYNC();
