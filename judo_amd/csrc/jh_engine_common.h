@@ -156,6 +156,31 @@ __device__ __forceinline__ float cone_eval(const float* jar, const float* D, flo
   return 0.5f * Dm * NT * NT;
 }
 
+// cone_eval in two steps, for callers that skip a separated contact (the top zone) before anything else: cone_top returns the zone test and keeps the quantities the
+// other two zones need; cone_below is cone_eval's bottom / middle part, expression for expression (same bits)
+struct ConeZ { float U1, U2, N, iT, T; };
+__device__ __forceinline__ bool cone_top(const float* jar, float mu, float fri, ConeZ& z) {
+  float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
+  float N = U0, T2 = U1 * U1 + U2 * U2;
+  float iT = T2 > 0.f ? __frsqrt_rn(T2) : 0.f, T = T2 * iT;
+  z.U1 = U1; z.U2 = U2; z.N = N; z.iT = iT; z.T = T;
+  return N >= mu * T;
+}
+__device__ __forceinline__ void cone_below(const float* jar, const float* D, float Dm, float mu, float fri, const ConeZ& z, float* f, float* W) {
+  const float N = z.N, T = z.T, iT = z.iT, U1 = z.U1, U2 = z.U2;
+  if (mu * N + T <= 0.f) {
+    f[0] = -D[0] * jar[0]; f[1] = -D[1] * jar[1]; f[2] = -D[2] * jar[2];
+    W[0] = D[0]; W[1] = 0.f; W[2] = D[1]; W[3] = 0.f; W[4] = 0.f; W[5] = D[2];
+    return;
+  }
+  const float NT = N - mu * T, a1 = U1 * iT, a2 = U2 * iT;
+  f[0] = -Dm * NT * mu; f[1] = -f[0] * a1 * fri; f[2] = -f[0] * a2 * fri;
+  const float k1 = Dm * mu * mu, k2 = Dm * NT * mu * iT;
+  const float h01 = -Dm * mu * a1, h02 = -Dm * mu * a2;
+  const float h11 = k1 * a1 * a1 - k2 * (1.f - a1 * a1), h12 = (k1 + k2) * a1 * a2, h22 = k1 * a2 * a2 - k2 * (1.f - a2 * a2);
+  W[0] = mu * Dm * mu; W[1] = fri * h01 * mu; W[2] = fri * h11 * fri; W[3] = fri * h02 * mu; W[4] = fri * h12 * fri; W[5] = fri * h22 * fri;
+}
+
 // directional derivatives of one elliptic-cone contact's cost along jp at jar (the exact line search needs only these two scalars):
 // middle zone s = 1/2 Dm e^2 with e = N - mu T  =>  s' = Dm e e',  s'' = Dm (e'^2 + e e''),  T' = (U.V)/T,  T'' = (|V|^2 - T'^2)/T.
 // Branch-free: the three zones are evaluated side by side and selected (lanes of a wave sit in different zones anyway);

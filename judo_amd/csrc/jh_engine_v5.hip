@@ -96,7 +96,7 @@ constexpr int NCH = 4, NLK = 4;
 // the loop, do not fit in the register file and are spilled and reloaded in every iteration.
 #define OPAQUE(x) asm volatile("" : "+v"(x))
 #ifndef JH_V5_RSPAD
-#define JH_V5_RSPAD 8
+#define JH_V5_RSPAD 4
 #endif
 #ifndef JH_V5_LCN
 #define JH_V5_LCN 25
@@ -169,7 +169,7 @@ __device__ __forceinline__ bool static_code(int b) { return b == 0 || b >= NMB; 
 constexpr int MAXK = JH_V5_MAXK;
 
 // per-lane model constants staged in LDS (index = lane & 15)
-enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_HCC0 = LC_SI + 5, LC_HCC1, LC_N = JH_V5_LCN };  // (LC_HCC0 / 1: what the cube's inertia adds to the packed 6 x 6 block's entries l and 16 + l)  // (row stride of the LDS table: odd, so that the 16 lanes' rows start in 16 different banks)
+enum { LC_DAMP = 0, LC_KVD, LC_KP, LC_KV, LC_CLO, LC_CHI, LC_CLIM, LC_FL, LC_FB, LC_FD, LC_INVW, LC_LIMITED, LC_LO, LC_HI, LC_LK, LC_LB, LC_SI, LC_IMCK = LC_SI + 5, LC_N = JH_V5_LCN };  // (LC_IMCK: 1 / (the cube's mass or inertia of dof l), lanes 0..5; zero elsewhere)  // (row stride of the LDS table: odd, so that the 16 lanes' rows start in 16 different banks)
 
 #ifdef JH_V5_X_DIET  // occupancy experiments on the cube-only instantiations: the arrays only the hand's own contacts use shrink to stubs
 constexpr int RS_NBC = 1, RS_NBPL = 4, RS_NHX = 1, RS_NDH = 4;
@@ -183,6 +183,7 @@ struct __attribute__((aligned(16))) RS {  // per-rollout shared state in LDS
   float acn[6];       // constraint-consistent cube acceleration of this step (every lane integrates the replicated cube state)
   float Mbb[NCH][10];
   float rhs6[6];
+  float cmd[4];      // the cube's mass and its three principal inertias: the diagonal of its mass block, next to rhs6 so that the Schur step's reads bring it along
   union {
     struct {
       float bs[RS_NBC][4];   // bounding sphere of the hand bodies (0, 17.. = static geometry, 1..16 = finger links): world centre, radius (the centre is the
@@ -356,6 +357,26 @@ __device__ __forceinline__ void slot_Jx(const Slot& s, const RS& S, const float*
   out[0] = dot3(s.fr, w); out[1] = dot3(s.fr + 3, w); out[2] = dot3(s.fr + 6, w);
 }
 
+// slot_Jx for a cube contact of the copy without the hand's own contacts, FIRST slot, without a branch: the finger part is computed whatever the slot holds (an empty slot or a
+// contact between the cube and the static geometry reads valid addresses -- link code 0 gives chain -1, entries 2..5 of `vec`) and dropped by a select; an empty slot's frame is
+// zero, so its image is zero.  The same fused multiply-adds in the same order as slot_Jx: same bits.
+__device__ __forceinline__ void slot_Jx_first(const Slot& s, const float* xl, const float* wang, const float* vec, float* out, const float* c3c) {
+  float wx[3]; cross3(wx, wang, s.rc);
+  const float w0[3] = {-(xl[0] + wx[0]), -(xl[1] + wx[1]), -(xl[2] + wx[2])};
+  const int ch = (s.lb - 1) >> 2, dep = (s.lb - 1) & 3;
+  float c3[NLK][3]; load_c3(c3c, c3);
+  float w[3] = {w0[0], w0[1], w0[2]};
+#pragma unroll
+  for (int j = 0; j < NLK; j++) {
+    const float vj = vec[6 + 4 * ch + j];
+    const float xj = j <= dep ? vj : 0.f;
+    w[0] = fmaf(c3[j][0], xj, w[0]); w[1] = fmaf(c3[j][1], xj, w[1]); w[2] = fmaf(c3[j][2], xj, w[2]);
+  }
+  const bool lk = s.lb > 0;
+  w[0] = lk ? w[0] : w0[0]; w[1] = lk ? w[1] : w0[1]; w[2] = lk ? w[2] : w0[2];
+  out[0] = dot3(s.fr, w); out[1] = dot3(s.fr + 3, w); out[2] = dot3(s.fr + 6, w);
+}
+
 struct DofRows { float fl, fD, fR, faref, lims, laref, lD, jf, jl, pf, pl; };  // fR = 1/fD
 
 __device__ __forceinline__ float cone_cost(const Slot& s) {
@@ -377,12 +398,14 @@ __device__ __forceinline__ float dof_rows_cost(const DofRows& dr) {
 }
 
 // slope and curvature of the lane's rows along the search direction at step al (line search)
+// (`used`: bit k set iff some lane of the WAVE has a contact in slot k.  An empty slot is all zeros -- its cone test reads `top`, its terms are zero -- so a slot is evaluated
+// by every lane or skipped by the whole wave: no exec-masked region inside the line search's loop.)
 template <int NS>
-__device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr, float al, float* d1, float* d2) {
+__device__ __forceinline__ void lane_rows_dir(const Slot* sl, const DofRows& dr, float al, float* d1, float* d2, unsigned used) {
   float g1 = 0.f, g2 = 0.f;
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    if (sl[k].la < 0) continue;
+    if (k > 0 && !((used >> k) & 1u)) continue;
     const float* jp = sl[k].jp;
     const float jar[3] = {fmaf(al, jp[0], sl[k].jar[0]), fmaf(al, jp[1], sl[k].jar[1]), fmaf(al, jp[2], sl[k].jar[2])};
     const float D[3] = {sl[k].D0, sl[k].D1, sl[k].D1};
@@ -526,10 +549,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     lc[LC_LIMITED] = df[DF_LIMITED]; lc[LC_LO] = df[DF_LO]; lc[LC_HI] = df[DF_HI]; lc[LC_LK] = df[DF_LK]; lc[LC_LB] = df[DF_LB];
     for (int k = 0; k < 5; k++) lc[LC_SI + k] = df[DF_SOLIMP + k];
     lc[LC_KP] = af[AF_KP]; lc[LC_KV] = af[AF_KV]; lc[LC_CLIM] = af[AF_CLIM]; lc[LC_CLO] = af[AF_CLO]; lc[LC_CHI] = af[AF_CHI];
-    // the diagonal of the cube's mass block at its packed positions tri(q, q) = 0, 2, 5, 9, 14, 20: one LDS read per iteration instead of a select chain over scalars that
-    // the register allocator keeps spilled (sixteen v_readlane to get one of them back)
-    lc[LC_HCC0] = (l == 0 || l == 2 || l == 5) ? gF[HF_CMASS] : (l == 9 ? gF[HF_CINERTIA] : (l == 14 ? gF[HF_CINERTIA + 1] : 0.f));
-    lc[LC_HCC1] = l == 4 ? gF[HF_CINERTIA + 2] : 0.f;
+    // (the convergence test's scale of the cube's dofs: read from here in every iteration -- kept in a register across the loop it is spilled to scratch memory)
+    lc[LC_IMCK] = l < 6 ? 1.f / (l < 3 ? gF[HF_CMASS] : gF[HF_CINERTIA + (l < 3 ? 0 : l - 3)]) : 0.f;
   }
   const float* lc = sLane + l * LC_N;
   // Rollout handled by this row of 16 lanes.  A launch too small to fill the GPU (`dshift` > 0, chosen by the launcher) gives a wave 4 >> dshift rollouts instead of four and
@@ -545,7 +566,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
   const float cK = gF[HF_CK], cB = gF[HF_CB];
   float csi[5]; for (int k = 0; k < 5; k++) csi[k] = gF[HF_SOLIMP + k];
   // own cube dof (lanes 0..5): inertia and its inverse; zero elsewhere
-  const float mck = (l < 3 ? cmass : (l == 3 ? cI[0] : (l == 4 ? cI[1] : (l == 5 ? cI[2] : 0.f)))), imck = l < 6 ? 1.f / mck : 0.f;
+  const float mck = (l < 3 ? cmass : (l == 3 ? cI[0] : (l == 4 ? cI[1] : (l == 5 ? cI[2] : 0.f))));
   // ---- state: own joint + replicated cube
   float q, qd, qc[7], vc[6];
   {
@@ -570,6 +591,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     if (knots_out && live) for (int k = 0; k < K; k++) knots_out[(size_t)(k * NU + l) * ldn + n] = knot_at(k, l, nc);
   }
   S.ws[6 + l] = 0.f; if (l < 6) S.ws[l] = 0.f;
+  if (l < 4) S.cmd[l] = l == 0 ? cmass : (l == 1 ? cI[0] : (l == 2 ? cI[1] : cI[2]));
   int n_iters = 0, n_maxed = 0, n_wave_iters = 0;  // (the last: iterations this wave ran -- per step the maximum over its four rollouts)
   float acc = 0.f;
 #ifdef JH_V5_TICKS  // shader-clock totals per phase (diagnostic builds; tools/diag/profile_v5.py): 0 kinematics+dynamics, 1 broad phase, 2 narrow phase, 3 rows+warm start,
@@ -961,6 +983,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         sl[k].la = -1; sl[k].lb = 0;
         for (int i = 0; i < 9; i++) sl[k].fr[i] = 0.f;
         sl[k].rc[0] = sl[k].rc[1] = sl[k].rc[2] = 0.f;
+        sl[k].D0 = sl[k].D1 = sl[k].Dm = sl[k].mu = sl[k].fri = 0.f;  // (an empty slot is all zeros: the line search evaluates it like any other and gets zero, lane_rows_dir)
+        for (int i = 0; i < 3; i++) sl[k].aref[i] = sl[k].jar[i] = sl[k].jp[i] = 0.f;
         if (idx < ncon) {
           const float* e = (NOVF == 0 || idx < NCP) ? S.pool[idx] : ovf_all + (size_t)nc * (NOVF * POOL_F) + (idx - NCP) * POOL_F;
           sl[k].rc[0] = e[0] - qc[0]; sl[k].rc[1] = e[1] - qc[1]; sl[k].rc[2] = e[2] - qc[2];
@@ -1003,10 +1027,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     // Without a cycle in that graph (every coupled step of the headline workload: one pair, mostly middle-ring, or a chain touching both neighbours) the
     // arrow elimination runs in stages, leaf chains first: a chain is eliminated when at most one coupled neighbour is left (its parent `par`, whose
     // blocks take the Schur update and which factorises at a later stage `lvl`); then the cube.  A graph with a cycle takes the dense direction.
-    bool anyslot = false; int cmask = 0;
+    bool anyslot = false; int cmask = 0; unsigned used = 0;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       anyslot |= sl[k].la >= 0;
+      used |= __any(sl[k].la >= 0) ? 1u << k : 0u;
       if (HC && sl[k].la > 0 && sl[k].la != CUBE && sl[k].lb > 0 && ((sl[k].la - 1) >> 2) != ((sl[k].lb - 1) >> 2)) cmask |= 1 << (4 * ((sl[k].la - 1) >> 2) + ((sl[k].lb - 1) >> 2));
     }
     int lvl = 0, par = -1, nlev = 0; bool dense_row = false;
@@ -1029,7 +1054,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
     // ================================================================ Newton solver (rows distributed over the 16 lanes)
     const float Mdiag_own = sel4(Mrow, s), iMd = 1.f / Mdiag_own;
     const float fsc_own = mck * a0c_own;
-    const float snorm = gsum(fs_own * fs_own * iMd + fsc_own * fsc_own * imck);
+    const float snorm = gsum(fs_own * fs_own * iMd + fsc_own * fsc_own * lc[LC_IMCK]);
     const bool has_rows = gor((int)(anyslot || dr.fl > 0.f || dr.lims != 0.f)) != 0;
     iters_this = 0;
     if (!has_rows) { a_own = a0_own; ac_own = a0c_own; }
@@ -1112,19 +1137,22 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         {  // the own dof's friction-loss and limit rows (selects: see lane_rows_dir)
           const float D = dr.fD, x = dr.jf, fl = dr.fl, lim = dr.fR * fl;
           const bool has = fl > 0.f, lo_ = x <= -lim, hi_ = x >= lim, mid = has & !lo_ & !hi_;
-          g_own = has ? (lo_ ? g_own - fl : (hi_ ? g_own + fl : fmaf(D, x, g_own))) : g_own;
+          float ga = g_own - fl, gb = g_own + fl, gm = fmaf(D, x, g_own); asm volatile("" : "+v"(ga), "+v"(gb), "+v"(gm));  // (all three computed: selects, not branches)
+          g_own = has ? (lo_ ? ga : (hi_ ? gb : gm)) : g_own;
           hd = mid ? hd + D : hd;
           const bool lon = (dr.lims != 0.f) & (dr.jl < 0.f);
           g_own = lon ? fmaf(dr.lims * dr.lD, dr.jl, g_own) : g_own;
           hd = lon ? hd + dr.lD : hd;
         }
-        if (act) S.g[6 + l] = g_own;
+        S.g[6 + l] = g_own;  // (this and the block initialisation below are stored whatever the rollout's state -- nothing of a converged rollout is read again this step, a dense
+                             // row's matrix is zeroed after them -- so that the top of an iteration has no exec-masked region in front of the contact pass)
         // One pass over the contacts builds the gradient AND the Hessian of this iterate: the joint columns axis x (pos - anchor), the world force and the cone weights are
         // computed once instead of once per pass.  The pass that finds a rollout converged has then assembled a Hessian nobody reads (one iteration in ten).
         const bool aact0 = act && !(DENSE && dense_row);
-        if (aact0) {
+        {
+          float* hb = &S.Hbb[c][tri(s, 0)];  // row s of the chain's block: entries j < s, then the diagonal -- written once per column index j, the columns beyond the diagonal land on it again
 #pragma unroll
-          for (int j = 0; j < NLK; j++) if (j <= s) S.Hbb[c][tri(s, j)] = Mrow[j] + (j == s ? hd : 0.f);
+          for (int j = 0; j < NLK; j++) hb[j < s ? j : s] = j < s ? Mrow[j] : Mdiag_own + hd;
           for (int k = 0; k < 6; k++) S.Hcb[c][s * 6 + k] = 0.f;
           if (HC) for (int k = 0; k < 6; k++) S.Hx[0][l * 6 + k] = 0.f;
         }
@@ -1140,13 +1168,14 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             const Slot& t = sl[k];
             float f[3], Wk[6];
             const float D[3] = {t.D0, t.D1, t.D1};
-            cone_eval(t.jar, D, t.Dm, t.mu, t.fri, f, Wk);
-            // separated contact (the cone's top zone: no force, no weights).  Outside the dense-capable copy `aact0` is `act`, true in here, and a contact whose weights
-            // vanish has no force: the test is the weights alone, and `on` a compile-time constant -- three exec-masked regions below merge into straight-line code
-            const bool nz = !((Wk[0] == 0.f) & (Wk[2] == 0.f) & (Wk[5] == 0.f));
+            // separated contact (the cone's top zone: no force, no weights): skipped on the zone test itself, before any of the other zones' arithmetic.  (The other two zones have
+            // a positive W[0]: `weights all zero` and `top zone` are the same set of contacts.)  Outside the dense-capable copy `aact0` is `act`, true in here: `on` is a
+            // compile-time constant there
+            ConeZ cz;
+            if (cone_top(t.jar, t.mu, t.fri, cz)) continue;
+            cone_below(t.jar, D, t.Dm, t.mu, t.fri, cz, f, Wk);
             bool on = true;
-            if constexpr (DENSE) { on = aact0 & nz; if ((f[0] == 0.f) & (f[1] == 0.f) & (f[2] == 0.f) & !on) continue; }
-            else { if (!nz) continue; }
+            if constexpr (DENSE) on = aact0;
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
             const float pos[3] = {t.rc[0] + qc[0], t.rc[1] + qc[1], t.rc[2] + qc[2]};
             const bool cube = !HC || t.la == CUBE;
@@ -1220,6 +1249,28 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
               const int cha = linkA ? (t.la - 1) >> 2 : 0, depa = linkA ? (t.la - 1) & 3 : -1;
               const bool same = linkA && cha == ch;
               float cb[NLK][3]; if (V5_C3C(k)) load_c3(V5_C3C(k), cb); else link_c3(S, ch, pos, cb);
+              if constexpr (!HC) {
+                // cube contact on a finger link (the copy without the hand's own contacts): joint u4 of the chain carries the contact iff u4 <= dep -- its gradient entry, its row
+                // of the chain block and its coupling to the cube under ONE test per joint (the general form below: one for the force, one for the rows, and the columns
+                // beyond the link's depth zeroed first -- here they are never read)
+#pragma unroll
+                for (int u4 = 0; u4 < NLK; u4++) if (u4 <= dep) {
+                  atomicAdd(&S.g[6 + 4 * ch + u4], -dot3(cb[u4], Fw));
+                  float y[3]; Amul(cb[u4], y);
+#pragma unroll
+                  for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], dot3(cb[v4], y));
+#pragma unroll
+                  for (int q = 0; q < 3; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + q], -y[q]);
+#if JH_V5_WORLDROT
+                  atomicAdd(&S.Hcb[ch][u4 * 6 + 3], t.rc[2] * y[1] - t.rc[1] * y[2]);  // -(e_q x r) . y
+                  atomicAdd(&S.Hcb[ch][u4 * 6 + 4], t.rc[0] * y[2] - t.rc[2] * y[0]);
+                  atomicAdd(&S.Hcb[ch][u4 * 6 + 5], t.rc[1] * y[0] - t.rc[0] * y[1]);
+#else
+#pragma unroll
+                  for (int q = 0; q < 3; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + 3 + q], -dot3(cq[q], y));
+#endif
+                }
+              } else {
 #pragma unroll
               for (int j = 0; j < NLK; j++) {
                 const float fj = dot3(cb[j], Fw);
@@ -1267,6 +1318,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                   }
                 }
               }
+              }
             }
           }
         }
@@ -1281,16 +1333,16 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
         gcl = fmaf(mck, dcl, gcl);
         {
-          if (aact0) {
-            S.Hcc[l] = h0 + lc[LC_HCC0];
-            if (l < 5) S.Hcc[16 + l] = h1 + lc[LC_HCC1];
-          }
+          // (stored whatever the rollout's state: nothing of a converged rollout is read again this step, and a dense row's matrix is zeroed after this.  The cube's own
+          // mass diagonal is added where the block is read back: no LDS read -- a round trip behind the atomics above -- between the sums and the convergence test)
+          S.Hcc[l] = h0;
+          if (l < 5) S.Hcc[16 + l] = h1;
         }
         WSYNC();
         V5_TICK(4)
         // ---- (2) convergence on the scaled gradient; the wave leaves the loop before any Hessian work once all its rollouts are done
         g_own = S.g[6 + l];
-        const float gn = gsum(g_own * g_own * iMd + gcl * gcl * imck);
+        const float gn = gsum(g_own * g_own * iMd + gcl * gcl * lc[LC_IMCK]);
         act = act & !(gn <= tol * tol * fmaxf(snorm, 1e-12f));
         if (!__any(act)) break;
         iters_this += act ? 1 : 0;
@@ -1313,7 +1365,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           fwd4(L, Linv, zb);
         };
         factor_block();
-        if (aact && l < 6) S.rhs6[l] = -gcl;
+        if (l < 6) S.rhs6[l] = -gcl;
         float Xs[NLK] = {0.f, 0.f, 0.f, 0.f};  // column s of X = L^-1 H(a,P) of a chain a with a parent P
         if constexpr (HC) {
 #pragma unroll 1
@@ -1375,7 +1427,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #pragma unroll
           for (int q6 = 0; q6 < 6; q6++) {
 #pragma unroll
-            for (int r6 = 0; r6 <= q6; r6++) Lc[tri(q6, r6)] = S.Hcc[tri(q6, r6)] - (q6 < 4 ? quad_get(dar[r6], q6) : quad_get(dbr[r6], q6 - 4));
+            for (int r6 = 0; r6 <= q6; r6++) Lc[tri(q6, r6)] = (r6 == q6 ? S.Hcc[tri(q6, r6)] + S.cmd[q6 < 3 ? 0 : q6 - 2] : S.Hcc[tri(q6, r6)]) - (q6 < 4 ? quad_get(dar[r6], q6) : quad_get(dbr[r6], q6 - 4));
             xc6[q6] = S.rhs6[q6] - (q6 < 4 ? quad_get(ra, q6) : quad_get(rb, q6 - 4));
           }
           float ci[6];
@@ -1402,7 +1454,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           // back-substitution through the coupling: pc = L^-T (zb - sum_q Y_q x_q); each lane contributes its columns, summed over the chain
           const float xa = sel4(xc6, s), xb = s == 0 ? xc6[4] : xc6[5];
 #pragma unroll
-          for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(Ya[j] * xa + (hasb ? Yb[j] * xb : 0.f));
+          for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(fmaf(Ya[j], xa, Yb[j] * xb));  // (Yb is zero in the lanes without a second column)
           if constexpr (HC) {
             if (__any(aact && nlev > 0)) {
               // p_a = L_a^-T (zb_a - Y_a x_c - X p_P): parents finish first (last stage first) and publish their part of the direction
@@ -1427,7 +1479,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         }
         float p_own = sel4(pc4, s);
         float xcl = l == 0 ? xc6[0] : (l == 1 ? xc6[1] : (l == 2 ? xc6[2] : (l == 3 ? xc6[3] : (l == 4 ? xc6[4] : (l == 5 ? xc6[5] : 0.f)))));
-        if (aact) { S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl; }
+        S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl;
         WSYNC();
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
         // LDS, Cholesky by rows in registers and the two triangular solves with the rollout's 16 lanes (rows l and l + 16)
@@ -1576,7 +1628,11 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           float wa[3]; mulMV(wa, S.xR[0], xc6 + 3);
 #endif
 #pragma unroll
-          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) slot_Jx<HC>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp, V5_C3C(k));
+          for (int k = 0; k < NS; k++) {
+            if (!HC && JH_V5_C3CACHE && k == 0) { slot_Jx_first(sl[0], xc6, wa, S.p, sl[0].jp, V5_C3C(0)); continue; }
+            if (k > 0 && !((used >> k) & 1u)) continue;  // (wave-uniform: nobody's slot k holds a contact)
+            if (sl[k].la >= 0) slot_Jx<HC>(sl[k], S, qc, xc6, wa, S.p, sl[k].jp, V5_C3C(k));
+          }
         }
         dr.pf = p_own; dr.pl = dr.lims * p_own;
 #if JH_V5_LSKINK
@@ -1609,7 +1665,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #ifdef JH_V5_CENSUS
           cen_ls += lsact; cen_lsw++;
 #endif
-          lane_rows_dir<NS>(sl, dr, alpha, &d1, &d2);
+          lane_rows_dir<NS>(sl, dr, alpha, &d1, &d2, used);
           d1 = gsum(d1) + pMd + alpha * pMp; d2 = gsum(d2) + pMp;
 #if JH_V5_LSKINK
           bool trouble = false; float nx = alpha;
