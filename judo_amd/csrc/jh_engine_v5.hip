@@ -455,6 +455,16 @@ __device__ __forceinline__ void bwd4(const float* L, const float* inv, float* x)
 // element j (run-time, wave-nonuniform) of a 4-array held in registers: compare-and-select
 __device__ __forceinline__ float sel4(const float* a, int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
 
+// the same as two levels of selects with opaque results: the compiler cannot turn the chain into a branch on j and copy what follows into both sides (a quad holds all four j:
+// it would run every copy)
+__device__ __forceinline__ float sel4o(const float* a, int j) {
+  float lo = (j & 1) ? a[1] : a[0], hi = (j & 1) ? a[3] : a[2];
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  float r = (j & 2) ? hi : lo;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
 // Elimination order of the four finger chains when contacts couple them (hand self-collision).  `cmask` has bit 4a + b for every coupled pair a < b.
 // A coupling graph without a cycle is eliminated leaf first: every chain is eliminated when at most one of its neighbours is left (its parent, which
 // receives the Schur update); `level` is the stage at which chain c goes, `maxlev` the last stage of the rollout.  Returns false for a graph with a
@@ -1162,17 +1172,19 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         bool hcany = false;
         WSYNC();
         float gcp[6] = {0, 0, 0, 0, 0, 0};  // cube part of -J'f: every contact of the rollout lands on the same six entries -> row sums, not atomics
-        if (act) {
+        {
 #pragma unroll
-          for (int k = 0; k < NS; k++) if (sl[k].la >= 0) {
+          for (int k = 0; k < NS; k++) {
+            if (k > 0 && !((used >> k) & 1u)) continue;  // (wave-uniform)
             const Slot& t = sl[k];
             float f[3], Wk[6];
             const float D[3] = {t.D0, t.D1, t.D1};
             // separated contact (the cone's top zone: no force, no weights): skipped on the zone test itself, before any of the other zones' arithmetic.  (The other two zones have
             // a positive W[0]: `weights all zero` and `top zone` are the same set of contacts.)  Outside the dense-capable copy `aact0` is `act`, true in here: `on` is a
             // compile-time constant there
+            // One exec-masked region per slot: an empty slot is all zeros and reads `top`, a converged rollout is masked by the same test.
             ConeZ cz;
-            if (cone_top(t.jar, t.mu, t.fri, cz)) continue;
+            if (cone_top(t.jar, t.mu, t.fri, cz) | !act) continue;
             cone_below(t.jar, D, t.Dm, t.mu, t.fri, cz, f, Wk);
             bool on = true;
             if constexpr (DENSE) on = aact0;
@@ -1335,8 +1347,12 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         {
           // (stored whatever the rollout's state: nothing of a converged rollout is read again this step, and a dense row's matrix is zeroed after this.  The cube's own
           // mass diagonal is added where the block is read back: no LDS read -- a round trip behind the atomics above -- between the sums and the convergence test)
-          S.Hcc[l] = h0;
-          if (l < 5) S.Hcc[16 + l] = h1;
+          // (addressed from the lane's gradient entry, the address the next statement reads: the hand-capable copy had `&S.Hcc[l]` spilled to scratch memory -- a reload
+          // and its wait between the sums and the convergence test)
+          constexpr int HCC_G = ((int)offsetof(RS, Hcc) - (int)offsetof(RS, g)) / 4 - 6;
+          float* gl = &S.g[6 + l];
+          gl[HCC_G] = h0;
+          if (l < 5) gl[HCC_G + 16] = h1;
         }
         WSYNC();
         V5_TICK(4)
@@ -1361,6 +1377,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           chol4(L, Linv);
           for (int j = 0; j < NLK; j++) { Ya[j] = S.Hcb[c][j * 6 + s]; const float yb = (&S.Hcb[0][0])[c * 24 + j * 6 + 4 + (s & 1)]; Yb[j] = hasb ? yb : 0.f; }  // (unconditional load, then select)
           fwd4(L, Linv, Ya); fwd4(L, Linv, Yb);
+          asm volatile("" : "+v"(Yb[0]), "+v"(Yb[1]), "+v"(Yb[2]), "+v"(Yb[3]));  // (the compiler forgets that they are zero where `hasb` is false: it split everything downstream into a copy per case, and a quad runs both)
           for (int j = 0; j < NLK; j++) zb[j] = -S.g[6 + 4 * c + j];
           fwd4(L, Linv, zb);
         };
@@ -1452,7 +1469,8 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
             for (int k = i + 1; k < 6; k++) sv -= Lc[tri(k, i)] * xc6[k];
             xc6[i] = sv * ci[i]; }
           // back-substitution through the coupling: pc = L^-T (zb - sum_q Y_q x_q); each lane contributes its columns, summed over the chain
-          const float xa = sel4(xc6, s), xb = s == 0 ? xc6[4] : xc6[5];
+          asm volatile("" : "+v"(xc6[0]), "+v"(xc6[1]), "+v"(xc6[2]), "+v"(xc6[3]), "+v"(xc6[4]), "+v"(xc6[5]));  // (the solution is complete in every lane before anything is picked from it: the picks stay selects)
+          float xa = sel4o(xc6, s), xb = s == 0 ? xc6[4] : xc6[5]; asm volatile("" : "+v"(xb));
 #pragma unroll
           for (int j = 0; j < NLK; j++) pc4[j] = zb[j] - csum(fmaf(Ya[j], xa, Yb[j] * xb));  // (Yb is zero in the lanes without a second column)
           if constexpr (HC) {
@@ -1477,8 +1495,10 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
           }
           bwd4(L, Linv, pc4);
         }
-        float p_own = sel4(pc4, s);
-        float xcl = l == 0 ? xc6[0] : (l == 1 ? xc6[1] : (l == 2 ? xc6[2] : (l == 3 ? xc6[3] : (l == 4 ? xc6[4] : (l == 5 ? xc6[5] : 0.f)))));
+        asm volatile("" : "+v"(pc4[0]), "+v"(pc4[1]), "+v"(pc4[2]), "+v"(pc4[3]));
+        float p_own = sel4o(pc4, s);
+        float xcl;  // own entry of the cube's part of the direction (lanes 0..5), zero elsewhere: selects with opaque results (see sel4o)
+        { float x03 = sel4o(xc6, l & 3), x45 = (l & 1) ? xc6[5] : xc6[4]; asm volatile("" : "+v"(x45)); xcl = l < 4 ? x03 : (l < 6 ? x45 : 0.f); asm volatile("" : "+v"(xcl)); }
         S.p[6 + l] = p_own; if (l < 6) S.p[l] = xcl;
         WSYNC();
         // ---- (4b) dense path: rollouts with a contact between two finger chains (hand self-collision; rare).  H = M + J'WJ as a packed 22 x 22 matrix in
