@@ -789,26 +789,32 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
         S.bs[1 + l][0] = cw[0] + pw[0]; S.bs[1 + l][1] = cw[1] + pw[1]; S.bs[1 + l][2] = cw[2] + pw[2]; S.bs[1 + l][3] = b8[3];
         if (l < 4) { S.bs[0][l] = sBB[l]; for (int b = NMB; b < NBC; b++) S.bs[b][l] = sBB[8 * b + l]; }
       }
-      for (int i = 0; i < lgm; i++) {
-        int gid = sLaneG[l * lgm + i];
-        bool hit = false;
-        if (gid >= 0) {
-          const float* gf = sGeomF + gid * GEOM_F;
-          float gp[3];
-          if (sGeomI[gid * GEOM_I] < 0) { gp[0] = gf[GF_POS]; gp[1] = gf[GF_POS + 1]; gp[2] = gf[GF_POS + 2]; }
-          else { mulMV(gp, Rw, gf + GF_POS); gp[0] += pw[0]; gp[1] += pw[1]; gp[2] += pw[2]; }
-          float dc[3] = {gp[0] - qc[0], gp[1] - qc[1], gp[2] - qc[2]}, rs = gf[GF_RBOUND] + crb;
-          hit = dot3(dc, dc) <= rs * rs;
-          if (hit) {
-            float cl[3]; mulMTV(cl, Rc, dc);
-            hit = fabsf(cl[0]) <= chs[0] + gf[GF_RBOUND] && fabsf(cl[1]) <= chs[1] + gf[GF_RBOUND] && fabsf(cl[2]) <= chs[2] + gf[GF_RBOUND];
-            if (hit && sGeomI[gid * GEOM_I + 1] == GBOX) {
-              float gR[9], gl[3];
-              if (sGeomI[gid * GEOM_I] < 0) { for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; } else mulMM(gR, Rw, gf + GF_R);
-              mulMTV(gl, gR, dc);
-              hit = fabsf(gl[0]) <= gf[GF_SIZE] + crb && fabsf(gl[1]) <= gf[GF_SIZE + 1] + crb && fabsf(gl[2]) <= gf[GF_SIZE + 2] + crb;
-            }
-          }
+      // (round 6: shaped for latency, the same tests.  The loop was a chain of eight dependent LDS round trips per geom -- its id, its body, its position, ... each
+      // behind the test before it -- and nine exec-masked regions.  Now: the lane's geom ids in one batch of loads, a geom's record in one more, the sphere test and the
+      // cube-frame box test as straight-line code, one region for the geom's own box.)
+      float pwr[3], Rwr[9];
+      for (int k = 0; k < 3; k++) pwr[k] = pw[k];
+      for (int k = 0; k < 9; k++) Rwr[k] = Rw[k];
+      int gids[MAXLG];
+#pragma unroll
+      for (int i = 0; i < MAXLG; i++) gids[i] = i < lgm ? sLaneG[l * lgm + i] : -1;
+#pragma unroll
+      for (int i = 0; i < MAXLG; i++) {
+        if (i >= lgm) break;
+        const int gid = gids[i], g0 = gid < 0 ? 0 : gid;
+        const float* gf = sGeomF + g0 * GEOM_F;
+        const int gbody = sGeomI[g0 * GEOM_I], gtype = sGeomI[g0 * GEOM_I + 1];
+        const float lp[3] = {gf[GF_POS], gf[GF_POS + 1], gf[GF_POS + 2]}, rb = gf[GF_RBOUND];
+        float gp[3]; mulMV(gp, Rwr, lp); gp[0] += pwr[0]; gp[1] += pwr[1]; gp[2] += pwr[2];
+        if (gbody < 0) { gp[0] = lp[0]; gp[1] = lp[1]; gp[2] = lp[2]; }
+        const float dc[3] = {gp[0] - qc[0], gp[1] - qc[1], gp[2] - qc[2]}, rs = rb + crb;
+        float cl[3]; mulMTV(cl, Rc, dc);
+        bool hit = (gid >= 0) & (dot3(dc, dc) <= rs * rs) & (fabsf(cl[0]) <= chs[0] + rb) & (fabsf(cl[1]) <= chs[1] + rb) & (fabsf(cl[2]) <= chs[2] + rb);
+        if (hit && gtype == GBOX) {
+          float gR[9], gl[3];
+          if (gbody < 0) { for (int k = 0; k < 9; k++) gR[k] = gf[GF_R + k]; } else mulMM(gR, Rwr, gf + GF_R);
+          mulMTV(gl, gR, dc);
+          hit = fabsf(gl[0]) <= gf[GF_SIZE] + crb && fabsf(gl[1]) <= gf[GF_SIZE + 1] + crb && fabsf(gl[2]) <= gf[GF_SIZE + 2] + crb;
         }
         unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
         int pos = nh + __popc(m16 & ((1u << l) - 1u));
@@ -821,24 +827,37 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #ifndef JH_V5_X_NOL1
       // hand self-collision, level 1: body pairs whose bounding spheres overlap (106 candidate pairs after MuJoCo's static filters, 16 per pass)
       int nbl = 0;
-      for (int base = 0; base < nBP; base += G) {
-        const int pi = base + l;
-        bool hit = false;
-        if (pi < nBP) {
-          const int ba = sBP[2 * pi], bb = sBP[2 * pi + 1];
-          const float* sa = S.bs[ba]; const float* sb = S.bs[bb];
+      {
+        // (round 6: shaped for latency, the same tests in the same order.  Per pass of 16 pairs the loop was three dependent LDS round trips -- the pair, its two spheres, the
+        // boxes' poses -- times seven passes.  Now: every pass's pair in one batch of loads, every pass's sphere test in a second, then the box test of the passes that
+        // have a survivor.)
+        constexpr int NPASS = MAXBP / G;
+        int pab[NPASS]; unsigned sph = 0;
+#pragma unroll
+        for (int i = 0; i < NPASS; i++) { const int pi = i * G + l, pj = pi < nBP ? pi : 0; pab[i] = sBP[2 * pj] | sBP[2 * pj + 1] << 8; }
+#pragma unroll
+        for (int i = 0; i < NPASS; i++) {
+          const float* sa = S.bs[pab[i] & 0xFF]; const float* sb = S.bs[pab[i] >> 8];
           const float d[3] = {sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2]}, rs = sa[3] + sb[3];
-          hit = dot3(d, d) <= rs * rs;
+          sph |= ((i * G + l < nBP) & (dot3(d, d) <= rs * rs)) ? 1u << i : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; i++) {
+          if (i * G >= nBP) break;
+          const int pi = i * G + l;
+          bool hit = (sph >> i) & 1u;
           if (hit) {  // the two bodies' bounding boxes (static geometry: axis-aligned in the world)
+            const int ba = pab[i] & 0xFF, bb = pab[i] >> 8;
+            const float* sa = S.bs[ba]; const float* sb = S.bs[bb];
             const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             float Ra[9]; for (int k = 0; k < 9; k++) Ra[k] = static_code(ba) ? I9[k] : S.xR[ba][k];  // (side A is the static one of a pair, if any)
             hit = obb_face_overlap(sa, Ra, sBB + 8 * ba + 4, sb, S.xR[bb], sBB + 8 * bb + 4);
           }
+          unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
+          int pos = nbl + __popc(m16 & ((1u << l) - 1u));
+          if (hit && pos < MAXBPL) S.bpl[pos] = (unsigned char)pi;
+          nbl += __popc(m16);
         }
-        unsigned m16 = (unsigned)((__ballot(hit) >> (16 * r)) & 0xFFFFull);
-        int pos = nbl + __popc(m16 & ((1u << l) - 1u));
-        if (hit && pos < MAXBPL) S.bpl[pos] = (unsigned char)pi;
-        nbl += __popc(m16);
       }
       if (nbl > MAXBPL) { if (l == 0 && live && stats) atomicAdd(stats, nbl - MAXBPL); nbl = MAXBPL; }  // (counted with the dropped contacts)
 #ifdef JH_V5_COUNT
