@@ -133,52 +133,71 @@ __device__ __forceinline__ void pyramid_dir(const float* jar, const float* jp, f
   }
 }
 
-// world velocity of the point `pos` carried by body b for the generalised velocity (xc = free-body part: linear world, angular body frame; xa = arm part by
-// arm index, LDS or registers), times `sign`, added to w.  Arm bodies: the hinges of links 1 .. min(b, 7), plus the own slide for a finger.
-template <class XA>
-__device__ __forceinline__ void body_point_vel(const RS6& S, int b, const float* pos, const float* xc, const XA& xa, float sign, float* w) {
-  if (b == 0) {
-    float wa[3], rc[3] = {pos[0] - S.xpos[0][0], pos[1] - S.xpos[0][1], pos[2] - S.xpos[0][2]}, wx[3];
-    mulMV(wa, S.xR[0], xc + 3); cross3(wx, wa, rc);
-    w[0] = fmaf(sign, xc[0] + wx[0], w[0]); w[1] = fmaf(sign, xc[1] + wx[1], w[1]); w[2] = fmaf(sign, xc[2] + wx[2], w[2]);
-  } else if (b >= 1) {
-#pragma unroll
-    for (int j = 0; j < NCHAIN; j++) if (j < b) {
-      const float rb[3] = {pos[0] - S.xpos[1 + j][0], pos[1] - S.xpos[1 + j][1], pos[2] - S.xpos[1 + j][2]}; float c3[3];
-      cross3(c3, S.axw[1 + j], rb);
-      const float xj = sign * xa[j];
-      w[0] = fmaf(c3[0], xj, w[0]); w[1] = fmaf(c3[1], xj, w[1]); w[2] = fmaf(c3[2], xj, w[2]);
-    }
-    if (b > NCHAIN) {
-      const float xj = sign * (b == LF ? xa[NCHAIN] : xa[NCHAIN + 1]);
-      w[0] = fmaf(S.axw[b][0], xj, w[0]); w[1] = fmaf(S.axw[b][1], xj, w[1]); w[2] = fmaf(S.axw[b][2], xj, w[2]);
-    }
-  }
+// A general contact has at most one side on the free box and at most one on the arm (arm against arm is the finger-finger case, in slots of its own): `csign` = +1 / -1 / 0 for
+// the box on side B / side A / neither, `ab` = the arm-side body (0: none) and `asign` its side's sign.
+struct Sides6 { float csign, asign; int ab; };
+__device__ __forceinline__ Sides6 slot_sides(int sa, int sb) {
+  Sides6 z;
+  z.csign = (sb == 0 ? 1.f : 0.f) - (sa == 0 ? 1.f : 0.f);
+  z.ab = sa >= 1 ? sa : (sb >= 1 ? sb : 0);
+  z.asign = sb >= 1 ? 1.f : -1.f;
+  return z;
 }
-// J x of one slot (contact frame): relative point velocity, side B minus side A
+// the world columns of the arm's eight dofs for a point carried by the arm: hinge j -> axis_j x (pos - anchor_j), entry 7 -> the slide axis of finger `fb` (8 or 9).  ALL of
+// them, whatever the depth of the link (round 6: the per-joint form `if (j < b) { load; cross; }` put every joint's LDS loads under an exec mask of their own -- nine regions and
+// as many dependent round trips per call, 528 branches in the kernel's listing; the columns a shallower link does not use are cheaper than the regions).
+__device__ __forceinline__ void arm_cols(const RS6& S, const float* pos, int fb, float (*c3)[3]) {
+#pragma unroll
+  for (int j = 0; j < NCHAIN; j++) {
+    const float rb[3] = {pos[0] - S.xpos[1 + j][0], pos[1] - S.xpos[1 + j][1], pos[2] - S.xpos[1 + j][2]};
+    cross3(c3[j], S.axw[1 + j], rb);
+  }
+  c3[NCHAIN][0] = S.axw[fb][0]; c3[NCHAIN][1] = S.axw[fb][1]; c3[NCHAIN][2] = S.axw[fb][2];
+}
+// J x of one slot (contact frame): relative point velocity, side B minus side A, for the generalised velocity (xc = free-body part: linear world, angular body frame; xa = arm
+// part by arm index, LDS or registers).  The box's part is computed whatever the slot holds and scaled by csign (an empty slot: sides -2, everything zero); the arm's under one test.
 template <class XA>
 __device__ __forceinline__ void slot_Jx(const Slot6& t, const RS6& S, const float* xc, const XA& xa, float* out) {
-  float w[3] = {0.f, 0.f, 0.f};
-  body_point_vel(S, t.sa, t.pos, xc, xa, -1.f, w);
-  body_point_vel(S, t.sb, t.pos, xc, xa, 1.f, w);
+  const Sides6 z = slot_sides(t.sa, t.sb);
+  float w[3];
+  {
+    float wa[3], rc[3] = {t.pos[0] - S.xpos[0][0], t.pos[1] - S.xpos[0][1], t.pos[2] - S.xpos[0][2]}, wx[3];
+    mulMV(wa, S.xR[0], xc + 3); cross3(wx, wa, rc);
+    w[0] = z.csign * (xc[0] + wx[0]); w[1] = z.csign * (xc[1] + wx[1]); w[2] = z.csign * (xc[2] + wx[2]);
+  }
+  if (z.ab >= 1) {
+    const int fb = z.ab > NCHAIN ? z.ab : LF;
+    float c3[NCHAIN + 1][3]; arm_cols(S, t.pos, fb, c3);
+#pragma unroll
+    for (int j = 0; j < NCHAIN; j++) {
+      const float xj = j < z.ab ? z.asign * xa[j] : 0.f;
+      w[0] = fmaf(c3[j][0], xj, w[0]); w[1] = fmaf(c3[j][1], xj, w[1]); w[2] = fmaf(c3[j][2], xj, w[2]);
+    }
+    const float xs7 = xa[NCHAIN], xs8 = xa[NCHAIN + 1];
+    const float xs = z.ab > NCHAIN ? z.asign * (z.ab == LF ? xs7 : xs8) : 0.f;
+    w[0] = fmaf(c3[NCHAIN][0], xs, w[0]); w[1] = fmaf(c3[NCHAIN][1], xs, w[1]); w[2] = fmaf(c3[NCHAIN][2], xs, w[2]);
+  }
   out[0] = dot3(t.fr, w); out[1] = dot3(t.fr + 3, w); out[2] = dot3(t.fr + 6, w);
 }
-// -J'F of body b (F = world force on side B; sign = +1 for side B, -1 for side A): float atomics into the gradient
+// -J'F of one slot (F = world force on side B): the arm's rows as float atomics into the gradient, the free box's six entries into gcp
 // (the free box's six entries: every contact of the rollout that touches the box lands on the same six addresses, and same-address LDS atomics serialise -- they are summed
 // over the rollout's lanes instead: 9.77 -> 9.57 ms on recorded inputs; the leap kernel's cube block taught this: jh_engine_v5.hip, the note on the Newton iteration's formulation)
-__device__ __forceinline__ void body_force(RS6& S, int b, const float* pos, const float* Fw, float sign, float* gcp) {
-  if (b == 0) {
-    float rc[3] = {pos[0] - S.xpos[0][0], pos[1] - S.xpos[0][1], pos[2] - S.xpos[0][2]}, tq[3], tb[3];
+__device__ __forceinline__ void slot_force(RS6& S, const Slot6& t, const float* Fw, float* gcp) {
+  const Sides6 z = slot_sides(t.sa, t.sb);
+  {
+    float rc[3] = {t.pos[0] - S.xpos[0][0], t.pos[1] - S.xpos[0][1], t.pos[2] - S.xpos[0][2]}, tq[3], tb[3];
     cross3(tq, rc, Fw); mulMTV(tb, S.xR[0], tq);
-    gcp[0] -= sign * Fw[0]; gcp[1] -= sign * Fw[1]; gcp[2] -= sign * Fw[2]; gcp[3] -= sign * tb[0]; gcp[4] -= sign * tb[1]; gcp[5] -= sign * tb[2];
-  } else if (b >= 1) {
+    gcp[0] -= z.csign * Fw[0]; gcp[1] -= z.csign * Fw[1]; gcp[2] -= z.csign * Fw[2]; gcp[3] -= z.csign * tb[0]; gcp[4] -= z.csign * tb[1]; gcp[5] -= z.csign * tb[2];
+  }
+  if (z.ab >= 1) {
+    const int fb = z.ab > NCHAIN ? z.ab : LF;
+    float c3[NCHAIN + 1][3]; arm_cols(S, t.pos, fb, c3);
+    float v[NCHAIN + 1];
 #pragma unroll
-    for (int j = 0; j < NCHAIN; j++) if (j < b) {
-      const float rb[3] = {pos[0] - S.xpos[1 + j][0], pos[1] - S.xpos[1 + j][1], pos[2] - S.xpos[1 + j][2]}; float c3[3];
-      cross3(c3, S.axw[1 + j], rb);
-      atomicAdd(&S.g[6 + j], -sign * dot3(c3, Fw));
-    }
-    if (b > NCHAIN) atomicAdd(&S.g[6 + b - 1], -sign * dot3(S.axw[b], Fw));
+    for (int j = 0; j <= NCHAIN; j++) v[j] = -z.asign * dot3(c3[j], Fw);
+#pragma unroll
+    for (int j = 0; j < NCHAIN; j++) if (j < z.ab) atomicAdd(&S.g[6 + j], v[j]);
+    if (z.ab > NCHAIN) atomicAdd(&S.g[6 + z.ab - 1], v[NCHAIN]);
   }
 }
 // J'WJ of one slot into the dof-space Hessian.  Every dof column of the contact is a world 3-vector col_x with J[w][x] = fr_w . col_x, so the contribution
@@ -202,8 +221,9 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
   auto Amul = [&](const float* v, float* y) __attribute__((always_inline)) {
     y[0] = A[0] * v[0] + A[1] * v[1] + A[3] * v[2]; y[1] = A[1] * v[0] + A[2] * v[1] + A[4] * v[2]; y[2] = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
   };
-  const bool cube = t.sa == 0 || t.sb == 0;
-  const int ab = t.sa >= 1 ? t.sa : (t.sb >= 1 ? t.sb : 0);  // the arm-side body, 0 = none
+  const Sides6 z = slot_sides(t.sa, t.sb);
+  const bool cube = z.csign != 0.f;
+  const int ab = z.ab;  // the arm-side body, 0 = none
   // the signs of the two sides cancel in every product of two columns of the same body and give -1 between the free box and the arm
   float c3[3][3];
   if (cube) {
@@ -214,38 +234,30 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
     for (int e = 0; e < 6; e++) hcp[e] += A[e];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-      float z[3]; Amul(c3[q], z);
+      float z3[3]; Amul(c3[q], z3);
 #pragma unroll
-      for (int r2 = 0; r2 < 3; r2++) hcp[tri(3 + q, r2)] += z[r2];
+      for (int r2 = 0; r2 < 3; r2++) hcp[tri(3 + q, r2)] += z3[r2];
 #pragma unroll
-      for (int r2 = 0; r2 <= q; r2++) hcp[tri(3 + q, 3 + r2)] += dot3(c3[r2], z);
+      for (int r2 = 0; r2 <= q; r2++) hcp[tri(3 + q, 3 + r2)] += dot3(c3[r2], z3);
     }
   }
   if (ab >= 1) {
-#pragma unroll 1
-    for (int u = 0; u < NCHAIN + 1; u++) {  // arm columns 0..6 = hinges, 7 = the finger's slide
-      const bool slide = u == NCHAIN;
-      if (slide ? ab <= NCHAIN : u >= ab) continue;
-      float cu[3];
-      if (slide) { cu[0] = S.axw[ab][0]; cu[1] = S.axw[ab][1]; cu[2] = S.axw[ab][2]; }
-      else { const float rb[3] = {t.pos[0] - S.xpos[1 + u][0], t.pos[1] - S.xpos[1 + u][1], t.pos[2] - S.xpos[1 + u][2]}; cross3(cu, S.axw[1 + u], rb); }
-      float y[3]; Amul(cu, y);
-      const int du = slide ? 6 + ab - 1 : 6 + u;
-#pragma unroll 1
-      for (int v = 0; v <= u; v++) {
-        const bool vslide = v == NCHAIN;
-        if (vslide ? ab <= NCHAIN : v >= ab) continue;
-        float cv[3];
-        if (vslide) { cv[0] = S.axw[ab][0]; cv[1] = S.axw[ab][1]; cv[2] = S.axw[ab][2]; }
-        else { const float rb[3] = {t.pos[0] - S.xpos[1 + v][0], t.pos[1] - S.xpos[1 + v][1], t.pos[2] - S.xpos[1 + v][2]}; cross3(cv, S.axw[1 + v], rb); }
-        const int dv = vslide ? 6 + ab - 1 : 6 + v;
-        atomicAdd(&S.H[tri(du, dv)], dot3(cv, y));
-      }
+    // (round 6: the arm's columns once per contact -- arm_cols -- instead of once per ENTRY: the two rolled loops over (u, v) recomputed column v inside every pair, each behind
+    // its own loads, and tested every pair; a valid column u has all columns v <= u valid, so one test per column decides its whole row)
+    const int fb = ab > NCHAIN ? ab : LF, dsl = 6 + ab - 1;
+    float cu[NCHAIN + 1][3]; arm_cols(S, t.pos, fb, cu);
+#pragma unroll
+    for (int u = 0; u <= NCHAIN; u++) {  // arm columns 0..6 = hinges, 7 = the finger's slide
+      if (!(u < NCHAIN ? u < ab : ab > NCHAIN)) continue;
+      float y[3]; Amul(cu[u], y);
+      const int du = u < NCHAIN ? 6 + u : dsl, rowu = du * (du + 1) / 2;
+#pragma unroll
+      for (int v = 0; v <= u; v++) atomicAdd(&S.H[rowu + (v < NCHAIN ? 6 + v : dsl)], dot3(cu[v], y));
       if (cube) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) atomicAdd(&S.H[tri(du, q)], -y[q]);
+        for (int q = 0; q < 3; q++) atomicAdd(&S.H[rowu + q], -y[q]);
 #pragma unroll
-        for (int q = 0; q < 3; q++) atomicAdd(&S.H[tri(du, 3 + q)], -dot3(c3[q], y));
+        for (int q = 0; q < 3; q++) atomicAdd(&S.H[rowu + 3 + q], -dot3(c3[q], y));
       }
     }
   }
@@ -909,8 +921,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
             float f[3], Wm[6]; pyramid_eval(t.jar, t.D, t.mu, f, Wm);
             if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f) continue;  // separated contact
             const float Fw[3] = {t.fr[0] * f[0] + t.fr[3] * f[1] + t.fr[6] * f[2], t.fr[1] * f[0] + t.fr[4] * f[1] + t.fr[7] * f[2], t.fr[2] * f[0] + t.fr[5] * f[1] + t.fr[8] * f[2]};
-            body_force(S, t.sa, t.pos, Fw, -1.f, gcp);
-            body_force(S, t.sb, t.pos, Fw, 1.f, gcp);
+            slot_force(S, t, Fw, gcp);
           }
         }
         if (arm_any) {
