@@ -8,6 +8,7 @@
 //   finger slide: +-axis_f
 // and J'WJ = col_x' (Fr' W Fr) col_y goes into a dof-space Hessian in LDS with float atomics, whose rows the lanes then factorise as before.
 // Same lane roles as jh_engine_v3.hip (lane l < 6: free-body dof l; 6..14: arm dof l - 6; 15: right-hand side), same solver, same results to summation order.
+#include <cstddef>
 #include <type_traits>
 
 #include "jh_coop.h"
@@ -79,9 +80,11 @@ struct __attribute__((aligned(16))) RS6 {  // per-rollout shared state
   float sn[16], cs[16];                         // sin / cos of the hinge angles (each evaluated once, by its owner lane)
   float M[NA][NA];
   float vec[3][16];
+  float pad16_;                                 // (the union below starts on a 16-byte boundary: its rows move as ds_read / ds_write_b128)
   union {                                       // the raw contact pool is dead once the slots are loaded; the Newton matrices then reuse its storage
     float raw[NCP][RAW_F];                      // pos3, normal3, dist, pair
-    float H[NVT * (NVT + 1) / 2];               // dof-space Hessian, packed lower triangle
+    float H[16][16];                            // dof-space Hessian, row r = lane r's row, entries j <= r meaningful (round 6: full rows -- the pool's 256 floats hold them -- so
+                                                // that a lane stores and fetches its row with four 16-byte accesses instead of fifteen exec-masked dwords each way)
   };
   float ffraw[NFF][FF_F];                       // finger-finger contacts between narrow phase and slots: normal3, dist, pair
   float g[16];                                  // gradient (own rows + contact forces by float atomics)
@@ -91,6 +94,8 @@ struct __attribute__((aligned(16))) RS6 {  // per-rollout shared state
   unsigned short hits[MAXHIT];
   int ncon, nhit, nff;
 };
+
+static_assert(offsetof(RS6, H) % 16 == 0 && sizeof(RS6) % 16 == 0, "RS6: the Hessian rows are moved 16 bytes at a time");
 
 struct Sink6 {  // contact sink of the narrow phase
   RS6* S; int* overflow; int pair; bool ff; float* ovf;  // ovf: this rollout's row of the global overflow pool (NOVF x RAW_F floats), or null
@@ -250,14 +255,14 @@ __device__ __forceinline__ void slot_assemble(RS6& S, const Slot6& t, const floa
     for (int u = 0; u <= NCHAIN; u++) {  // arm columns 0..6 = hinges, 7 = the finger's slide
       if (!(u < NCHAIN ? u < ab : ab > NCHAIN)) continue;
       float y[3]; Amul(cu[u], y);
-      const int du = u < NCHAIN ? 6 + u : dsl, rowu = du * (du + 1) / 2;
+      const int du = u < NCHAIN ? 6 + u : dsl;
 #pragma unroll
-      for (int v = 0; v <= u; v++) atomicAdd(&S.H[rowu + (v < NCHAIN ? 6 + v : dsl)], dot3(cu[v], y));
+      for (int v = 0; v <= u; v++) atomicAdd(&S.H[du][v < NCHAIN ? 6 + v : dsl], dot3(cu[v], y));
       if (cube) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) atomicAdd(&S.H[rowu + q], -y[q]);
+        for (int q = 0; q < 3; q++) atomicAdd(&S.H[du][q], -y[q]);
 #pragma unroll
-        for (int q = 0; q < 3; q++) atomicAdd(&S.H[rowu + 3 + q], -dot3(c3[q], y));
+        for (int q = 0; q < 3; q++) atomicAdd(&S.H[du][3 + q], -dot3(c3[q], y));
       }
     }
   }
@@ -964,9 +969,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         if (l == 14) { Hrow[13] += ffh; Hrow[14] += ffh; }
         // the rows go to LDS, the general contacts add J'WJ there (float atomics, matrix-free columns), the lanes take their rows back
         if (arm_any) {
-          if (hasdof && act) {
+          {  // (whole rows, whatever the lane's role and the rollout's state: entries beyond the diagonal and the rows of lanes without a dof are never read)
+            float4* hr = reinterpret_cast<float4*>(S.H[l]);
 #pragma unroll
-            for (int j = 0; j < NVT; j++) if (j <= l) S.H[tri(l, j)] = Hrow[j];
+            for (int j4 = 0; j4 < 4; j4++) hr[j4] = make_float4(Hrow[4 * j4], Hrow[4 * j4 + 1], Hrow[4 * j4 + 2], Hrow[4 * j4 + 3]);
           }
           __syncthreads();
         }
@@ -983,9 +989,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(JH_V6_WPE,
         }
         if (arm_any) {
           __syncthreads();
-          if (hasdof && act) {
+          {
+            const float4* hr = reinterpret_cast<const float4*>(S.H[l]);
 #pragma unroll
-            for (int j = 0; j < NVT; j++) if (j <= l) Hrow[j] = S.H[tri(l, j)];
+            for (int j4 = 0; j4 < 4; j4++) {
+              const float4 v = hr[j4]; const bool on = hasdof && act;
+              Hrow[4 * j4] = on ? v.x : Hrow[4 * j4]; Hrow[4 * j4 + 1] = on ? v.y : Hrow[4 * j4 + 1]; Hrow[4 * j4 + 2] = on ? v.z : Hrow[4 * j4 + 2]; Hrow[4 * j4 + 3] = on ? v.w : Hrow[4 * j4 + 3];
+            }
           }
         }
 #pragma unroll
