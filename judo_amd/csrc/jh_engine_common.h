@@ -108,7 +108,8 @@ __device__ __forceinline__ float capsule_box_closest(const float* pb, const floa
   auto slope = [&](float t) __attribute__((always_inline)) {
     float g = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { const float sk = fmaf(t, a[k], c[k]); g = fmaf(sk > hb[k] ? sk - hb[k] : (sk < -hb[k] ? sk + hb[k] : 0.f), a[k], g); }
+    for (int k = 0; k < 3; k++) {  // sk minus its clamp to [-hb, hb]: sk - hb above, sk + hb below, exactly zero inside (one v_med3_f32: the ternary form became two exec-masked regions per axis, 24 times per pair)
+      const float sk = fmaf(t, a[k], c[k]); g = fmaf(sk - __builtin_amdgcn_fmed3f(sk, -hb[k], hb[k]), a[k], g); }
     return g;
   };
   float lo = -L, hi = L;

@@ -142,7 +142,8 @@ __device__ __forceinline__ void pyramid_dir4(const float* jar, const float* jp, 
   for (int k = 0; k < 4; k++) {
     const float sg = (k & 1) ? -mu : mu;
     const float x = jar[0] + sg * (k < 2 ? jar[1] : jar[2]), xp = jp[0] + sg * (k < 2 ? jp[1] : jp[2]);
-    if (x < 0.f) { *d1 += D * x * xp; *d2 += D * xp * xp; }
+    float n1 = *d1 + D * x * xp, n2 = *d2 + D * xp * xp; asm volatile("" : "+v"(n1), "+v"(n2));  // (both sums computed, then selected -- the same fused multiply-adds: the branch form was four exec-masked regions per evaluation of the line search)
+    *d1 = x < 0.f ? n1 : *d1; *d2 = x < 0.f ? n2 : *d2;
   }
 }
 __device__ __forceinline__ float lane_cost4(const Slot4& sl, const DofRows4& dr) {
@@ -156,16 +157,27 @@ __device__ __forceinline__ float lane_cost4(const Slot4& sl, const DofRows4& dr)
   return cs;
 }
 __device__ __forceinline__ void lane_dir4(const Slot4& sl, const DofRows4& dr, float al, float* d1, float* d2) {
+  // Straight-line code (round 6; the leap kernel's lane_rows_dir): a lane without a contact has D = 0 and a zero jar / jp -- its terms are zero -- and the dof rows are selects
+  // on the same expressions as the branches they replace (same bits).
   float g1 = 0.f, g2 = 0.f;
-  if (sl.valid) {
+  {
     float jar[3] = {fmaf(al, sl.jp[0], sl.jar[0]), fmaf(al, sl.jp[1], sl.jar[1]), fmaf(al, sl.jp[2], sl.jar[2])};
-    pyramid_dir4(jar, sl.jp, sl.D, sl.mu, &g1, &g2);
+    float c1 = 0.f, c2 = 0.f; pyramid_dir4(jar, sl.jp, sl.D, sl.mu, &c1, &c2);
+    g1 = sl.valid ? c1 : 0.f; g2 = sl.valid ? c2 : 0.f;
   }
-  if (dr.fl > 0.f) {
+  {
     const float jp = dr.pf, x = fmaf(al, jp, dr.jf), fl = dr.fl, lim = dr.fR * fl;
-    if (x <= -lim) g1 -= fl * jp; else if (x >= lim) g1 += fl * jp; else { g1 += dr.fD * x * jp; g2 += dr.fD * jp * jp; }
+    const bool has = fl > 0.f, lo_ = x <= -lim, hi_ = x >= lim, mid = has & !lo_ & !hi_;
+    float ta = g1 - fl * jp, tb = g1 + fl * jp, tm = g1 + dr.fD * x * jp, t2 = g2 + dr.fD * jp * jp; asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tm), "+v"(t2));
+    g1 = has ? (lo_ ? ta : (hi_ ? tb : tm)) : g1;
+    g2 = mid ? t2 : g2;
   }
-  if (dr.lims != 0.f) { const float jp = dr.pl, x = fmaf(al, jp, dr.jl); if (x < 0.f) { g1 += dr.lD * x * jp; g2 += dr.lD * jp * jp; } }
+  {
+    const float jp = dr.pl, x = fmaf(al, jp, dr.jl);
+    const bool on = (dr.lims != 0.f) & (x < 0.f);
+    float t1 = g1 + dr.lD * x * jp, t2 = g2 + dr.lD * jp * jp; asm volatile("" : "+v"(t1), "+v"(t2));
+    g1 = on ? t1 : g1; g2 = on ? t2 : g2;
+  }
   *d1 = g1; *d2 = g2;
 }
 
@@ -1076,15 +1088,14 @@ __global__ __launch_bounds__(WAVE, 1) void k_tree_v4(const float* __restrict__ g
           float d1, d2;
           lane_dir4(sl, dr, alpha, &d1, &d2);
           d1 = gsum32(d1) + pMd + alpha * pMp; d2 = gsum32(d2) + pMp;
-          if (lsact) {
-            if (fabsf(d1) <= lstol * fabsf(gp)) lsact = false;
-            else {
-              if (d1 < 0.f) lo = alpha; else hi = alpha;
-              float nx = alpha - d1 * __frcp_rn(d2);
-              if (hi < 0.f) { if (nx <= lo) nx = 2.f * alpha; }
-              else if (nx <= lo || nx >= hi) nx = 0.5f * (lo + hi);
-              alpha = nx;
-            }
+          {  // safeguarded Newton step on the slope, as selects (the leap kernel's form: the same arithmetic as the nested branches it replaces)
+            const bool upd = lsact & !(fabsf(d1) <= lstol * fabsf(gp)), neg = d1 < 0.f;
+            lo = (upd & neg) ? alpha : lo; hi = (upd & !neg) ? alpha : hi;
+            float nx = alpha - d1 * __frcp_rn(d2);
+            const bool out_lo = nx <= lo, out_hi = nx >= hi;
+            float dbl = 2.f * alpha, mid_ = 0.5f * (lo + hi); asm volatile("" : "+v"(dbl), "+v"(mid_));
+            nx = hi < 0.f ? (out_lo ? dbl : nx) : ((out_lo | out_hi) ? mid_ : nx);
+            alpha = upd ? nx : alpha; lsact = upd;
           }
         }
         PH(8)
