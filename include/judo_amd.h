@@ -199,7 +199,12 @@ int jh_update_fused(const float* costs, const float* knots_nku, const float* nom
 /* One iteration of Controller.update_action's loop (judo/controller/controller.py:250-299) on ONE GPU as one call: upload of the packed host block
  * [x0 | nominal | sigma | task params | ctrl bounds] (float offsets o_* into it) into blk_dev, jh_rollout_cost_traced, jh_update_fused with its outputs at
  * out = [nominal K*nu | sigma K*nu | E x (2 + row_floats) trace records] (device memory, or device-visible pinned host memory: then no download is needed), and the
- * completion mark of jh_download_begin (zero bytes).  Asynchronous on `stream`; jh_download_end waits.  `trace` NULL: no trace records (E ignored). */
+ * completion mark of jh_download_begin (zero bytes).  Asynchronous on `stream`; jh_download_end waits.  `trace` NULL: no trace records (E ignored).
+ * Round 6, for plan steps whose kernels are a few tens of microseconds (cartpole, cylinder_push):
+ *  - those models run rollout + cost + update as ONE launch (the update's tail inside the rollout kernel's launch: same bits as the two launches);
+ *  - blk_dev == blk_host (a device-visible pinned host block): no upload, the kernel reads the block in place;
+ *  - out_host_mark != out: a 4-byte word in device-visible pinned host memory; the update's last workgroup stores (its value at the time of this call) + 1 there behind
+ *    the results and jh_download_end polls that word instead of waiting for the stream's event (one outstanding plan step per word).  out_host_mark == out: the event. */
 int jh_plan_step(const jh_model* m, void* blk_dev, const void* blk_host, size_t blk_bytes, int o_nominal, int o_sigma, int o_tp, int o_lohi, const float* noise, int ldn,
                  const float* W, int phase, int N, int n_offset, int H, int K, float* costs, float* knots_out, float* trace, int mode, float lambda, int k, int tie_high, int E,
                  int row_floats, int colmajor, float* scratch, float* out, void* out_host_mark, void* const* timing, void* stream);

@@ -58,6 +58,8 @@ class _PlanBuffers:
         self.rec = torch.empty(max(rec_floats, 1), dtype=torch.float32, device=dev)
         self.fused_scratch = torch.zeros(int(L.jh_update_fused_scratch_floats(n_local, K, nu)), dtype=torch.float32, device=dev)  # (zero: it holds jh_update_fused's ticket counter)
         self.dev = dev
+        self.done = torch.zeros(4, dtype=torch.int32).pin_memory()  # completion word of jh_plan_step: the update's last workgroup sets it behind the results, jh_download_end polls it
+        self.done_ptr = self.done.data_ptr()
         self.size_out(2 * K * nu)
         self.shard_rec, self.shard_all = None, None  # several ranks: this rank's record of the plan step, and the all-gathered records
         self.trace_buf = None   # (n_local * H * trace floats) when the fused kernel writes the trace sensors
@@ -124,6 +126,8 @@ class Controller:
         self._noise_ahead = None
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
         self.zero_copy_out = True  # jh_update_fused writes nominal | sigma | trace records into the pinned host block itself (no download command)
+        self.poll_completion = True  # one GPU: wait for the completion word the update's last workgroup writes behind its results instead of the stream's event (jh_plan_step, out_host_mark)
+        self.host_block_in_place = True  # closed-form models: the plan-step kernel reads x0 | nominal | sigma | task params | bounds from the pinned host block (no copy in front of the launch)
         self.fused_update = True  # one GPU: the whole update (block partials, merge, trace elites) in one launch and one download (jh_update_fused); False: the separate kernels
         self._prefetch_args = None
         self.keep_candidates = False
@@ -441,8 +445,16 @@ class Controller:
         n = b.sizes[2]; h[o : o + n] = 0.0 if sigma_raw is None else sigma_raw.reshape(-1); o += n
         n = b.sizes[3]; h[o : o + n] = self.task.task_params(self.system_metadata); o += n
         h[o:] = lohi
+        b.blk_stale = not upload
         if upload:
             _lib.check(_lib.lib().jh_upload_async(b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, self._stream), "jh_upload_async")
+
+    def _ensure_block(self, b: _PlanBuffers) -> None:
+        """The device copy of the plan block holds what the pinned host block holds.  A plan step whose kernel read the host block in place (`host_block_in_place`)
+        leaves the device copy behind; the few consumers of the device views outside the plan step (`candidate_knots`, the knot-record form of the trace stage) bring it up first."""
+        if getattr(b, "blk_stale", False):
+            _lib.check(_lib.lib().jh_upload_async(b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, current_stream_ptr()), "jh_upload_async")
+            b.blk_stale = False
 
     def _raw_bounds(self, nrm: Normalizer) -> np.ndarray:
         r = self.task.actuator_ctrlrange
@@ -523,13 +535,17 @@ class Controller:
                 self.exchange_events.append((evs[1], evs[2]))
             off = np.cumsum([0] + b.sizes)
             if one_call:
-                st = lib.jh_plan_step(self.model.handle, b.blk.data_ptr(), b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W), int(task.phase),
+                in_place = self.host_block_in_place and self.model.closed_form and knots_out is None
+                blk_dev = b.host_ptr if in_place else b.blk.data_ptr()
+                b.blk_stale = in_place  # (jh_plan_step uploads the block itself unless it is read in place)
+                st = lib.jh_plan_step(self.model.handle, blk_dev, b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W), int(task.phase),
                                       shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el, tie, E_t, row,
-                                      int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.out_host_ptr, timing, stream)
+                                      int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.done_ptr if self.poll_completion else b.out_host_ptr, timing, stream)
                 what = "jh_plan_step"
             else:
                 # ---- several ranks: launch (rollout + cost + this rank's record [update record | E trace records]) -> one all-gather -> merge on every rank into
                 # the same pinned output block; everything behind this branch is the one-GPU code
+                b.blk_stale = False  # (jh_plan_step_shard uploads the block)
                 L = int(lib.jh_shard_record_floats(K, nu, mode, k_el, E_t, row))
                 if b.shard_rec is None or b.shard_rec.numel() != L:
                     b.shard_rec = torch.empty(L, dtype=torch.float32, device=self.device)
@@ -740,6 +756,7 @@ class Controller:
             if f is None:
                 return np.tile(self.nominal_knots, (self.optimizer_cfg.num_rollouts, 1, 1))
             b, sh = f["b"], f["shard"]
+            self._ensure_block(b)
             out = torch.empty((sh.count, f["K"], f["nu"]), dtype=torch.float32, device=self.device)
             st = _lib.lib().jh_sample_knots(_lib.ptr(b.nominal), f["noise_p"], f["ldn"], _lib.ptr(b.sigma), _lib.ptr(b.lohi), sh.count, sh.offset, f["K"], f["nu"],
                                             _lib.ptr(out), current_stream_ptr())
@@ -811,6 +828,7 @@ class Controller:
             trace_rec = b.trace_recs[b.trace_flip]  # the previous plan step's stage may still be read from the other buffer
             if kl < E:
                 trace_rec.fill_(float("inf"))
+            self._ensure_block(b)
             st = lib.jh_topk_partial(_lib.ptr(costs), _lib.ptr(state["knots_nku"]), _lib.ptr(b.nominal), state["noise_p"], state["ldn"], _lib.ptr(b.sigma), _lib.ptr(b.lohi),
                                      shard.count, shard.offset, K, nu, kl, 1, _lib.ptr(b.scratch), _lib.ptr(trace_rec), stream)
             _lib.check(st, "jh_topk_partial")

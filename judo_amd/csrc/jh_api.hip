@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "jh_internal.h"
+#include "jh_update_dev.h"
 
 static thread_local char g_err[512] = "";
 
@@ -197,10 +198,11 @@ extern "C" int jh_download_wait(void* dst, const void* src, size_t nbytes, void*
 namespace {
 struct DlMark { void* stream; hipEvent_t ev; };
 thread_local std::vector<DlMark> g_dl_marks;     // events owned by this thread, one per stream it has downloaded on
-thread_local std::vector<hipEvent_t> g_dl_pending;  // marks set by `begin` and not yet waited for, oldest first
+struct DlPending { hipEvent_t ev; const unsigned* flag; unsigned expect; };  // flag non-null: a word in pinned host memory the last workgroup of the update sets (jh_plan_step)
+thread_local std::vector<DlPending> g_dl_pending;  // marks set by `begin` and not yet waited for, oldest first
 }  // namespace
 
-extern "C" int jh_download_begin(void* dst, const void* src, size_t nbytes, void* stream) {
+static int download_begin(void* dst, const void* src, size_t nbytes, void* stream, const unsigned* flag, unsigned expect) {
   JH_REQUIRE(dst && src, "download_begin: null pointer");
   hipEvent_t ev = nullptr;
   for (const DlMark& mk : g_dl_marks) if (mk.stream == stream) ev = mk.ev;
@@ -217,15 +219,29 @@ extern "C" int jh_download_begin(void* dst, const void* src, size_t nbytes, void
   }
   if (nbytes > 0) JH_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));  // (0 bytes: the kernels wrote the pinned host block themselves; the mark alone)
   JH_HIP(hipEventRecord(ev, (hipStream_t)stream));
-  g_dl_pending.push_back(ev);
+  g_dl_pending.push_back({ev, flag, expect});
   return JH_OK;
 }
 
+extern "C" int jh_download_begin(void* dst, const void* src, size_t nbytes, void* stream) { return download_begin(dst, src, nbytes, stream, nullptr, 0u); }
+
 extern "C" int jh_download_end(void) {
   JH_REQUIRE(!g_dl_pending.empty(), "download_end without download_begin");
-  hipEvent_t ev = g_dl_pending.front();
+  const DlPending pd = g_dl_pending.front();
   g_dl_pending.erase(g_dl_pending.begin());
-  JH_HIP(hipEventSynchronize(ev));
+  if (pd.flag) {
+    // The update's last workgroup stored `expect` behind its results (system-scope release): the host sees them some microseconds before the stream's event -- the kernel's
+    // end-of-launch write-back, the marker packet and its signal -- would report.  The event is looked at every few thousand polls so that a launch that died cannot hang the host.
+    for (unsigned spin = 1;; spin++) {
+      if (__atomic_load_n(pd.flag, __ATOMIC_ACQUIRE) == pd.expect) return JH_OK;
+      if ((spin & 0x3FFFu) == 0u) {
+        const hipError_t q = hipEventQuery(pd.ev);
+        if (q == hipSuccess) { if (__atomic_load_n(pd.flag, __ATOMIC_ACQUIRE) != pd.expect) { jh_set_error("download_end: the launch finished without setting its completion flag"); return JH_ERR_HIP; } return JH_OK; }
+        if (q != hipErrorNotReady) JH_HIP(q);
+      }
+    }
+  }
+  JH_HIP(hipEventSynchronize(pd.ev));
   return JH_OK;
 }
 
@@ -262,6 +278,14 @@ extern "C" int jh_rollout_cost_traced(const jh_model* m, const float* x0, const 
   return g_xcheck.rollout_cost(m, m->kernel_gen, x0, nominal, noise, ldn, sigma, W, lohi, tp, phase, N, n_offset, H, K, costs, knots_out, stream);
 }
 
+// Closed-form models (cartpole, cylinder_push): the rollout kernels are ~50 us, so a second launch and the gap in front of it are a fifth of the plan step -- the two run as
+// one launch (jh_simple.hip).  JUDO_AMD_PLAN_STEP_LAUNCHES=2 keeps the two launches (A/B, tests/test_gpu_simple.py compares the two forms bit for bit).
+static bool one_launch_plan_step(const jh_model* m, int N, int H, int K, const float* costs, const float* knots_out, const float* W, const float* noise, int ldn) {
+  static const bool two = [] { const char* e = getenv("JUDO_AMD_PLAN_STEP_LAUNCHES"); return e && e[0] == '2'; }();
+  if (two || !(m->kind == JH_TASK_CARTPOLE || m->kind == JH_TASK_CYLINDER_PUSH) || knots_out || !costs || !W || !noise) return false;
+  return N > 0 && H > 0 && K >= 1 && ldn >= N && K * m->nu <= JH_MAX_KNOT_DIM && jh_simple_plan_step_fits(m, H, K);
+}
+
 // One plan-step iteration on one GPU as ONE call (Controller.update_action's loop body, judo/controller/controller.py:250-299): the packed host block
 // x0 | nominal | sigma | task params | bounds goes up, the fused rollout + cost kernel runs, jh_update_fused reduces the costs to nominal | sigma | trace
 // records -- written where `out` points, normally the pinned host block itself -- and the completion mark of jh_download_begin is set: jh_download_end waits for
@@ -272,15 +296,36 @@ extern "C" int jh_plan_step(const jh_model* m, void* blk_dev, const void* blk_ho
   JH_REQUIRE(m && blk_dev && blk_host && out && scratch, "plan_step: null pointer");
   const float* b = (const float*)blk_dev;
   hipStream_t st = (hipStream_t)stream;
-  int rc = jh_upload_async(blk_dev, blk_host, blk_bytes, stream);
+  // blk_dev == blk_host: a device-visible pinned host block the kernels read in place (the closed-form models: a few hundred bytes read once per workgroup cost less than the copy in front of the launch)
+  int rc = blk_dev == blk_host ? JH_OK : jh_upload_async(blk_dev, blk_host, blk_bytes, stream);
   if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[0], st));
+  const int KU = K * m->nu;
+  // out_host_mark != out: a 4-byte word in device-visible pinned host memory -- the update's last workgroup stores its old value + 1 there behind the results and jh_download_end
+  // polls it instead of waiting for the stream's event
+  unsigned* flag = (out_host_mark && out_host_mark != (void*)out) ? (unsigned*)out_host_mark : nullptr;
+  const unsigned expect = flag ? __atomic_load_n(flag, __ATOMIC_RELAXED) + 1u : 0u;
+  if (rc == JH_OK && one_launch_plan_step(m, N, H, K, costs, knots_out, W, noise, ldn)) {
+    // closed-form models: rollout + cost + the update's tail in ONE launch (jh_simple.hip k_plan_step); the rollout / update split of the timing events collapses
+    jh_upd::TailArgs a;
+    rc = jh_update_tail_args("plan_step", costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace, row_floats,
+                             colmajor, scratch, out, out + KU, (trace && E > 0) ? out + 2 * KU : nullptr, nullptr, &a);
+    a.done_flag = flag; a.done_value = expect;
+    if (rc == JH_OK) rc = jh_simple_plan_step(m, b, W, b + o_tp, H, K, a, st);
+    if (rc == JH_OK && timing) { JH_HIP(hipEventRecord((hipEvent_t)timing[1], st)); JH_HIP(hipEventRecord((hipEvent_t)timing[2], st)); }
+    if (rc == JH_OK) rc = download_begin(out, out, 0, stream, flag, expect);
+    return rc;
+  }
   if (rc == JH_OK) rc = jh_rollout_cost_traced(m, b, b + o_nominal, noise, ldn, b + o_sigma, W, b + o_lohi, b + o_tp, phase, N, n_offset, H, K, costs, knots_out, trace, stream);
   if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[1], st));
-  const int KU = K * m->nu;
-  if (rc == JH_OK) rc = jh_update_fused(costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace, row_floats,
-                                        colmajor, scratch, out, out + KU, (trace && E > 0) ? out + 2 * KU : nullptr, stream);
+  if (rc == JH_OK) {
+    jh_upd::TailArgs a;
+    rc = jh_update_tail_args("plan_step", costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace, row_floats,
+                             colmajor, scratch, out, out + KU, (trace && E > 0) ? out + 2 * KU : nullptr, nullptr, &a);
+    a.done_flag = flag; a.done_value = expect;
+    if (rc == JH_OK) rc = jh_update_tail_launch(a, st);
+  }
   if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[2], st));
-  if (rc == JH_OK) rc = jh_download_begin(out_host_mark, out, 0, stream);
+  if (rc == JH_OK) rc = download_begin(out, out, 0, stream, flag, expect);
   return rc;
 }
 
@@ -294,8 +339,16 @@ extern "C" int jh_plan_step_shard(const jh_model* m, void* blk_dev, const void* 
   JH_REQUIRE(m && blk_dev && blk_host && rec_out && scratch, "plan_step_shard: null pointer");
   const float* b = (const float*)blk_dev;
   hipStream_t st = (hipStream_t)stream;
-  int rc = jh_upload_async(blk_dev, blk_host, blk_bytes, stream);
+  int rc = blk_dev == blk_host ? JH_OK : jh_upload_async(blk_dev, blk_host, blk_bytes, stream);
   if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[0], st));
+  if (rc == JH_OK && one_launch_plan_step(m, N, H, K, costs, knots_out, W, noise, ldn)) {
+    jh_upd::TailArgs a;
+    rc = jh_update_tail_args("plan_step_shard", costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace,
+                             row_floats, colmajor, scratch, nullptr, nullptr, nullptr, rec_out, &a);
+    if (rc == JH_OK) rc = jh_simple_plan_step(m, b, W, b + o_tp, H, K, a, st);
+    if (rc == JH_OK && timing) { JH_HIP(hipEventRecord((hipEvent_t)timing[1], st)); JH_HIP(hipEventRecord((hipEvent_t)timing[2], st)); }
+    return rc;
+  }
   if (rc == JH_OK) rc = jh_rollout_cost_traced(m, b, b + o_nominal, noise, ldn, b + o_sigma, W, b + o_lohi, b + o_tp, phase, N, n_offset, H, K, costs, knots_out, trace, stream);
   if (rc == JH_OK && timing) JH_HIP(hipEventRecord((hipEvent_t)timing[1], st));
   if (rc == JH_OK) rc = jh_update_shard(costs, nullptr, b + o_nominal, noise, ldn, b + o_sigma, b + o_lohi, N, n_offset, K, m->nu, mode, lambda, k, tie_high, trace ? E : 0, trace, row_floats,

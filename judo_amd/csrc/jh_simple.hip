@@ -16,6 +16,7 @@
 // a = (M + h*diag(damping))^-1 (qfrc_smooth + qfrc_constraint); soft constraints by solref/solimp.
 #include <cstdint>
 #include "jh_internal.h"
+#include "jh_update_dev.h"
 
 namespace {
 
@@ -23,18 +24,18 @@ constexpr int kBlock = 64;
 
 struct SplineCtx {
   const float* W;      // LDS  H*K
-  const float* knots;  // LDS  (K*nu) x kBlock, lane fastest
+  const float* knots;  // LDS  (K*nu) x workgroup size, lane fastest
   int K;
 };
 
-template <int NU>
+template <int NU, int BS = kBlock>
 __device__ __forceinline__ void spline_controls(const SplineCtx& s, int h, int lane, float* u) {
 #pragma unroll
   for (int j = 0; j < NU; j++) u[j] = 0.f;
   for (int k = 0; k < s.K; k++) {
     float w = s.W[h * s.K + k];
 #pragma unroll
-    for (int j = 0; j < NU; j++) u[j] = fmaf(w, s.knots[(k * NU + j) * kBlock + lane], u[j]);
+    for (int j = 0; j < NU; j++) u[j] = fmaf(w, s.knots[(k * NU + j) * BS + lane], u[j]);
   }
 }
 
@@ -160,8 +161,8 @@ struct CylinderPush {
 };
 
 // ------------------------------------------------------------------------------------------------ kernels
-template <class T>
-__global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict__ P, const float* __restrict__ x0,
+template <class T, int BS>
+__device__ __forceinline__ void rollout_cost_body(const float* __restrict__ P, const float* __restrict__ x0,
                                                          const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
                                                          const float* __restrict__ sigma, const float* __restrict__ W,
                                                          const float* __restrict__ lohi, const float* __restrict__ tp, int N, int n_offset,
@@ -169,16 +170,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
   extern __shared__ float lds[];
   const int KU = K * T::NU;
   float* sW = lds;                 // H*K
-  float* sKn = sW + H * K;         // KU * kBlock
-  float* sP = sKn + KU * kBlock;   // NP
+  float* sKn = sW + H * K;         // KU * BS
+  float* sP = sKn + KU * BS;   // NP
   float* sTp = sP + T::NP;         // NTP
   float* sX0 = sTp + T::NTP;       // NX
   const int lane = threadIdx.x;
-  for (int i = lane; i < H * K; i += kBlock) sW[i] = W[i];
-  for (int i = lane; i < T::NP; i += kBlock) sP[i] = P[i];
-  for (int i = lane; i < T::NTP; i += kBlock) sTp[i] = tp[i];
-  for (int i = lane; i < T::NX; i += kBlock) sX0[i] = x0[i];
-  const int n = blockIdx.x * kBlock + lane;
+  for (int i = lane; i < H * K; i += BS) sW[i] = W[i];
+  for (int i = lane; i < T::NP; i += BS) sP[i] = P[i];
+  for (int i = lane; i < T::NTP; i += BS) sTp[i] = tp[i];
+  for (int i = lane; i < T::NX; i += BS) sX0[i] = x0[i];
+  const int n = blockIdx.x * BS + lane;
   const bool live = n < N;
   const int nc = live ? n : N - 1;
   // sample + clip: knot = clip(nominal + sigma * noise); global sample 0 keeps the nominal (also clipped, controller.py:253)
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
     if (n_offset + nc != 0) v = fmaf(sigma[i], noise[(size_t)i * ldn + nc], v);
     int u = i % T::NU;
     v = jh_clampf(v, lohi[u], lohi[T::NU + u]);
-    sKn[i * kBlock + lane] = v;
+    sKn[i * BS + lane] = v;
     if (knots_out && live) knots_out[(size_t)i * ldn + n] = v;
   }
   __syncthreads();
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
   float acc = 0.f;
   for (int h = 0; h < H; h++) {
     float u[T::NU];
-    spline_controls<T::NU>(sp, h, lane, u);
+    spline_controls<T::NU, BS>(sp, h, lane, u);
     if (trace) {  // jh_rollout_cost_traced: the sensors of this forward pass (all of them are trace sensors in these two models), column-major: element (n, i) at [i * N + n]
       float y[T::NS]; s.sensors(sP, y);
       if (live) for (int k = 0; k < T::NS; k++) trace[(size_t)(h * T::NS + k) * N + n] = y[k];
@@ -205,6 +206,28 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict
     acc += s.cost(sTp, u);
   }
   if (live) costs[n] = T::finish(acc, H);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_rollout_cost(const float* __restrict__ P, const float* __restrict__ x0,
+                                                         const float* __restrict__ nominal, const float* __restrict__ noise, int ldn,
+                                                         const float* __restrict__ sigma, const float* __restrict__ W,
+                                                         const float* __restrict__ lohi, const float* __restrict__ tp, int N, int n_offset,
+                                                         int H, int K, float* __restrict__ costs, float* __restrict__ knots_out, float* __restrict__ trace) {
+  rollout_cost_body<T, kBlock>(P, x0, nominal, noise, ldn, sigma, W, lohi, tp, N, n_offset, H, K, costs, knots_out, trace);
+}
+
+// The plan step of a closed-form model as ONE launch (round 6): the rollout + cost body above in workgroups of the update's size (thread t of workgroup b holds local
+// rollout b * kUB + t, the layout the update's block stage assumes), then the update's tail in the same launch -- every workgroup's partial records, a ticket, the last
+// workgroup merges (jh_update_dev.h; Controller.update_action's body, judo/controller/controller.py:246-299).  A rollout's arithmetic does not depend on the workgroup
+// size, the tail is the code of k_update_tail: the same nominal, sigma and trace records as the two launches, one launch latency (and the idle gap in front of it) less.
+template <class T>
+__global__ __launch_bounds__(jh_upd::kUB) void k_plan_step(const float* __restrict__ P, const float* __restrict__ x0, const float* __restrict__ W, const float* __restrict__ tp, int H, int K,
+                                                           jh_upd::TailArgs a) {
+  rollout_cost_body<T, jh_upd::kUB>(P, x0, a.src.nominal, a.src.noise, a.src.ldn, a.src.sigma, W, a.src.lohi, tp, a.N, a.n_offset, H, K, const_cast<float*>(a.costs), nullptr,
+                                    const_cast<float*>(a.trace));
+  __syncthreads();  // (a thread reads back the cost it wrote; the trace rows are read by the last workgroup only, behind the tail's own fence and ticket)
+  jh_upd::update_tail_body(a);
 }
 
 // Drop-in RolloutBackend.rollout: this path IS bound by HBM (it streams 4*H*(nx+ns+nu) bytes per rollout), so the row-major
@@ -323,7 +346,31 @@ int launch_cost(const jh_model* m, const float* x0, const float* nominal, const 
   return JH_OK;
 }
 
+template <class T>
+int launch_plan_step(const jh_model* m, const float* x0, const float* W, const float* tp, int H, int K, const jh_upd::TailArgs& a, hipStream_t st) {
+  constexpr int BS = jh_upd::kUB;
+  size_t lds = sizeof(float) * ((size_t)H * K + (size_t)K * T::NU * BS + T::NP + T::NTP + T::NX);
+  JH_REQUIRE(lds <= 48 * 1024, "plan_step: H*K too large for the LDS staging of the one-launch plan step (%zu bytes)", lds);
+  int grid = (a.N + BS - 1) / BS;
+  hipLaunchKernelGGL(k_plan_step<T>, dim3(grid), dim3(BS), lds, st, m->d_f, x0, W, tp, H, K, a);
+  JH_HIP(hipGetLastError());
+  return JH_OK;
+}
+
 }  // namespace
+
+// can the plan step of this model run as one launch?  (closed-form models; the knots of a workgroup of 256 rollouts must fit the LDS staging next to the update's own 9 KB)
+bool jh_simple_plan_step_fits(const jh_model* m, int H, int K) {
+  if (m->kind != JH_TASK_CARTPOLE && m->kind != JH_TASK_CYLINDER_PUSH) return false;
+  const int nu = m->kind == JH_TASK_CARTPOLE ? Cartpole::NU : CylinderPush::NU;
+  const int np = m->kind == JH_TASK_CARTPOLE ? Cartpole::NP + Cartpole::NTP + Cartpole::NX : CylinderPush::NP + CylinderPush::NTP + CylinderPush::NX;
+  return sizeof(float) * ((size_t)H * K + (size_t)K * nu * jh_upd::kUB + np) <= 48 * 1024;
+}
+
+int jh_simple_plan_step(const jh_model* m, const float* x0, const float* W, const float* tp, int H, int K, const jh_upd::TailArgs& a, hipStream_t st) {
+  if (m->kind == JH_TASK_CARTPOLE) return launch_plan_step<Cartpole>(m, x0, W, tp, H, K, a, st);
+  return launch_plan_step<CylinderPush>(m, x0, W, tp, H, K, a, st);
+}
 
 // largest K for which launch_cost's LDS staging (W, the lanes' knots, model / task constants, x0) fits the 64 KiB it may ask for
 template <class T>

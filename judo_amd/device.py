@@ -92,6 +92,7 @@ class GpuModel:
         self.self_collision = self.desc.get("family", self.task) == "leap_cube"  # library default: on where the kernel models it
         # contacts a rollout can hold.  The leap kernel exists in two builds (48, all in LDS; 64 with 16 in global memory, 2.8 % slower): the headline model drops 2e-6
         # contacts per rollout-step at 48, the SHIPPED workloads of the caged / primitive-hand variants 2e-4 .. 4e-4 (tools/diag/shipped_config_stats.py): those take 64
+        self.closed_form = self.task in ("cartpole", "cylinder_push")  # jh_simple.hip: rollout kernels of ~50 us -- the plan step runs as one launch that reads its host block in place
         self.contact_capacity = 0
         if self.desc.get("family", self.task) == "leap_cube":
             self.set_contact_capacity(48 if self.task == "leap_cube" else 64)

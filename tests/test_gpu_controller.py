@@ -348,8 +348,11 @@ def test_fused_update_is_bit_identical_to_the_separate_kernels(gpu, task_name, o
     from judo_amd.controller import make_controller
 
     outs = []
-    for fused, zero_copy in ((True, True), (True, False), (False, False)):  # jh_plan_step (one call, results written into the pinned host block) / jh_update_fused + download / separate kernels
+    # jh_plan_step (one call, results written into the pinned host block; cartpole / cylinder_push: ONE launch that reads its host block in place; completion word polled) /
+    # the same call with the uploaded block and the stream's event / jh_update_fused + download / separate kernels
+    for fused, zero_copy, lean in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
         ctrl = make_controller(task_name, opt_name)
+        ctrl.poll_completion = ctrl.host_block_in_place = lean
         ctrl.optimizer.config.num_rollouts = N
         ctrl.reset()
         ctrl.current_state = ctrl.task.default_state()
