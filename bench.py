@@ -40,7 +40,7 @@ WORKLOADS = {
     "spot_navigate": ("mppi", 65536, 100),
 }
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = "r05_traffic.json"
+TRAFFIC_FILE = "r06_traffic.json"
 
 
 def usable_cpus() -> int:
@@ -318,7 +318,8 @@ def main() -> None:
         t_plan += 1.0 / ctrl.controller_cfg.control_freq
     ctrl.kernel_events.clear()
     ctrl.exchange_events.clear()
-    ctrl.reserve_timing_events(4 * args.steps * max(1, ctrl.max_opt_iters) + 8)  # (the timed region records HIP events, it does not create them)
+    ctrl.noise_events.clear()
+    ctrl.reserve_timing_events(7 * args.steps * max(1, ctrl.max_opt_iters) + 8)  # (the timed region records HIP events, it does not create them)
     ctrl.solver_warnings = False
     if not is_policy:
         ctrl.solver_stats()  # zero the kernels' counters: the line reports the timed steps alone
@@ -381,6 +382,14 @@ def main() -> None:
     # (host: time shift, packing, launches, the one wait for the new nominal).  With several GPUs every rank reports its own split.
     split = {"rank": rank, "rollouts": int(ctrl.last_shard.count), "kernel_ms": kern_ms, "exchange_ms": exch_ms, "plan_step_ms": float(np.mean(per_step) * 1e3),
              "host_and_launch_ms": float(np.mean(per_step) * 1e3 - kern_ms - exch_ms)}
+    if world > 1 and getattr(ctrl, "noise_events", None) and len(ctrl.noise_events) >= len(ctrl.exchange_events) > 0:
+        # the next iteration's noise draw (side stream) on the exchange's clock: both measured from the event behind the rollout + record launch
+        nev = ctrl.noise_events[-len(ctrl.exchange_events):]
+        n0 = float(np.mean([x[0].elapsed_time(n[0]) for x, n in zip(ctrl.exchange_events, nev)]))
+        n1 = float(np.mean([x[0].elapsed_time(n[1]) for x, n in zip(ctrl.exchange_events, nev)]))
+        inside = float(np.mean([x[0].elapsed_time(n[1]) <= x[0].elapsed_time(x[1]) for x, n in zip(ctrl.exchange_events, nev)]))
+        split["noise_draw_on_side_stream"] = {"start_ms": n0, "end_ms": n1, "exchange_end_ms": exch_ms, "finished_inside_exchange": inside,
+                                              "note": "ms relative to the event behind this rank's rollout + record launch (negative: while that launch still runs): the next iteration's noise is drawn on a second stream, enqueued in front of the all-gather -- it runs beside the rollout kernel and the exchange, never between the record and the collective"}
     per_rank = [split]
     if world > 1:
         per_rank = [None] * world

@@ -232,6 +232,7 @@ int jh_plan_merge(const float* recs, int G, int K, int nu, int mode, float lambd
 int jh_event_create(void** out);
 void jh_event_destroy(void* ev);
 int jh_event_record(void* ev, void* stream);
+int jh_stream_wait_event(void* stream, void* ev); /* work enqueued on `stream` after this call waits (on the device) for `ev`, recorded on another stream */
 int jh_event_elapsed_ms(void* a, void* b, float* ms);
 /* Merge G*k records -> global k elites -> mean and clipped population std (ddof 0).  sigma_out may be NULL (PS, k=1). */
 int jh_elite_merge(const float* recs, int G, int k, int K, int nu, int tie_high, float sigma_min, float sigma_max, float* nominal_out,

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "jh_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "jh_event_destroy": (None, [C.c_void_p]),
     "jh_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jh_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jh_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "jh_elite_merge": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
 }

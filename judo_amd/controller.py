@@ -124,6 +124,8 @@ class Controller:
         self._noise_bufs: list[torch.Tensor] | None = None
         self._noise_cur = 0
         self._noise_ahead = None
+        self._side_stream = None  # several ranks: the next iteration's noise draw runs here while the update records are all-gathered
+        self.noise_events: list = []  # (start, end) of the side-stream noise draws when record_kernel_events is set
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
         self.zero_copy_out = True  # jh_update_fused writes nominal | sigma | trace records into the pinned host block itself (no download command)
         self.poll_completion = True  # one GPU: wait for the completion word the update's last workgroup writes behind its results instead of the stream's event (jh_plan_step, out_host_mark)
@@ -342,23 +344,43 @@ class Controller:
             K, nu = opt.num_nodes, self.nu
             ahead, self._noise_ahead = self._noise_ahead, None
             if ahead is not None and ahead[0] == (K, nu, n_local, n_offset) and ahead[1] is opt._generator and ahead[1] is not None:
+                if ahead[3] is not None:  # drawn on the side stream: the launch stream waits for it (device side; the host does not)
+                    _lib.check(_lib.lib().jh_stream_wait_event(current_stream_ptr(), ahead[3].handle), "jh_stream_wait_event")
                 opt.last_noise = ahead[2]
                 return ahead[2]
+            if ahead is not None and ahead[3] is not None:  # a side-stream draw that is not used after all (reseed, new shape): its buffer may be the one drawn into next
+                _lib.check(_lib.lib().jh_stream_wait_event(current_stream_ptr(), ahead[3].handle), "jh_stream_wait_event")
             return opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
         self._noise_ahead = None
         return opt.draw_noise(n_local, n_offset, self.device)
 
-    def _prefetch_noise(self, n_local: int, n_offset: int) -> None:
+    def _prefetch_noise(self, n_local: int, n_offset: int, side: bool = False) -> None:
         """Enqueue the next iteration's noise draw now (behind the download of this one's result): it leaves the critical path of the next plan step.
-        Only for the library's own `draw_noise` with the device generator; a reseed, an injected noise array or a changed shape discards the draw."""
+        Only for the library's own `draw_noise` with the device generator; a reseed, an injected noise array or a changed shape discards the draw.
+        `side` (several ranks): the draw goes on a second stream, enqueued BEFORE the all-gather of the update records -- the collective (RCCL's own stream, ordered
+        behind the launch stream by events) and the merge behind it do not wait for it, it runs while the records travel; the next plan step's rollout
+        kernel waits for its event.  The buffer it writes was last read by the plan step before the current one, which the host has waited for."""
         opt = self.optimizer
         if not self.prefetch_noise or opt.injected_noise is not None or type(opt).draw_noise is not Optimizer.draw_noise or opt._generator is None:
             return
         K, nu = opt.num_nodes, self.nu
         keep = opt.last_noise
-        noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
+        ready = None
+        if side:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._side_stream):
+                t0 = None
+                if self.record_kernel_events:
+                    t0 = self._timing_event(); t0.record()
+                noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
+                ready = self._timing_event(); ready.record()
+                if t0 is not None:
+                    self.noise_events.append((t0, ready))
+        else:
+            noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
         opt.last_noise = keep
-        self._noise_ahead = ((K, nu, n_local, n_offset), opt._generator, noise)
+        self._noise_ahead = ((K, nu, n_local, n_offset), opt._generator, noise, ready)
 
     # ---- the plan step -------------------------------------------------------------------------------------------
     @property
@@ -553,6 +575,9 @@ class Controller:
                                             int(task.phase), shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el,
                                             tie, E_t, row, int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), _lib.ptr(b.shard_rec), timing, stream)
                 _lib.check(st, "jh_plan_step_shard")
+                if self._prefetch_args is not None:  # the next iteration's noise on the side stream, enqueued in front of the collective: it overlaps the exchange
+                    self._prefetch_noise(*self._prefetch_args, side=True)
+                    self._prefetch_args = None
                 b.shard_all = all_gather_records(b.shard_rec, self.group)  # (world * L,), rank-major; kept alive until the merge has run
                 done = None
                 if self.record_kernel_events:

@@ -371,6 +371,11 @@ extern "C" int jh_plan_merge(const float* recs, int G, int K, int nu, int mode, 
 extern "C" int jh_event_create(void** out) { JH_REQUIRE(out, "event_create: null pointer"); hipEvent_t e; JH_HIP(hipEventCreate(&e)); *out = e; return JH_OK; }
 extern "C" void jh_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 extern "C" int jh_event_record(void* ev, void* stream) { JH_REQUIRE(ev, "event_record: null pointer"); JH_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return JH_OK; }
+extern "C" int jh_stream_wait_event(void* stream, void* ev) {  // device-side: work enqueued on `stream` after this call waits for `ev` (recorded on another stream)
+  JH_REQUIRE(ev, "stream_wait_event: null pointer");
+  JH_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+  return JH_OK;
+}
 extern "C" int jh_event_elapsed_ms(void* a, void* b, float* ms) {  // waits for b
   JH_REQUIRE(a && b && ms, "event_elapsed_ms: null pointer");
   JH_HIP(hipEventSynchronize((hipEvent_t)b));
