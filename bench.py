@@ -516,9 +516,9 @@ def main() -> None:
             "config": {"workload": f"{args.task} {opt_name.upper()} {N} rollouts x H={H} (K={K}, nu={nu}, spline {ctrl.spline_order}, dt={ctrl.task.dt})",
                        "rollouts": N, "horizon_steps": H, "num_nodes": K, "parallelism": f"rollout-shard x{world}", "max_opt_iters": ctrl.max_opt_iters,
                        "noise_seed": args.seed,
-                       "closed_loop": "every plan step starts from the previous plan: ms_per_step depends on where the noise stream leads it, chaotically (leap_cube, final "
-                                      "round-4 build: eight seeds 57.6-72.4 ms, mean 63.2 over 20 steps; four seeds 63.4-68.8, mean 66.4 over 100 steps; profiles/r04_seed_sweep.txt; "
-                                      "round 3: 74.0-87.8, mean 81.9; 85.8-96.8, mean 89.4)",
+                       "closed_loop": "every plan step starts from the previous plan: ms_per_step depends on where the noise stream leads it, chaotically (leap_cube, "
+                                      "round-6 build: eight seeds 46.3-59.5 ms, mean 51.4 over 20 steps -- the default seed 1234: 53.8 --; four seeds 51.8-55.7, mean 53.2 over 100 steps; "
+                                      "profiles/r06_seed_sweep.txt; round 4: 57.6-72.4, mean 63.2; 63.4-68.8, mean 66.4; round 3: 74.0-87.8, mean 81.9; 85.8-96.8, mean 89.4)",
                        "hand_self_collision": self_on if args.task.startswith("leap") else None,
                        "traces": ("read inside every timed plan step (update_traces is part of the reference's update_action): the fused kernel writes every rollout's trace sensors, "
                                   "the elites' rows are gathered on the device" if traces_in_step else "not read inside the timed steps; see plan_step_ms_with_traces")},
