@@ -229,6 +229,9 @@ __global__ __launch_bounds__(jh_upd::kUB) void k_plan_step(const float* __restri
   __syncthreads();  // (a thread reads back the cost it wrote; the trace rows are read by the last workgroup only, behind the tail's own fence and ticket)
   jh_upd::update_tail_body(a);
 }
+#ifdef JH_TAIL_TICKS
+__global__ void k_tail_ticks_start() { if (threadIdx.x == 0) jh_upd::g_tail_ticks[8] = wall_clock64(); }
+#endif
 
 // Drop-in RolloutBackend.rollout: this path IS bound by HBM (it streams 4*H*(nx+ns+nu) bytes per rollout), so the row-major
 // (N,H,.) arrays the interface prescribes are moved in tiles: a wave owns 64 rollouts, stages TS time steps of controls /
@@ -367,6 +370,9 @@ bool jh_simple_plan_step_fits(const jh_model* m, int H, int K) {
   return sizeof(float) * ((size_t)H * K + (size_t)K * nu * jh_upd::kUB + np) <= 48 * 1024;
 }
 
+#ifdef JH_TAIL_TICKS
+extern "C" int jh_debug_tail_ticks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(jh_upd::g_tail_ticks), 16 * sizeof(long long)) == hipSuccess ? 0 : -2; }
+#endif
 int jh_simple_plan_step(const jh_model* m, const float* x0, const float* W, const float* tp, int H, int K, const jh_upd::TailArgs& a, hipStream_t st) {
   if (m->kind == JH_TASK_CARTPOLE) return launch_plan_step<Cartpole>(m, x0, W, tp, H, K, a, st);
   return launch_plan_step<CylinderPush>(m, x0, W, tp, H, K, a, st);

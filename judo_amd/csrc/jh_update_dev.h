@@ -199,6 +199,12 @@ struct TailArgs {
                        // MPPI [beta, S, V(KU)] or k x [cost, index, knots(KU)], then the E trace records; jh_shard_merge finishes the update on every rank
 };
 // (the body of k_update_tail: also the tail of the closed-form rollout kernels' one-launch plan step, jh_simple.hip -- a workgroup of kUB threads whose thread t holds local rollout blockIdx.x * kUB + t)
+#ifdef JH_TAIL_TICKS  // diagnostic builds (tools/diag/tail_ticks.py): 100 MHz wall-clock stamps of the last workgroup's way through the tail
+__device__ long long g_tail_ticks[16];
+#define TAIL_TICK(i) do { if (threadIdx.x == 0) g_tail_ticks[i] = wall_clock64(); } while (0)
+#else
+#define TAIL_TICK(i)
+#endif
 __device__ __forceinline__ void update_tail_body(const TailArgs& a) {
   __shared__ float sred[4];
   __shared__ float sS;
@@ -213,14 +219,27 @@ __device__ __forceinline__ void update_tail_body(const TailArgs& a) {
   float* s_topA = s_mppi + (size_t)nb * (2 + KU);
   float* s_topB = s_topA + (size_t)nb * a.k * 2;
   float* s_rec = s_topB + (size_t)nb * a.E * 2;
+#ifdef JH_TAIL_TICKS
+  const long long t_in = wall_clock64();
+#endif
   if (a.mode == 0) mppi_block_body(a.costs, a.src, a.N, a.inv_lambda, s_mppi, sred, sV);
   else topk_block_body(a.costs, a.N, a.n_offset, a.k, a.tie_high, s_topA, cred);
+#ifdef JH_TAIL_TICKS
+  const long long t_b1 = wall_clock64();
+#endif
   if (a.E > 0) { __syncthreads(); topk_block_body(a.costs, a.N, a.n_offset, a.E, 1, s_topB, cred); }
+#ifdef JH_TAIL_TICKS
+  const long long t_b2 = wall_clock64();
+#endif
   __threadfence();
   __syncthreads();
   if (tid == 0) s_last = (atomicAdd(counter, 1u) == (unsigned)(nb - 1));
   __syncthreads();
   if (!s_last) return;
+#ifdef JH_TAIL_TICKS
+  if (tid == 0) { g_tail_ticks[0] = t_in; g_tail_ticks[1] = t_b1; g_tail_ticks[2] = t_b2; }
+#endif
+  TAIL_TICK(3);
   __threadfence();
   if (tid == 0) *counter = 0u;  // (the next launch on this stream finds it reset)
   if (a.rec_out) {  // shard form: the record itself (what jh_mppi_partial / jh_topk_partial write), merged across the ranks by jh_shard_merge
@@ -234,9 +253,11 @@ __device__ __forceinline__ void update_tail_body(const TailArgs& a) {
     __syncthreads();
     elite_merge_body(s_rec, a.k, a.k, KU, a.tie_high, 0.f, INFINITY, a.nominal_out, a.sigma_out, ichosen);
   }
+  TAIL_TICK(4);
   if (a.E > 0) {
     __syncthreads();
     topk_choose(s_topB, nb * a.E, a.E, 1, cred, chosen);
+    TAIL_TICK(5);
     for (int e = 0; e < a.E; e++) {
       const float cost = chosen[e].c; const int gi = chosen[e].i, li = gi - a.n_offset;
       float* o = a.trace_out + (size_t)e * (2 + a.row);
@@ -245,11 +266,13 @@ __device__ __forceinline__ void update_tail_body(const TailArgs& a) {
       for (int i = tid; i < a.row; i += kUB) o[2 + i] = ok ? (a.colmajor ? a.trace[(size_t)i * a.N + li] : a.trace[(size_t)li * a.row + i]) : 0.f;
     }
   }
+  TAIL_TICK(6);
   if (a.done_flag) {  // completion flag for the polling host: every thread's stores to the (host) output block first, system scope
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  TAIL_TICK(7);
 }
 
 }  // namespace jh_upd
