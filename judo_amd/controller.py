@@ -128,7 +128,7 @@ class Controller:
         self.noise_events: list = []  # (start, end) of the side-stream noise draws when record_kernel_events is set
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
         self.zero_copy_out = True  # jh_update_fused writes nominal | sigma | trace records into the pinned host block itself (no download command)
-        self.poll_completion = True  # one GPU: wait for the completion word the update's last workgroup writes behind its results instead of the stream's event (jh_plan_step, out_host_mark)
+        self.poll_completion = True  # one GPU, closed-form models (plan steps of ~0.1 ms): wait for the completion word the update's last workgroup writes behind its results instead of the stream's event (jh_plan_step, out_host_mark); the articulated models' 7-50 ms plan steps keep the event
         self.host_block_in_place = True  # closed-form models: the plan-step kernel reads x0 | nominal | sigma | task params | bounds from the pinned host block (no copy in front of the launch)
         self.fused_update = True  # one GPU: the whole update (block partials, merge, trace elites) in one launch and one download (jh_update_fused); False: the separate kernels
         self._prefetch_args = None
@@ -562,7 +562,7 @@ class Controller:
                 b.blk_stale = in_place  # (jh_plan_step uploads the block itself unless it is read in place)
                 st = lib.jh_plan_step(self.model.handle, blk_dev, b.host_ptr, b.nblk_bytes, int(off[1]), int(off[2]), int(off[3]), int(off[4]), noise_p, ldn, _lib.ptr(W), int(task.phase),
                                       shard.count, shard.offset, H, K, _lib.ptr(b.costs), _lib.ptr(knots_out), _lib.ptr(b.trace_buf) if nfl else None, mode, lam, k_el, tie, E_t, row,
-                                      int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.done_ptr if self.poll_completion else b.out_host_ptr, timing, stream)
+                                      int(self._trace_colmajor) if nfl else 0, _lib.ptr(b.fused_scratch), b.out_host_ptr, b.done_ptr if (self.poll_completion and self.model.closed_form) else b.out_host_ptr, timing, stream)
                 what = "jh_plan_step"
             else:
                 # ---- several ranks: launch (rollout + cost + this rank's record [update record | E trace records]) -> one all-gather -> merge on every rank into

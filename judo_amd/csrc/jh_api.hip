@@ -234,6 +234,7 @@ extern "C" int jh_download_end(void) {
     // end-of-launch write-back, the marker packet and its signal -- would report.  The event is looked at every few thousand polls so that a launch that died cannot hang the host.
     for (unsigned spin = 1;; spin++) {
       if (__atomic_load_n(pd.flag, __ATOMIC_ACQUIRE) == pd.expect) return JH_OK;
+      __builtin_ia32_pause();
       if ((spin & 0x3FFFu) == 0u) {
         const hipError_t q = hipEventQuery(pd.ev);
         if (q == hipSuccess) { if (__atomic_load_n(pd.flag, __ATOMIC_ACQUIRE) != pd.expect) { jh_set_error("download_end: the launch finished without setting its completion flag"); return JH_ERR_HIP; } return JH_OK; }
