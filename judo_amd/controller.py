@@ -125,6 +125,7 @@ class Controller:
         self._noise_cur = 0
         self._noise_ahead = None
         self._side_stream = None  # several ranks: the next iteration's noise draw runs here while the update records are all-gathered
+        self._side_events, self._side_flip = None, 0
         self.noise_events: list = []  # (start, end) of the side-stream noise draws when record_kernel_events is set
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
         self.zero_copy_out = True  # jh_update_fused writes nominal | sigma | trace records into the pinned host block itself (no download command)
@@ -374,9 +375,15 @@ class Controller:
                 if self.record_kernel_events:
                     t0 = self._timing_event(); t0.record()
                 noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
-                ready = self._timing_event(); ready.record()
                 if t0 is not None:
+                    ready = self._timing_event()
                     self.noise_events.append((t0, ready))
+                else:  # two events, alternated: the one of the draw before this one was waited for by the plan step now in flight
+                    if self._side_events is None:
+                        self._side_events = [HipEvent(), HipEvent()]
+                    self._side_flip ^= 1
+                    ready = self._side_events[self._side_flip]
+                ready.record()
         else:
             noise = opt.draw_noise(n_local, n_offset, self.device, out=self._noise_buffer((K, nu, n_local)))
         opt.last_noise = keep
