@@ -77,6 +77,9 @@ constexpr int NCH = 4, NLK = 4;
                           // anywhere in a Newton iteration (gradient torque, Hessian columns, J p of the line search).  The warm start and the integrated acceleration stay in
                           // the body frame (MuJoCo's free-joint convention): two 3 x 3 products per STEP.  Same minimiser, different rounding than the body-frame form.
 #endif
+#ifndef JH_V5_HCMERGE
+#define JH_V5_HCMERGE 1  // (round 6) the hand-capable copy's chain part with one exec-masked region per joint (see the contact pass)
+#endif
 #ifndef JH_V5_C3PAD
 #define JH_V5_C3PAD 278
 #endif
@@ -1302,6 +1305,44 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
 #endif
                 }
               } else {
+#if JH_V5_HCMERGE
+              // (round 6, the hand-capable copy as the other one: a joint's gradient entry, its row of the chain block and its coupling to the cube under ONE test per joint; the
+              // coupling of a contact that is not the cube's is added as zeros instead of sitting in a nested exec-masked region per joint; the opposite force of a contact with both
+              // sides in one chain -- rare -- behind one wave-uniform test.  The same values reach the same addresses in the same order.)
+              float fjs[NLK];
+#pragma unroll
+              for (int u4 = 0; u4 < NLK; u4++) {
+                fjs[u4] = dot3(cb[u4], Fw);
+                const float sg = (u4 <= dep ? 1.f : 0.f) - ((same && u4 <= depa) ? 1.f : 0.f);
+                cb[u4][0] *= sg; cb[u4][1] *= sg; cb[u4][2] *= sg;
+                if (u4 <= dep) {
+                  atomicAdd(&S.g[6 + 4 * ch + u4], -fjs[u4]);  // side B: -J'f
+                  if (on) {
+                    float y[3]; Amul(cb[u4], y);
+#pragma unroll
+                    for (int v4 = 0; v4 <= u4; v4++) atomicAdd(&S.Hbb[ch][tri(u4, v4)], dot3(cb[v4], y));
+#if JH_V5_WORLDROT
+                    const float hv[6] = {-y[0], -y[1], -y[2], t.rc[2] * y[1] - t.rc[1] * y[2], t.rc[0] * y[2] - t.rc[2] * y[0], t.rc[1] * y[0] - t.rc[0] * y[1]};  // -(e_q x r) . y
+#else
+                    const float hv[6] = {-y[0], -y[1], -y[2], -dot3(cq[0], y), -dot3(cq[1], y), -dot3(cq[2], y)};
+#endif
+#if JH_V5_HCMERGE > 1
+#pragma unroll
+                    for (int q = 0; q < 6; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + q], cube ? hv[q] : 0.f);
+#else
+                    if (cube) {
+#pragma unroll
+                      for (int q = 0; q < 6; q++) atomicAdd(&S.Hcb[ch][u4 * 6 + q], hv[q]);
+                    }
+#endif
+                  }
+                }
+              }
+              if (__any(same)) {
+#pragma unroll
+                for (int j = 0; j < NLK; j++) if (same && j <= depa) atomicAdd(&S.g[6 + 4 * ch + j], fjs[j]);  // side A of the same chain: the opposite force
+              }
+#else
 #pragma unroll
               for (int j = 0; j < NLK; j++) {
                 const float fj = dot3(cb[j], Fw);
@@ -1330,6 +1371,7 @@ __global__ __launch_bounds__(WAVE * WPB, JH_V5_WAVES_PER_EU) JH_V5_REGATTR void 
                   }
                 }
               }
+#endif
               if (linkA && !same) {  // side A sits in another chain: its own block, and the pair's coupling block -Jb'W Ja in Hx (B's chain is always the higher one)
                 float ca[NLK][3]; link_c3(S, cha, pos, ca);
 #pragma unroll
