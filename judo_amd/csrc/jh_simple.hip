@@ -104,7 +104,7 @@ struct Cartpole {
   // running cost of judo/tasks/cartpole.py:61-78 (w = w_vertical,w_centered,w_velocity,w_control,p_vertical,p_centered)
   __device__ float cost(const float* w, const float* u) const {
     float cv = cs - 1.f;
-    return w[0] * (sqrtf(cv * cv + w[4] * w[4]) - w[4]) + w[1] * (sqrtf(x * x + w[5] * w[5]) - w[5]) +
+    return w[0] * (__builtin_amdgcn_sqrtf(cv * cv + w[4] * w[4]) - w[4]) + w[1] * (__builtin_amdgcn_sqrtf(x * x + w[5] * w[5]) - w[5]) +  // (v_sqrt_f32, 1 ulp: a correctly rounded root is a dozen dependent instructions)
            w[2] * 0.5f * (xd * xd + thd * thd) + w[3] * 0.5f * u[0] * u[0];
   }
   __device__ static float finish(float acc, int /*H*/) { return acc; }
@@ -127,33 +127,38 @@ struct CylinderPush {
     float sp0 = -P[CY_DAMP_P] * pvx + fx, sp1 = -P[CY_DAMP_P] * pvy + fy;  // qfrc_smooth (no gravity / Coriolis in the plane)
     float sc0 = -P[CY_DAMP_C] * cvx, sc1 = -P[CY_DAMP_C] * cvy;
     // circle-circle contact; normal from the pusher (geom 1) to the cart (geom 2)
-    float dx = cx - px, dy = cy - py, dn = sqrtf(dx * dx + dy * dy);
+    float dx = cx - px, dy = cy - py, dn = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);  // (v_sqrt_f32, 1 ulp)
     float dist = dn - P[CY_RSUM];
     float q0 = 0.f, q1 = 0.f;  // constraint force on the cart (= -force on the pusher)
+    // (round 6: v_rcp_f32 (1 ulp) and reciprocals of the two masses where the step had nine correctly rounded divisions -- ten dependent instructions each in a step that is one
+    // dependent chain; the same choice as cartpole's determinant)
+    const float imp_ = __builtin_amdgcn_rcpf(mp), imc_ = __builtin_amdgcn_rcpf(mc);
     if (dist < P[CY_MARGIN] && dn > 1e-12f) {
-      float nx = dx / dn, ny = dy / dn;
+      const float idn = __builtin_amdgcn_rcpf(dn);
+      float nx = dx * idn, ny = dy * idn;
       float imp = impedance_pow(P + CY_SOLIMP0, dist - P[CY_MARGIN]);
       float mu = P[CY_MU];
       // pyramidal cone with mu -> 1e-5: the 2*(condim-1) edge rows coincide with the normal row up to O(mu); their common
       // regulariser is Rpy = 2 mu^2 R_n, so the summed normal force obeys (A + Rpy/4) F = aref - J a0
-      float Rn = fmaxf(1e-15f, (1.f - imp) / imp * P[CY_TRAN] * (1.f + mu * mu));
+      float Rn = fmaxf(1e-15f, (1.f - imp) * __builtin_amdgcn_rcpf(imp) * P[CY_TRAN] * (1.f + mu * mu));
       float Rpy = fmaxf(1e-15f, 2.f * mu * mu * Rn);
       float vn = (cvx - pvx) * nx + (cvy - pvy) * ny;
       float aref = -P[CY_CON_B] * vn - P[CY_CON_K] * imp * (dist - P[CY_MARGIN]);
-      float a0n = (sc0 / mc - sp0 / mp) * nx + (sc1 / mc - sp1 / mp) * ny;
-      float A = 1.f / mp + 1.f / mc;
-      float F = fmaxf(0.f, (aref - a0n) / (A + 0.25f * Rpy));
+      float a0n = (sc0 * imc_ - sp0 * imp_) * nx + (sc1 * imc_ - sp1 * imp_) * ny;
+      float A = imp_ + imc_;
+      float F = fmaxf(0.f, (aref - a0n) * __builtin_amdgcn_rcpf(A + 0.25f * Rpy));
       q0 = F * nx; q1 = F * ny;
     }
-    float ip = 1.f / (mp + h * P[CY_DAMP_P]), ic = 1.f / (mc + h * P[CY_DAMP_C]);
+    float ip = __builtin_amdgcn_rcpf(mp + h * P[CY_DAMP_P]), ic = __builtin_amdgcn_rcpf(mc + h * P[CY_DAMP_C]);
     pvx = fmaf(h, (sp0 - q0) * ip, pvx); pvy = fmaf(h, (sp1 - q1) * ip, pvy);
     cvx = fmaf(h, (sc0 + q0) * ic, cvx); cvy = fmaf(h, (sc1 + q1) * ic, cvy);
     px = fmaf(h, pvx, px); py = fmaf(h, pvy, py); cx = fmaf(h, cvx, cx); cy = fmaf(h, cvy, cy);
   }
   // judo/tasks/cylinder_push.py:65-93 (w = w_pusher_proximity, w_pusher_velocity, w_cart_position, offset, goal_x, goal_y)
   __device__ float cost(const float* w, const float* /*u*/) const {
-    float gx = w[4] - cx, gy = w[5] - cy, gn = sqrtf(gx * gx + gy * gy);
-    float tx = cx - w[3] * gx / gn, ty = cy - w[3] * gy / gn;  // no epsilon guard, as in the reference
+    float gx = w[4] - cx, gy = w[5] - cy, gn = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
+    const float ign = __builtin_amdgcn_rcpf(gn);
+    float tx = cx - w[3] * gx * ign, ty = cy - w[3] * gy * ign;  // no epsilon guard, as in the reference (gn = 0: inf * 0 = NaN, as 0 / 0)
     float ex = px - tx, ey = py - ty;
     return w[0] * 0.5f * (ex * ex + ey * ey) + w[1] * 0.5f * (pvx * pvx + pvy * pvy) + w[2] * 0.5f * (gx * gx + gy * gy);
   }
