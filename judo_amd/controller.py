@@ -48,6 +48,7 @@ class _PlanBuffers:
         L = _lib.lib()
         self.sizes = [nx, K * nu, K * nu, ntp, 2 * nu]
         nblk = sum(self.sizes)
+        self.offsets = [int(v) for v in np.cumsum([0] + self.sizes)]
         self.host = torch.empty(nblk, dtype=torch.float32).pin_memory()
         self.host_np = self.host.numpy()
         self.host_ptr, self.nblk_bytes = self.host.data_ptr(), 4 * nblk
@@ -204,7 +205,11 @@ class Controller:
 
     @property
     def num_timesteps(self) -> int:
-        return int(np.ceil(self.horizon / self.task.dt))
+        key = (self.horizon, self.task.dt)
+        c = getattr(self, "_nts_cache", None)
+        if c is None or c[0] != key:  # (read several times per plan step: a small plan step is 0.1 ms)
+            c = self._nts_cache = (key, int(np.ceil(self.horizon / self.task.dt)))
+        return c[1]
 
     @property
     def rollout_times(self) -> np.ndarray:
@@ -562,7 +567,7 @@ class Controller:
                 timing = (C.c_void_p * 3)(*[e.handle for e in evs])
                 self.kernel_events.append((evs[0], evs[1]))
                 self.exchange_events.append((evs[1], evs[2]))
-            off = np.cumsum([0] + b.sizes)
+            off = b.offsets
             if one_call:
                 in_place = self.host_block_in_place and self.model.closed_form and knots_out is None
                 blk_dev = b.host_ptr if in_place else b.blk.data_ptr()

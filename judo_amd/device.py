@@ -84,6 +84,7 @@ class GpuModel:
         st = _lib.lib().jh_model_create(buf, len(blob), self.device.index or 0, C.byref(handle))
         _lib.check(st, "jh_model_create")
         self.handle = handle
+        self._max_knots_cache: dict[int, int] = {}
         self.kernel_generation = 3 if self.desc.get("family", self.task) in ("leap_cube", "fr3_pick") else 2  # library defaults (jh_model_create)
         self._self_collision_requested = True
         gen = os.environ.get("JUDO_AMD_FR3_KERNEL")  # diagnostic: run the fr3_pick tests / benches on another kernel generation of the library
@@ -100,6 +101,7 @@ class GpuModel:
     def set_kernel(self, generation: int) -> None:
         """Select the articulated-engine kernel generation (3 = cooperative, two waves per SIMD: the default; 2 = cooperative, one wave per SIMD; 1 = one lane per rollout)."""
         _lib.check(_lib.lib().jh_model_set_kernel(self.handle, int(generation)), "jh_model_set_kernel")
+        self._max_knots_cache.clear()
         self.kernel_generation = int(generation)
         # only generation 3 of the leap family models the hand's own contacts: what bench.py / tests report must follow the kernel actually selected
         self.self_collision = self._self_collision_requested and self.kernel_generation == 3 and self.desc.get("family", self.task) == "leap_cube"
@@ -107,6 +109,7 @@ class GpuModel:
     def set_contact_capacity(self, contacts: int) -> None:
         """leap_cube family: 48 or 64 contacts per rollout (`jh_model_set_contact_capacity`)."""
         _lib.check(_lib.lib().jh_model_set_contact_capacity(self.handle, int(contacts)), "jh_model_set_contact_capacity")
+        self._max_knots_cache.clear()
         self.contact_capacity = int(contacts)
 
     def set_self_collision(self, on: bool) -> None:
@@ -137,9 +140,13 @@ class GpuModel:
 
     def max_fused_knots_at(self, H: int) -> int:
         """Largest K `jh_rollout_cost` accepts for a launch of H steps (the one-lane kernels stage W and the knots in LDS: it depends on H)."""
-        k = int(_lib.lib().jh_model_max_fused_knots(self.handle, int(H)))
-        if k < 0:
-            _lib.check(k, "jh_model_max_fused_knots")
+        H = int(H)
+        k = self._max_knots_cache.get(H)  # (asked once per plan step; the answer changes with the kernel generation / contact capacity only: those setters clear the cache)
+        if k is None:
+            k = int(_lib.lib().jh_model_max_fused_knots(self.handle, H))
+            if k < 0:
+                _lib.check(k, "jh_model_max_fused_knots")
+            self._max_knots_cache[H] = k
         return k
 
     def stats(self, reset: bool = True) -> dict:
