@@ -272,6 +272,15 @@ def main() -> None:
     N = args.rollouts or N
     H = args.horizon_steps or H
     ctrl = make_controller(args.task, opt_name)
+    # JUDO_BENCH_RCCL_ONE_RANK=1 (one GPU): a process group of ONE rank on the nccl backend and the controller on the sharded path -- launch -> all_gather_into_tensor through
+    # RCCL -> merge -- so that per_rank.exchange_ms is the exchange's cost with the real transport (its floor: no peer to wait for).  An exhibit, not the driver's line.
+    rccl_one = os.environ.get("JUDO_BENCH_RCCL_ONE_RANK") == "1" and world == 1
+    if rccl_one:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29791")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        ctrl.group = dist.group.WORLD
+        ctrl.force_shard_path = True
     ctrl.optimizer.config.num_rollouts = N
     ctrl.controller_cfg.horizon = H * ctrl.task.dt
     ctrl.reset()
@@ -387,7 +396,7 @@ def main() -> None:
     # (host: time shift, packing, launches, the one wait for the new nominal).  With several GPUs every rank reports its own split.
     split = {"rank": rank, "rollouts": int(ctrl.last_shard.count), "kernel_ms": kern_ms, "exchange_ms": exch_ms, "plan_step_ms": float(np.mean(per_step) * 1e3),
              "host_and_launch_ms": float(np.mean(per_step) * 1e3 - kern_ms - exch_ms), "kernel_events_every_n_steps": ev_every}
-    if world > 1 and getattr(ctrl, "noise_events", None) and len(ctrl.noise_events) >= len(ctrl.exchange_events) > 0:
+    if (world > 1 or rccl_one) and getattr(ctrl, "noise_events", None) and len(ctrl.noise_events) >= len(ctrl.exchange_events) > 0:
         # the next iteration's noise draw (side stream) on the exchange's clock: both measured from the event behind the rollout + record launch
         nev = ctrl.noise_events[-len(ctrl.exchange_events):]
         n0 = float(np.mean([x[0].elapsed_time(n[0]) for x, n in zip(ctrl.exchange_events, nev)]))
@@ -554,7 +563,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_policy(ctrl) if is_policy else cpu_baseline(args.task, ctrl)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or rccl_one:
         dist.destroy_process_group()
 
 

@@ -130,6 +130,7 @@ class Controller:
         self.noise_events: list = []  # (start, end) of the side-stream noise draws when record_kernel_events is set
         self.prefetch_noise = True  # draw the next iteration's noise behind this iteration's download
         self.zero_copy_out = True  # jh_update_fused writes nominal | sigma | trace records into the pinned host block itself (no download command)
+        self.force_shard_path = False  # tests: take launch -> all-gather -> merge with ONE rank as well (the RCCL branch of the exchange on a one-GPU box)
         self.poll_completion = True  # one GPU, closed-form models (plan steps of ~0.1 ms): wait for the completion word the update's last workgroup writes behind its results instead of the stream's event (jh_plan_step, out_host_mark); the articulated models' 7-50 ms plan steps keep the event
         self.host_block_in_place = True  # closed-form models: the plan-step kernel reads x0 | nominal | sigma | task params | bounds from the pinned host block (no copy in front of the launch)
         self.fused_update = True  # one GPU: the whole update (block partials, merge, trace elites) in one launch and one download (jh_update_fused); False: the separate kernels
@@ -531,10 +532,10 @@ class Controller:
         nominal_raw = nrm.denormalize(nominal_n)
         sigma_raw = sigma_n * scale[None, :]
         fused_cost = self.uses_fused_cost
-        one_call = world == 1 and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
+        one_call = world == 1 and not self.force_shard_path and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
         # several ranks, same conditions: the same shape -- launch (rollout + this rank's record) -> ONE all-gather -> merge -- instead of the chain of separate partial /
         # gather / merge / trace-gather launches with two collectives, which remains for the cases below (plugin costs, running normaliser statistics)
-        shard_call = world > 1 and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
+        shard_call = (world > 1 or self.force_shard_path) and fused_cost and self.fused_update and self.zero_copy_out and hasattr(opt, "fused_update_args") and not nrm.needs_moments
         self._pack_block(b, nominal_raw, sigma_raw, self._raw_bounds(nrm), upload=not (one_call or shard_call))
         noise = self._draw_noise(shard.count, shard.offset)  # (K, nu, shard.count), possibly a view into the full draw
         self._prefetch_args = (shard.count, shard.offset)
@@ -590,7 +591,7 @@ class Controller:
                 if self._prefetch_args is not None:  # the next iteration's noise on the side stream, enqueued in front of the collective: it overlaps the exchange
                     self._prefetch_noise(*self._prefetch_args, side=True)
                     self._prefetch_args = None
-                b.shard_all = all_gather_records(b.shard_rec, self.group)  # (world * L,), rank-major; kept alive until the merge has run
+                b.shard_all = all_gather_records(b.shard_rec, self.group, force=self.force_shard_path)  # (world * L,), rank-major; kept alive until the merge has run
                 done = None
                 if self.record_kernel_events:
                     done = self._timing_event()

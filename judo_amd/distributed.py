@@ -43,10 +43,11 @@ def world_info(group=None) -> tuple[int, int]:
     return 1, 0
 
 
-def all_gather_records(rec: torch.Tensor, group=None) -> torch.Tensor:
-    """(L,) record per rank -> (world*L,) on every rank, rank-major."""
+def all_gather_records(rec: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """(L,) record per rank -> (world*L,) on every rank, rank-major.  `force`: run the collective on a process group of ONE rank as well (tests/test_gpu_nccl.py: the
+    RCCL branch below on a one-GPU box)."""
     world, _ = world_info(group)
-    if world == 1:
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return rec
     if rec.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no device all-gather: stage the (<= few KB) record through the host.  This is the rendezvous used when several
