@@ -21,6 +21,7 @@
 // between two different chains (leg against leg, arm against leg) needs a second chain block (J2, at most NX2 such contacts per rollout and step) and couples the two
 // chains in the Hessian: the fill-in-free tree factorisation does not apply, and the rollouts that have such a contact in a step take a dense 25 x 25 Cholesky
 // (dense_cholesky_solve: one row per lane in registers, pivot rows broadcast through LDS) for that step's Newton systems.
+#include <cstddef>
 #include "jh_coop.h"
 
 #include <vector>
@@ -84,6 +85,7 @@ struct __attribute__((aligned(16))) RS4T {  // per-rollout shared state; positio
   int ncon, nx2;
 };
 using RS4 = RS4T<false>;
+static_assert(offsetof(RS4T<true>, Hc) % 16 == 0 && offsetof(RS4T<false>, Hc) % 16 == 0 && sizeof(RS4T<true>) % 16 == 0 && sizeof(RS4T<false>) % 16 == 0, "Hc rows are moved as 16-byte vectors");
 // cinfo: bits 0-2 side B's chain (0 = the base body, 1 + chain otherwise), 3-5 its depth in the chain, 6-8 / 9-11 the same for side A, 12 side A is a robot geom (a
 // robot-robot contact; else the plane), 13-16 cross index + 1 (0: both sides move with the base and at most one chain), 17 dead (a cross contact above NX2: dropped)
 __device__ __forceinline__ int ci_chB(int ci) { return ci & 7; }
@@ -213,7 +215,10 @@ __device__ __forceinline__ float chain_entry(const float* row, int cid, int m) {
   if (m < 3) {  // (pinned: otherwise the selects fold back into one load from a computed address, i.e. the row moves to scratch memory)
     float c0 = row[CS(0) + m], c1 = row[CS(1) + m], c2 = row[CS(2) + m], c3 = row[CS(3) + m];
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-    v = cid == 0 ? c0 : (cid == 1 ? c1 : (cid == 2 ? c2 : (cid == 3 ? c3 : v)));
+    // (four single selects: the nested ternary came out as exec-masked regions -- fifteen per solve)
+    float r = cid == 3 ? c3 : v; r = cid == 2 ? c2 : r; r = cid == 1 ? c1 : r; r = cid == 0 ? c0 : r;
+    asm volatile("" : "+v"(r));
+    v = r;
   }
   return v;
 }
@@ -243,17 +248,29 @@ template <class RS>
 __device__ __forceinline__ float tree_cholesky_solve(float* row, RS& S, const Role& R, int k, float* xb PA_PARAM) {
   PHS_DECL
   if (R.isjoint) {
+    // (round 6: the whole 8-float row as two 16-byte stores.  Entries beyond the lane's own chain position are never read -- a reader takes [m] for m <= the row's position --
+    // and `if (m <= R.cdepth)` in front of each of seven stores was seven exec-masked regions on a wave that has its SIMD to itself.)
+    float v[8];
 #pragma unroll
-    for (int m = 0; m < 7; m++) { const float v = chain_entry(row, R.cid, m); if (m <= R.cdepth) S.Hc[k][m] = v; }
+    for (int m = 0; m < 7; m++) v[m] = chain_entry(row, R.cid, m);
+    float4* o = reinterpret_cast<float4*>(S.Hc[k]);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]); o[1] = make_float4(v[4], v[5], v[6], 0.f);
   }
   __syncthreads();
   const int fcs = R.isjoint ? R.cstart : CS(4), flen = R.isjoint ? R.clen : 7;
   float L[28];
 #pragma unroll
   for (int pp = 0; pp < 7; pp++) {
+    // (every row is LOADED whatever the lane's chain length -- S.Hc[fcs + pp] is a valid row for every pp: fcs + 6 <= 18 -- and the identity padding of a leg's 3 x 3 block is a
+    // select: a load in one arm of the ternary was an exec-masked region per entry, 28 of them)
     const float* hr = S.Hc[fcs + pp];
+    float hv[7];
+    {
+      const float4 h0 = *reinterpret_cast<const float4*>(hr), h1 = *reinterpret_cast<const float4*>(hr + 4);
+      hv[0] = h0.x; hv[1] = h0.y; hv[2] = h0.z; hv[3] = h0.w; hv[4] = h1.x; hv[5] = h1.y; hv[6] = h1.z;
+    }
 #pragma unroll
-    for (int m = 0; m <= pp; m++) L[tri4(pp, m)] = pp < flen ? hr[m] : (m == pp ? 1.f : 0.f);
+    for (int m = 0; m <= pp; m++) L[tri4(pp, m)] = pp < flen ? hv[m] : (m == pp ? 1.f : 0.f);
   }
   chol_packed<7>(L);
   PHS(10)
