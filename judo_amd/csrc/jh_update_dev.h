@@ -92,11 +92,30 @@ __device__ __forceinline__ bool better(const Cand& a, const Cand& b, int tie_hig
   if (a.i < 0 || b.i < 0) return a.i >= 0;
   return tie_high ? a.i > b.i : a.i < b.i;
 }
+// Best candidate of the wave, in every lane.  Round 6: the six exchange levels stay in the VALU -- four DPP row modifiers (quad xor 1, quad xor 2, half mirror, mirror), then
+// gfx950's v_permlane16_swap / v_permlane32_swap (with both operands the same register they leave (row0, row0, row2, row2) | (row1, row1, row3, row3), resp. the two halves) --
+// instead of six `__shfl_xor` = ds_bpermute trips through the LDS crossbar of ~100 cycles each: the arg-min rounds of the update's tail run on waves that have their SIMD
+// to themselves.  `better` is a strict total order on distinct candidates, so every lane ends with the same winner whatever the pairing.
+template <int CTRL>
+__device__ __forceinline__ Cand dpp_cand(const Cand& v) {
+  return Cand{__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.c), CTRL, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, v.i, CTRL, 0xF, 0xF, true)};
+}
 __device__ __forceinline__ Cand wave_best(Cand v, int tie_high) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Cand w{__shfl_xor(v.c, o, 64), __shfl_xor(v.i, o, 64)};
-    if (better(w, v, tie_high)) v = w;
+  { const Cand w = dpp_cand<0xB1>(v); if (better(w, v, tie_high)) v = w; }
+  { const Cand w = dpp_cand<0x4E>(v); if (better(w, v, tie_high)) v = w; }
+  { const Cand w = dpp_cand<0x141>(v); if (better(w, v, tie_high)) v = w; }
+  { const Cand w = dpp_cand<0x140>(v); if (better(w, v, tie_high)) v = w; }
+  {
+    const auto rc = __builtin_amdgcn_permlane16_swap(__float_as_uint(v.c), __float_as_uint(v.c), false, false);
+    const auto ri = __builtin_amdgcn_permlane16_swap((unsigned)v.i, (unsigned)v.i, false, false);
+    const Cand a{__uint_as_float(rc[0]), (int)ri[0]}, b{__uint_as_float(rc[1]), (int)ri[1]};
+    v = better(b, a, tie_high) ? b : a;
+  }
+  {
+    const auto rc = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.c), __float_as_uint(v.c), false, false);
+    const auto ri = __builtin_amdgcn_permlane32_swap((unsigned)v.i, (unsigned)v.i, false, false);
+    const Cand a{__uint_as_float(rc[0]), (int)ri[0]}, b{__uint_as_float(rc[1]), (int)ri[1]};
+    v = better(b, a, tie_high) ? b : a;
   }
   return v;
 }
@@ -120,6 +139,32 @@ __device__ __forceinline__ void topk_block_body(const float* __restrict__ costs,
 // one workgroup: choose k best of ncand (cost, global index) pairs; emit records [cost, index, knots...]
 __device__ __forceinline__ void topk_choose(const float* __restrict__ cand, int ncand, int k, int tie_high, Cand* sred, Cand* chosen) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int OWN = 4;  // candidates a thread keeps in registers: up to OWN * kUB = 1 024 of them are read from memory ONCE (round 6) instead of once per round -- the
+                          // candidates were written by other workgroups, on other XCDs: every read is a trip to memory, and the rounds are a dependent chain
+  if (ncand <= OWN * kUB) {
+    Cand own[OWN];
+#pragma unroll
+    for (int j = 0; j < OWN; j++) {
+      const int r = tid + j * kUB;
+      own[j] = r < ncand ? Cand{cand[(size_t)r * 2], __float_as_int(cand[(size_t)r * 2 + 1])} : Cand{INFINITY, -1};
+    }
+    for (int e = 0; e < k; e++) {
+      Cand mine{INFINITY, -1};
+#pragma unroll
+      for (int j = 0; j < OWN; j++) if (own[j].i >= 0 && better(own[j], mine, tie_high)) mine = own[j];
+      Cand b = wave_best(mine, tie_high);
+      if (lane == 0) sred[wave] = b;
+      __syncthreads();
+      Cand best = sred[0];
+      for (int w = 1; w < 4; w++) if (better(sred[w], best, tie_high)) best = sred[w];
+      __syncthreads();
+      if (tid == 0) chosen[e] = best;
+#pragma unroll
+      for (int j = 0; j < OWN; j++) if (best.i >= 0 && own[j].i == best.i) own[j].i = -1;  // (global rollout indices are unique)
+    }
+    __syncthreads();  // `chosen` is read by every thread behind this call
+    return;
+  }
   for (int e = 0; e < k; e++) {
     Cand mine{INFINITY, -1};
     for (int r = tid; r < ncand; r += kUB) {
