@@ -274,6 +274,15 @@ __device__ __forceinline__ float tree_cholesky_solve(float* row, RS& S, const Ro
   }
   chol_packed<7>(L);
   PHS(10)
+  // (round 6) A leg's lanes have just factorised the leg's 3 x 3 block (the leading block of their padded 7 x 7): the lane at chain position p puts row p of the FACTOR back
+  // where row p of the block was, and the base lanes read the four factors instead of factorising the four blocks again -- 4 x chol_packed<3> per base lane and call, on a
+  // phase (base rows + Schur) that only seven lanes of the wave work in.  Row p of chol_packed<3> and of chol_packed<7> are the same expressions on the same numbers.
+  if (R.isjoint && R.cid < 4) {
+    const int cd = R.cdepth;
+    const float f0 = cd == 0 ? L[0] : (cd == 1 ? L[1] : L[3]), f1 = cd == 1 ? L[2] : L[4], f2 = L[5];
+    float* o = S.Hc[k]; o[0] = f0; o[1] = f1; o[2] = f2;  // (entries beyond the own position are never read)
+  }
+  __syncthreads();
   if (R.bl >= 0) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -283,7 +292,6 @@ __device__ __forceinline__ float tree_cholesky_solve(float* row, RS& S, const Ro
 #pragma unroll
         for (int m = 0; m <= pp; m++) Lg[tri4(pp, m)] = S.Hc[CS(c) + pp][m];
       }
-      chol_packed<3>(Lg);
       fwd_packed<3>(row + CS(c), Lg);
     }
     fwd_packed<7>(row + CS(4), L);
