@@ -601,3 +601,16 @@ def test_controller_helper_properties_of_the_reference_exist():
         assert inspect.getattr_static(Controller, name).fset is not None, name
     for name in ("update_action", "action", "update_spline", "reset", "update_traces", "update_states"):
         assert callable(getattr(Controller, name)), name
+
+
+def test_bench_reads_a_committed_traffic_file():
+    """`bench.py`'s `roofline.traffic` / `roofline.issue` come from the round's committed PMC passes (profiles/<TRAFFIC_FILE>, written by tools/collect_profiles.py): the file
+    the bench names exists and holds the headline kernel's HBM bytes per launch and its issue-side counters."""
+    import json
+    import re
+
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    name = re.search(r'^TRAFFIC_FILE = "([^"]+)"', src, re.M).group(1)
+    t = json.load(open(os.path.join(ROOT, "profiles", name)))
+    for case in ("leap_cube", "leap_cube_cube_only", "fr3_pick"):
+        assert t[case]["hbm_bytes_per_launch"] > 0 and t[case]["issue"]["cycles_per_valu_instruction_per_simd"] > 2.0, case
